@@ -1,0 +1,147 @@
+/*
+ * oa_icp.h -- C-ABI of liboa_icp.so: the MI355X (gfx950) ICP hot path.
+ *
+ * This is the drop-in boundary for the one hot path of patmo141/object_alignment
+ * (SURVEY.md section 8b): what a maintainer's ctypes binding would call instead of
+ *
+ *   functions/general.py:257   make_pairs(align_obj, base_obj, base_bvh, vlist, thresh, sample, calc_stats)
+ *   functions/general.py:105   affine_matrix_from_points(v0, v1, shear=False, scale, usesvd=True)
+ *   operators/icp_align.py:96  the `while n < iters and not converged` loop of
+ *                              OBJECT_OT_icp_align.execute
+ *
+ * Conventions
+ *   - plain C, no torch / C++ types; all matrices are 4x4 ROW-major;
+ *     `float` matrices carry Blender's float32 matrix_world values.
+ *   - host buffers are caller-owned and only touched during the call; device
+ *     buffers are library-owned and released by oa_destroy.
+ *   - every function returns OA_OK (0) or a negative error code; the text of the
+ *     last error on the calling thread is oa_last_error().  No C++ exception
+ *     crosses this boundary.
+ *   - one context = one GPU = one host thread at a time (not internally locked).
+ *     Multi-GPU = one process (and one context) per GPU; the per-iteration
+ *     exchange is 24 doubles (oa_iter_partial -> all-reduce(sum) -> oa_iter_finish).
+ *   - there is NO CPU fallback: every compute entry point fails with
+ *     OA_E_NO_DEVICE / OA_E_HIP when no gfx950 device is usable.
+ *
+ * Correspondence rule: nearest target VERTEX (fp32, d2 = fma(dz,dz,fma(dy,dy,dx*dx)),
+ * lowest index wins ties) -- see DESIGN.md "D2".
+ */
+#ifndef OA_ICP_H
+#define OA_ICP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OA_OK                 0
+#define OA_E_BAD_ARG         -1
+#define OA_E_HIP             -2
+#define OA_E_TOO_FEW_PAIRS   -3   /* K < 3: the reference raises ValueError (functions/general.py:150-157) */
+#define OA_E_SINGULAR        -4   /* matrix_world not invertible (functions/general.py:265-266) */
+#define OA_E_NO_DEVICE       -5
+#define OA_E_STATE           -6   /* source / target / matrices not set */
+#define OA_E_BAD_THRESH      -7   /* thresh <= 0: the reference returns None (functions/general.py:277) */
+#define OA_E_CAPACITY        -8
+
+#define OA_NSUMS 24               /* doubles exchanged per iteration (see oa_iter_partial) */
+
+typedef struct oa_ctx oa_ctx;
+
+/* Loop parameters: lib/preferences.py:31-72 as read at operators/icp_align.py:82-89 */
+typedef struct oa_settings {
+    int32_t iters;            /* icp_iterations (50) */
+    int32_t use_target;       /* use_target (1): calc d_stats and run the convergence test */
+    int32_t with_scale;       /* align_meth == '1' (ROT_LOC_SCALE) */
+    int32_t early_exit;       /* 1 = stop when converged (reference behaviour); 0 = always run `iters` (timing runs) */
+    double  thresh;           /* min_start (0.5) */
+    double  target_d;         /* target_d (0.01) */
+} oa_settings;
+
+typedef struct oa_report {
+    int32_t iters_done;
+    int32_t converged;
+    int32_t status;               /* OA_OK or the error that stopped the loop */
+    int32_t reserved;
+    int64_t last_K;               /* pairs used by the last iteration (all shards) */
+    double  last_translation;     /* |new_mat.to_translation()| of the last iteration */
+    double  mean_dist, std_dist;  /* d_stats of the last iteration (NaN when use_target = 0) */
+    double  mean_rot_angle;       /* mean |rotation angle| over the last <=5 iterations (radians) */
+    double  nn_ms_total;          /* hipEvent time summed over the correspondence kernels */
+    double  loop_ms;              /* hipEvent time of the whole device-resident loop */
+} oa_report;
+
+/* ---- lifetime ------------------------------------------------------------------ */
+int         oa_device_count(void);
+int         oa_create(oa_ctx **out, int device);
+void        oa_destroy(oa_ctx *ctx);
+const char *oa_last_error(void);
+const char *oa_version(void);
+/* stream: a hipStream_t to enqueue on (e.g. torch's current stream); NULL = the context's own stream */
+int         oa_set_stream(oa_ctx *ctx, void *stream);
+
+/* ---- one-time uploads (replaces BVHTree.FromObject, operators/icp_align.py:53, and the vlist
+ *      walk over align_obj.data.vertices, functions/general.py:280-284) ------------------------ */
+/* target (base object) vertices, base-LOCAL, n x 3 float32.  on_device != 0: xyz is a device pointer. */
+int oa_set_target(oa_ctx *ctx, const float *xyz, int64_t n, int on_device);
+/* source (align object) vertices, align-LOCAL, n_verts x 3 float32.
+ * vlist (host, may be NULL = all vertices) is the operator's vertex list; stride > 1 applies
+ * vlist[0::stride] (functions/general.py:274-275).  The selected list is then cut into
+ * shard_count contiguous shards and this context keeps shard shard_index. */
+int oa_set_source(oa_ctx *ctx, const float *xyz, int64_t n_verts, int on_device,
+                  const int64_t *vlist, int64_t n_vlist, int32_t stride,
+                  int32_t shard_index, int32_t shard_count);
+/* matrix_world of the align and base objects (functions/general.py:262-263) */
+int oa_set_matrices(oa_ctx *ctx, const float mx_align[16], const float mx_base[16]);
+int oa_get_matrix_world(oa_ctx *ctx, float mx_align[16]);
+int64_t oa_num_selected(oa_ctx *ctx);     /* selected source points held by this context (its shard) */
+
+/* ---- contract 1: make_pairs (functions/general.py:257-329) ------------------------------------ */
+/* A, B: caller-allocated 3 x cap row-major doubles (row = axis); pairs come out in vlist order.
+ * dstats = [mean, population std] of the world-space pair distances when calc_stats. */
+int oa_make_pairs(oa_ctx *ctx, double thresh, int calc_stats,
+                  double *A, double *B, int64_t cap, int64_t *K, double dstats[2]);
+/* the correspondence search alone: nearest target vertex index and fp32 squared distance
+ * (base-local) for every selected source point of this shard.  idx/d2 may be NULL (timing). */
+int oa_nn_search(oa_ctx *ctx, int64_t *idx, float *d2, double *kernel_ms);
+
+/* ---- contract 2: affine_matrix_from_points(v0=A, v1=B, shear=False, scale, usesvd=True)
+ *      (functions/general.py:105-217); alias calc_target_matrix in the Python host ------------ */
+/* A, B: 3 x K row-major doubles with leading dimension ld (host). */
+int oa_kabsch(oa_ctx *ctx, const double *A, const double *B, int64_t K, int64_t ld,
+              int with_scale, double M[16]);
+/* same solve from the OA_NSUMS accumulated sums (host array; layout in DESIGN.md).  The sums are taken
+ * relative to `pivot` (a' = a - pivot, b' = b - pivot); pivot == NULL means the origin. */
+int oa_kabsch_from_sums(oa_ctx *ctx, const double sums[OA_NSUMS], const double pivot[3], int with_scale,
+                        double M[16]);
+/* the pivot this context subtracts before accumulating (the first selected source vertex) */
+int oa_get_pivot(oa_ctx *ctx, double pivot[3]);
+
+/* ---- fused fast path: the operator loop (operators/icp_align.py:91-151) ----------------------- */
+/* one iteration, synchronous (the modal operator's per-tick step, icp_align_feedback.py:250-288):
+ * M_step = this iteration's 4x4 (float64); stats = [K, mean_dist, std_dist, |translation|, rot_angle, converged] */
+int oa_iterate(oa_ctx *ctx, const oa_settings *st, double M_step[16], double stats[6]);
+/* the whole loop, device resident (no host round trip per iteration) */
+int oa_run(oa_ctx *ctx, const oa_settings *st, oa_report *rep);
+/* per-iteration history of the last oa_run / oa_iterate sequence (each may be NULL):
+ * step_M n x 16 doubles, step_new n x 16 floats (new_mat, operators/icp_align.py:116-119),
+ * step_K n, step_stats n x 2, step_trans n.  Returns the number of iterations recorded. */
+int oa_get_history(oa_ctx *ctx, int32_t max_n, double *step_M, float *step_new,
+                   int64_t *step_K, double *step_stats, double *step_trans);
+
+/* ---- split-phase loop for one-process-per-GPU sharding ---------------------------------------- */
+/* oa_run_begin resets the loop state (ring buffer, counters) on the device. */
+int oa_run_begin(oa_ctx *ctx, const oa_settings *st);
+/* enqueue correspondence search + pair accumulation for this shard; the OA_NSUMS partial sums
+ * land in d_sums (DEVICE pointer, e.g. a torch tensor) ready for an all-reduce(sum). */
+int oa_iter_partial(oa_ctx *ctx, double *d_sums);
+/* enqueue solve + matrix_world update + convergence ring from the (all-reduced) sums. */
+int oa_iter_finish(oa_ctx *ctx, const double *d_sums);
+/* synchronise and fetch the report. */
+int oa_run_end(oa_ctx *ctx, oa_report *rep);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OA_ICP_H */

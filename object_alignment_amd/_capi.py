@@ -1,0 +1,121 @@
+"""ctypes binding of liboa_icp.so (include/oa_icp.h) -- the only way Python reaches the HIP kernels.
+
+There is no fallback: if the shared library is missing or no GPU is usable the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboa_icp.so")
+
+OA_OK = 0
+OA_E_BAD_ARG = -1
+OA_E_HIP = -2
+OA_E_TOO_FEW_PAIRS = -3
+OA_E_SINGULAR = -4
+OA_E_NO_DEVICE = -5
+OA_E_STATE = -6
+OA_E_BAD_THRESH = -7
+OA_E_CAPACITY = -8
+OA_NSUMS = 24
+
+# every symbol include/oa_icp.h declares (tests check that the library exports all of them)
+SYMBOLS = [
+    "oa_device_count", "oa_create", "oa_destroy", "oa_last_error", "oa_version", "oa_set_stream",
+    "oa_set_target", "oa_set_source", "oa_set_matrices", "oa_get_matrix_world", "oa_num_selected",
+    "oa_make_pairs", "oa_nn_search", "oa_kabsch", "oa_kabsch_from_sums", "oa_get_pivot",
+    "oa_iterate", "oa_run", "oa_get_history", "oa_run_begin", "oa_iter_partial", "oa_iter_finish", "oa_run_end",
+]
+
+
+class Settings(C.Structure):
+    _fields_ = [("iters", C.c_int32), ("use_target", C.c_int32), ("with_scale", C.c_int32),
+                ("early_exit", C.c_int32), ("thresh", C.c_double), ("target_d", C.c_double)]
+
+
+class Report(C.Structure):
+    _fields_ = [("iters_done", C.c_int32), ("converged", C.c_int32), ("status", C.c_int32),
+                ("reserved", C.c_int32), ("last_K", C.c_int64), ("last_translation", C.c_double),
+                ("mean_dist", C.c_double), ("std_dist", C.c_double), ("mean_rot_angle", C.c_double),
+                ("nn_ms_total", C.c_double), ("loop_ms", C.c_double)]
+
+
+class OaError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("oa_icp error %d: %s" % (code, msg))
+        self.code = code
+        self.msg = msg
+
+
+_lib = None
+
+
+def load():
+    """Load liboa_icp.so.  Raises (loudly) when the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "object_alignment_amd: %s is missing -- build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, fp, dp, ip = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int64)
+    L.oa_device_count.restype = C.c_int
+    L.oa_create.argtypes = [C.POINTER(vp), C.c_int]
+    L.oa_destroy.argtypes = [vp]
+    L.oa_destroy.restype = None
+    L.oa_last_error.restype = C.c_char_p
+    L.oa_version.restype = C.c_char_p
+    L.oa_set_stream.argtypes = [vp, vp]
+    L.oa_set_target.argtypes = [vp, vp, C.c_int64, C.c_int]
+    L.oa_set_source.argtypes = [vp, vp, C.c_int64, C.c_int, ip, C.c_int64, C.c_int32, C.c_int32, C.c_int32]
+    L.oa_set_matrices.argtypes = [vp, fp, fp]
+    L.oa_get_matrix_world.argtypes = [vp, fp]
+    L.oa_num_selected.argtypes = [vp]
+    L.oa_num_selected.restype = C.c_int64
+    L.oa_make_pairs.argtypes = [vp, C.c_double, C.c_int, dp, dp, C.c_int64, ip, dp]
+    L.oa_nn_search.argtypes = [vp, ip, fp, dp]
+    L.oa_kabsch.argtypes = [vp, dp, dp, C.c_int64, C.c_int64, C.c_int, dp]
+    L.oa_kabsch_from_sums.argtypes = [vp, dp, dp, C.c_int, dp]
+    L.oa_get_pivot.argtypes = [vp, dp]
+    L.oa_iterate.argtypes = [vp, C.POINTER(Settings), dp, dp]
+    L.oa_run.argtypes = [vp, C.POINTER(Settings), C.POINTER(Report)]
+    L.oa_get_history.argtypes = [vp, C.c_int32, dp, fp, ip, dp, dp]
+    L.oa_run_begin.argtypes = [vp, C.POINTER(Settings)]
+    L.oa_iter_partial.argtypes = [vp, vp]
+    L.oa_iter_finish.argtypes = [vp, vp]
+    L.oa_run_end.argtypes = [vp, C.POINTER(Report)]
+    for name in SYMBOLS:
+        fn = getattr(L, name)
+        if fn.restype is C.c_int and name not in ("oa_device_count",):
+            pass
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != OA_OK:
+        raise OaError(rc, load().oa_last_error().decode("utf-8", "replace"))
+    return rc
+
+
+def fptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def iptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int64))
+
+
+def as_f32(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a.reshape(shape) if shape is not None else a

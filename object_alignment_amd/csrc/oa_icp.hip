@@ -1,0 +1,755 @@
+// oa_icp.hip -- C-ABI (include/oa_icp.h) over the gfx950 kernels in oa_kernels.hpp.
+//
+// Host side of the drop-in boundary: context lifetime, uploads/packing, launch geometry, the device-resident
+// iterate loop and its split-phase form for one-process-per-GPU sharding.  No CPU fallback lives here: every
+// compute entry point needs a usable HIP device and fails loudly otherwise.
+#include "oa_kernels.hpp"
+#include "../../include/oa_icp.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#define OA_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(OA_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+template <typename T> void dev_free(T *&p)
+{
+    if (p) { (void)hipFree(p); p = nullptr; }
+}
+
+int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+}  // namespace
+
+struct oa_ctx {
+    int device = 0;
+    int n_cu = 256;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    // target
+    int nt = 0, n_groups_pad = 0;
+    float *d_tgt_xyz = nullptr;
+    float4 *d_tg = nullptr;
+    // source (this shard)
+    int ns = 0, ns_pad = 0, R = 4;
+    float4 *d_src4 = nullptr;
+    unsigned long long *d_keys = nullptr;
+    double pivot[3] = { 0, 0, 0 };
+    // launch geometry for k_nn_search
+    int n_splits = 1, groups_per_split = 0, acc_blocks = 1;
+    // device state
+    oa::DevState h_state;
+    oa::DevState *d_state = nullptr;
+    bool have_mats = false, loop_active = false;
+    oa::StepRecord *d_hist = nullptr;
+    int max_records = 0;
+    double *d_partials = nullptr, *d_sums = nullptr, *d_solve = nullptr;
+    // make_pairs scratch (sized to ns)
+    int emit_cap = 0;
+    unsigned char *d_valid = nullptr;
+    float *d_b = nullptr;
+    double *d_dist = nullptr;
+    int *d_counts = nullptr;
+    long long *d_offsets = nullptr;
+    double *d_A = nullptr, *d_B = nullptr;
+    // timing
+    std::vector<hipEvent_t> ev;
+    int ev_used = 0;
+    hipEvent_t ev_loop0 = nullptr, ev_loop1 = nullptr;
+    oa_settings settings;
+};
+
+namespace {
+
+int use_device(oa_ctx *c)
+{
+    HIPCHK(hipSetDevice(c->device));
+    return OA_OK;
+}
+
+void plan_geometry(oa_ctx *c)
+{
+    if (c->ns <= 0 || c->nt <= 0) return;
+    const int src_blocks = c->ns_pad / (oa::NN_THREADS * c->R);
+    const int tiles_total = c->n_groups_pad / oa::TILE_GROUPS;
+    const int want = env_int("OA_NN_TARGET_BLOCKS", c->n_cu * 8);
+    int splits = (want + src_blocks - 1) / src_blocks;
+    splits = std::max(1, std::min(splits, tiles_total));
+    const int forced = env_int("OA_NN_SPLITS", 0);
+    if (forced > 0) splits = std::min(forced, tiles_total);
+    const int tiles_per_split = (tiles_total + splits - 1) / splits;
+    c->groups_per_split = tiles_per_split * oa::TILE_GROUPS;
+    c->n_splits = (tiles_total + tiles_per_split - 1) / tiles_per_split;
+    c->acc_blocks = std::max(1, std::min(oa::ACC_MAX_BLOCKS, (c->ns + oa::ACC_THREADS - 1) / oa::ACC_THREADS));
+}
+
+int ensure_common(oa_ctx *c)
+{
+    if (!c->d_state) HIPCHK(hipMalloc(&c->d_state, sizeof(oa::DevState)));
+    if (!c->d_partials) HIPCHK(hipMalloc(&c->d_partials, sizeof(double) * oa::NSUMS * oa::ACC_MAX_BLOCKS));
+    if (!c->d_sums) HIPCHK(hipMalloc(&c->d_sums, sizeof(double) * oa::NSUMS));
+    if (!c->d_solve) HIPCHK(hipMalloc(&c->d_solve, sizeof(double) * 32));
+    return OA_OK;
+}
+
+int ensure_history(oa_ctx *c, int n)
+{
+    n = std::max(16, std::min(n, 1 << 16));
+    if (n <= c->max_records) return OA_OK;
+    dev_free(c->d_hist);
+    HIPCHK(hipMalloc(&c->d_hist, sizeof(oa::StepRecord) * (size_t)n));
+    c->max_records = n;
+    return OA_OK;
+}
+
+int ensure_events(oa_ctx *c, int n_pairs)
+{
+    while ((int)c->ev.size() < 2 * n_pairs) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        c->ev.push_back(e);
+    }
+    if (!c->ev_loop0) { HIPCHK(hipEventCreate(&c->ev_loop0)); HIPCHK(hipEventCreate(&c->ev_loop1)); }
+    return OA_OK;
+}
+
+int check_ready(oa_ctx *c)
+{
+    if (!c) return fail(OA_E_BAD_ARG, "null context");
+    if (c->nt <= 0 || !c->d_tg) return fail(OA_E_STATE, "target not set (oa_set_target)");
+    if (!c->d_src4) return fail(OA_E_STATE, "source not set (oa_set_source)");
+    if (!c->have_mats) return fail(OA_E_STATE, "matrices not set (oa_set_matrices)");
+    return OA_OK;
+}
+
+int launch_nn(oa_ctx *c)
+{
+    if (c->ns <= 0) return OA_OK;
+    dim3 grid(c->ns_pad / (oa::NN_THREADS * c->R), c->n_splits);
+    dim3 block(oa::NN_THREADS);
+    switch (c->R) {
+    case 1: hipLaunchKernelGGL(oa::k_nn_search<1>, grid, block, 0, c->stream, c->d_state, c->d_src4, c->d_tg, c->groups_per_split, c->n_groups_pad, c->d_keys); break;
+    case 2: hipLaunchKernelGGL(oa::k_nn_search<2>, grid, block, 0, c->stream, c->d_state, c->d_src4, c->d_tg, c->groups_per_split, c->n_groups_pad, c->d_keys); break;
+    case 8: hipLaunchKernelGGL(oa::k_nn_search<8>, grid, block, 0, c->stream, c->d_state, c->d_src4, c->d_tg, c->groups_per_split, c->n_groups_pad, c->d_keys); break;
+    default: hipLaunchKernelGGL(oa::k_nn_search<4>, grid, block, 0, c->stream, c->d_state, c->d_src4, c->d_tg, c->groups_per_split, c->n_groups_pad, c->d_keys); break;
+    }
+    HIPCHK(hipGetLastError());
+    return OA_OK;
+}
+
+int launch_accumulate(oa_ctx *c, bool emit, int *nn_idx, float *nn_d2)
+{
+    oa::PairOut po{};
+    if (emit) {
+        po.valid = c->d_valid; po.b = c->d_b; po.dist = c->d_dist; po.nn_idx = nn_idx; po.nn_d2 = nn_d2;
+        hipLaunchKernelGGL(oa::k_pair_accumulate<true>, dim3(c->acc_blocks), dim3(oa::ACC_THREADS), 0, c->stream,
+                           c->d_state, c->d_src4, c->ns, c->d_tgt_xyz, c->d_keys, c->d_partials, po);
+    } else {
+        hipLaunchKernelGGL(oa::k_pair_accumulate<false>, dim3(c->acc_blocks), dim3(oa::ACC_THREADS), 0, c->stream,
+                           c->d_state, c->d_src4, c->ns, c->d_tgt_xyz, c->d_keys, c->d_partials, po);
+    }
+    HIPCHK(hipGetLastError());
+    return OA_OK;
+}
+
+int launch_reduce(oa_ctx *c, double *d_sums)
+{
+    hipLaunchKernelGGL(oa::k_reduce_partials, dim3(1), dim3(256), 0, c->stream, c->d_partials, c->acc_blocks, d_sums);
+    HIPCHK(hipGetLastError());
+    return OA_OK;
+}
+
+void init_loop_state(oa_ctx *c, const oa_settings *st, int iters)
+{
+    oa::DevState &s = c->h_state;
+    for (int k = 0; k < 3; ++k) s.pivot[k] = c->pivot[k];
+    s.thresh = st->thresh;
+    s.target_d = st->target_d;
+    for (int k = 0; k < 5; ++k) { s.ring_t[k] = st->target_d * 2.0; s.ring_r[k] = 0.0; }   // icp_align.py:93-94
+    s.iters = iters;
+    s.use_target = st->use_target ? 1 : 0;
+    s.with_scale = st->with_scale ? 1 : 0;
+    s.early_exit = st->early_exit ? 1 : 0;
+    s.n = 0; s.converged = 0; s.status = 0; s.halt = (iters <= 0) ? 1 : 0;
+    s.max_records = c->max_records; s.pad0 = 0;
+}
+
+int begin_loop(oa_ctx *c, const oa_settings *st, int iters)
+{
+    int rc = check_ready(c);
+    if (rc) return rc;
+    if (!st) return fail(OA_E_BAD_ARG, "null settings");
+    if (!(st->thresh > 0.0)) return fail(OA_E_BAD_THRESH, "thresh must be > 0 (the reference's make_pairs returns None)");
+    if ((rc = use_device(c))) return rc;
+    if ((rc = ensure_common(c))) return rc;
+    if ((rc = ensure_history(c, iters))) return rc;
+    c->settings = *st;
+    init_loop_state(c, st, iters);
+    HIPCHK(hipMemcpyAsync(c->d_state, &c->h_state, sizeof(oa::DevState), hipMemcpyHostToDevice, c->stream));
+    c->ev_used = 0;
+    c->loop_active = true;
+    return OA_OK;
+}
+
+int iter_partial(oa_ctx *c, double *d_sums, bool timed)
+{
+    int rc;
+    if (timed) {
+        if ((rc = ensure_events(c, c->ev_used + 1))) return rc;
+        HIPCHK(hipEventRecord(c->ev[2 * c->ev_used], c->stream));
+    }
+    if ((rc = launch_nn(c))) return rc;
+    if (timed) {
+        HIPCHK(hipEventRecord(c->ev[2 * c->ev_used + 1], c->stream));
+        c->ev_used++;
+    }
+    if ((rc = launch_accumulate(c, false, nullptr, nullptr))) return rc;
+    return launch_reduce(c, d_sums);
+}
+
+int iter_finish(oa_ctx *c, const double *d_sums)
+{
+    hipLaunchKernelGGL(oa::k_solve_update, dim3(1), dim3(64), 0, c->stream, c->d_state, d_sums, c->d_hist);
+    HIPCHK(hipGetLastError());
+    return OA_OK;
+}
+
+int fetch_state(oa_ctx *c)
+{
+    HIPCHK(hipMemcpyAsync(&c->h_state, c->d_state, sizeof(oa::DevState), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return OA_OK;
+}
+
+int fill_report(oa_ctx *c, oa_report *rep)
+{
+    int rc = fetch_state(c);
+    if (rc) return rc;
+    const oa::DevState &s = c->h_state;
+    memset(rep, 0, sizeof *rep);
+    rep->iters_done = s.n;
+    rep->converged = s.converged;
+    rep->status = s.status;
+    rep->mean_dist = rep->std_dist = NAN;
+    if (s.n > 0 && c->d_hist) {
+        oa::StepRecord r;
+        HIPCHK(hipMemcpy(&r, c->d_hist + ((s.n - 1) % c->max_records), sizeof r, hipMemcpyDeviceToHost));
+        rep->last_K = (int64_t)r.K;
+        rep->last_translation = r.trans;
+        if (s.use_target) { rep->mean_dist = r.mean_d; rep->std_dist = r.std_d; }
+        double a = 0.0;
+        const int m = std::min(s.n, 5);
+        if (s.use_target) { for (int k = 0; k < m; ++k) a += s.ring_r[k]; rep->mean_rot_angle = a / m; }
+        else rep->mean_rot_angle = r.angle;
+    }
+    double nn_ms = 0.0;
+    for (int k = 0; k < c->ev_used; ++k) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->ev[2 * k], c->ev[2 * k + 1]) == hipSuccess) nn_ms += ms;
+    }
+    rep->nn_ms_total = nn_ms;
+    return OA_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+// lifetime
+// ================================================================================================
+OA_EXPORT const char *oa_last_error(void) { return g_err.c_str(); }
+OA_EXPORT const char *oa_version(void) { return "oa_icp 0.1 (gfx950)"; }
+
+OA_EXPORT int oa_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+OA_EXPORT int oa_create(oa_ctx **out, int device)
+{
+    if (!out) return fail(OA_E_BAD_ARG, "oa_create: null out pointer");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(OA_E_NO_DEVICE, "no HIP device available: the oa_icp engine has no CPU fallback");
+    }
+    if (device < 0 || device >= n) return fail(OA_E_BAD_ARG, "device %d out of range (0..%d)", device, n - 1);
+    oa_ctx *c = new (std::nothrow) oa_ctx();
+    if (!c) return fail(OA_E_HIP, "out of host memory");
+    c->device = device;
+    memset(&c->h_state, 0, sizeof c->h_state);
+    memset(&c->settings, 0, sizeof c->settings);
+    hipError_t e = hipSetDevice(device);
+    hipDeviceProp_t prop;
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+    if (e == hipSuccess) { c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; }
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return fail(OA_E_HIP, "oa_create: %s", hipGetErrorString(e)); }
+    c->stream = c->own_stream;
+    c->R = env_int("OA_NN_R", 4);
+    if (c->R != 1 && c->R != 2 && c->R != 4 && c->R != 8) c->R = 4;
+    *out = c;
+    return OA_OK;
+}
+
+OA_EXPORT void oa_destroy(oa_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    dev_free(c->d_tgt_xyz); dev_free(c->d_tg); dev_free(c->d_src4); dev_free(c->d_keys); dev_free(c->d_state);
+    dev_free(c->d_hist); dev_free(c->d_partials); dev_free(c->d_sums); dev_free(c->d_solve);
+    dev_free(c->d_valid); dev_free(c->d_b); dev_free(c->d_dist); dev_free(c->d_counts); dev_free(c->d_offsets);
+    dev_free(c->d_A); dev_free(c->d_B);
+    for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+    if (c->ev_loop0) (void)hipEventDestroy(c->ev_loop0);
+    if (c->ev_loop1) (void)hipEventDestroy(c->ev_loop1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+OA_EXPORT int oa_set_stream(oa_ctx *c, void *stream)
+{
+    if (!c) return fail(OA_E_BAD_ARG, "null context");
+    c->stream = stream ? (hipStream_t)stream : c->own_stream;
+    return OA_OK;
+}
+
+// ================================================================================================
+// uploads
+// ================================================================================================
+OA_EXPORT int oa_set_target(oa_ctx *c, const float *xyz, int64_t n, int on_device)
+{
+    if (!c) return fail(OA_E_BAD_ARG, "null context");
+    if (n < 0 || n > 0x7FFF0000ll) return fail(OA_E_BAD_ARG, "target vertex count %lld out of range", (long long)n);
+    if (n > 0 && !xyz) return fail(OA_E_BAD_ARG, "null target pointer");
+    int rc = use_device(c);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    dev_free(c->d_tgt_xyz); dev_free(c->d_tg);
+    c->nt = (int)n;
+    c->n_groups_pad = 0;
+    if (n == 0) return OA_OK;
+    HIPCHK(hipMalloc(&c->d_tgt_xyz, sizeof(float) * 3 * (size_t)n));
+    HIPCHK(hipMemcpyAsync(c->d_tgt_xyz, xyz, sizeof(float) * 3 * (size_t)n,
+                          on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+    const long long groups = (n + 3) / 4;
+    const long long tiles = (groups + oa::TILE_GROUPS - 1) / oa::TILE_GROUPS;
+    c->n_groups_pad = (int)(tiles * oa::TILE_GROUPS);
+    HIPCHK(hipMalloc(&c->d_tg, sizeof(float4) * 3 * (size_t)c->n_groups_pad));
+    hipLaunchKernelGGL(oa::k_pack_target, dim3((c->n_groups_pad + 255) / 256), dim3(256), 0, c->stream, c->d_tgt_xyz,
+                       c->nt, c->n_groups_pad, c->d_tg);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    plan_geometry(c);
+    return OA_OK;
+}
+
+OA_EXPORT int oa_set_source(oa_ctx *c, const float *xyz, int64_t n_verts, int on_device, const int64_t *vlist,
+                            int64_t n_vlist, int32_t stride, int32_t shard_index, int32_t shard_count)
+{
+    if (!c) return fail(OA_E_BAD_ARG, "null context");
+    if (n_verts < 0 || (n_verts > 0 && !xyz)) return fail(OA_E_BAD_ARG, "bad source array");
+    if (vlist && n_vlist < 0) return fail(OA_E_BAD_ARG, "negative vlist length");
+    if (shard_count < 1 || shard_index < 0 || shard_index >= shard_count)
+        return fail(OA_E_BAD_ARG, "bad shard %d of %d", shard_index, shard_count);
+    const long long step = stride > 1 ? stride : 1;                 // sample > 1 -> vlist[0::sample] (general.py:274)
+    const long long n_all = vlist ? n_vlist : n_verts;
+    const long long n_sel = (n_all + step - 1) / step;
+    if (vlist)
+        for (long long i = 0; i < n_vlist; ++i)
+            if (vlist[i] < 0 || vlist[i] >= n_verts)
+                return fail(OA_E_BAD_ARG, "vlist[%lld] = %lld outside 0..%lld", i, (long long)vlist[i], (long long)n_verts - 1);
+    const long long per = (n_sel + shard_count - 1) / shard_count;
+    const long long begin = std::min(n_sel, per * shard_index);
+    const long long count = std::max(0ll, std::min(per, n_sel - begin));
+    if (count > 0x7FF00000ll) return fail(OA_E_BAD_ARG, "shard too large");
+    int rc = use_device(c);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    dev_free(c->d_src4); dev_free(c->d_keys);
+    dev_free(c->d_valid); dev_free(c->d_b); dev_free(c->d_dist); dev_free(c->d_counts); dev_free(c->d_offsets);
+    dev_free(c->d_A); dev_free(c->d_B);
+    c->emit_cap = 0;
+    c->ns = (int)count;
+    const int chunk = oa::NN_THREADS * c->R;
+    c->ns_pad = (int)(((count + chunk - 1) / chunk) * chunk);
+    if (c->ns_pad == 0) c->ns_pad = chunk;
+    HIPCHK(hipMalloc(&c->d_src4, sizeof(float4) * (size_t)c->ns_pad));
+    HIPCHK(hipMalloc(&c->d_keys, sizeof(unsigned long long) * (size_t)c->ns_pad));
+    c->pivot[0] = c->pivot[1] = c->pivot[2] = 0.0;
+    if (n_sel > 0) {
+        const float *d_xyz = xyz;
+        float *tmp_xyz = nullptr;
+        long long *d_vlist = nullptr;
+        if (!on_device) {
+            HIPCHK(hipMalloc(&tmp_xyz, sizeof(float) * 3 * (size_t)n_verts));
+            HIPCHK(hipMemcpyAsync(tmp_xyz, xyz, sizeof(float) * 3 * (size_t)n_verts, hipMemcpyHostToDevice, c->stream));
+            d_xyz = tmp_xyz;
+        }
+        if (vlist) {
+            HIPCHK(hipMalloc(&d_vlist, sizeof(long long) * (size_t)n_vlist));
+            HIPCHK(hipMemcpyAsync(d_vlist, vlist, sizeof(long long) * (size_t)n_vlist, hipMemcpyHostToDevice, c->stream));
+        }
+        // pivot = first selected vertex of the WHOLE selection (identical on every shard)
+        const long long v0 = vlist ? vlist[0] : 0;
+        float p0[3];
+        if (on_device) HIPCHK(hipMemcpyAsync(p0, xyz + 3 * v0, sizeof p0, hipMemcpyDeviceToHost, c->stream));
+        else memcpy(p0, xyz + 3 * v0, sizeof p0);
+        hipLaunchKernelGGL(oa::k_pack_source, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, d_xyz, d_vlist,
+                           step, begin, c->ns, c->ns_pad, c->d_src4);
+        hipLaunchKernelGGL(oa::k_fill_keys, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, c->d_keys, c->ns_pad);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        dev_free(tmp_xyz); dev_free(d_vlist);
+        if (e != hipSuccess) return fail(OA_E_HIP, "oa_set_source: %s", hipGetErrorString(e));
+        for (int k = 0; k < 3; ++k) c->pivot[k] = (double)p0[k];
+    } else {
+        HIPCHK(hipMemsetAsync(c->d_src4, 0, sizeof(float4) * (size_t)c->ns_pad, c->stream));
+        hipLaunchKernelGGL(oa::k_fill_keys, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, c->d_keys, c->ns_pad);
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    plan_geometry(c);
+    return OA_OK;
+}
+
+OA_EXPORT int oa_set_matrices(oa_ctx *c, const float mx_align[16], const float mx_base[16])
+{
+    if (!c || !mx_align || !mx_base) return fail(OA_E_BAD_ARG, "oa_set_matrices: null argument");
+    float i1[16], i2[16];
+    if (!oa::m4_inverted(mx_align, i1)) return fail(OA_E_SINGULAR, "align matrix_world has no inverse");
+    if (!oa::m4_inverted(mx_base, i2)) return fail(OA_E_SINGULAR, "base matrix_world has no inverse");
+    memcpy(c->h_state.mx1, mx_align, sizeof i1);
+    memcpy(c->h_state.mx2, mx_base, sizeof i1);
+    memcpy(c->h_state.imx1, i1, sizeof i1);
+    memcpy(c->h_state.imx2, i2, sizeof i2);
+    c->have_mats = true;
+    c->loop_active = false;
+    return OA_OK;
+}
+
+OA_EXPORT int oa_get_matrix_world(oa_ctx *c, float mx_align[16])
+{
+    if (!c || !mx_align) return fail(OA_E_BAD_ARG, "null argument");
+    if (!c->have_mats) return fail(OA_E_STATE, "matrices not set");
+    memcpy(mx_align, c->h_state.mx1, sizeof(float) * 16);
+    return OA_OK;
+}
+
+OA_EXPORT int64_t oa_num_selected(oa_ctx *c) { return c ? c->ns : 0; }
+
+OA_EXPORT int oa_get_pivot(oa_ctx *c, double pivot[3])
+{
+    if (!c || !pivot) return fail(OA_E_BAD_ARG, "null argument");
+    for (int k = 0; k < 3; ++k) pivot[k] = c->pivot[k];
+    return OA_OK;
+}
+
+// ================================================================================================
+// correspondence search alone
+// ================================================================================================
+namespace {
+// copies the host mirror (matrices, pivot) to the device with a neutral loop state
+int push_state_for_oneshot(oa_ctx *c, double thresh)
+{
+    oa_settings st{};
+    st.iters = 1; st.use_target = 1; st.with_scale = 0; st.early_exit = 0; st.thresh = thresh; st.target_d = 0.0;
+    init_loop_state(c, &st, 1);
+    HIPCHK(hipMemcpyAsync(c->d_state, &c->h_state, sizeof(oa::DevState), hipMemcpyHostToDevice, c->stream));
+    c->loop_active = false;
+    return OA_OK;
+}
+}  // namespace
+
+OA_EXPORT int oa_nn_search(oa_ctx *c, int64_t *idx, float *d2, double *kernel_ms)
+{
+    int rc = check_ready(c);
+    if (rc) return rc;
+    if ((rc = use_device(c))) return rc;
+    if ((rc = ensure_common(c))) return rc;
+    if ((rc = ensure_events(c, 1))) return rc;
+    if ((rc = push_state_for_oneshot(c, 1.0))) return rc;
+    if (kernel_ms) *kernel_ms = 0.0;
+    if (c->ns <= 0) return OA_OK;
+    long long *d_idx = nullptr;
+    float *d_d2 = nullptr;
+    hipError_t e = hipSuccess;
+    if (idx) e = hipMalloc(&d_idx, sizeof(long long) * (size_t)c->ns);
+    if (e == hipSuccess && d2) e = hipMalloc(&d_d2, sizeof(float) * (size_t)c->ns);
+    if (e == hipSuccess) e = hipEventRecord(c->ev[0], c->stream);
+    if (e == hipSuccess) { rc = launch_nn(c); if (rc) { dev_free(d_idx); dev_free(d_d2); return rc; } }
+    if (e == hipSuccess) e = hipEventRecord(c->ev[1], c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(oa::k_decode_keys, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, c->d_keys,
+                           c->ns_pad, c->ns, d_idx, d_d2);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && idx) e = hipMemcpyAsync(idx, d_idx, sizeof(long long) * (size_t)c->ns, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && d2) e = hipMemcpyAsync(d2, d_d2, sizeof(float) * (size_t)c->ns, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dev_free(d_idx); dev_free(d_d2);
+    if (e != hipSuccess) return fail(OA_E_HIP, "oa_nn_search: %s", hipGetErrorString(e));
+    if (kernel_ms) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+        *kernel_ms = ms;
+    }
+    return OA_OK;
+}
+
+// ================================================================================================
+// contract 1: make_pairs
+// ================================================================================================
+OA_EXPORT int oa_make_pairs(oa_ctx *c, double thresh, int calc_stats, double *A, double *B, int64_t cap, int64_t *K,
+                            double dstats[2])
+{
+    int rc = check_ready(c);
+    if (rc) return rc;
+    if (!K || cap < 0 || (cap > 0 && (!A || !B))) return fail(OA_E_BAD_ARG, "oa_make_pairs: bad output arguments");
+    if (!(thresh > 0.0)) return fail(OA_E_BAD_THRESH, "thresh must be > 0 (the reference's make_pairs returns None)");
+    if ((rc = use_device(c))) return rc;
+    if ((rc = ensure_common(c))) return rc;
+    *K = 0;
+    if (dstats) { dstats[0] = NAN; dstats[1] = NAN; }
+    if (c->ns == 0) return OA_OK;
+    const int n_blocks = (c->ns + 255) / 256;
+    if (c->emit_cap < c->ns) {
+        dev_free(c->d_valid); dev_free(c->d_b); dev_free(c->d_dist); dev_free(c->d_counts); dev_free(c->d_offsets);
+        dev_free(c->d_A); dev_free(c->d_B);
+        HIPCHK(hipMalloc(&c->d_valid, (size_t)c->ns));
+        HIPCHK(hipMalloc(&c->d_b, sizeof(float) * 3 * (size_t)c->ns));
+        HIPCHK(hipMalloc(&c->d_dist, sizeof(double) * (size_t)c->ns));
+        HIPCHK(hipMalloc(&c->d_counts, sizeof(int) * (size_t)n_blocks));
+        HIPCHK(hipMalloc(&c->d_offsets, sizeof(long long) * (size_t)(n_blocks + 1)));
+        HIPCHK(hipMalloc(&c->d_A, sizeof(double) * 3 * (size_t)c->ns));
+        HIPCHK(hipMalloc(&c->d_B, sizeof(double) * 3 * (size_t)c->ns));
+        c->emit_cap = c->ns;
+    }
+    if ((rc = push_state_for_oneshot(c, thresh))) return rc;
+    if ((rc = launch_nn(c))) return rc;
+    if ((rc = launch_accumulate(c, true, nullptr, nullptr))) return rc;
+    if ((rc = launch_reduce(c, c->d_sums))) return rc;
+    hipLaunchKernelGGL(oa::k_block_counts, dim3(n_blocks), dim3(256), 0, c->stream, c->d_valid, c->ns, c->d_counts);
+    hipLaunchKernelGGL(oa::k_scan_counts, dim3(1), dim3(1024), 0, c->stream, c->d_counts, n_blocks, c->d_offsets);
+    hipLaunchKernelGGL(oa::k_scatter_pairs, dim3(n_blocks), dim3(256), 0, c->stream, c->d_valid, c->ns, c->d_src4,
+                       c->d_b, c->d_offsets, (long long)c->ns, c->d_A, c->d_B);
+    HIPCHK(hipGetLastError());
+    double sums[oa::NSUMS];
+    long long total = 0;
+    HIPCHK(hipMemcpyAsync(sums, c->d_sums, sizeof sums, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(&total, c->d_offsets + n_blocks, sizeof total, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (total > cap) return fail(OA_E_CAPACITY, "oa_make_pairs: %lld pairs but capacity %lld", total, (long long)cap);
+    for (int a = 0; a < 3 && total > 0; ++a) {
+        HIPCHK(hipMemcpyAsync(A + (size_t)a * cap, c->d_A + (size_t)a * c->ns, sizeof(double) * (size_t)total, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(B + (size_t)a * cap, c->d_B + (size_t)a * c->ns, sizeof(double) * (size_t)total, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *K = total;
+    if (calc_stats && dstats && total > 0) {
+        const double kk = sums[oa::S_K];
+        const double mean = sums[oa::S_D] / kk;
+        double var = sums[oa::S_DD] / kk - mean * mean;
+        if (var < 0.0) var = 0.0;
+        dstats[0] = mean;                                           // np.mean(dists)  (general.py:324)
+        dstats[1] = sqrt(var);                                      // np.std(dists)   (general.py:325)
+    }
+    return OA_OK;
+}
+
+// ================================================================================================
+// contract 2: affine_matrix_from_points (shear=False, usesvd=True)
+// ================================================================================================
+namespace {
+int solve_on_device(oa_ctx *c, const double *d_sums, const double pv[3], int with_scale, double M[16])
+{
+    hipLaunchKernelGGL(oa::k_solve_only, dim3(1), dim3(64), 0, c->stream, d_sums, pv[0], pv[1], pv[2], with_scale, c->d_solve);
+    HIPCHK(hipGetLastError());
+    double out[17];
+    HIPCHK(hipMemcpyAsync(out, c->d_solve, sizeof out, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (out[16] != 1.0) return fail(OA_E_TOO_FEW_PAIRS, "input arrays are of wrong shape or type");
+    memcpy(M, out, sizeof(double) * 16);
+    return OA_OK;
+}
+}  // namespace
+
+OA_EXPORT int oa_kabsch(oa_ctx *c, const double *A, const double *B, int64_t K, int64_t ld, int with_scale, double M[16])
+{
+    if (!c || !M) return fail(OA_E_BAD_ARG, "oa_kabsch: null argument");
+    if (K < 3) return fail(OA_E_TOO_FEW_PAIRS, "input arrays are of wrong shape or type");   // general.py:150-157
+    if (!A || !B || ld < K) return fail(OA_E_BAD_ARG, "oa_kabsch: bad arrays");
+    int rc = use_device(c);
+    if (rc) return rc;
+    if ((rc = ensure_common(c))) return rc;
+    double *dA = nullptr, *dB = nullptr;
+    HIPCHK(hipMalloc(&dA, sizeof(double) * 3 * (size_t)K));
+    hipError_t e = hipMalloc(&dB, sizeof(double) * 3 * (size_t)K);
+    if (e != hipSuccess) { dev_free(dA); return fail(OA_E_HIP, "oa_kabsch: %s", hipGetErrorString(e)); }
+    for (int a = 0; a < 3 && e == hipSuccess; ++a) {
+        e = hipMemcpyAsync(dA + (size_t)a * K, A + (size_t)a * ld, sizeof(double) * (size_t)K, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(dB + (size_t)a * K, B + (size_t)a * ld, sizeof(double) * (size_t)K, hipMemcpyHostToDevice, c->stream);
+    }
+    const double pv[3] = { A[0], A[ld], A[2 * ld] };
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(oa::ACC_MAX_BLOCKS, (K + oa::ACC_THREADS - 1) / oa::ACC_THREADS));
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(oa::k_accumulate_pairs, dim3(blocks), dim3(oa::ACC_THREADS), 0, c->stream, dA, dB,
+                           (long long)K, (long long)K, pv[0], pv[1], pv[2], c->d_partials);
+        hipLaunchKernelGGL(oa::k_reduce_partials, dim3(1), dim3(256), 0, c->stream, c->d_partials, blocks, c->d_sums);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) rc = solve_on_device(c, c->d_sums, pv, with_scale, M);
+    else rc = fail(OA_E_HIP, "oa_kabsch: %s", hipGetErrorString(e));
+    (void)hipStreamSynchronize(c->stream);
+    dev_free(dA); dev_free(dB);
+    return rc;
+}
+
+OA_EXPORT int oa_kabsch_from_sums(oa_ctx *c, const double sums[OA_NSUMS], const double pivot[3], int with_scale,
+                                  double M[16])
+{
+    if (!c || !sums || !M) return fail(OA_E_BAD_ARG, "oa_kabsch_from_sums: null argument");
+    int rc = use_device(c);
+    if (rc) return rc;
+    if ((rc = ensure_common(c))) return rc;
+    const double zero[3] = { 0, 0, 0 };
+    HIPCHK(hipMemcpyAsync(c->d_sums, sums, sizeof(double) * oa::NSUMS, hipMemcpyHostToDevice, c->stream));
+    return solve_on_device(c, c->d_sums, pivot ? pivot : zero, with_scale, M);
+}
+
+// ================================================================================================
+// the loop
+// ================================================================================================
+OA_EXPORT int oa_run_begin(oa_ctx *c, const oa_settings *st)
+{
+    if (!c || !st) return fail(OA_E_BAD_ARG, "oa_run_begin: null argument");
+    int rc = begin_loop(c, st, st->iters);
+    if (rc) return rc;
+    if ((rc = ensure_events(c, std::max(1, st->iters)))) return rc;
+    HIPCHK(hipEventRecord(c->ev_loop0, c->stream));
+    return OA_OK;
+}
+
+OA_EXPORT int oa_iter_partial(oa_ctx *c, double *d_sums)
+{
+    if (!c || !d_sums) return fail(OA_E_BAD_ARG, "oa_iter_partial: null argument");
+    if (!c->loop_active) return fail(OA_E_STATE, "oa_iter_partial outside oa_run_begin/oa_run_end");
+    int rc = use_device(c);
+    if (rc) return rc;
+    return iter_partial(c, d_sums, true);
+}
+
+OA_EXPORT int oa_iter_finish(oa_ctx *c, const double *d_sums)
+{
+    if (!c || !d_sums) return fail(OA_E_BAD_ARG, "oa_iter_finish: null argument");
+    if (!c->loop_active) return fail(OA_E_STATE, "oa_iter_finish outside oa_run_begin/oa_run_end");
+    int rc = use_device(c);
+    if (rc) return rc;
+    return iter_finish(c, d_sums);
+}
+
+OA_EXPORT int oa_run_end(oa_ctx *c, oa_report *rep)
+{
+    if (!c || !rep) return fail(OA_E_BAD_ARG, "oa_run_end: null argument");
+    int rc = use_device(c);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(c->ev_loop1, c->stream));
+    if ((rc = fill_report(c, rep))) return rc;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->ev_loop0, c->ev_loop1) == hipSuccess) rep->loop_ms = ms;
+    c->loop_active = false;
+    if (rep->status == OA_E_TOO_FEW_PAIRS) return fail(OA_E_TOO_FEW_PAIRS, "input arrays are of wrong shape or type");
+    if (rep->status == OA_E_SINGULAR) return fail(OA_E_SINGULAR, "align matrix_world became singular");
+    return OA_OK;
+}
+
+OA_EXPORT int oa_run(oa_ctx *c, const oa_settings *st, oa_report *rep)
+{
+    if (!c || !st || !rep) return fail(OA_E_BAD_ARG, "oa_run: null argument");
+    int rc = oa_run_begin(c, st);
+    if (rc) return rc;
+    for (int it = 0; it < st->iters; ++it) {
+        if ((rc = iter_partial(c, c->d_sums, true))) return rc;
+        if ((rc = iter_finish(c, c->d_sums))) return rc;
+    }
+    return oa_run_end(c, rep);
+}
+
+OA_EXPORT int oa_iterate(oa_ctx *c, const oa_settings *st, double M_step[16], double stats[6])
+{
+    if (!c || !st) return fail(OA_E_BAD_ARG, "oa_iterate: null argument");
+    int rc;
+    if (!c->loop_active) {
+        if ((rc = begin_loop(c, st, 0x7FFFFFFF))) return rc;
+    }
+    if ((rc = use_device(c))) return rc;
+    c->ev_used = 0;
+    if ((rc = iter_partial(c, c->d_sums, false))) return rc;
+    if ((rc = iter_finish(c, c->d_sums))) return rc;
+    if ((rc = fetch_state(c))) return rc;
+    const oa::DevState &s = c->h_state;
+    if (s.status == OA_E_TOO_FEW_PAIRS) { c->loop_active = false; return fail(OA_E_TOO_FEW_PAIRS, "input arrays are of wrong shape or type"); }
+    if (s.status == OA_E_SINGULAR) { c->loop_active = false; return fail(OA_E_SINGULAR, "align matrix_world became singular"); }
+    if (s.n <= 0) return fail(OA_E_STATE, "oa_iterate: loop already halted");
+    oa::StepRecord r;
+    HIPCHK(hipMemcpy(&r, c->d_hist + ((s.n - 1) % c->max_records), sizeof r, hipMemcpyDeviceToHost));
+    if (M_step) memcpy(M_step, r.M, sizeof r.M);
+    if (stats) {
+        stats[0] = r.K; stats[1] = s.use_target ? r.mean_d : NAN; stats[2] = s.use_target ? r.std_d : NAN;
+        stats[3] = r.trans; stats[4] = r.angle; stats[5] = (double)s.converged;
+    }
+    return OA_OK;
+}
+
+OA_EXPORT int oa_get_history(oa_ctx *c, int32_t max_n, double *step_M, float *step_new, int64_t *step_K,
+                             double *step_stats, double *step_trans)
+{
+    if (!c) return fail(OA_E_BAD_ARG, "null context");
+    if (use_device(c)) return OA_E_HIP;
+    const int n = std::min(std::min(c->h_state.n, c->max_records), (int)max_n);
+    if (n <= 0) return 0;
+    std::vector<oa::StepRecord> h((size_t)n);
+    if (hipMemcpy(h.data(), c->d_hist, sizeof(oa::StepRecord) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess)
+        return fail(OA_E_HIP, "oa_get_history: copy failed");
+    for (int i = 0; i < n; ++i) {
+        if (step_M) memcpy(step_M + 16 * i, h[i].M, sizeof h[i].M);
+        if (step_new) memcpy(step_new + 16 * i, h[i].new_mat, sizeof h[i].new_mat);
+        if (step_K) step_K[i] = (int64_t)h[i].K;
+        if (step_stats) { step_stats[2 * i] = h[i].mean_d; step_stats[2 * i + 1] = h[i].std_d; }
+        if (step_trans) step_trans[i] = h[i].trans;
+    }
+    return n;
+}

@@ -1,0 +1,641 @@
+// oa_kernels.hpp -- gfx950 (CDNA4, wave64) device code of the ICP hot path.
+//
+// Kernels (one ICP iteration = k_nn_search -> k_pair_accumulate -> k_reduce_partials -> [all-reduce] -> k_solve_update):
+//   k_nn_search        brute-force nearest target vertex per source point; target tiles staged through LDS and
+//                      read back as wave-uniform (broadcast) ds_read_b128; fp32 VALU bound
+//   k_pair_accumulate  world-space threshold test + fp64 sums (functions/general.py:299-306 fused with the
+//                      reductions affine_matrix_from_points needs, :160-167,:181,:208-212)
+//   k_reduce_partials  fixed-order reduction of the per-workgroup partials (bitwise reproducible, no float atomics)
+//   k_solve_update     3x3 Kabsch/SVD solve, matrix_world update, convergence ring (operators/icp_align.py:106-149)
+//
+// Arithmetic conventions are spelled out in DESIGN.md ("float32 semantics") and are shared bit-for-bit with the
+// CPU oracle.  This translation unit is compiled with -ffp-contract=off: every fma below is written explicitly.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+namespace oa {
+
+constexpr int NSUMS = 24;
+// layout of the per-iteration sums (all relative to `pivot`, a' = a - pivot, b' = b - pivot):
+//   [0..2] sum a'   [3..5] sum b'   [6..14] sum b'_i a'_j (row i, col j)   [15] sum |a'|^2   [16] sum |b'|^2
+//   [17] K          [18] sum d      [19] sum d^2        [20..23] reserved (0)
+constexpr int S_A = 0, S_B = 3, S_H = 6, S_AA = 15, S_BB = 16, S_K = 17, S_D = 18, S_DD = 19;
+
+constexpr unsigned long long KEY_EMPTY = ~0ull;
+constexpr uint32_t IDX_NONE = 0xFFFFFFFFu;
+
+constexpr int NN_THREADS = 256;
+constexpr int TILE_GROUPS = 256;          // groups of 4 targets per LDS tile (1024 targets, 12 KiB)
+constexpr int ACC_THREADS = 256;
+constexpr int ACC_MAX_BLOCKS = 512;
+
+struct StepRecord {
+    double M[16];
+    float  new_mat[16];
+    double K, mean_d, std_d, trans, angle, pad;
+};
+
+struct DevState {
+    float  mx1[16], mx2[16], imx1[16], imx2[16];   // align / base matrix_world and inverses (float32, row-major)
+    double pivot[3];
+    double thresh, target_d;
+    double ring_t[5], ring_r[5];
+    int32_t iters, use_target, with_scale, early_exit;
+    int32_t n, converged, status, halt;
+    int32_t max_records, pad0;
+};
+
+// ------------------------------------------------------------------------------------------------
+// float32 "mathutils" arithmetic (host + device, identical bits)
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ inline void m4_mul_v3(const float *M, float x, float y, float z, float &ox, float &oy, float &oz)
+{
+    // per row: double accumulation of float products, w = 1  (mathutils column_vector_multiplication)
+    float r[3];
+    for (int row = 0; row < 3; ++row) {
+        const float *m = M + 4 * row;
+        float p0 = m[0] * x, p1 = m[1] * y, p2 = m[2] * z, p3 = m[3] * 1.0f;
+        double acc = 0.0;
+        acc += (double)p0; acc += (double)p1; acc += (double)p2; acc += (double)p3;
+        r[row] = (float)acc;
+    }
+    ox = r[0]; oy = r[1]; oz = r[2];
+}
+
+__host__ __device__ inline void m4_mul_m4(const float *A, const float *B, float *out)
+{
+    float r[16];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            double acc = 0.0;
+            for (int k = 0; k < 4; ++k) { float p = A[4 * i + k] * B[4 * k + j]; acc += (double)p; }
+            r[4 * i + j] = (float)acc;
+        }
+    for (int i = 0; i < 16; ++i) out[i] = r[i];
+}
+
+__host__ __device__ inline double v3_length(float x, float y, float z)
+{
+    double acc = 0.0;
+    float pz = z * z, py = y * y, px = x * x;
+    acc += (double)pz; acc += (double)py; acc += (double)px;   // last component first (mathutils dot_vn_vn)
+    return sqrt(acc);
+}
+
+// adjugate / determinant in double, fixed operation order, rounded to float32.  false if singular.
+__host__ __device__ inline bool m4_inverted(const float *Af, float *out)
+{
+    double a[16];
+    for (int i = 0; i < 16; ++i) a[i] = (double)Af[i];
+    const double s0 = a[0] * a[5] - a[4] * a[1], s1 = a[0] * a[6] - a[4] * a[2], s2 = a[0] * a[7] - a[4] * a[3];
+    const double s3 = a[1] * a[6] - a[5] * a[2], s4 = a[1] * a[7] - a[5] * a[3], s5 = a[2] * a[7] - a[6] * a[3];
+    const double c5 = a[10] * a[15] - a[14] * a[11], c4 = a[9] * a[15] - a[13] * a[11], c3 = a[9] * a[14] - a[13] * a[10];
+    const double c2 = a[8] * a[15] - a[12] * a[11], c1 = a[8] * a[14] - a[12] * a[10], c0 = a[8] * a[13] - a[12] * a[9];
+    const double det = ((((s0 * c5 - s1 * c4) + s2 * c3) + s3 * c2) - s4 * c1) + s5 * c0;
+    if (det == 0.0) return false;
+    double b[16];
+    b[0]  = (( a[5] * c5 - a[6] * c4) + a[7] * c3) / det;
+    b[1]  = ((-a[1] * c5 + a[2] * c4) - a[3] * c3) / det;
+    b[2]  = (( a[13] * s5 - a[14] * s4) + a[15] * s3) / det;
+    b[3]  = ((-a[9] * s5 + a[10] * s4) - a[11] * s3) / det;
+    b[4]  = ((-a[4] * c5 + a[6] * c2) - a[7] * c1) / det;
+    b[5]  = (( a[0] * c5 - a[2] * c2) + a[3] * c1) / det;
+    b[6]  = ((-a[12] * s5 + a[14] * s2) - a[15] * s1) / det;
+    b[7]  = (( a[8] * s5 - a[10] * s2) + a[11] * s1) / det;
+    b[8]  = (( a[4] * c4 - a[5] * c2) + a[7] * c0) / det;
+    b[9]  = ((-a[0] * c4 + a[1] * c2) - a[3] * c0) / det;
+    b[10] = (( a[12] * s4 - a[13] * s2) + a[15] * s0) / det;
+    b[11] = ((-a[8] * s4 + a[9] * s2) - a[11] * s0) / det;
+    b[12] = ((-a[4] * c3 + a[5] * c1) - a[6] * c0) / det;
+    b[13] = (( a[0] * c3 - a[1] * c1) + a[2] * c0) / det;
+    b[14] = ((-a[12] * s3 + a[13] * s1) - a[14] * s0) / det;
+    b[15] = (( a[8] * s3 - a[9] * s1) + a[10] * s0) / det;
+    for (int i = 0; i < 16; ++i) out[i] = (float)b[i];
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3x3 rotation from the covariance H = sum b a^T (Kabsch; functions/general.py:181-187).
+// One-sided Jacobi gives H V = U S; the reflection-corrected rotation U diag(1,1,det(UV^T)) V^T equals
+// [u1 u2 u1xu2][v1 v2 v1xv2]^T, so only the two leading singular triplets are needed (rank >= 2).
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ inline void rotation_from_covariance(const double H[9], double R[9])
+{
+    double g[3][3], v[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) { g[i][j] = H[3 * i + j]; v[i][j] = (i == j) ? 1.0 : 0.0; }
+    for (int sweep = 0; sweep < 64; ++sweep) {
+        bool any = false;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                const double npp = g[0][p] * g[0][p] + g[1][p] * g[1][p] + g[2][p] * g[2][p];
+                const double nqq = g[0][q] * g[0][q] + g[1][q] * g[1][q] + g[2][q] * g[2][q];
+                const double dpq = g[0][p] * g[0][q] + g[1][p] * g[1][q] + g[2][p] * g[2][q];
+                if (dpq == 0.0 || fabs(dpq) <= 1e-17 * sqrt(npp * nqq)) continue;
+                any = true;
+                const double zeta = (nqq - npp) / (2.0 * dpq);
+                const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+                for (int r = 0; r < 3; ++r) {
+                    const double gp = g[r][p], gq = g[r][q], vp = v[r][p], vq = v[r][q];
+                    g[r][p] = c * gp - s * gq; g[r][q] = s * gp + c * gq;
+                    v[r][p] = c * vp - s * vq; v[r][q] = s * vp + c * vq;
+                }
+            }
+        if (!any) break;
+    }
+    double sg[3];
+    for (int j = 0; j < 3; ++j) sg[j] = sqrt(g[0][j] * g[0][j] + g[1][j] * g[1][j] + g[2][j] * g[2][j]);
+    int j1 = 0;
+    if (sg[1] > sg[j1]) j1 = 1;
+    if (sg[2] > sg[j1]) j1 = 2;
+    int j2 = (j1 == 0) ? 1 : 0;
+    for (int j = 0; j < 3; ++j) if (j != j1 && sg[j] > sg[j2]) j2 = j;
+    double u1[3], u2[3], v1[3], v2[3];
+    for (int r = 0; r < 3; ++r) {
+        v1[r] = v[r][j1]; v2[r] = v[r][j2];
+        u1[r] = (sg[j1] > 0.0) ? g[r][j1] / sg[j1] : (r == 0 ? 1.0 : 0.0);
+        u2[r] = (sg[j2] > 0.0) ? g[r][j2] / sg[j2] : 0.0;
+    }
+    if (!(sg[j2] > 0.0)) {   // rank <= 1: the rotation is not unique; complete u2 deterministically
+        int m = 0;
+        if (fabs(u1[1]) < fabs(u1[m])) m = 1;
+        if (fabs(u1[2]) < fabs(u1[m])) m = 2;
+        double e[3] = { 0.0, 0.0, 0.0 };
+        e[m] = 1.0;
+        const double d = e[0] * u1[0] + e[1] * u1[1] + e[2] * u1[2];
+        double nn = 0.0;
+        for (int r = 0; r < 3; ++r) { u2[r] = e[r] - d * u1[r]; nn += u2[r] * u2[r]; }
+        nn = sqrt(nn);
+        for (int r = 0; r < 3; ++r) u2[r] /= nn;
+    }
+    const double u3[3] = { u1[1] * u2[2] - u1[2] * u2[1], u1[2] * u2[0] - u1[0] * u2[2], u1[0] * u2[1] - u1[1] * u2[0] };
+    const double v3[3] = { v1[1] * v2[2] - v1[2] * v2[1], v1[2] * v2[0] - v1[0] * v2[2], v1[0] * v2[1] - v1[1] * v2[0] };
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) R[3 * i + j] = u1[i] * v1[j] + u2[i] * v2[j] + u3[i] * v3[j];
+}
+
+// Solve from the accumulated sums.  Returns false when K < 3 (the reference's ValueError).
+__host__ __device__ inline bool solve_from_sums(const double *s, const double pivot[3], bool with_scale, double M[16])
+{
+    const double K = s[S_K];
+    if (!(K >= 3.0)) return false;
+    double ca[3], cb[3];
+    for (int i = 0; i < 3; ++i) { ca[i] = s[S_A + i] / K; cb[i] = s[S_B + i] / K; }     // centroids (:160,:164)
+    double H[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) H[3 * i + j] = s[S_H + 3 * i + j] - K * cb[i] * ca[j];  // dot(v1c, v0c.T) (:181)
+    double R[9];
+    rotation_from_covariance(H, R);
+    double sc = 1.0;
+    if (with_scale) {                                                                    // :208-212
+        const double n0 = s[S_AA] - K * (ca[0] * ca[0] + ca[1] * ca[1] + ca[2] * ca[2]);
+        const double n1 = s[S_BB] - K * (cb[0] * cb[0] + cb[1] * cb[1] + cb[2] * cb[2]);
+        sc = sqrt(n1 / n0);
+    }
+    // back to un-pivoted coordinates: c0 = ca + pivot, c1 = cb + pivot;  t = c1 - sR c0   (:215)
+    for (int i = 0; i < 3; ++i) {
+        double t = cb[i] + pivot[i];
+        for (int j = 0; j < 3; ++j) {
+            M[4 * i + j] = sc * R[3 * i + j];
+            t -= sc * R[3 * i + j] * (ca[j] + pivot[j]);
+        }
+        M[4 * i + 3] = t;
+    }
+    M[12] = 0.0; M[13] = 0.0; M[14] = 0.0; M[15] = 1.0;
+    return true;
+}
+
+__host__ __device__ inline double rotation_angle_3x3(const double M[16])
+{
+    // |angle| of the rotation part (columns normalised first, so uniform scale does not matter)
+    double c[3];
+    for (int j = 0; j < 3; ++j) c[j] = sqrt(M[j] * M[j] + M[4 + j] * M[4 + j] + M[8 + j] * M[8 + j]);
+    double tr = 0.0;
+    for (int j = 0; j < 3; ++j) tr += (c[j] > 0.0) ? M[4 * j + j] / c[j] : 1.0;
+    double x = (tr - 1.0) * 0.5;
+    x = x > 1.0 ? 1.0 : (x < -1.0 ? -1.0 : x);
+    return acos(x);
+}
+
+#if defined(__HIPCC__)
+
+// ------------------------------------------------------------------------------------------------
+// packing kernels (one-time)
+// ------------------------------------------------------------------------------------------------
+// source: gather xyz[vlist[(begin + i) * stride]] -> float4; the tail up to ns_pad repeats the last point
+__global__ void k_pack_source(const float *__restrict__ xyz, const long long *__restrict__ vlist, long long stride,
+                              long long begin, int ns, int ns_pad, float4 *__restrict__ src4)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ns_pad) return;
+    const long long s = begin + (long long)(i < ns ? i : (ns > 0 ? ns - 1 : 0));
+    const long long v = vlist ? vlist[s * stride] : s * stride;
+    float4 p;
+    p.x = xyz[3 * v]; p.y = xyz[3 * v + 1]; p.z = xyz[3 * v + 2]; p.w = 0.f;
+    src4[i] = p;
+}
+
+// target: groups of 4 vertices as [x0..x3][y0..y3][z0..z3]; vertices past nt are +INF (never selected)
+__global__ void k_pack_target(const float *__restrict__ xyz, int nt, int n_groups_pad, float4 *__restrict__ tg)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_groups_pad) return;
+    float c[3][4];
+    for (int k = 0; k < 4; ++k) {
+        const long long v = 4ll * g + k;
+        for (int a = 0; a < 3; ++a) c[a][k] = (v < nt) ? xyz[3 * v + a] : INFINITY;
+    }
+    for (int a = 0; a < 3; ++a) tg[3 * (long long)g + a] = make_float4(c[a][0], c[a][1], c[a][2], c[a][3]);
+}
+
+__global__ void k_fill_keys(unsigned long long *keys, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keys[i] = KEY_EMPTY;
+}
+
+// (d2, idx) keys -> separate arrays (first n_out entries); resets all n keys for the next search
+__global__ void k_decode_keys(unsigned long long *__restrict__ keys, int n, int n_out, long long *__restrict__ idx,
+                              float *__restrict__ d2)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long key = keys[i];
+    keys[i] = KEY_EMPTY;
+    if (i >= n_out) return;
+    const uint32_t j = (uint32_t)key;
+    if (idx) idx[i] = (j == IDX_NONE) ? -1ll : (long long)j;
+    if (d2) d2[i] = __uint_as_float((uint32_t)(key >> 32));
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_nn_search
+// ------------------------------------------------------------------------------------------------
+// grid = (ns_pad / (256*R), n_splits).  Each thread owns R source points (registers); the workgroup streams its
+// split of the target through a double-buffered LDS tile.  All 64 lanes of a wave read the SAME LDS address
+// (broadcast, conflict-free), so one ds_read_b128 feeds 4 targets x R points x 64 lanes = 256 R pair evaluations.
+//
+// Per group of 4 targets and per point: 4 x (3 sub, 1 mul, 2 fma) + 2 min3 + 1 compare = 27 VALU ops; the index
+// is only resolved inside the (rare, exec-masked) `improved` branch.  Strict `<` against the running best and a
+// lowest-k scan inside the group give "lowest index wins ties" exactly as the oracle's linear scan does.
+__device__ __forceinline__ float d2_metric(float px, float py, float pz, float qx, float qy, float qz)
+{
+    const float dx = qx - px, dy = qy - py, dz = qz - pz;
+    float t = dx * dx;
+    t = __builtin_fmaf(dy, dy, t);
+    t = __builtin_fmaf(dz, dz, t);
+    return t;
+}
+
+template <int R>
+__global__ __launch_bounds__(NN_THREADS) void k_nn_search(const DevState *__restrict__ st,
+                                                          const float4 *__restrict__ src4,
+                                                          const float4 *__restrict__ tg, int groups_per_split,
+                                                          int n_groups_pad, unsigned long long *__restrict__ keys)
+{
+    if (st->halt) return;
+    __shared__ float4 tile[2][TILE_GROUPS * 3];
+    const int tid = threadIdx.x;
+    const int base = blockIdx.x * (NN_THREADS * R);
+
+    float px[R], py[R], pz[R], best[R];
+    uint32_t bidx[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const float4 p = src4[base + r * NN_THREADS + tid];
+        float wx, wy, wz;
+        m4_mul_v3(st->mx1, p.x, p.y, p.z, wx, wy, wz);           // mx1 @ vert.co          (general.py:287)
+        m4_mul_v3(st->imx2, wx, wy, wz, px[r], py[r], pz[r]);    // imx2 @ (...) = co_find (general.py:287)
+        best[r] = INFINITY;
+        bidx[r] = IDX_NONE;
+    }
+
+    const int g_begin = blockIdx.y * groups_per_split;
+    int g_end = g_begin + groups_per_split;
+    if (g_end > n_groups_pad) g_end = n_groups_pad;
+    const int n_tiles = (g_end - g_begin) / TILE_GROUPS;           // splits are whole tiles by construction
+    const float4 *tsrc = tg + 3ll * g_begin;
+
+    // prologue: tile 0
+    float4 s0 = tsrc[tid], s1 = tsrc[NN_THREADS + tid], s2 = tsrc[2 * NN_THREADS + tid];
+    tile[0][tid] = s0; tile[0][NN_THREADS + tid] = s1; tile[0][2 * NN_THREADS + tid] = s2;
+    __syncthreads();
+
+    for (int t = 0; t < n_tiles; ++t) {
+        const int cur = t & 1;
+        const bool more = (t + 1 < n_tiles);
+        if (more) {                                               // next tile: global -> registers, hidden under compute
+            const float4 *nsrc = tsrc + 3ll * TILE_GROUPS * (t + 1);
+            s0 = nsrc[tid]; s1 = nsrc[NN_THREADS + tid]; s2 = nsrc[2 * NN_THREADS + tid];
+        }
+        const uint32_t jbase = (uint32_t)(g_begin + t * TILE_GROUPS) * 4u;
+#pragma unroll 2
+        for (int g = 0; g < TILE_GROUPS; ++g) {
+            const float4 X = tile[cur][3 * g], Y = tile[cur][3 * g + 1], Z = tile[cur][3 * g + 2];
+            const uint32_t j = jbase + 4u * (uint32_t)g;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float d0 = d2_metric(px[r], py[r], pz[r], X.x, Y.x, Z.x);
+                const float d1 = d2_metric(px[r], py[r], pz[r], X.y, Y.y, Z.y);
+                const float d2 = d2_metric(px[r], py[r], pz[r], X.z, Y.z, Z.z);
+                const float d3 = d2_metric(px[r], py[r], pz[r], X.w, Y.w, Z.w);
+                const float m = __builtin_fminf(__builtin_fminf(d0, d1), d2);
+                const float nb = __builtin_fminf(__builtin_fminf(m, d3), best[r]);
+                if (nb < best[r]) {                                // rare after the first tiles
+                    const uint32_t k = (d0 == nb) ? 0u : (d1 == nb) ? 1u : (d2 == nb) ? 2u : 3u;
+                    bidx[r] = j + k;
+                    best[r] = nb;
+                }
+            }
+        }
+        if (more) {
+            tile[cur ^ 1][tid] = s0; tile[cur ^ 1][NN_THREADS + tid] = s1; tile[cur ^ 1][2 * NN_THREADS + tid] = s2;
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const unsigned long long key = ((unsigned long long)__float_as_uint(best[r]) << 32) | bidx[r];
+        unsigned long long *dst = keys + base + r * NN_THREADS + tid;
+        if (gridDim.y == 1) *dst = key;
+        else atomicMin(dst, key);                                  // (d2, idx) lexicographic: lowest index on ties
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_pair_accumulate
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+struct PairOut {            // optional per-point outputs for the make_pairs contract
+    unsigned char *valid;   // ns
+    float  *b;              // ns x 3  (imx1 @ (mx2 @ co1))
+    double *dist;           // ns
+    int    *nn_idx;         // ns
+    float  *nn_d2;          // ns
+};
+
+template <bool EMIT>
+__global__ __launch_bounds__(ACC_THREADS) void k_pair_accumulate(const DevState *__restrict__ st,
+                                                                 const float4 *__restrict__ src4, int ns,
+                                                                 const float *__restrict__ tgt_xyz,
+                                                                 unsigned long long *__restrict__ keys,
+                                                                 double *__restrict__ partials, PairOut out)
+{
+    __shared__ double red[ACC_THREADS / 64][NSUMS];
+    double acc[NSUMS];
+#pragma unroll
+    for (int k = 0; k < NSUMS; ++k) acc[k] = 0.0;
+    const bool halted = st->halt != 0;
+    const double thresh = st->thresh;
+    const double pvx = st->pivot[0], pvy = st->pivot[1], pvz = st->pivot[2];
+
+    if (!halted) {
+        for (int i = blockIdx.x * ACC_THREADS + threadIdx.x; i < ns; i += gridDim.x * ACC_THREADS) {
+            const unsigned long long key = keys[i];
+            keys[i] = KEY_EMPTY;                                   // ready for the next iteration's atomicMin
+            const uint32_t idx = (uint32_t)key;
+            bool valid = false;
+            float bx = 0.f, by = 0.f, bz = 0.f;
+            double dist = 0.0;
+            const float4 p = src4[i];
+            if (idx != IDX_NONE) {
+                float wx, wy, wz, cx, cy, cz;
+                m4_mul_v3(st->mx1, p.x, p.y, p.z, wx, wy, wz);
+                m4_mul_v3(st->imx2, wx, wy, wz, cx, cy, cz);       // co_find                   (general.py:287)
+                const float qx = tgt_xyz[3ll * idx], qy = tgt_xyz[3ll * idx + 1], qz = tgt_xyz[3ll * idx + 2];
+                float ax, ay, az, wbx, wby, wbz;
+                m4_mul_v3(st->mx2, cx, cy, cz, ax, ay, az);         // mx2 @ co_find             (general.py:299)
+                m4_mul_v3(st->mx2, qx, qy, qz, wbx, wby, wbz);      // mx2 @ co1                 (general.py:299)
+                dist = v3_length(ax - wbx, ay - wby, az - wbz);
+                valid = dist < thresh;                             // face_index != -1 always holds (general.py:302)
+                if (valid) m4_mul_v3(st->imx1, wbx, wby, wbz, bx, by, bz);   // imx1 @ (mx2 @ co1)  (general.py:304)
+            }
+            if (EMIT) {
+                out.valid[i] = valid ? 1 : 0;
+                out.b[3ll * i] = bx; out.b[3ll * i + 1] = by; out.b[3ll * i + 2] = bz;
+                out.dist[i] = dist;
+                if (out.nn_idx) { out.nn_idx[i] = (int)idx; out.nn_d2[i] = __uint_as_float((uint32_t)(key >> 32)); }
+            }
+            if (valid) {
+                const double a0 = (double)p.x - pvx, a1 = (double)p.y - pvy, a2 = (double)p.z - pvz;
+                const double b0 = (double)bx - pvx, b1 = (double)by - pvy, b2 = (double)bz - pvz;
+                acc[S_A] += a0; acc[S_A + 1] += a1; acc[S_A + 2] += a2;
+                acc[S_B] += b0; acc[S_B + 1] += b1; acc[S_B + 2] += b2;
+                acc[S_H + 0] += b0 * a0; acc[S_H + 1] += b0 * a1; acc[S_H + 2] += b0 * a2;
+                acc[S_H + 3] += b1 * a0; acc[S_H + 4] += b1 * a1; acc[S_H + 5] += b1 * a2;
+                acc[S_H + 6] += b2 * a0; acc[S_H + 7] += b2 * a1; acc[S_H + 8] += b2 * a2;
+                acc[S_AA] += (a0 * a0 + a1 * a1) + a2 * a2;
+                acc[S_BB] += (b0 * b0 + b1 * b1) + b2 * b2;
+                acc[S_K] += 1.0;
+                acc[S_D] += dist;
+                acc[S_DD] += dist * dist;
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NSUMS; ++k) {
+        const double v = wave_sum(acc[k]);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NSUMS) {
+        double v = red[0][threadIdx.x];
+        for (int w = 1; w < ACC_THREADS / 64; ++w) v += red[w][threadIdx.x];
+        partials[(long long)blockIdx.x * NSUMS + threadIdx.x] = v;
+    }
+}
+
+// fixed-order reduction of the per-block partials: 8 interleaved slices, then slice 0..7 in order
+__global__ __launch_bounds__(256) void k_reduce_partials(const double *__restrict__ partials, int n_blocks,
+                                                         double *__restrict__ sums)
+{
+    __shared__ double red[8][32];
+    const int j = threadIdx.x & 31, s = threadIdx.x >> 5;
+    double v = 0.0;
+    if (j < NSUMS)
+        for (int b = s; b < n_blocks; b += 8) v += partials[(long long)b * NSUMS + j];
+    red[s][j] = v;
+    __syncthreads();
+    if (threadIdx.x < NSUMS) {
+        double t = red[0][threadIdx.x];
+        for (int k = 1; k < 8; ++k) t += red[k][threadIdx.x];
+        sums[threadIdx.x] = t;
+    }
+}
+
+// sums over explicit pairs (contract 2: oa_kabsch).  A, B: 3 x K row-major with leading dimension ld.
+__global__ __launch_bounds__(ACC_THREADS) void k_accumulate_pairs(const double *__restrict__ A,
+                                                                  const double *__restrict__ B, long long K,
+                                                                  long long ld, double pvx, double pvy, double pvz,
+                                                                  double *__restrict__ partials)
+{
+    __shared__ double red[ACC_THREADS / 64][NSUMS];
+    double acc[NSUMS];
+#pragma unroll
+    for (int k = 0; k < NSUMS; ++k) acc[k] = 0.0;
+    for (long long i = (long long)blockIdx.x * ACC_THREADS + threadIdx.x; i < K; i += (long long)gridDim.x * ACC_THREADS) {
+        const double a0 = A[i] - pvx, a1 = A[ld + i] - pvy, a2 = A[2 * ld + i] - pvz;
+        const double b0 = B[i] - pvx, b1 = B[ld + i] - pvy, b2 = B[2 * ld + i] - pvz;
+        acc[S_A] += a0; acc[S_A + 1] += a1; acc[S_A + 2] += a2;
+        acc[S_B] += b0; acc[S_B + 1] += b1; acc[S_B + 2] += b2;
+        acc[S_H + 0] += b0 * a0; acc[S_H + 1] += b0 * a1; acc[S_H + 2] += b0 * a2;
+        acc[S_H + 3] += b1 * a0; acc[S_H + 4] += b1 * a1; acc[S_H + 5] += b1 * a2;
+        acc[S_H + 6] += b2 * a0; acc[S_H + 7] += b2 * a1; acc[S_H + 8] += b2 * a2;
+        acc[S_AA] += (a0 * a0 + a1 * a1) + a2 * a2;
+        acc[S_BB] += (b0 * b0 + b1 * b1) + b2 * b2;
+        acc[S_K] += 1.0;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NSUMS; ++k) {
+        const double v = wave_sum(acc[k]);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NSUMS) {
+        double v = red[0][threadIdx.x];
+        for (int w = 1; w < ACC_THREADS / 64; ++w) v += red[w][threadIdx.x];
+        partials[(long long)blockIdx.x * NSUMS + threadIdx.x] = v;
+    }
+}
+
+// one thread: solve only (oa_kabsch / oa_kabsch_from_sums).  out[0..15] = M, out[16] = ok flag
+__global__ void k_solve_only(const double *__restrict__ sums, double pvx, double pvy, double pvz, int with_scale,
+                             double *__restrict__ out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s[NSUMS], M[16];
+    for (int k = 0; k < NSUMS; ++k) s[k] = sums[k];
+    const double pv[3] = { pvx, pvy, pvz };
+    const bool ok = solve_from_sums(s, pv, with_scale != 0, M);
+    for (int k = 0; k < 16; ++k) out[k] = ok ? M[k] : 0.0;
+    out[16] = ok ? 1.0 : 0.0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_solve_update : operators/icp_align.py:106-149, one thread
+// ------------------------------------------------------------------------------------------------
+__global__ void k_solve_update(DevState *__restrict__ st, const double *__restrict__ sums, StepRecord *__restrict__ hist)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (st->halt) return;
+    double s[NSUMS], M[16];
+    for (int k = 0; k < NSUMS; ++k) s[k] = sums[k];
+    if (!solve_from_sums(s, st->pivot, st->with_scale != 0, M)) {   // K < 3 -> ValueError in the reference
+        st->status = -3;                                            // OA_E_TOO_FEW_PAIRS
+        st->halt = 1;
+        return;
+    }
+    float new_mat[16];
+    for (int k = 0; k < 16; ++k) new_mat[k] = (float)M[k];          // new_mat[y][z] = M[y][z]      (:116-119)
+    float mw[16];
+    m4_mul_m4(st->mx1, new_mat, mw);                                // matrix_world @ new_mat       (:121)
+    for (int k = 0; k < 16; ++k) st->mx1[k] = mw[k];
+    float inv[16];
+    if (!m4_inverted(mw, inv)) { st->status = -4; st->halt = 1; }   // next make_pairs would raise   (general.py:265)
+    else for (int k = 0; k < 16; ++k) st->imx1[k] = inv[k];
+    const double trans = v3_length(new_mat[3], new_mat[7], new_mat[11]);   // new_mat.to_translation().length (:129,:138)
+    const double angle = rotation_angle_3x3(M);
+    const double K = s[S_K];
+    const double mean_d = s[S_D] / K;
+    double var = s[S_DD] / K - mean_d * mean_d;
+    if (var < 0.0) var = 0.0;
+    const int n = st->n;
+    if (hist && st->max_records > 0) {
+        StepRecord &r = hist[n % st->max_records];
+        for (int k = 0; k < 16; ++k) { r.M[k] = M[k]; r.new_mat[k] = new_mat[k]; }
+        r.K = K; r.mean_d = mean_d; r.std_d = sqrt(var); r.trans = trans; r.angle = angle; r.pad = 0.0;
+    }
+    if (st->use_target) {                                           // if d_stats:                  (:136)
+        st->ring_t[n % 5] = trans;                                  // conv_t_list[i] = trans.length (:137-138)
+        st->ring_r[n % 5] = angle;
+        bool all = true;
+        for (int k = 0; k < 5; ++k) all = all && (st->ring_t[k] < st->target_d);   // (:141)
+        if (all) st->converged = 1;
+    }
+    st->n = n + 1;                                                  // n += 1                        (:151)
+    if ((st->converged && st->early_exit) || st->n >= st->iters) st->halt = 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ordered compaction for make_pairs' A, B outputs (functions/general.py:313-321)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_block_counts(const unsigned char *__restrict__ valid, int ns, int *__restrict__ counts)
+{
+    __shared__ int wsum[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool v = (i < ns) && valid[i];
+    const unsigned long long m = __ballot(v);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// single block exclusive scan of counts[n] -> offsets[n], total in offsets[n]
+__global__ __launch_bounds__(1024) void k_scan_counts(const int *__restrict__ counts, int n, long long *__restrict__ offsets)
+{
+    __shared__ long long wtot[16];
+    __shared__ long long carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        long long v = (i < n) ? counts[i] : 0;
+        long long x = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const long long y = __shfl_up(x, off, 64);
+            if (lane >= off) x += y;
+        }
+        if (lane == 63) wtot[wave] = x;
+        __syncthreads();
+        long long wpre = 0;
+        for (int w = 0; w < wave; ++w) wpre += wtot[w];
+        long long tot = 0;
+        for (int w = 0; w < 16; ++w) tot += wtot[w];
+        const long long c = carry;
+        if (i < n) offsets[i] = c + wpre + x - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) offsets[n] = carry;
+}
+
+__global__ __launch_bounds__(256) void k_scatter_pairs(const unsigned char *__restrict__ valid, int ns,
+                                                       const float4 *__restrict__ src4, const float *__restrict__ b,
+                                                       const long long *__restrict__ offsets, long long cap,
+                                                       double *__restrict__ A, double *__restrict__ B)
+{
+    __shared__ int wsum[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool v = (i < ns) && valid[i];
+    const unsigned long long m = __ballot(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wsum[wave] = __popcll(m);
+    __syncthreads();
+    if (!v) return;
+    int pre = __popcll(m & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; ++w) pre += wsum[w];
+    const long long k = offsets[blockIdx.x] + pre;
+    if (k >= cap) return;
+    const float4 p = src4[i];
+    A[k] = (double)p.x; A[cap + k] = (double)p.y; A[2 * cap + k] = (double)p.z;
+    B[k] = (double)b[3ll * i]; B[cap + k] = (double)b[3ll * i + 1]; B[2 * cap + k] = (double)b[3ll * i + 2];
+}
+
+#endif  // __HIPCC__
+
+}  // namespace oa

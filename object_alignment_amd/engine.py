@@ -1,0 +1,233 @@
+"""IcpEngine: thin Python object over one `oa_ctx` (one GPU).
+
+Holds no arithmetic of its own -- every number comes back from liboa_icp.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _capi as capi
+
+REF_VALUEERROR = "input arrays are of wrong shape or type"    # functions/general.py:157
+
+
+@dataclass
+class RunResult:
+    iters_done: int
+    converged: bool
+    matrix_world: np.ndarray          # float32 4x4: align_obj.matrix_world after the loop
+    last_K: int
+    last_translation: float
+    mean_dist: float
+    std_dist: float
+    mean_rot_angle: float
+    nn_ms_total: float
+    loop_ms: float
+    step_M: np.ndarray                # n x 4 x 4 float64, the per-iteration affine_matrix_from_points result
+    step_new: np.ndarray              # n x 4 x 4 float32, new_mat (operators/icp_align.py:116-119)
+    step_K: np.ndarray
+    step_stats: np.ndarray            # n x 2 [mean, std]
+    step_trans: np.ndarray
+
+
+def _device_ptr(x):
+    """(pointer, on_device, keepalive) for a numpy array or a torch tensor."""
+    if hasattr(x, "data_ptr") and hasattr(x, "is_cuda"):          # torch tensor, without importing torch
+        if x.is_cuda:
+            import torch
+            t = x.detach().to(dtype=torch.float32).contiguous().reshape(-1, 3)
+            return C.c_void_p(t.data_ptr()), 1, t, t.shape[0]
+        x = x.detach().cpu().numpy()
+    a = capi.as_f32(np.asarray(x)).reshape(-1, 3)
+    return C.c_void_p(a.ctypes.data), 0, a, a.shape[0]
+
+
+class IcpEngine:
+    """One GPU context.  `device` is the HIP device ordinal (LOCAL_RANK in multi-process runs)."""
+
+    def __init__(self, device: int = 0):
+        self._L = capi.load()
+        h = C.c_void_p()
+        capi.check(self._L.oa_create(C.byref(h), int(device)))
+        self._h = h
+        self.device = int(device)
+        self.n_target = 0
+        self.n_selected = 0
+
+    # ---- lifetime
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.oa_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_stream(self, stream_handle):
+        """stream_handle: integer hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or None."""
+        capi.check(self._L.oa_set_stream(self._h, C.c_void_p(stream_handle or 0)))
+
+    # ---- uploads
+    def set_target(self, xyz):
+        p, on_dev, keep, n = _device_ptr(xyz)
+        capi.check(self._L.oa_set_target(self._h, p, n, on_dev))
+        self.n_target = n
+        del keep
+
+    def set_source(self, xyz, vlist=None, stride=0, shard_index=0, shard_count=1):
+        p, on_dev, keep, n = _device_ptr(xyz)
+        if vlist is not None:
+            vl = np.ascontiguousarray(vlist, dtype=np.int64)
+            vp, nv = capi.iptr(vl), len(vl)
+        else:
+            vl, vp, nv = None, None, 0
+        capi.check(self._L.oa_set_source(self._h, p, n, on_dev, vp, nv, int(stride), int(shard_index), int(shard_count)))
+        self.n_selected = int(self._L.oa_num_selected(self._h))
+        del keep, vl
+
+    def set_matrices(self, mx_align, mx_base):
+        a, b = capi.as_f32(mx_align, (4, 4)), capi.as_f32(mx_base, (4, 4))
+        capi.check(self._L.oa_set_matrices(self._h, capi.fptr(a), capi.fptr(b)))
+
+    def matrix_world(self) -> np.ndarray:
+        out = np.empty((4, 4), np.float32)
+        capi.check(self._L.oa_get_matrix_world(self._h, capi.fptr(out)))
+        return out
+
+    def pivot(self) -> np.ndarray:
+        out = np.empty(3, np.float64)
+        capi.check(self._L.oa_get_pivot(self._h, capi.dptr(out)))
+        return out
+
+    # ---- contract 1
+    def make_pairs(self, thresh, calc_stats=False):
+        cap = max(1, self.n_selected)
+        A = np.zeros((3, cap), np.float64)
+        B = np.zeros((3, cap), np.float64)
+        K = C.c_int64(0)
+        ds = np.zeros(2, np.float64)
+        capi.check(self._L.oa_make_pairs(self._h, float(thresh), int(bool(calc_stats)), capi.dptr(A), capi.dptr(B),
+                                         cap, C.byref(K), capi.dptr(ds)))
+        k = int(K.value)
+        d_stats = [float(ds[0]), float(ds[1])] if calc_stats else None
+        return np.ascontiguousarray(A[:, :k]), np.ascontiguousarray(B[:, :k]), d_stats
+
+    def nn_search(self, want_output=True):
+        """Nearest target vertex per selected source point: (idx int64[n], d2 float32[n], kernel_ms)."""
+        ms = C.c_double(0.0)
+        if want_output:
+            idx = np.empty(max(1, self.n_selected), np.int64)
+            d2 = np.empty(max(1, self.n_selected), np.float32)
+            capi.check(self._L.oa_nn_search(self._h, capi.iptr(idx), capi.fptr(d2), C.byref(ms)))
+            return idx[: self.n_selected], d2[: self.n_selected], float(ms.value)
+        capi.check(self._L.oa_nn_search(self._h, None, None, C.byref(ms)))
+        return None, None, float(ms.value)
+
+    # ---- contract 2
+    def kabsch(self, A, B, scale=False) -> np.ndarray:
+        A = np.ascontiguousarray(A, np.float64)
+        B = np.ascontiguousarray(B, np.float64)
+        M = np.empty((4, 4), np.float64)
+        rc = self._L.oa_kabsch(self._h, capi.dptr(A), capi.dptr(B), A.shape[1], A.shape[1], int(bool(scale)), capi.dptr(M))
+        if rc == capi.OA_E_TOO_FEW_PAIRS:
+            raise ValueError(REF_VALUEERROR)
+        capi.check(rc)
+        return M
+
+    def kabsch_from_sums(self, sums, pivot=None, scale=False) -> np.ndarray:
+        s = np.ascontiguousarray(sums, np.float64).reshape(capi.OA_NSUMS)
+        pv = np.ascontiguousarray(pivot, np.float64).reshape(3) if pivot is not None else None
+        M = np.empty((4, 4), np.float64)
+        rc = self._L.oa_kabsch_from_sums(self._h, capi.dptr(s), capi.dptr(pv) if pv is not None else None,
+                                         int(bool(scale)), capi.dptr(M))
+        if rc == capi.OA_E_TOO_FEW_PAIRS:
+            raise ValueError(REF_VALUEERROR)
+        capi.check(rc)
+        return M
+
+    # ---- the loop
+    @staticmethod
+    def _settings(iters, thresh, target_d, use_target, with_scale, early_exit):
+        return capi.Settings(int(iters), int(bool(use_target)), int(bool(with_scale)), int(bool(early_exit)),
+                             float(thresh), float(target_d))
+
+    def _history(self, n):
+        n = max(0, int(n))
+        m = max(1, n)
+        sM = np.zeros((m, 4, 4), np.float64)
+        sN = np.zeros((m, 4, 4), np.float32)
+        sK = np.zeros(m, np.int64)
+        sS = np.zeros((m, 2), np.float64)
+        sT = np.zeros(m, np.float64)
+        got = self._L.oa_get_history(self._h, m, capi.dptr(sM), capi.fptr(sN), capi.iptr(sK), capi.dptr(sS), capi.dptr(sT))
+        got = max(0, min(int(got), n))
+        return sM[:got], sN[:got], sK[:got], sS[:got], sT[:got]
+
+    def _result(self, rep) -> RunResult:
+        sM, sN, sK, sS, sT = self._history(rep.iters_done)
+        return RunResult(rep.iters_done, bool(rep.converged), self.matrix_world(), int(rep.last_K),
+                         rep.last_translation, rep.mean_dist, rep.std_dist, rep.mean_rot_angle, rep.nn_ms_total,
+                         rep.loop_ms, sM, sN, sK, sS, sT)
+
+    def run(self, iters=50, thresh=0.5, target_d=0.01, use_target=True, with_scale=False, early_exit=True) -> RunResult:
+        st = self._settings(iters, thresh, target_d, use_target, with_scale, early_exit)
+        rep = capi.Report()
+        rc = self._L.oa_run(self._h, C.byref(st), C.byref(rep))
+        if rc == capi.OA_E_TOO_FEW_PAIRS:
+            raise ValueError(REF_VALUEERROR)
+        capi.check(rc)
+        return self._result(rep)
+
+    def iterate(self, thresh=0.5, target_d=0.01, use_target=True, with_scale=False):
+        """One iteration (modal operator step).  Returns (M float64 4x4, stats dict)."""
+        st = self._settings(1, thresh, target_d, use_target, with_scale, False)
+        M = np.empty((4, 4), np.float64)
+        s = np.empty(6, np.float64)
+        rc = self._L.oa_iterate(self._h, C.byref(st), capi.dptr(M), capi.dptr(s))
+        if rc == capi.OA_E_TOO_FEW_PAIRS:
+            raise ValueError(REF_VALUEERROR)
+        capi.check(rc)
+        return M, dict(K=int(s[0]), mean_dist=s[1], std_dist=s[2], translation=s[3], rot_angle=s[4],
+                       converged=bool(s[5]))
+
+    # ---- split phase (one process per GPU)
+    def run_begin(self, iters=50, thresh=0.5, target_d=0.01, use_target=True, with_scale=False, early_exit=True):
+        st = self._settings(iters, thresh, target_d, use_target, with_scale, early_exit)
+        capi.check(self._L.oa_run_begin(self._h, C.byref(st)))
+
+    def iter_partial(self, sums_device_ptr: int):
+        capi.check(self._L.oa_iter_partial(self._h, C.c_void_p(sums_device_ptr)))
+
+    def iter_finish(self, sums_device_ptr: int):
+        capi.check(self._L.oa_iter_finish(self._h, C.c_void_p(sums_device_ptr)))
+
+    def run_end(self) -> RunResult:
+        rep = capi.Report()
+        rc = self._L.oa_run_end(self._h, C.byref(rep))
+        if rc == capi.OA_E_TOO_FEW_PAIRS:
+            raise ValueError(REF_VALUEERROR)
+        capi.check(rc)
+        return self._result(rep)
+
+
+def device_count() -> int:
+    return int(capi.load().oa_device_count())
+
+
+def shard_bounds(n_selected: int, shard_index: int, shard_count: int):
+    """[begin, end) of shard `shard_index` -- the same contiguous split oa_set_source applies."""
+    per = -(-n_selected // shard_count) if shard_count > 0 else n_selected
+    begin = min(n_selected, per * shard_index)
+    return begin, min(n_selected, begin + per)

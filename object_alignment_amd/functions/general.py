@@ -1,0 +1,134 @@
+"""Drop-in mirror of the reference's functions/general.py for the ICP hot path.
+
+Same names, positional signatures and error behaviour as
+  /root/reference/functions/general.py:257  make_pairs
+  /root/reference/functions/general.py:105  affine_matrix_from_points
+plus the alias `calc_target_matrix` that BASELINE.json's north_star names (the reference has no function of
+that name -- SURVEY.md D1).  All arithmetic runs in liboa_icp.so on the GPU; this file only adapts arguments.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from ..engine import IcpEngine, REF_VALUEERROR
+
+__all__ = ["make_pairs", "affine_matrix_from_points", "calc_target_matrix", "GpuBVH", "AlignObject", "default_engine"]
+
+_default_engine = None
+
+
+def default_engine(device: int = 0) -> IcpEngine:
+    """Process-wide engine used by the free functions (created on first use)."""
+    global _default_engine
+    if _default_engine is None:
+        _default_engine = IcpEngine(device)
+    return _default_engine
+
+
+# ------------------------------------------------------------------ object adapters
+
+def _matrix_to_np(m) -> np.ndarray:
+    if isinstance(m, np.ndarray):
+        return np.ascontiguousarray(m, dtype=np.float32).reshape(4, 4)
+    return np.array([[float(m[r][c]) for c in range(4)] for r in range(4)], dtype=np.float32)
+
+
+def _coords_of(obj) -> np.ndarray:
+    """n x 3 float32 local coordinates of a Blender-like object or an AlignObject."""
+    if hasattr(obj, "xyz"):
+        return obj.xyz
+    cached = getattr(obj, "_oa_xyz_cache", None)
+    verts = obj.data.vertices
+    if cached is not None and len(cached) == len(verts):
+        return cached
+    if hasattr(verts, "foreach_get"):                        # real bpy mesh: one C call
+        flat = np.empty(len(verts) * 3, dtype=np.float32)
+        verts.foreach_get("co", flat)
+        xyz = flat.reshape(-1, 3)
+    else:
+        xyz = np.array([[v.co[0], v.co[1], v.co[2]] for v in verts], dtype=np.float32).reshape(-1, 3)
+    try:
+        obj._oa_xyz_cache = xyz
+    except Exception:
+        pass
+    return xyz
+
+
+class AlignObject:
+    """Blender-free stand-in for an object: local coordinates + matrix_world (float32 4x4)."""
+
+    def __init__(self, xyz, matrix_world=None, name="object"):
+        self.xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        self.matrix_world = (np.identity(4, dtype=np.float32) if matrix_world is None
+                             else np.ascontiguousarray(matrix_world, dtype=np.float32).reshape(4, 4))
+        self.name = name
+        self.type = "MESH"
+
+
+class GpuBVH:
+    """What `base_bvh` is in this build: the target vertices resident on the GPU.
+
+    Mirrors `BVHTree.FromObject(base_obj, depsgraph)` (operators/icp_align.py:53).  The search it
+    serves is nearest target VERTEX, not closest point on the triangle surface.
+    """
+
+    def __init__(self, target_xyz, engine: IcpEngine | None = None):
+        self.engine = engine if engine is not None else default_engine()
+        self.target = np.ascontiguousarray(target_xyz, dtype=np.float32).reshape(-1, 3)
+        self.engine.set_target(self.target)
+        self._src_key = None
+
+    @classmethod
+    def FromObject(cls, base_obj, depsgraph=None, engine: IcpEngine | None = None):
+        return cls(_coords_of(base_obj), engine)
+
+    def _bind_source(self, xyz, vlist, sample):
+        key = (id(xyz), xyz.shape, None if vlist is None else (len(vlist), hash(bytes(memoryview(vlist)))), sample)
+        if key != self._src_key:
+            self.engine.set_source(xyz, vlist=vlist, stride=sample)
+            self._src_key = key
+            self._keep = xyz
+
+
+def make_pairs(align_obj, base_obj, base_bvh, vlist, thresh, sample=0, calc_stats=False):
+    """Same contract as the reference's make_pairs (functions/general.py:257-329).
+
+    vlist: vertex indices of align_obj to use; returns (A, B, d_stats) with A, B float64[3, K] in
+    align_obj LOCAL space, or None when thresh <= 0 (the reference falls off the end, :277).
+    """
+    if not thresh > 0:
+        return None
+    if base_bvh is None:
+        base_bvh = GpuBVH.FromObject(base_obj)
+    if not isinstance(base_bvh, GpuBVH):
+        raise TypeError("base_bvh must be an object_alignment_amd GpuBVH (GpuBVH.FromObject(base_obj))")
+    xyz = _coords_of(align_obj)
+    vl = np.ascontiguousarray(vlist, dtype=np.int64)
+    base_bvh._bind_source(xyz, vl, int(sample))
+    eng = base_bvh.engine
+    eng.set_matrices(_matrix_to_np(align_obj.matrix_world), _matrix_to_np(base_obj.matrix_world))
+    return eng.make_pairs(thresh, calc_stats)
+
+
+def affine_matrix_from_points(v0, v1, shear=True, scale=True, usesvd=True):
+    """Same contract as the reference's affine_matrix_from_points (functions/general.py:105-217)
+    for the branch the ICP operators use: 3-D, shear=False (rigid, or similarity when scale=True)."""
+    v0 = np.array(v0, dtype=np.float64, copy=True)
+    v1 = np.array(v1, dtype=np.float64, copy=True)
+    if v0.ndim != 2 or v1.ndim != 2:
+        raise ValueError(REF_VALUEERROR)
+    ndims = v0.shape[0]
+    if ndims < 2 or v0.shape[1] < ndims or v0.shape != v1.shape:       # :150
+        raise ValueError(REF_VALUEERROR)                                # :157
+    if shear:
+        raise NotImplementedError("shear=True (full affine) is not on the ICP path; no ICP caller selects it")
+    if ndims != 3:
+        raise NotImplementedError("only 3-D point sets are on the ICP path")
+    # usesvd=False (Horn's quaternion branch, :191-206) minimises the same objective and has the same
+    # optimum; it is served by the same device solve.
+    return default_engine().kabsch(v0, v1, scale=bool(scale))
+
+
+def calc_target_matrix(A, B, scale=False):
+    """north_star's name for the solve: affine_matrix_from_points(A, B, shear=False, scale=scale, usesvd=True)."""
+    return affine_matrix_from_points(A, B, shear=False, scale=scale, usesvd=True)

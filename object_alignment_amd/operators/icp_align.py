@@ -1,0 +1,160 @@
+"""Drop-in mirror of the reference's operators/icp_align.py (OBJECT_OT_icp_align).
+
+`IcpAlign.run` is the Blender-free form of `execute` (operators/icp_align.py:82-161): the whole
+`while n < iters and not converged` loop runs device-resident in liboa_icp.so (oa_run).
+`OBJECT_OT_icp_align` keeps the operator surface (bl_idname / bl_label / bl_options / poll / execute) and
+adapts duck-typed or real Blender objects to it.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+from ..engine import IcpEngine, RunResult
+from ..functions.general import _coords_of, _matrix_to_np, default_engine
+
+try:                                              # inside Blender the operator registers as usual
+    import bpy as _bpy                            # noqa: F401
+    from bpy.types import Operator as _OperatorBase
+except Exception:                                 # outside Blender it is a plain class
+    _bpy = None
+    _OperatorBase = object
+
+
+@dataclass
+class IcpSettings:
+    """Names and defaults of the add-on preferences the loop reads (lib/preferences.py:31-72)."""
+    icp_iterations: int = 50
+    redraw_frequency: int = 10
+    use_sample: bool = False          # never consulted by the reference either
+    sample_fraction: float = 0.5
+    min_start: float = 0.5
+    target_d: float = 0.01
+    use_target: bool = True
+    take_m_with: bool = False
+    align_meth: str = "0"             # '0' RIGID, '1' ROT_LOC_SCALE
+
+
+_prefs = IcpSettings()
+
+
+def get_addon_preferences() -> IcpSettings:
+    """Stand-in for functions/common/blender.py:48-55; returns the process-wide settings object."""
+    return _prefs
+
+
+def build_vlist(align_obj):
+    """The vertex list `execute` builds from the icp_include / icp_exclude groups (operators/icp_align.py:56-80)."""
+    groups = getattr(align_obj, "vertex_groups", None)
+    verts = align_obj.data.vertices if hasattr(align_obj, "data") else None
+    if verts is None:
+        return list(range(len(_coords_of(align_obj))))
+    vlist = []
+    group_lookup = {g.name: g.index for g in groups} if groups is not None else {}
+    if "icp_include" in group_lookup:
+        group = group_lookup["icp_include"]
+        for v in verts:
+            for g in v.groups:
+                if g.group == group and g.weight > 0.9:
+                    vlist.append(v.index)
+    elif "icp_exclude" in group_lookup:
+        group = group_lookup["icp_exclude"]
+        for v in verts:
+            v_groups = [g.group for g in v.groups]
+            if group not in v_groups:
+                vlist.append(v.index)
+            else:
+                for g in v.groups:
+                    if g.group == group and g.weight < 0.1:
+                        vlist.append(v.index)
+    else:
+        vlist = [v.index for v in verts]
+    return vlist
+
+
+def vlist_from_weights(n_verts, include=None, exclude=None):
+    """Array form of the same mask: include / exclude are None or iterables of (vertex_index, weight)."""
+    if include is not None:
+        return [int(v) for v, w in sorted(include, key=lambda t: t[0]) if np.float32(w) > 0.9]
+    if exclude is not None:
+        member = {int(v): np.float32(w) for v, w in exclude}
+        return [v for v in range(n_verts) if v not in member or member[v] < 0.1]
+    return list(range(n_verts))
+
+
+class IcpAlign:
+    """The ICP loop of OBJECT_OT_icp_align.execute without Blender."""
+
+    def __init__(self, settings: IcpSettings | None = None, engine: IcpEngine | None = None):
+        self.settings = settings if settings is not None else get_addon_preferences()
+        self.engine = engine if engine is not None else default_engine()
+
+    def run(self, source_xyz, target_xyz, mx_align, mx_base, vlist=None, early_exit=True) -> RunResult:
+        s = self.settings
+        thresh = s.min_start                                   # :83
+        factor = round(1 / s.sample_fraction)                  # :89  (ZeroDivisionError at 0, as the reference)
+        if not thresh > 0:
+            # make_pairs returns None and `(A, B, d_stats) = None` raises   (:101, general.py:277)
+            raise TypeError("cannot unpack non-iterable NoneType object")
+        eng = self.engine
+        eng.set_target(target_xyz)
+        eng.set_source(source_xyz, vlist=vlist, stride=factor)
+        eng.set_matrices(mx_align, mx_base)
+        return eng.run(iters=s.icp_iterations, thresh=thresh, target_d=s.target_d, use_target=s.use_target,
+                       with_scale=(s.align_meth == "1"), early_exit=early_exit)
+
+
+def _assign_matrix(obj, new_np):
+    old = obj.matrix_world
+    if isinstance(old, np.ndarray):
+        obj.matrix_world = np.array(new_np, dtype=np.float32)
+        return
+    try:
+        obj.matrix_world = type(old)([[float(x) for x in row] for row in new_np])
+    except Exception:
+        obj.matrix_world = np.array(new_np, dtype=np.float32)
+
+
+class OBJECT_OT_icp_align(_OperatorBase):
+    """Uses ICP alignment to iteratevely aligne two objects"""
+    bl_idname = "object.align_icp"
+    bl_label = "ICP Align"
+    bl_options = {'REGISTER', 'UNDO'}
+
+    @classmethod
+    def poll(cls, context):
+        condition_1 = len(context.selected_objects) == 2
+        condition_2 = context.object.type == 'MESH'
+        return condition_1 and condition_2
+
+    def execute(self, context):
+        settings = get_addon_preferences()
+        align_obj = context.object
+        base_obj = [obj for obj in context.selected_objects if obj != align_obj][0]
+        try:
+            align_obj.rotation_mode = 'QUATERNION'
+        except Exception:
+            pass
+        vlist = build_vlist(align_obj)
+        res = IcpAlign(settings).run(_coords_of(align_obj), _coords_of(base_obj),
+                                     _matrix_to_np(align_obj.matrix_world), _matrix_to_np(base_obj.matrix_world),
+                                     vlist=vlist)
+        _assign_matrix(align_obj, res.matrix_world)
+        if settings.take_m_with:                                # :123-127, replayed in iteration order
+            from .. import _hostmath
+            scene = getattr(context, "scene", None) or getattr(getattr(_bpy, "context", None), "scene", None)
+            for obj in (scene.objects if scene is not None else []):
+                if obj.name[:2] == "m_":
+                    m = _matrix_to_np(obj.matrix_world)
+                    for new_mat in res.step_new:
+                        m = _hostmath.mat4_mul(m, new_mat)
+                    _assign_matrix(obj, m)
+                    if hasattr(obj, "update_tag"):
+                        obj.update_tag()
+        if hasattr(align_obj, "update_tag"):
+            align_obj.update_tag()
+        if hasattr(context, "view_layer") and hasattr(context.view_layer, "update"):
+            context.view_layer.update()
+        self.last_result = res
+        return {'FINISHED'}

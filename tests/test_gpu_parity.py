@@ -1,0 +1,407 @@
+"""Parity tests proper: the HIP path (through the C-ABI) against the CPU oracle and the
+reference-derived golden fixtures.  Needs a real MI355X: run with `pytest -m gpu`."""
+import os
+import types
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FROB_TOL = 1e-5            # north_star: final transform within 1e-5 Frobenius of the reference CPU path
+F32_ULP = 2.5e-7           # one float32 ulp at magnitude ~1-2 (matrix_world entries)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from object_alignment_amd.engine import IcpEngine
+    e = IcpEngine(0)
+    yield e
+    e.close()
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"), allow_pickle=False)
+
+
+def _cofind(orc, src, mxa, mxb):
+    """co_find = imx2 @ (mx1 @ co) with the oracle's float32 arithmetic (functions/general.py:287)."""
+    imx2 = orc.mat4_inverted(mxb)
+    return np.array([orc.mat4_mul_vec3(imx2, orc.mat4_mul_vec3(mxa, p)) for p in src], np.float32)
+
+
+# ------------------------------------------------------------------ extension really is the thing under test
+
+def test_extension_loaded_and_gpu_present():
+    from object_alignment_amd import _capi
+    L = _capi.load()
+    assert L.oa_device_count() >= 1
+    with open("/proc/self/maps") as f:
+        assert "liboa_icp.so" in f.read()
+
+
+# ------------------------------------------------------------------ contract 2: affine_matrix_from_points
+
+def test_affine_matrix_from_points_golden(golden_dir):
+    from object_alignment_amd.functions import affine_matrix_from_points, calc_target_matrix
+    g = _load(golden_dir, "kabsch")
+    for i in range(int(g["n_cases"])):
+        p = "c%02d_" % i
+        name = str(g[p + "name"])
+        A, B, M, sc = g[p + "A"], g[p + "B"], g[p + "M"], bool(g[p + "scale"])
+        got = affine_matrix_from_points(A, B, shear=False, scale=sc, usesvd=True)
+        tol = (5e-9 if ("K3" in name or "coplanar" in name) else 1e-10) * max(1.0, float(np.abs(M).max()))
+        assert np.abs(got - M).max() <= tol, (name, np.abs(got - M).max())
+        assert np.array_equal(calc_target_matrix(A, B, scale=sc), got)
+    with pytest.raises(ValueError, match=str(g["valueerror_msg"])):
+        affine_matrix_from_points(np.zeros((3, 2)), np.zeros((3, 2)), shear=False, scale=False)
+
+
+def test_kabsch_properties(eng):
+    from object_alignment_amd import synth
+    rng = np.random.default_rng(0)
+    A = rng.uniform(-1, 1, size=(3, 1000))
+    R = synth.rotation_from_rotvec([0, 0, np.deg2rad(15.0)])
+    t = np.array([0.1, 0.2, 0.3])
+    M = eng.kabsch(A, R @ A + t[:, None])
+    assert np.abs(M[:3, :3] - R).max() < 1e-12 and np.abs(M[:3, 3] - t).max() < 1e-12
+    M = eng.kabsch(A, 1.7 * (R @ A + t[:, None]), scale=True)
+    assert abs(np.cbrt(np.linalg.det(M[:3, :3])) - 1.7) < 1e-12
+    M = eng.kabsch(A, np.diag([1.0, 1.0, -1.0]) @ A)             # reflection input -> proper rotation
+    assert abs(np.linalg.det(M[:3, :3]) - 1.0) < 1e-12
+    # K = 1e6, far from the origin (pivoted one-pass accumulation)
+    A = rng.uniform(-1, 1, size=(3, 1_000_000)) + np.array([[100.0], [-50.0], [25.0]])
+    B = R @ A + t[:, None] + rng.normal(0, 1e-3, size=A.shape)
+    from oracle import oracle as orc
+    assert np.abs(eng.kabsch(A, B) - orc.affine_matrix_from_points(A, B)).max() < 1e-9
+
+
+# ------------------------------------------------------------------ correspondence search: bit exact
+
+@pytest.mark.parametrize("ns,nt", [(1, 1), (3, 5), (257, 1023), (2562, 2562), (5000, 4097), (20000, 30000)])
+def test_nn_search_bit_exact(eng, orc, ns, nt):
+    rng = np.random.default_rng(ns * 7919 + nt)
+    tgt = rng.normal(size=(nt, 3)).astype(np.float32)
+    src = rng.normal(size=(ns, 3)).astype(np.float32)
+    mxa = np.identity(4, dtype=np.float32)
+    mxa[:3, 3] = [0.01, -0.02, 0.03]
+    mxb = np.identity(4, dtype=np.float32)
+    eng.set_target(tgt)
+    eng.set_source(src)
+    eng.set_matrices(mxa, mxb)
+    idx, d2, ms = eng.nn_search()
+    ridx, rd2 = orc.nn_brute(_cofind(orc, src, mxa, mxb), tgt)
+    assert np.array_equal(idx, ridx)
+    assert np.array_equal(d2, rd2)
+
+
+def test_nn_search_ties_lowest_index(eng, orc):
+    rng = np.random.default_rng(3)
+    tgt = rng.integers(-4, 5, size=(6000, 3)).astype(np.float32)          # many exact duplicates / ties
+    src = rng.integers(-5, 6, size=(3000, 3)).astype(np.float32) + np.float32(0.5)
+    eye = np.identity(4, dtype=np.float32)
+    eng.set_target(tgt)
+    eng.set_source(src)
+    eng.set_matrices(eye, eye)
+    idx, d2, _ = eng.nn_search()
+    ridx, rd2 = orc.nn_brute(src, tgt)
+    assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2)
+
+
+@pytest.mark.parametrize("R,splits", [(1, 0), (2, 3), (8, 0), (4, 7)])
+def test_nn_search_geometry_variants(orc, R, splits, monkeypatch):
+    """Points-per-thread and target-split variants (atomicMin merge) give the same answers."""
+    from object_alignment_amd.engine import IcpEngine
+    monkeypatch.setenv("OA_NN_R", str(R))
+    if splits:
+        monkeypatch.setenv("OA_NN_SPLITS", str(splits))
+    rng = np.random.default_rng(R * 10 + splits)
+    tgt = rng.normal(size=(9000, 3)).astype(np.float32)
+    src = rng.normal(size=(4100, 3)).astype(np.float32)
+    eye = np.identity(4, dtype=np.float32)
+    with IcpEngine(0) as e:
+        e.set_target(tgt)
+        e.set_source(src)
+        e.set_matrices(eye, eye)
+        idx, d2, _ = e.nn_search()
+    ridx, rd2 = orc.nn_brute(src, tgt)
+    assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2)
+
+
+def test_nn_search_full_size_self_match(eng):
+    """BASELINE config 3 size (1M <-> 1M): every point finds itself (property test, no oracle needed)."""
+    rng = np.random.default_rng(1234)
+    n = 1_000_000
+    tgt = rng.uniform(-1, 1, size=(n, 3)).astype(np.float32)
+    perm = rng.permutation(n)
+    src = tgt[perm]
+    eye = np.identity(4, dtype=np.float32)
+    eng.set_target(tgt)
+    eng.set_source(src)
+    eng.set_matrices(eye, eye)
+    idx, d2, ms = eng.nn_search()
+    assert np.all(d2 == 0.0)
+    # duplicates in a float32 uniform cloud are possible: idx must be <= perm (lowest index wins), equal coords
+    assert np.all(idx <= perm)
+    assert np.array_equal(tgt[idx], src)
+    assert np.count_nonzero(idx != perm) < 100
+
+
+# ------------------------------------------------------------------ contract 1: make_pairs
+
+def test_make_pairs_golden(golden_dir):
+    from object_alignment_amd.functions import make_pairs, GpuBVH, AlignObject
+    g = _load(golden_dir, "make_pairs")
+    for i in range(int(g["n_cases"])):
+        p = "c%02d_" % i
+        align = AlignObject(g[p + "src"], g[p + "mx_align"])
+        base = AlignObject(g[p + "tgt"], g[p + "mx_base"])
+        bvh = GpuBVH.FromObject(base, None)
+        A, B, ds = make_pairs(align, base, bvh, g[p + "vlist"].tolist(), float(g[p + "thresh"]),
+                              int(g[p + "sample"]), calc_stats=bool(g[p + "calc_stats"]))
+        name = str(g[p + "name"])
+        assert A.shape == g[p + "A"].shape, name
+        assert np.array_equal(A, g[p + "A"]), name
+        assert np.array_equal(B, g[p + "B"]), name
+        if bool(g[p + "calc_stats"]):
+            assert np.allclose(ds, g[p + "d_stats"], rtol=1e-9, atol=1e-13), name
+        else:
+            assert ds is None
+    # thresh == 0 -> None, like the reference (functions/general.py:277)
+    assert make_pairs(align, base, bvh, [0, 1, 2], 0.0) is None
+
+
+def test_make_pairs_duck_typed_blender_objects(golden_dir, orc):
+    """Same call the reference operator makes, with objects exposing .matrix_world / .data.vertices[i].co."""
+    from object_alignment_amd.functions import make_pairs, GpuBVH
+    g = _load(golden_dir, "make_pairs")
+    p = "c04_"
+    align = orc.MeshObject(g[p + "src"], g[p + "mx_align"])
+    base = orc.MeshObject(g[p + "tgt"], g[p + "mx_base"])
+    A, B, ds = make_pairs(align, base, GpuBVH.FromObject(base, None), g[p + "vlist"].tolist(), float(g[p + "thresh"]),
+                          int(g[p + "sample"]), calc_stats=True)
+    assert np.array_equal(A, g[p + "A"]) and np.array_equal(B, g[p + "B"])
+
+
+def test_make_pairs_empty_and_ragged(eng, orc):
+    rng = np.random.default_rng(9)
+    tgt = rng.normal(size=(37, 3)).astype(np.float32)
+    src = rng.normal(size=(301, 3)).astype(np.float32)
+    eye = np.identity(4, dtype=np.float32)
+    eng.set_target(tgt)
+    eng.set_matrices(eye, eye)
+    for vlist, stride in ((None, 0), (None, 7), (list(range(300, -1, -3)), 2), ([], 0), ([5], 0)):
+        eng.set_source(src, vlist=vlist, stride=stride)
+        A, B, ds = eng.make_pairs(0.8, calc_stats=True)
+        rA, rB, rds = orc.make_pairs(src, tgt, eye, eye, 0.8, vlist=vlist, sample=stride, calc_stats=True)
+        assert np.array_equal(A, rA) and np.array_equal(B, rB)
+        if rA.shape[1]:
+            assert np.allclose(ds, rds, rtol=1e-9, atol=1e-13)
+        else:
+            assert np.isnan(ds[0])
+
+
+# ------------------------------------------------------------------ the operator loop
+
+LOOPS = ["icp_loop_ico_10", "icp_loop_bumpy_converge", "icp_loop_bumpy_scale", "icp_loop_include",
+         "icp_loop_exclude"]
+
+
+def _settings_from(g):
+    from object_alignment_amd.operators import IcpSettings
+    iters, frac, min_start, target_d, use_target, take_m, meth = g["prefs"]
+    return IcpSettings(icp_iterations=int(iters), sample_fraction=float(frac), min_start=float(min_start),
+                       target_d=float(target_d), use_target=bool(use_target), take_m_with=bool(take_m),
+                       align_meth=str(int(meth)))
+
+
+@pytest.mark.parametrize("name", LOOPS)
+def test_icp_align_run_golden(golden_dir, name):
+    """IcpAlign.run reproduces what the reference's execute() produced, iteration by iteration."""
+    from object_alignment_amd.operators import IcpAlign
+    g = _load(golden_dir, name)
+    res = IcpAlign(_settings_from(g)).run(g["src"], g["tgt"], g["mx_align"], g["mx_base"], vlist=g["vlist"])
+    assert res.iters_done == int(g["iters_done"])
+    assert res.converged == bool(g["converged"])
+    assert np.array_equal(res.step_K, g["step_K"])
+    assert np.abs(res.step_M - g["step_M"]).max() < 1e-9
+    assert np.abs(res.matrix_world - g["final_world"]).max() <= F32_ULP
+    assert np.linalg.norm(res.matrix_world.astype(np.float64) - g["final_world"].astype(np.float64)) <= FROB_TOL
+    if bool(g["prefs"][4]):
+        assert np.allclose(res.step_stats, g["step_stats"], rtol=1e-8, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["icp_loop_include", "icp_loop_exclude", "icp_loop_bumpy_scale"])
+def test_operator_execute_duck_typed(golden_dir, orc, name):
+    """OBJECT_OT_icp_align.execute on duck-typed Blender objects, vertex groups and m_ objects included."""
+    from object_alignment_amd import synth
+    from object_alignment_amd.operators import OBJECT_OT_icp_align, icp_align
+    g = _load(golden_dir, name)
+    st = _settings_from(g)
+    for k, v in st.__dict__.items():
+        setattr(icp_align.get_addon_preferences(), k, v)
+
+    def obj(xyz, mw, nm, inc=None, exc=None):
+        o = orc.MeshObject(xyz, mw, nm)
+        o.type = "MESH"
+        groups, gi = {}, 1
+        for v in o.data.vertices:
+            v.groups = []
+        for gname, members in (("icp_include", inc), ("icp_exclude", exc)):
+            if members is None:
+                continue
+            groups[gname] = types.SimpleNamespace(name=gname, index=gi)
+            for vi, w in members:
+                o.data.vertices[int(vi)].groups.append(types.SimpleNamespace(group=gi, weight=float(np.float32(w))))
+            gi += 1
+        o.vertex_groups = list(groups.values())
+        return o
+
+    inc = [tuple(r) for r in g["include"]] if "include" in g.files else None
+    exc = [tuple(r) for r in g["exclude"]] if "exclude" in g.files else None
+    align = obj(g["src"], g["mx_align"], "align", inc, exc)
+    base = obj(g["tgt"], g["mx_base"], "base")
+    m0 = synth.rigid4(synth.rotation_from_rotvec([0.4, 0.1, 0.2]), [1.0, 2.0, 3.0])
+    m_obj = types.SimpleNamespace(name="m_0", matrix_world=m0.copy())
+    ctx = types.SimpleNamespace(object=align, selected_objects=[base, align],
+                                scene=types.SimpleNamespace(objects=[align, base, m_obj]))
+    assert OBJECT_OT_icp_align.poll(ctx)
+    op = OBJECT_OT_icp_align()
+    assert op.execute(ctx) == {"FINISHED"}
+    got = np.array([[align.matrix_world[r][c] for c in range(4)] for r in range(4)], np.float32)
+    assert np.abs(got - g["final_world"]).max() <= F32_ULP
+    if g["m_final"].shape[0]:
+        assert np.abs(np.asarray(m_obj.matrix_world) - g["m_final"][0]).max() <= 1e-6
+    for k, v in icp_align.IcpSettings().__dict__.items():
+        setattr(icp_align.get_addon_preferences(), k, v)
+
+
+def test_step_mode_equals_fused_loop(golden_dir):
+    from object_alignment_amd.engine import IcpEngine
+    g = _load(golden_dir, "icp_loop_bumpy_converge")
+    with IcpEngine(0) as e:
+        e.set_target(g["tgt"])
+        e.set_source(g["src"], stride=1)
+        e.set_matrices(g["mx_align"], g["mx_base"])
+        Ms = []
+        for it in range(int(g["iters_done"])):
+            M, st = e.iterate(thresh=0.5, target_d=0.01, use_target=True)
+            Ms.append(M)
+        assert st["converged"] == bool(g["converged"])
+        assert np.abs(np.array(Ms) - g["step_M"]).max() < 1e-9
+        assert np.abs(e.matrix_world() - g["final_world"]).max() <= F32_ULP
+
+
+def test_error_paths(eng):
+    from object_alignment_amd.operators import IcpAlign, IcpSettings
+    from object_alignment_amd import _capi
+    rng = np.random.default_rng(1)
+    tgt = rng.normal(size=(500, 3)).astype(np.float32)
+    src = rng.normal(size=(400, 3)).astype(np.float32) + np.float32(100.0)     # nothing within thresh
+    eye = np.identity(4, dtype=np.float32)
+    with pytest.raises(ValueError, match="input arrays are of wrong shape or type"):
+        IcpAlign(IcpSettings(icp_iterations=5, sample_fraction=1.0)).run(src, tgt, eye, eye)
+    with pytest.raises(TypeError):
+        IcpAlign(IcpSettings(min_start=0.0)).run(src, tgt, eye, eye)
+    with pytest.raises(ZeroDivisionError):
+        IcpAlign(IcpSettings(sample_fraction=0.0)).run(src, tgt, eye, eye)
+    with pytest.raises(_capi.OaError) as ei:
+        eng.set_matrices(np.zeros((4, 4), np.float32), eye)
+    assert ei.value.code == _capi.OA_E_SINGULAR
+    with pytest.raises(_capi.OaError) as ei:
+        eng.set_source(src, vlist=[0, 400])
+    assert ei.value.code == _capi.OA_E_BAD_ARG
+
+
+# ------------------------------------------------------------------ BASELINE configs against the oracle
+
+def test_c2_bunny_100k_50_iters(orc):
+    """Config 2: 100k <-> 100k, 50 iterations; final transform within 1e-5 Frobenius of the CPU path."""
+    from object_alignment_amd import synth
+    from object_alignment_amd.engine import IcpEngine
+    src, tgt, mxa, mxb = synth.c2_bunny_pair(100_000)
+    with IcpEngine(0) as e:
+        e.set_target(tgt)
+        e.set_source(src, stride=1)
+        e.set_matrices(mxa, mxb)
+        res = e.run(iters=50, thresh=0.5, target_d=0.01, use_target=True, early_exit=False)
+    ref = orc.icp_run(src, tgt, mxa, mxb, iters=50, sample=1, thresh=0.5, target_d=1e-300, use_target=True,
+                      kd=orc.KDTree(tgt))
+    assert res.iters_done == 50 == ref["iters_done"]
+    assert np.array_equal(res.step_K, ref["step_K"])
+    err = np.linalg.norm(res.matrix_world.astype(np.float64) - ref["matrix_world"].astype(np.float64))
+    assert err <= FROB_TOL, err
+    assert np.abs(res.step_M - ref["step_M"]).max() < 1e-9
+
+
+def test_c3_random_1m_few_iters(orc):
+    """Config 3 at full size, 3 iterations (the oracle's KD-tree keeps this to seconds)."""
+    from object_alignment_amd import synth
+    from object_alignment_amd.engine import IcpEngine
+    src, tgt, mxa, mxb = synth.c3_random_pair(1_000_000)
+    with IcpEngine(0) as e:
+        e.set_target(tgt)
+        e.set_source(src, stride=1)
+        e.set_matrices(mxa, mxb)
+        res = e.run(iters=3, thresh=0.5, target_d=0.01, use_target=True, early_exit=False)
+    ref = orc.icp_run(src, tgt, mxa, mxb, iters=3, sample=1, thresh=0.5, target_d=1e-300, use_target=True,
+                      kd=orc.KDTree(tgt))
+    assert np.array_equal(res.step_K, ref["step_K"])
+    err = np.linalg.norm(res.matrix_world.astype(np.float64) - ref["matrix_world"].astype(np.float64))
+    assert err <= FROB_TOL, err
+    assert np.abs(res.step_M - ref["step_M"]).max() < 1e-9
+
+
+# ------------------------------------------------------------------ sharded (split-phase) path on one GPU
+
+def test_two_shards_on_one_gpu_equal_unsharded(golden_dir):
+    """Two contexts holding shard 0/2 and 1/2, sums added, identical solve: what 2 ranks would do."""
+    import torch
+    from object_alignment_amd.engine import IcpEngine, shard_bounds
+    from object_alignment_amd import _capi
+    g = _load(golden_dir, "icp_loop_bumpy_converge")
+    dev = torch.device("cuda:0")
+    kw = dict(iters=int(g["iters_done"]), thresh=0.5, target_d=0.01, use_target=True, early_exit=True)
+    engs = [IcpEngine(0) for _ in range(2)]
+    try:
+        sums = [torch.zeros(_capi.OA_NSUMS, dtype=torch.float64, device=dev) for _ in range(2)]
+        for r, e in enumerate(engs):
+            e.set_stream(torch.cuda.current_stream().cuda_stream)
+            e.set_target(g["tgt"])
+            e.set_source(g["src"], stride=1, shard_index=r, shard_count=2)
+            b, en = shard_bounds(len(g["src"]), r, 2)
+            assert e.n_selected == en - b
+            e.set_matrices(g["mx_align"], g["mx_base"])
+            e.run_begin(**kw)
+        for it in range(kw["iters"]):
+            for r, e in enumerate(engs):
+                e.iter_partial(sums[r].data_ptr())
+            total = sums[0] + sums[1]                       # stands in for the all-reduce
+            for e in engs:
+                e.iter_finish(total.data_ptr())
+        res = [e.run_end() for e in engs]
+    finally:
+        for e in engs:
+            e.close()
+    assert np.array_equal(res[0].matrix_world, res[1].matrix_world)
+    assert res[0].iters_done == int(g["iters_done"]) and res[0].converged == bool(g["converged"])
+    assert np.array_equal(res[0].step_K, g["step_K"])
+    assert np.abs(res[0].step_M - g["step_M"]).max() < 1e-9
+    assert np.abs(res[0].matrix_world - g["final_world"]).max() <= F32_ULP
+
+
+def test_run_sharded_world1_torch_stream(golden_dir):
+    """distributed.run_sharded with world_size 1 (no collective) on torch's current stream."""
+    import torch
+    from object_alignment_amd.engine import IcpEngine
+    from object_alignment_amd.distributed import EngineShard, run_sharded, new_sums_tensor
+    g = _load(golden_dir, "icp_loop_bumpy_converge")
+    with IcpEngine(0) as e:
+        e.set_target(torch.from_numpy(g["tgt"]).cuda())          # device-resident inputs
+        e.set_source(torch.from_numpy(g["src"]).cuda(), stride=1)
+        e.set_matrices(g["mx_align"], g["mx_base"])
+        sums = new_sums_tensor(torch.device("cuda:0"))
+        res = run_sharded(EngineShard(e, iters=30, thresh=0.5, target_d=0.01, use_target=True, early_exit=True),
+                          30, sums, world_size=1)
+    assert res.iters_done == int(g["iters_done"]) and res.converged
+    assert np.abs(res.matrix_world - g["final_world"]).max() <= F32_ULP

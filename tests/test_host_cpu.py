@@ -1,0 +1,138 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every declared symbol, argument
+validation mirrors the reference, vlist mask semantics, shard partition.  No GPU compute is attempted."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as ge
+    ge.build_hip()
+    return True
+
+
+def test_cabi_exports_every_declared_symbol(built):
+    from object_alignment_amd import _capi
+    L = _capi.load()
+    hdr = open(os.path.join(ROOT, "include", "oa_icp.h")).read()
+    declared = set(re.findall(r"\b(oa_[a-z_0-9]+)\s*\(", hdr))
+    declared -= {"oa_ctx", "oa_settings", "oa_report"}
+    assert declared == set(_capi.SYMBOLS), declared ^ set(_capi.SYMBOLS)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert b"gfx950" in L.oa_version()
+
+
+def test_struct_layouts_match_header(built):
+    import ctypes as C
+    from object_alignment_amd import _capi
+    assert C.sizeof(_capi.Settings) == 32
+    assert C.sizeof(_capi.Report) == 72
+
+
+def test_no_cpu_fallback_fails_loudly(built):
+    """Without a GPU the engine must refuse to run rather than compute on the host."""
+    from object_alignment_amd import _capi
+    from object_alignment_amd.engine import IcpEngine
+    if _capi.load().oa_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(_capi.OaError) as ei:
+        IcpEngine(0)
+    assert ei.value.code == _capi.OA_E_NO_DEVICE
+    assert "no CPU fallback" in str(ei.value)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "object_alignment_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "oracle" not in txt.replace("the CPU oracle", "").replace("CPU oracle", "") or \
+                    not re.search(r"^\s*(from|import)\s+oracle", txt, re.M), f
+                assert not re.search(r"^\s*(from|import)\s+oracle", txt, re.M), f
+                assert "liboa_oracle" not in txt, f
+    for f in ("bench.py",):
+        p = os.path.join(ROOT, f)
+        if os.path.exists(p):
+            assert "/root/reference" not in open(p).read()
+
+
+def test_affine_matrix_from_points_validation_matches_reference(built):
+    from object_alignment_amd.functions import affine_matrix_from_points
+    msg = "input arrays are of wrong shape or type"
+    with pytest.raises(ValueError, match=msg):
+        affine_matrix_from_points(np.zeros((3, 2)), np.zeros((3, 2)), shear=False)       # K < ndims
+    with pytest.raises(ValueError, match=msg):
+        affine_matrix_from_points(np.zeros((3, 5)), np.zeros((3, 6)), shear=False)       # shape mismatch
+    with pytest.raises(ValueError, match=msg):
+        affine_matrix_from_points(np.zeros((1, 5)), np.zeros((1, 5)), shear=False)       # ndims < 2
+    with pytest.raises(NotImplementedError):
+        affine_matrix_from_points(np.zeros((3, 5)), np.zeros((3, 5)))                    # shear=True default
+
+
+def test_make_pairs_thresh_zero_returns_none(built):
+    from object_alignment_amd.functions import make_pairs
+    assert make_pairs(None, None, None, [0, 1], 0.0) is None
+    assert make_pairs(None, None, None, [0, 1], -1.0) is None
+
+
+def test_settings_defaults_match_preferences():
+    from object_alignment_amd.operators import IcpSettings, OBJECT_OT_icp_align
+    s = IcpSettings()
+    # /root/reference/lib/preferences.py:31-72
+    assert (s.icp_iterations, s.redraw_frequency, s.use_sample, s.sample_fraction) == (50, 10, False, 0.5)
+    assert (s.min_start, s.target_d, s.use_target, s.take_m_with, s.align_meth) == (0.5, 0.01, True, False, "0")
+    assert round(1 / 0.4) == 2 and round(1 / s.sample_fraction) == 2     # banker's rounding, icp_align.py:89
+    assert OBJECT_OT_icp_align.bl_idname == "object.align_icp"
+    assert OBJECT_OT_icp_align.bl_label == "ICP Align"
+    assert OBJECT_OT_icp_align.bl_options == {"REGISTER", "UNDO"}
+
+
+LOOPS = ["icp_loop_include", "icp_loop_exclude", "icp_loop_bumpy_converge"]
+
+
+@pytest.mark.parametrize("name", LOOPS)
+def test_vlist_mask_semantics_golden(golden_dir, name):
+    """vlist built from (vertex, weight) memberships == the vlist the reference's execute() built."""
+    from object_alignment_amd.operators.icp_align import vlist_from_weights
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    inc = [tuple(r) for r in g["include"]] if "include" in g.files else None
+    exc = [tuple(r) for r in g["exclude"]] if "exclude" in g.files else None
+    got = vlist_from_weights(len(g["src"]), inc, exc)
+    assert np.array_equal(np.array(got, dtype=np.int64), g["vlist"])
+
+
+def test_shard_bounds_cover_exactly():
+    from object_alignment_amd.engine import shard_bounds
+    for n in (0, 1, 7, 8, 9, 1000, 1_000_000, 10_000_001):
+        for w in (1, 2, 3, 4, 8):
+            cuts = [shard_bounds(n, r, w) for r in range(w)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            for (b0, e0), (b1, e1) in zip(cuts, cuts[1:]):
+                assert e0 == b1 and b0 <= e0
+            assert max(e - b for b, e in cuts) - min(e - b for b, e in cuts) <= max(1, -(-n // w))
+
+
+def test_hostmath_matches_oracle(orc):
+    from object_alignment_amd import _hostmath
+    rng = np.random.default_rng(2)
+    for _ in range(20):
+        a = rng.normal(size=(4, 4)).astype(np.float32)
+        b = rng.normal(size=(4, 4)).astype(np.float32)
+        assert np.array_equal(_hostmath.mat4_mul(a, b), orc.mat4_mul(a, b))
+
+
+def test_synthetic_configs_are_deterministic():
+    from object_alignment_amd import synth
+    assert synth.icosphere(4).shape == (2562, 3)
+    a = synth.c3_random_pair(1000)
+    b = synth.c3_random_pair(1000)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    s, t, _, _ = synth.c2_bunny_pair(5000)
+    assert s.shape == t.shape == (5000, 3) and s.dtype == np.float32
