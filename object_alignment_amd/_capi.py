@@ -59,6 +59,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: PyTorch bundles its own libamdhip64.so.7.  If liboa_icp.so pulled in the
+    # system copy first, torch would later fail with "No HIP GPUs are available"; importing torch first makes both
+    # bind to the same runtime.  Without torch installed the system runtime is used.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             "object_alignment_amd: %s is missing -- build the HIP extension first "
@@ -90,10 +97,6 @@ def load():
     L.oa_iter_partial.argtypes = [vp, vp]
     L.oa_iter_finish.argtypes = [vp, vp]
     L.oa_run_end.argtypes = [vp, C.POINTER(Report)]
-    for name in SYMBOLS:
-        fn = getattr(L, name)
-        if fn.restype is C.c_int and name not in ("oa_device_count",):
-            pass
     _lib = L
     return L
 

@@ -61,7 +61,7 @@ struct oa_ctx {
     float *d_tgt_xyz = nullptr;
     float4 *d_tg = nullptr;
     // source (this shard)
-    int ns = 0, ns_pad = 0, R = 4;
+    int ns = 0, ns_pad = 0, R = 8;
     float4 *d_src4 = nullptr;
     unsigned long long *d_keys = nullptr;
     double pivot[3] = { 0, 0, 0 };
@@ -102,7 +102,7 @@ void plan_geometry(oa_ctx *c)
     if (c->ns <= 0 || c->nt <= 0) return;
     const int src_blocks = c->ns_pad / (oa::NN_THREADS * c->R);
     const int tiles_total = c->n_groups_pad / oa::TILE_GROUPS;
-    const int want = env_int("OA_NN_TARGET_BLOCKS", c->n_cu * 8);
+    const int want = env_int("OA_NN_TARGET_BLOCKS", c->n_cu * 16);
     int splits = (want + src_blocks - 1) / src_blocks;
     splits = std::max(1, std::min(splits, tiles_total));
     const int forced = env_int("OA_NN_SPLITS", 0);
@@ -160,8 +160,8 @@ int launch_nn(oa_ctx *c)
     switch (c->R) {
     case 1: hipLaunchKernelGGL(oa::k_nn_search<1>, grid, block, 0, c->stream, c->d_state, c->d_src4, c->d_tg, c->groups_per_split, c->n_groups_pad, c->d_keys); break;
     case 2: hipLaunchKernelGGL(oa::k_nn_search<2>, grid, block, 0, c->stream, c->d_state, c->d_src4, c->d_tg, c->groups_per_split, c->n_groups_pad, c->d_keys); break;
-    case 8: hipLaunchKernelGGL(oa::k_nn_search<8>, grid, block, 0, c->stream, c->d_state, c->d_src4, c->d_tg, c->groups_per_split, c->n_groups_pad, c->d_keys); break;
-    default: hipLaunchKernelGGL(oa::k_nn_search<4>, grid, block, 0, c->stream, c->d_state, c->d_src4, c->d_tg, c->groups_per_split, c->n_groups_pad, c->d_keys); break;
+    case 4: hipLaunchKernelGGL(oa::k_nn_search<4>, grid, block, 0, c->stream, c->d_state, c->d_src4, c->d_tg, c->groups_per_split, c->n_groups_pad, c->d_keys); break;
+    default: hipLaunchKernelGGL(oa::k_nn_search<8>, grid, block, 0, c->stream, c->d_state, c->d_src4, c->d_tg, c->groups_per_split, c->n_groups_pad, c->d_keys); break;
     }
     HIPCHK(hipGetLastError());
     return OA_OK;
@@ -318,8 +318,8 @@ OA_EXPORT int oa_create(oa_ctx **out, int device)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fail(OA_E_HIP, "oa_create: %s", hipGetErrorString(e)); }
     c->stream = c->own_stream;
-    c->R = env_int("OA_NN_R", 4);
-    if (c->R != 1 && c->R != 2 && c->R != 4 && c->R != 8) c->R = 4;
+    c->R = env_int("OA_NN_R", 8);
+    if (c->R != 1 && c->R != 2 && c->R != 4 && c->R != 8) c->R = 8;
     *out = c;
     return OA_OK;
 }
