@@ -78,7 +78,10 @@ int         oa_create(oa_ctx **out, int device);
 void        oa_destroy(oa_ctx *ctx);
 const char *oa_last_error(void);
 const char *oa_version(void);
-/* stream: a hipStream_t to enqueue on (e.g. torch's current stream); NULL = the context's own stream */
+/* stream: the hipStream_t every later call enqueues on, used exactly as given -- NULL is HIP's legacy default
+ * stream (torch.cuda.current_stream() unless the caller changed it); OA_STREAM_OWN = the context's private
+ * non-blocking stream (the default after oa_create). */
+#define OA_STREAM_OWN ((void *)(intptr_t)-1)
 int         oa_set_stream(oa_ctx *ctx, void *stream);
 
 /* ---- one-time uploads (replaces BVHTree.FromObject, operators/icp_align.py:53, and the vlist

@@ -343,7 +343,9 @@ OA_EXPORT void oa_destroy(oa_ctx *c)
 OA_EXPORT int oa_set_stream(oa_ctx *c, void *stream)
 {
     if (!c) return fail(OA_E_BAD_ARG, "null context");
-    c->stream = stream ? (hipStream_t)stream : c->own_stream;
+    // the handle is used as given: NULL is HIP's legacy default stream (what torch.cuda.current_stream() is
+    // unless the caller switched streams); OA_STREAM_OWN selects the context's private non-blocking stream
+    c->stream = (stream == OA_STREAM_OWN) ? c->own_stream : (hipStream_t)stream;
     return OA_OK;
 }
 

@@ -76,8 +76,10 @@ class IcpEngine:
         self.close()
 
     def set_stream(self, stream_handle):
-        """stream_handle: integer hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or None."""
-        capi.check(self._L.oa_set_stream(self._h, C.c_void_p(stream_handle or 0)))
+        """stream_handle: integer hipStream_t, e.g. torch.cuda.current_stream().cuda_stream (0 = the legacy
+        default stream); None = the context's private stream."""
+        h = C.c_void_p(-1) if stream_handle is None else C.c_void_p(int(stream_handle))
+        capi.check(self._L.oa_set_stream(self._h, h))
 
     # ---- uploads
     def set_target(self, xyz):
