@@ -60,13 +60,19 @@ struct oa_ctx {
     int nt = 0, n_groups_pad = 0;
     float *d_tgt_xyz = nullptr;
     float4 *d_tg = nullptr;
+    float4 *d_tf = nullptr;          // filter image (k_nn_search_filtered)
+    bool filter_ok = false;
+    float tc[3] = { 0, 0, 0 };
+    double qmax = 0.0;
     // source (this shard)
-    int ns = 0, ns_pad = 0, R = 8;
+    int ns = 0, ns_pad = 0, R = 4;
     float4 *d_src4 = nullptr;
     unsigned long long *d_keys = nullptr;
+    int *d_prev = nullptr;           // nearest index of the previous search (seed), -1 = none
     double pivot[3] = { 0, 0, 0 };
     // launch geometry for k_nn_search
     int n_splits = 1, groups_per_split = 0, acc_blocks = 1;
+    bool use_filter = true, use_pk = true;
     // device state
     oa::DevState h_state;
     oa::DevState *d_state = nullptr;
@@ -102,7 +108,7 @@ void plan_geometry(oa_ctx *c)
     if (c->ns <= 0 || c->nt <= 0) return;
     const int src_blocks = c->ns_pad / (oa::NN_THREADS * c->R);
     const int tiles_total = c->n_groups_pad / oa::TILE_GROUPS;
-    const int want = env_int("OA_NN_TARGET_BLOCKS", c->n_cu * 16);
+    const int want = env_int("OA_NN_TARGET_BLOCKS", c->n_cu * 64);
     int splits = (want + src_blocks - 1) / src_blocks;
     splits = std::max(1, std::min(splits, tiles_total));
     const int forced = env_int("OA_NN_SPLITS", 0);
@@ -157,12 +163,34 @@ int launch_nn(oa_ctx *c)
     if (c->ns <= 0) return OA_OK;
     dim3 grid(c->ns_pad / (oa::NN_THREADS * c->R), c->n_splits);
     dim3 block(oa::NN_THREADS);
-    switch (c->R) {
-    case 1: hipLaunchKernelGGL(oa::k_nn_search<1>, grid, block, 0, c->stream, c->d_state, c->d_src4, c->d_tg, c->groups_per_split, c->n_groups_pad, c->d_keys); break;
-    case 2: hipLaunchKernelGGL(oa::k_nn_search<2>, grid, block, 0, c->stream, c->d_state, c->d_src4, c->d_tg, c->groups_per_split, c->n_groups_pad, c->d_keys); break;
-    case 4: hipLaunchKernelGGL(oa::k_nn_search<4>, grid, block, 0, c->stream, c->d_state, c->d_src4, c->d_tg, c->groups_per_split, c->n_groups_pad, c->d_keys); break;
-    default: hipLaunchKernelGGL(oa::k_nn_search<8>, grid, block, 0, c->stream, c->d_state, c->d_src4, c->d_tg, c->groups_per_split, c->n_groups_pad, c->d_keys); break;
+#define OA_NN_ARGS c->d_state, c->d_src4, c->d_tg, c->groups_per_split, c->n_groups_pad, c->d_keys
+#define OA_NNF_ARGS c->d_state, c->d_src4, c->d_tg, c->d_tf, c->d_tgt_xyz, c->d_prev, c->groups_per_split, c->n_groups_pad, c->d_keys
+    if (c->filter_ok && c->use_filter) {
+        if (c->use_pk) {
+            switch (c->R) {
+            case 1: hipLaunchKernelGGL((oa::k_nn_search_filtered<1, true>), grid, block, 0, c->stream, OA_NNF_ARGS); break;
+            case 2: hipLaunchKernelGGL((oa::k_nn_search_filtered<2, true>), grid, block, 0, c->stream, OA_NNF_ARGS); break;
+            case 8: hipLaunchKernelGGL((oa::k_nn_search_filtered<8, true>), grid, block, 0, c->stream, OA_NNF_ARGS); break;
+            default: hipLaunchKernelGGL((oa::k_nn_search_filtered<4, true>), grid, block, 0, c->stream, OA_NNF_ARGS); break;
+            }
+        } else {
+            switch (c->R) {
+            case 1: hipLaunchKernelGGL((oa::k_nn_search_filtered<1, false>), grid, block, 0, c->stream, OA_NNF_ARGS); break;
+            case 2: hipLaunchKernelGGL((oa::k_nn_search_filtered<2, false>), grid, block, 0, c->stream, OA_NNF_ARGS); break;
+            case 8: hipLaunchKernelGGL((oa::k_nn_search_filtered<8, false>), grid, block, 0, c->stream, OA_NNF_ARGS); break;
+            default: hipLaunchKernelGGL((oa::k_nn_search_filtered<4, false>), grid, block, 0, c->stream, OA_NNF_ARGS); break;
+            }
+        }
+    } else {
+        switch (c->R) {
+        case 1: hipLaunchKernelGGL(oa::k_nn_search<1>, grid, block, 0, c->stream, OA_NN_ARGS); break;
+        case 2: hipLaunchKernelGGL(oa::k_nn_search<2>, grid, block, 0, c->stream, OA_NN_ARGS); break;
+        case 8: hipLaunchKernelGGL(oa::k_nn_search<8>, grid, block, 0, c->stream, OA_NN_ARGS); break;
+        default: hipLaunchKernelGGL(oa::k_nn_search<4>, grid, block, 0, c->stream, OA_NN_ARGS); break;
+        }
     }
+#undef OA_NN_ARGS
+#undef OA_NNF_ARGS
     HIPCHK(hipGetLastError());
     return OA_OK;
 }
@@ -173,10 +201,10 @@ int launch_accumulate(oa_ctx *c, bool emit, int *nn_idx, float *nn_d2)
     if (emit) {
         po.valid = c->d_valid; po.b = c->d_b; po.dist = c->d_dist; po.nn_idx = nn_idx; po.nn_d2 = nn_d2;
         hipLaunchKernelGGL(oa::k_pair_accumulate<true>, dim3(c->acc_blocks), dim3(oa::ACC_THREADS), 0, c->stream,
-                           c->d_state, c->d_src4, c->ns, c->d_tgt_xyz, c->d_keys, c->d_partials, po);
+                           c->d_state, c->d_src4, c->ns, c->d_tgt_xyz, c->d_keys, c->d_prev, c->d_partials, po);
     } else {
         hipLaunchKernelGGL(oa::k_pair_accumulate<false>, dim3(c->acc_blocks), dim3(oa::ACC_THREADS), 0, c->stream,
-                           c->d_state, c->d_src4, c->ns, c->d_tgt_xyz, c->d_keys, c->d_partials, po);
+                           c->d_state, c->d_src4, c->ns, c->d_tgt_xyz, c->d_keys, c->d_prev, c->d_partials, po);
     }
     HIPCHK(hipGetLastError());
     return OA_OK;
@@ -202,6 +230,9 @@ void init_loop_state(oa_ctx *c, const oa_settings *st, int iters)
     s.early_exit = st->early_exit ? 1 : 0;
     s.n = 0; s.converged = 0; s.status = 0; s.halt = (iters <= 0) ? 1 : 0;
     s.max_records = c->max_records; s.pad0 = 0;
+    for (int k = 0; k < 3; ++k) s.tc[k] = c->tc[k];
+    s.pad1 = 0.f;
+    s.qmax = c->qmax;
 }
 
 int begin_loop(oa_ctx *c, const oa_settings *st, int iters)
@@ -318,8 +349,10 @@ OA_EXPORT int oa_create(oa_ctx **out, int device)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fail(OA_E_HIP, "oa_create: %s", hipGetErrorString(e)); }
     c->stream = c->own_stream;
-    c->R = env_int("OA_NN_R", 8);
-    if (c->R != 1 && c->R != 2 && c->R != 4 && c->R != 8) c->R = 8;
+    c->R = env_int("OA_NN_R", 4);
+    if (c->R != 1 && c->R != 2 && c->R != 4 && c->R != 8) c->R = 4;
+    c->use_filter = env_int("OA_NN_FILTER", 1) != 0;
+    c->use_pk = env_int("OA_NN_PK", 1) != 0;
     *out = c;
     return OA_OK;
 }
@@ -329,7 +362,7 @@ OA_EXPORT void oa_destroy(oa_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    dev_free(c->d_tgt_xyz); dev_free(c->d_tg); dev_free(c->d_src4); dev_free(c->d_keys); dev_free(c->d_state);
+    dev_free(c->d_tgt_xyz); dev_free(c->d_tg); dev_free(c->d_tf); dev_free(c->d_prev); dev_free(c->d_src4); dev_free(c->d_keys); dev_free(c->d_state);
     dev_free(c->d_hist); dev_free(c->d_partials); dev_free(c->d_sums); dev_free(c->d_solve);
     dev_free(c->d_valid); dev_free(c->d_b); dev_free(c->d_dist); dev_free(c->d_counts); dev_free(c->d_offsets);
     dev_free(c->d_A); dev_free(c->d_B);
@@ -352,6 +385,51 @@ OA_EXPORT int oa_set_stream(oa_ctx *c, void *stream)
 // ================================================================================================
 // uploads
 // ================================================================================================
+namespace {
+// filter image for k_nn_search_filtered: bbox centre, centred -2q / |q|^2 arrays, max |q - centre|
+int build_filter(oa_ctx *c)
+{
+    c->filter_ok = false;
+    const int nb = 256;
+    float *d_bb = nullptr;
+    double *d_mx = nullptr;
+    HIPCHK(hipMalloc(&d_bb, sizeof(float) * 6 * nb));
+    hipLaunchKernelGGL(oa::k_bbox_partial, dim3(nb), dim3(256), 0, c->stream, c->d_tgt_xyz, c->nt, d_bb);
+    std::vector<float> bb(6 * nb);
+    hipError_t e = hipMemcpyAsync(bb.data(), d_bb, sizeof(float) * 6 * nb, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dev_free(d_bb);
+    if (e != hipSuccess) return fail(OA_E_HIP, "build_filter: %s", hipGetErrorString(e));
+    double lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    bool finite = true;
+    for (int b = 0; b < nb; ++b)
+        for (int a = 0; a < 3; ++a) {
+            const float l = bb[6 * b + a], h = bb[6 * b + 3 + a];
+            if (l != l || h != h) finite = false;
+            if (l < lo[a]) lo[a] = l;
+            if (h > hi[a]) hi[a] = h;
+        }
+    for (int a = 0; a < 3; ++a) if (!(lo[a] <= hi[a]) || !(fabs(lo[a]) < 1e18) || !(fabs(hi[a]) < 1e18)) finite = false;
+    if (!finite) return OA_OK;                                   // exact kernel only
+    for (int a = 0; a < 3; ++a) c->tc[a] = (float)(0.5 * (lo[a] + hi[a]));
+    const int blocks = (c->n_groups_pad + 255) / 256;
+    HIPCHK(hipMalloc(&c->d_tf, sizeof(float4) * 4 * (size_t)c->n_groups_pad));
+    e = hipMalloc(&d_mx, sizeof(double) * (size_t)blocks);
+    if (e != hipSuccess) return fail(OA_E_HIP, "build_filter: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(oa::k_pack_filter, dim3(blocks), dim3(256), 0, c->stream, c->d_tgt_xyz, c->nt, c->n_groups_pad,
+                       c->tc[0], c->tc[1], c->tc[2], c->d_tf, d_mx);
+    std::vector<double> mx((size_t)blocks);
+    e = hipMemcpyAsync(mx.data(), d_mx, sizeof(double) * (size_t)blocks, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dev_free(d_mx);
+    if (e != hipSuccess) return fail(OA_E_HIP, "build_filter: %s", hipGetErrorString(e));
+    double m = 0.0;
+    for (double v : mx) if (v > m) m = v;
+    c->qmax = sqrt(m) * (1.0 + 1e-6);
+    c->filter_ok = (c->qmax < 1e18);
+    return OA_OK;
+}
+}  // namespace
 OA_EXPORT int oa_set_target(oa_ctx *c, const float *xyz, int64_t n, int on_device)
 {
     if (!c) return fail(OA_E_BAD_ARG, "null context");
@@ -360,9 +438,14 @@ OA_EXPORT int oa_set_target(oa_ctx *c, const float *xyz, int64_t n, int on_devic
     int rc = use_device(c);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
-    dev_free(c->d_tgt_xyz); dev_free(c->d_tg);
+    dev_free(c->d_tgt_xyz); dev_free(c->d_tg); dev_free(c->d_tf);
+    c->filter_ok = false;
     c->nt = (int)n;
     c->n_groups_pad = 0;
+    if (c->d_prev) {   // seeds index the old target
+        hipLaunchKernelGGL(oa::k_fill_int, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, c->d_prev, c->ns_pad, -1);
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
     if (n == 0) return OA_OK;
     HIPCHK(hipMalloc(&c->d_tgt_xyz, sizeof(float) * 3 * (size_t)n));
     HIPCHK(hipMemcpyAsync(c->d_tgt_xyz, xyz, sizeof(float) * 3 * (size_t)n,
@@ -375,6 +458,8 @@ OA_EXPORT int oa_set_target(oa_ctx *c, const float *xyz, int64_t n, int on_devic
                        c->nt, c->n_groups_pad, c->d_tg);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
+    int rcf = build_filter(c);
+    if (rcf) return rcf;
     plan_geometry(c);
     return OA_OK;
 }
@@ -401,7 +486,7 @@ OA_EXPORT int oa_set_source(oa_ctx *c, const float *xyz, int64_t n_verts, int on
     int rc = use_device(c);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
-    dev_free(c->d_src4); dev_free(c->d_keys);
+    dev_free(c->d_src4); dev_free(c->d_keys); dev_free(c->d_prev);
     dev_free(c->d_valid); dev_free(c->d_b); dev_free(c->d_dist); dev_free(c->d_counts); dev_free(c->d_offsets);
     dev_free(c->d_A); dev_free(c->d_B);
     c->emit_cap = 0;
@@ -411,6 +496,8 @@ OA_EXPORT int oa_set_source(oa_ctx *c, const float *xyz, int64_t n_verts, int on
     if (c->ns_pad == 0) c->ns_pad = chunk;
     HIPCHK(hipMalloc(&c->d_src4, sizeof(float4) * (size_t)c->ns_pad));
     HIPCHK(hipMalloc(&c->d_keys, sizeof(unsigned long long) * (size_t)c->ns_pad));
+    HIPCHK(hipMalloc(&c->d_prev, sizeof(int) * (size_t)c->ns_pad));
+    hipLaunchKernelGGL(oa::k_fill_int, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, c->d_prev, c->ns_pad, -1);
     c->pivot[0] = c->pivot[1] = c->pivot[2] = 0.0;
     if (n_sel > 0) {
         const float *d_xyz = xyz;

@@ -45,6 +45,9 @@ struct DevState {
     int32_t iters, use_target, with_scale, early_exit;
     int32_t n, converged, status, halt;
     int32_t max_records, pad0;
+    // conservative-filter data (k_nn_search_filtered): target bbox centre and max |q - centre|
+    float  tc[3], pad1;
+    double qmax;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -257,6 +260,12 @@ __global__ void k_fill_keys(unsigned long long *keys, int n)
     if (i < n) keys[i] = KEY_EMPTY;
 }
 
+__global__ void k_fill_int(int *a, int n, int v)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = v;
+}
+
 // (d2, idx) keys -> separate arrays (first n_out entries); resets all n keys for the next search
 __global__ void k_decode_keys(unsigned long long *__restrict__ keys, int n, int n_out, long long *__restrict__ idx,
                               float *__restrict__ d2)
@@ -367,6 +376,244 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_search(const DevState *__rest
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_nn_search_filtered : same answers as k_nn_search, ~4 VALU ops per pair instead of ~6.8
+// ------------------------------------------------------------------------------------------------
+// Idea: a cheap score that can only be used to PROVE "this target cannot win or tie", never to pick a winner.
+//   centred coordinates   qh = fl32(q - c),  ph = fl32(p - c)          (c = centre of the target bbox)
+//   score                 s_j = fma(ph.x, -2qh.x, fma(ph.y, -2qh.y, fma(ph.z, -2qh.z, w_j))),  w_j = fl32(|qh_j|^2)
+//                         ~ |ph - qh_j|^2 - |ph|^2                      (3 fma per pair instead of 3 sub + mul + 2 fma)
+//   threshold             T = round_up( best*(1+16u) + 16u*G^2 - |ph|^2 + 1e-30 ),  G = |ph| + max_j |qh_j|,  u = 2^-24
+// Claim: s_j > T  implies  d2_metric(p, q_j) > best  (strictly), so a group of 4 targets whose smallest score exceeds
+// T is skipped; every other group takes the exact path (difference-form d2, lexicographic (d2, index) update).
+// Proof sketch (full derivation in DESIGN.md): |s_j - S_j| <= 4.01u G^2 (three fma roundings + the rounding of w_j);
+// centring moves |ph-qh_j| by at most 1.01u G; the exact metric is within a factor (1 +- 5.01u) of the real squared
+// distance.  8u would already suffice for both terms; 16u is used.  T is rounded towards +inf.
+// Targets/queries with non-finite or astronomically large coordinates disable the filter on the host side
+// (k_nn_search is used instead).
+//
+// Seeding: `prev` holds each point's nearest index from the previous ICP iteration; its exact distance under the
+// new transform is a valid upper bound for the minimum, so the scan starts with a tight threshold and the exact
+// path is taken only for real improvements and near-ties.  Any seed gives the same final answer.
+constexpr double FILTER_K = 16.0 * 5.9604644775390625e-08;   // 16 u
+constexpr double FILTER_ABS = 1e-30;
+constexpr int FTILE_GROUPS = 256;                            // groups per LDS tile: 256 x 64 B = 16 KiB
+
+__device__ __forceinline__ float round_up_to_float(double x)
+{
+    float f = (float)x;
+    if ((double)f < x) {                                      // nextafter(f, +inf)
+        uint32_t b = __float_as_uint(f);
+        if (f > 0.f) b += 1u;
+        else if (f < 0.f) b -= 1u;
+        else b = 1u;
+        f = __uint_as_float(b);
+    }
+    return f;
+}
+
+__device__ __forceinline__ float filter_threshold(float best, float phx, float phy, float phz, double qmax)
+{
+    if (!(best < INFINITY)) return INFINITY;                  // nothing known yet: nothing can be skipped
+    const double P = (double)phx * (double)phx + (double)phy * (double)phy + (double)phz * (double)phz;
+    const double G = sqrt(P) * (1.0 + 1e-12) + qmax;
+    const double T = (double)best * (1.0 + FILTER_K) + FILTER_K * G * G - P + FILTER_ABS;
+    return round_up_to_float(T);
+}
+
+// filter image of the target: per group of 4 vertices [ax0..3][ay0..3][az0..3][w0..3]; padding can never pass
+__global__ void k_pack_filter(const float *__restrict__ xyz, int nt, int n_groups_pad, float cx, float cy, float cz,
+                              float4 *__restrict__ tf, double *__restrict__ block_max_q2)
+{
+    __shared__ double red[4];
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    double mx = 0.0;
+    if (g < n_groups_pad) {
+        float a[3][4], w[4];
+        for (int k = 0; k < 4; ++k) {
+            const long long v = 4ll * g + k;
+            if (v < nt) {
+                const float qx = (float)((double)xyz[3 * v] - (double)cx);
+                const float qy = (float)((double)xyz[3 * v + 1] - (double)cy);
+                const float qz = (float)((double)xyz[3 * v + 2] - (double)cz);
+                const double q2 = (double)qx * (double)qx + (double)qy * (double)qy + (double)qz * (double)qz;
+                a[0][k] = -2.0f * qx; a[1][k] = -2.0f * qy; a[2][k] = -2.0f * qz;
+                w[k] = (float)q2;
+                if (q2 > mx) mx = q2;
+            } else {
+                a[0][k] = 0.f; a[1][k] = 0.f; a[2][k] = 0.f; w[k] = 3.0e38f;   // score = 3e38 > any threshold
+            }
+        }
+        for (int c = 0; c < 3; ++c) tf[4ll * g + c] = make_float4(a[c][0], a[c][1], a[c][2], a[c][3]);
+        tf[4ll * g + 3] = make_float4(w[0], w[1], w[2], w[3]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_down(mx, off, 64); mx = o > mx ? o : mx; }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m = red[0];
+        for (int k = 1; k < (int)(blockDim.x >> 6); ++k) m = red[k] > m ? red[k] : m;
+        block_max_q2[blockIdx.x] = m;
+    }
+}
+
+// per-block bounding box of the target (min xyz, max xyz); NaN-poisoned if any coordinate is not finite
+__global__ void k_bbox_partial(const float *__restrict__ xyz, int nt, float *__restrict__ out /* blocks x 6 */)
+{
+    __shared__ float red[4][6];
+    float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    bool bad = false;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nt; i += gridDim.x * blockDim.x)
+        for (int a = 0; a < 3; ++a) {
+            const float v = xyz[3ll * i + a];
+            if (!(fabsf(v) < INFINITY)) bad = true;
+            lo[a] = fminf(lo[a], v); hi[a] = fmaxf(hi[a], v);
+        }
+    if (bad) { lo[0] = NAN; hi[0] = NAN; }
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float l = __shfl_down(lo[a], off, 64), h = __shfl_down(hi[a], off, 64);
+            lo[a] = (l != l || lo[a] != lo[a]) ? NAN : fminf(lo[a], l);
+            hi[a] = (h != h || hi[a] != hi[a]) ? NAN : fmaxf(hi[a], h);
+        }
+    }
+    if ((threadIdx.x & 63) == 0)
+        for (int a = 0; a < 3; ++a) { red[threadIdx.x >> 6][a] = lo[a]; red[threadIdx.x >> 6][3 + a] = hi[a]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int a = threadIdx.x;
+        float v = red[0][a];
+        for (int k = 1; k < (int)(blockDim.x >> 6); ++k) {
+            const float o = red[k][a];
+            v = (o != o || v != v) ? NAN : (a < 3 ? fminf(v, o) : fmaxf(v, o));
+        }
+        out[blockIdx.x * 6 + a] = v;
+    }
+}
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+template <int R, bool PK>
+__global__ __launch_bounds__(NN_THREADS) void k_nn_search_filtered(const DevState *__restrict__ st,
+                                                                   const float4 *__restrict__ src4,
+                                                                   const float4 *__restrict__ tg,
+                                                                   const float4 *__restrict__ tf,
+                                                                   const float *__restrict__ tgt_xyz,
+                                                                   const int *__restrict__ prev, int groups_per_split,
+                                                                   int n_groups_pad,
+                                                                   unsigned long long *__restrict__ keys)
+{
+    if (st->halt) return;
+    __shared__ float4 tile[2][FTILE_GROUPS * 4];
+    const int tid = threadIdx.x;
+    const int base = blockIdx.x * (NN_THREADS * R);
+    const double qmax = st->qmax;
+    const float cx = st->tc[0], cy = st->tc[1], cz = st->tc[2];
+
+    float px[R], py[R], pz[R], hx[R], hy[R], hz[R], best[R], thr[R];
+    uint32_t bidx[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = base + r * NN_THREADS + tid;
+        const float4 p = src4[i];
+        float wx, wy, wz;
+        m4_mul_v3(st->mx1, p.x, p.y, p.z, wx, wy, wz);
+        m4_mul_v3(st->imx2, wx, wy, wz, px[r], py[r], pz[r]);    // co_find (general.py:287)
+        hx[r] = (float)((double)px[r] - (double)cx);
+        hy[r] = (float)((double)py[r] - (double)cy);
+        hz[r] = (float)((double)pz[r] - (double)cz);
+        best[r] = INFINITY;
+        bidx[r] = IDX_NONE;
+        const int s = prev ? prev[i] : -1;
+        if (s >= 0) {                                           // seed: last iteration's nearest vertex
+            const float d = d2_metric(px[r], py[r], pz[r], tgt_xyz[3ll * s], tgt_xyz[3ll * s + 1], tgt_xyz[3ll * s + 2]);
+            if (d < INFINITY) { best[r] = d; bidx[r] = (uint32_t)s; }
+        }
+        thr[r] = filter_threshold(best[r], hx[r], hy[r], hz[r], qmax);
+    }
+
+    const int g_begin = blockIdx.y * groups_per_split;
+    int g_end = g_begin + groups_per_split;
+    if (g_end > n_groups_pad) g_end = n_groups_pad;
+    const int n_tiles = (g_end - g_begin) / FTILE_GROUPS;
+    const float4 *tsrc = tf + 4ll * g_begin;
+
+    float4 s0 = tsrc[tid], s1 = tsrc[NN_THREADS + tid], s2 = tsrc[2 * NN_THREADS + tid], s3 = tsrc[3 * NN_THREADS + tid];
+    tile[0][tid] = s0; tile[0][NN_THREADS + tid] = s1; tile[0][2 * NN_THREADS + tid] = s2; tile[0][3 * NN_THREADS + tid] = s3;
+    __syncthreads();
+
+    for (int t = 0; t < n_tiles; ++t) {
+        const int cur = t & 1;
+        const bool more = (t + 1 < n_tiles);
+        if (more) {
+            const float4 *nsrc = tsrc + 4ll * FTILE_GROUPS * (t + 1);
+            s0 = nsrc[tid]; s1 = nsrc[NN_THREADS + tid]; s2 = nsrc[2 * NN_THREADS + tid]; s3 = nsrc[3 * NN_THREADS + tid];
+        }
+        const int gbase = g_begin + t * FTILE_GROUPS;
+        // register double-buffer of the broadcast LDS reads: group g+1 is in flight while group g is evaluated
+        float4 nAX = tile[cur][0], nAY = tile[cur][1], nAZ = tile[cur][2], nW = tile[cur][3];
+#pragma unroll 2
+        for (int g = 0; g < FTILE_GROUPS; ++g) {
+            const float4 AX = nAX, AY = nAY, AZ = nAZ, W = nW;
+            {
+                const int gn = (g + 1) & (FTILE_GROUPS - 1);      // wraps on the last group (value unused)
+                nAX = tile[cur][4 * gn]; nAY = tile[cur][4 * gn + 1]; nAZ = tile[cur][4 * gn + 2]; nW = tile[cur][4 * gn + 3];
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float c0, c1, c2, c3;
+                if (PK) {      // two targets per v_pk_fma_f32 (same per-lane IEEE fma; fewer issue slots' worth of power)
+                    const v2f X = { hx[r], hx[r] }, Y = { hy[r], hy[r] }, Z = { hz[r], hz[r] };
+                    const v2f q0 = __builtin_elementwise_fma(X, v2f{ AX.x, AX.y }, __builtin_elementwise_fma(Y, v2f{ AY.x, AY.y },
+                                   __builtin_elementwise_fma(Z, v2f{ AZ.x, AZ.y }, v2f{ W.x, W.y })));
+                    const v2f q1 = __builtin_elementwise_fma(X, v2f{ AX.z, AX.w }, __builtin_elementwise_fma(Y, v2f{ AY.z, AY.w },
+                                   __builtin_elementwise_fma(Z, v2f{ AZ.z, AZ.w }, v2f{ W.z, W.w })));
+                    c0 = q0.x; c1 = q0.y; c2 = q1.x; c3 = q1.y;
+                } else {
+                    c0 = __builtin_fmaf(hx[r], AX.x, __builtin_fmaf(hy[r], AY.x, __builtin_fmaf(hz[r], AZ.x, W.x)));
+                    c1 = __builtin_fmaf(hx[r], AX.y, __builtin_fmaf(hy[r], AY.y, __builtin_fmaf(hz[r], AZ.y, W.y)));
+                    c2 = __builtin_fmaf(hx[r], AX.z, __builtin_fmaf(hy[r], AY.z, __builtin_fmaf(hz[r], AZ.z, W.z)));
+                    c3 = __builtin_fmaf(hx[r], AX.w, __builtin_fmaf(hy[r], AY.w, __builtin_fmaf(hz[r], AZ.w, W.w)));
+                }
+                const float m = __builtin_fminf(__builtin_fminf(c0, c1), __builtin_fminf(c2, c3));
+                if (!(m > thr[r])) {                              // cannot be ruled out: exact path
+                    const float4 *eg = tg + 3ll * (gbase + g);
+                    const float4 X = eg[0], Y = eg[1], Z = eg[2];
+                    const uint32_t j = (uint32_t)(gbase + g) * 4u;
+                    const float e0 = d2_metric(px[r], py[r], pz[r], X.x, Y.x, Z.x);
+                    const float e1 = d2_metric(px[r], py[r], pz[r], X.y, Y.y, Z.y);
+                    const float e2 = d2_metric(px[r], py[r], pz[r], X.z, Y.z, Z.z);
+                    const float e3 = d2_metric(px[r], py[r], pz[r], X.w, Y.w, Z.w);
+                    float b = best[r];
+                    uint32_t bi = bidx[r];
+                    if (e0 < b || (e0 == b && j < bi)) { b = e0; bi = j; }
+                    if (e1 < b || (e1 == b && j + 1u < bi)) { b = e1; bi = j + 1u; }
+                    if (e2 < b || (e2 == b && j + 2u < bi)) { b = e2; bi = j + 2u; }
+                    if (e3 < b || (e3 == b && j + 3u < bi)) { b = e3; bi = j + 3u; }
+                    if (b < best[r]) thr[r] = filter_threshold(b, hx[r], hy[r], hz[r], qmax);
+                    best[r] = b;
+                    bidx[r] = bi;
+                }
+            }
+        }
+        if (more) {
+            tile[cur ^ 1][tid] = s0; tile[cur ^ 1][NN_THREADS + tid] = s1;
+            tile[cur ^ 1][2 * NN_THREADS + tid] = s2; tile[cur ^ 1][3 * NN_THREADS + tid] = s3;
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const unsigned long long key = ((unsigned long long)__float_as_uint(best[r]) << 32) | bidx[r];
+        unsigned long long *dst = keys + base + r * NN_THREADS + tid;
+        if (gridDim.y == 1) *dst = key;
+        else atomicMin(dst, key);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_pair_accumulate
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double wave_sum(double v)
@@ -389,6 +636,7 @@ __global__ __launch_bounds__(ACC_THREADS) void k_pair_accumulate(const DevState 
                                                                  const float4 *__restrict__ src4, int ns,
                                                                  const float *__restrict__ tgt_xyz,
                                                                  unsigned long long *__restrict__ keys,
+                                                                 int *__restrict__ prev,
                                                                  double *__restrict__ partials, PairOut out)
 {
     __shared__ double red[ACC_THREADS / 64][NSUMS];
@@ -404,6 +652,7 @@ __global__ __launch_bounds__(ACC_THREADS) void k_pair_accumulate(const DevState 
             const unsigned long long key = keys[i];
             keys[i] = KEY_EMPTY;                                   // ready for the next iteration's atomicMin
             const uint32_t idx = (uint32_t)key;
+            if (prev) prev[i] = (idx == IDX_NONE) ? -1 : (int)idx;  // seed for the next iteration's filtered search
             bool valid = false;
             float bx = 0.f, by = 0.f, bz = 0.f;
             double dist = 0.0;

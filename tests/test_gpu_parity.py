@@ -108,11 +108,12 @@ def test_nn_search_ties_lowest_index(eng, orc):
     assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2)
 
 
-@pytest.mark.parametrize("R,splits", [(1, 0), (2, 3), (8, 0), (4, 7)])
-def test_nn_search_geometry_variants(orc, R, splits, monkeypatch):
-    """Points-per-thread and target-split variants (atomicMin merge) give the same answers."""
+@pytest.mark.parametrize("R,splits,filt", [(1, 0, 1), (2, 3, 1), (8, 0, 1), (4, 7, 1), (4, 0, 0), (8, 5, 0)])
+def test_nn_search_geometry_variants(orc, R, splits, filt, monkeypatch):
+    """Points-per-thread, target-split (atomicMin merge) and filtered/unfiltered kernels give the same answers."""
     from object_alignment_amd.engine import IcpEngine
     monkeypatch.setenv("OA_NN_R", str(R))
+    monkeypatch.setenv("OA_NN_FILTER", str(filt))
     if splits:
         monkeypatch.setenv("OA_NN_SPLITS", str(splits))
     rng = np.random.default_rng(R * 10 + splits)
@@ -126,6 +127,55 @@ def test_nn_search_geometry_variants(orc, R, splits, monkeypatch):
         idx, d2, _ = e.nn_search()
     ridx, rd2 = orc.nn_brute(src, tgt)
     assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2)
+
+
+@pytest.mark.parametrize("case", ["far_offset", "lattice_jitter", "query_outside", "flat_plane", "tiny_scale",
+                                  "huge_scale", "seeded_second_pass"])
+def test_nn_filter_adversarial(orc, case):
+    """Inputs chosen to stress the conservative filter of k_nn_search_filtered: it may only ever skip targets that
+    provably lose, so the answers must stay bit-identical to the oracle's brute force."""
+    from object_alignment_amd.engine import IcpEngine
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
+    nt, ns = 20000, 6000
+    eye = np.identity(4, dtype=np.float32)
+    mxa = eye.copy()
+    if case == "far_offset":                      # cloud extent 1 at distance 1000 from the origin
+        tgt = (rng.uniform(-0.5, 0.5, size=(nt, 3)) + [1000.0, -2000.0, 500.0]).astype(np.float32)
+        src = (rng.uniform(-0.5, 0.5, size=(ns, 3)) + [1000.0, -2000.0, 500.0]).astype(np.float32)
+    elif case == "lattice_jitter":                # near-ties everywhere: lattice + 1e-6 jitter
+        tgt = (rng.integers(-8, 9, size=(nt, 3)) * 0.125 + rng.normal(0, 1e-6, size=(nt, 3))).astype(np.float32)
+        src = (rng.integers(-8, 8, size=(ns, 3)) * 0.125 + 0.0625).astype(np.float32)
+    elif case == "query_outside":                 # queries far outside the target bounding box
+        tgt = rng.uniform(-1, 1, size=(nt, 3)).astype(np.float32)
+        src = (rng.normal(size=(ns, 3)) * 50.0).astype(np.float32)
+    elif case == "flat_plane":                    # degenerate bbox (zero thickness), duplicates
+        tgt = rng.uniform(-1, 1, size=(nt, 3)).astype(np.float32)
+        tgt[:, 2] = 0.25
+        tgt[::7] = tgt[3]
+        src = rng.uniform(-1, 1, size=(ns, 3)).astype(np.float32)
+    elif case == "tiny_scale":
+        tgt = (rng.uniform(-1, 1, size=(nt, 3)) * 1e-12).astype(np.float32)
+        src = (rng.uniform(-1, 1, size=(ns, 3)) * 1e-12).astype(np.float32)
+    elif case == "huge_scale":
+        tgt = (rng.uniform(-1, 1, size=(nt, 3)) * 1e12).astype(np.float32)
+        src = (rng.uniform(-1, 1, size=(ns, 3)) * 1e12).astype(np.float32)
+    else:
+        tgt = rng.uniform(-1, 1, size=(nt, 3)).astype(np.float32)
+        src = rng.uniform(-1, 1, size=(ns, 3)).astype(np.float32)
+    with IcpEngine(0) as e:
+        e.set_target(tgt)
+        e.set_source(src)
+        e.set_matrices(mxa, eye)
+        if case == "seeded_second_pass":
+            # a full iteration stores every point's nearest index as the seed of the next search; then move the cloud
+            e.iterate(thresh=10.0)
+            mxa = e.matrix_world()
+            mxa[:3, 3] += np.float32(0.013)
+            e.set_matrices(mxa, eye)
+        idx, d2, _ = e.nn_search()
+    ridx, rd2 = orc.nn_brute(_cofind(orc, src, mxa, eye), tgt)
+    assert np.array_equal(idx, ridx)
+    assert np.array_equal(d2, rd2)
 
 
 def test_nn_search_full_size_self_match(eng):
