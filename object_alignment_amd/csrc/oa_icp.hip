@@ -111,6 +111,7 @@ void plan_geometry(oa_ctx *c)
     const int want = env_int("OA_NN_TARGET_BLOCKS", c->n_cu * 64);
     int splits = (want + src_blocks - 1) / src_blocks;
     splits = std::max(1, std::min(splits, tiles_total));
+    if (splits > 8) splits = std::min(tiles_total, ((splits + 7) / 8) * 8);   // multiple of 8: one XCD per split residue
     const int forced = env_int("OA_NN_SPLITS", 0);
     if (forced > 0) splits = std::min(forced, tiles_total);
     const int tiles_per_split = (tiles_total + splits - 1) / splits;
@@ -161,7 +162,9 @@ int check_ready(oa_ctx *c)
 int launch_nn(oa_ctx *c)
 {
     if (c->ns <= 0) return OA_OK;
-    dim3 grid(c->ns_pad / (oa::NN_THREADS * c->R), c->n_splits);
+    if (c->ns_pad / (oa::NN_THREADS * c->R) > 65535)
+        return fail(OA_E_BAD_ARG, "shard of %d points exceeds the launch grid (use more shards or OA_NN_R=8)", c->ns);
+    dim3 grid(c->n_splits, c->ns_pad / (oa::NN_THREADS * c->R));
     dim3 block(oa::NN_THREADS);
 #define OA_NN_ARGS c->d_state, c->d_src4, c->d_tg, c->groups_per_split, c->n_groups_pad, c->d_keys
 #define OA_NNF_ARGS c->d_state, c->d_src4, c->d_tg, c->d_tf, c->d_tgt_xyz, c->d_prev, c->groups_per_split, c->n_groups_pad, c->d_keys

@@ -283,7 +283,9 @@ __global__ void k_decode_keys(unsigned long long *__restrict__ keys, int n, int 
 // ------------------------------------------------------------------------------------------------
 // k_nn_search
 // ------------------------------------------------------------------------------------------------
-// grid = (ns_pad / (256*R), n_splits).  Each thread owns R source points (registers); the workgroup streams its
+// grid = (n_splits, ns_pad / (256*R)): the split index is the FAST grid dimension, so with n_splits a multiple of 8
+// the dispatcher's block -> XCD round-robin (block b on XCD b % 8) pins each target split to one XCD and that XCD's
+// 4 MiB L2 keeps its 1/8 of the target image resident for the whole launch.  Each thread owns R source points (registers); the workgroup streams its
 // split of the target through a double-buffered LDS tile.  All 64 lanes of a wave read the SAME LDS address
 // (broadcast, conflict-free), so one ds_read_b128 feeds 4 targets x R points x 64 lanes = 256 R pair evaluations.
 //
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_search(const DevState *__rest
     if (st->halt) return;
     __shared__ float4 tile[2][TILE_GROUPS * 3];
     const int tid = threadIdx.x;
-    const int base = blockIdx.x * (NN_THREADS * R);
+    const int base = blockIdx.y * (NN_THREADS * R);
 
     float px[R], py[R], pz[R], best[R];
     uint32_t bidx[R];
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_search(const DevState *__rest
         bidx[r] = IDX_NONE;
     }
 
-    const int g_begin = blockIdx.y * groups_per_split;
+    const int g_begin = blockIdx.x * groups_per_split;
     int g_end = g_begin + groups_per_split;
     if (g_end > n_groups_pad) g_end = n_groups_pad;
     const int n_tiles = (g_end - g_begin) / TILE_GROUPS;           // splits are whole tiles by construction
@@ -370,7 +372,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_search(const DevState *__rest
     for (int r = 0; r < R; ++r) {
         const unsigned long long key = ((unsigned long long)__float_as_uint(best[r]) << 32) | bidx[r];
         unsigned long long *dst = keys + base + r * NN_THREADS + tid;
-        if (gridDim.y == 1) *dst = key;
+        if (gridDim.x == 1) *dst = key;
         else atomicMin(dst, key);                                  // (d2, idx) lexicographic: lowest index on ties
     }
 }
@@ -507,7 +509,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_search_filtered(const DevStat
     if (st->halt) return;
     __shared__ float4 tile[2][FTILE_GROUPS * 4];
     const int tid = threadIdx.x;
-    const int base = blockIdx.x * (NN_THREADS * R);
+    const int base = blockIdx.y * (NN_THREADS * R);
     const double qmax = st->qmax;
     const float cx = st->tc[0], cy = st->tc[1], cz = st->tc[2];
 
@@ -533,7 +535,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_search_filtered(const DevStat
         thr[r] = filter_threshold(best[r], hx[r], hy[r], hz[r], qmax);
     }
 
-    const int g_begin = blockIdx.y * groups_per_split;
+    const int g_begin = blockIdx.x * groups_per_split;
     int g_end = g_begin + groups_per_split;
     if (g_end > n_groups_pad) g_end = n_groups_pad;
     const int n_tiles = (g_end - g_begin) / FTILE_GROUPS;
@@ -608,7 +610,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_search_filtered(const DevStat
     for (int r = 0; r < R; ++r) {
         const unsigned long long key = ((unsigned long long)__float_as_uint(best[r]) << 32) | bidx[r];
         unsigned long long *dst = keys + base + r * NN_THREADS + tid;
-        if (gridDim.y == 1) *dst = key;
+        if (gridDim.x == 1) *dst = key;
         else atomicMin(dst, key);
     }
 }
