@@ -101,6 +101,7 @@ def main():
     src, tgt, mxa, mxb = synth.c3_random_pair(args.n_source, seed=1234, n_target=args.n_target)
     eng = IcpEngine(local_rank)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng.set_search_mode("brute")          # the north-star kernel: LDS-tiled brute force (grid path measured below)
     t0 = time.perf_counter()
     eng.set_target(tgt)
     eng.set_source(src, stride=1, shard_index=rank, shard_count=world)
@@ -114,21 +115,37 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # warmup (untimed), then restart from the initial pose so the timed run is the config's run
-    if args.warmup > 0:
+    def timed(steps, warmup):
+        """W untimed + exactly `steps` timed iterations from the initial pose; max over ranks."""
+        if warmup > 0:
+            eng.set_matrices(mxa, mxb)
+            run_sharded(EngineShard(eng, iters=warmup, **kw), warmup, sums, world_size=world)
         eng.set_matrices(mxa, mxb)
-        run_sharded(EngineShard(eng, iters=args.warmup, **kw), args.warmup, sums, world_size=world)
-    eng.set_matrices(mxa, mxb)
-    barrier()
-    t0 = time.perf_counter()
-    res = run_sharded(EngineShard(eng, iters=args.steps, **kw), args.steps, sums, world_size=world)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    nn_ms = res.nn_ms_total / max(1, args.steps)
-    if world > 1:
-        t = torch.tensor([elapsed, nn_ms], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, nn_ms = float(t[0]), float(t[1])
+        barrier()
+        t0 = time.perf_counter()
+        r = run_sharded(EngineShard(eng, iters=steps, **kw), steps, sums, world_size=world)
+        barrier()
+        dt = time.perf_counter() - t0
+        ms = r.nn_ms_total / max(1, steps)
+        if world > 1:
+            t = torch.tensor([dt, ms], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt, ms = float(t[0]), float(t[1])
+        return r, dt, ms
+
+    res, elapsed, nn_ms = timed(args.steps, args.warmup)
+
+    # SURVEY 8f rank 2 ("next" row, reported beside the headline, never instead of it): the same run with the
+    # uniform-grid exact search.  Correspondences are identical, so the final matrix must be bitwise the same.
+    grid = None
+    try:
+        eng.set_search_mode("grid")
+        g_steps = max(args.steps, 200)
+        gres, g_elapsed, g_nn_ms = timed(g_steps, max(args.warmup, 5))
+        gcheck, _, _ = timed(args.steps, 0)
+        grid = (g_steps, g_elapsed, g_nn_ms, bool(np.array_equal(gcheck.matrix_world, res.matrix_world)))
+    except Exception as exc:                                  # never lose the headline line
+        grid = ("error: %r" % (exc,),)
 
     if rank == 0:
         assert res.iters_done == args.steps, (res.iters_done, args.steps)
@@ -167,6 +184,21 @@ def main():
             "upload_ms": 1e3 * upload_s,
             "loop_ms_hipevents": res.loop_ms,
         }
+        if grid is not None and len(grid) == 4:
+            g_steps, g_elapsed, g_nn_ms, same = grid
+            g_bytes = 28.0 * ns_local + 16.0 * args.n_target        # source float4 + key + seed, sorted target image
+            out["grid_path"] = {
+                "what": "SURVEY 8f rank 2 (next row): k_nn_search_grid, exact uniform-grid search, same correspondences",
+                "value": g_steps / g_elapsed, "unit": "iterations/s", "steps": g_steps,
+                "ms_per_step": 1e3 * g_elapsed / g_steps, "ms_per_nn_search": g_nn_ms,
+                "final_matrix_bitwise_equal_to_brute_force": same,
+                "roofline": {"bound": "hbm", "achieved": g_bytes / (g_nn_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": g_bytes / (g_nn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "algorithmic_bytes_per_launch": g_bytes, "traffic": None,
+                             "note": "latency-bound dependent lookups (cell range -> vertices); not a streaming kernel"},
+            }
+        elif grid is not None:
+            out["grid_path"] = {"error": grid[0]}
         prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(prof):
             try:

@@ -1,0 +1,167 @@
+// oa_grid.hpp -- exact nearest-vertex search through a uniform grid.
+//
+// Same answers as k_nn_search (bit-identical (d2, index) per source point): candidates are evaluated with the same
+// fp32 difference-form metric on the ORIGINAL coordinates and merged lexicographically on (d2, original index); the
+// grid only decides which vertices need not be looked at, through a conservative bound.
+//
+// Build (once per target): bounding box -> cell ids -> histogram (atomics) -> exclusive scan -> scatter into
+// `sorted` (float4 {x, y, z, bits(original index)}), cells laid out x-fastest so a run of cells along x is one
+// contiguous range of `sorted`.
+//
+// Query (one thread per source point): project the query onto the grid's box (pc), search the cube of cells within
+// Chebyshev radius r = 0, 1, 2, ... around pc's cell.  Every vertex not yet seen lies outside that cube, hence at
+// real distance >= sqrt(|p - pc|^2 + m^2), m = distance from pc to the nearest cube face that is interior to the
+// grid.  The metric satisfies d2 >= D (1 - 5.01 u); the loop stops when (|p-pc|^2 + m^2)(1 - 1e-5) > best, i.e. no
+// unseen vertex can beat OR tie the current best.  Queries not settled within `r_max` rings are appended to a list and
+// finished by the brute-force kernel (k_nn_search_filtered in list mode), so the result is exact for any input.
+#pragma once
+#include "oa_kernels.hpp"
+
+namespace oa {
+
+struct GridParams {
+    double lo[3], hi[3];     // bounding box of the target
+    double h, inv_h;         // cell edge
+    int    n[3];             // cells per axis
+    int    r_max;            // rings searched before handing the query to the brute-force kernel
+    double slack;            // absolute slack subtracted from face distances (1e-10 x largest |coordinate|)
+};
+
+#if defined(__HIPCC__)
+
+__device__ __forceinline__ int grid_cell_coord(double q, double lo, double inv_h, int n)
+{
+    int k = (int)floor((q - lo) * inv_h);
+    k = k < 0 ? 0 : k;
+    return k >= n ? n - 1 : k;
+}
+
+__global__ void k_grid_count(const float *__restrict__ xyz, int nt, GridParams gp, int *__restrict__ cell_of,
+                             int *__restrict__ counts)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nt) return;
+    const int cx = grid_cell_coord((double)xyz[3ll * i], gp.lo[0], gp.inv_h, gp.n[0]);
+    const int cy = grid_cell_coord((double)xyz[3ll * i + 1], gp.lo[1], gp.inv_h, gp.n[1]);
+    const int cz = grid_cell_coord((double)xyz[3ll * i + 2], gp.lo[2], gp.inv_h, gp.n[2]);
+    const int c = (cz * gp.n[1] + cy) * gp.n[0] + cx;
+    cell_of[i] = c;
+    atomicAdd(&counts[c], 1);
+}
+
+// offsets (exclusive scan of counts, long long from k_scan_counts) -> int cell_start; fill cursors zeroed
+__global__ void k_grid_starts(const long long *__restrict__ offsets, int n_cells, int *__restrict__ cell_start,
+                              int *__restrict__ cursor)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n_cells) return;
+    cell_start[i] = (int)offsets[i];
+    if (i < n_cells) cursor[i] = 0;
+}
+
+__global__ void k_grid_scatter(const float *__restrict__ xyz, int nt, const int *__restrict__ cell_of,
+                               const int *__restrict__ cell_start, int *__restrict__ cursor,
+                               float4 *__restrict__ sorted)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nt) return;
+    const int c = cell_of[i];
+    const int pos = cell_start[c] + atomicAdd(&cursor[c], 1);    // order inside a cell is irrelevant: (d2, index) min
+    sorted[pos] = make_float4(xyz[3ll * i], xyz[3ll * i + 1], xyz[3ll * i + 2], __int_as_float(i));
+}
+
+__global__ __launch_bounds__(256) void k_nn_search_grid(const DevState *__restrict__ st,
+                                                        const float4 *__restrict__ src4, int ns, GridParams gp,
+                                                        const int *__restrict__ cell_start,
+                                                        const float4 *__restrict__ sorted,
+                                                        const float *__restrict__ tgt_xyz,
+                                                        const int *__restrict__ prev,
+                                                        unsigned long long *__restrict__ keys,
+                                                        int *__restrict__ todo_list, int *__restrict__ todo_count)
+{
+    if (st->halt) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ns) return;
+    const float4 p4 = src4[i];
+    float wx, wy, wz, px, py, pz;
+    m4_mul_v3(st->mx1, p4.x, p4.y, p4.z, wx, wy, wz);
+    m4_mul_v3(st->imx2, wx, wy, wz, px, py, pz);                // co_find (general.py:287)
+
+    float best = INFINITY;
+    uint32_t bidx = IDX_NONE;
+    const int s = prev ? prev[i] : -1;
+    if (s >= 0) {
+        const float d = d2_metric(px, py, pz, tgt_xyz[3ll * s], tgt_xyz[3ll * s + 1], tgt_xyz[3ll * s + 2]);
+        if (d < INFINITY) { best = d; bidx = (uint32_t)s; }
+    }
+
+    // projection of the query onto the grid's box, and its cell
+    const double p[3] = { (double)px, (double)py, (double)pz };
+    double pc[3], off2 = 0.0;
+    int c[3];
+    bool finite = true;
+    for (int a = 0; a < 3; ++a) {
+        if (!(fabs(p[a]) < INFINITY)) finite = false;
+        pc[a] = p[a] < gp.lo[a] ? gp.lo[a] : (p[a] > gp.hi[a] ? gp.hi[a] : p[a]);
+        const double d = p[a] - pc[a];
+        off2 += d * d;
+        c[a] = grid_cell_coord(pc[a], gp.lo[a], gp.inv_h, gp.n[a]);
+    }
+    bool settled = false;
+    if (finite) {
+        for (int r = 0; r <= gp.r_max && !settled; ++r) {
+            const int x0 = max(c[0] - r, 0), x1 = min(c[0] + r, gp.n[0] - 1);
+            const int y0 = max(c[1] - r, 0), y1 = min(c[1] + r, gp.n[1] - 1);
+            const int z0 = max(c[2] - r, 0), z1 = min(c[2] + r, gp.n[2] - 1);
+            for (int z = z0; z <= z1; ++z)
+                for (int y = y0; y <= y1; ++y) {
+                    // interior rows were fully covered by ring r-1: only their two end cells are new
+                    const bool shell_row = (r == 0) || z == c[2] - r || z == c[2] + r || y == c[1] - r || y == c[1] + r;
+                    const int row = (z * gp.n[1] + y) * gp.n[0];
+                    int segs[2][2];
+                    int n_seg;
+                    if (shell_row) { segs[0][0] = x0; segs[0][1] = x1; n_seg = 1; }
+                    else {
+                        n_seg = 0;
+                        if (c[0] - r >= 0) { segs[n_seg][0] = c[0] - r; segs[n_seg][1] = c[0] - r; ++n_seg; }
+                        if (c[0] + r < gp.n[0]) { segs[n_seg][0] = c[0] + r; segs[n_seg][1] = c[0] + r; ++n_seg; }
+                    }
+                    for (int sg = 0; sg < n_seg; ++sg) {
+                        const int j0 = cell_start[row + segs[sg][0]], j1 = cell_start[row + segs[sg][1] + 1];
+                        for (int j = j0; j < j1; ++j) {
+                            const float4 q = sorted[j];
+                            const float d = d2_metric(px, py, pz, q.x, q.y, q.z);
+                            const uint32_t qi = (uint32_t)__float_as_int(q.w);
+                            if (d < best || (d == best && qi < bidx)) { best = d; bidx = qi; }
+                        }
+                    }
+                }
+            // lower bound for everything outside the cube of radius r
+            double m = INFINITY;
+            for (int a = 0; a < 3; ++a) {
+                if (c[a] - r > 0) { const double f = pc[a] - (gp.lo[a] + (double)(c[a] - r) * gp.h); m = f < m ? f : m; }
+                if (c[a] + r + 1 < gp.n[a]) { const double f = (gp.lo[a] + (double)(c[a] + r + 1) * gp.h) - pc[a]; m = f < m ? f : m; }
+            }
+            if (!(m < INFINITY)) settled = true;                 // the cube covers the whole grid
+            else {
+                m -= gp.slack;
+                m = m > 0.0 ? m : 0.0;
+                const double bound = (off2 + m * m) * (1.0 - 1e-5) - 1e-30;
+                if (bound > (double)best) settled = true;        // no unseen vertex can beat or tie `best`
+            }
+        }
+    }
+    keys[i] = ((unsigned long long)__float_as_uint(best) << 32) | bidx;
+    if (!settled) todo_list[atomicAdd(todo_count, 1)] = i;      // finished exactly by the brute-force kernel
+}
+
+__global__ void k_count_nonzero(const int *__restrict__ a, int n, int *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool nz = (i < n) && a[i] != 0;
+    const unsigned long long m = __ballot(nz);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, __popcll(m));
+}
+
+#endif  // __HIPCC__
+}  // namespace oa

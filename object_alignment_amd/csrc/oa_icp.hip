@@ -4,6 +4,7 @@
 // iterate loop and its split-phase form for one-process-per-GPU sharding.  No CPU fallback lives here: every
 // compute entry point needs a usable HIP device and fails loudly otherwise.
 #include "oa_kernels.hpp"
+#include "oa_grid.hpp"
 #include "../../include/oa_icp.h"
 
 #include <algorithm>
@@ -61,6 +62,15 @@ struct oa_ctx {
     float *d_tgt_xyz = nullptr;
     float4 *d_tg = nullptr;
     float4 *d_tf = nullptr;          // filter image (k_nn_search_filtered)
+    double bb_lo[3] = { 0, 0, 0 }, bb_hi[3] = { 0, 0, 0 };
+    // uniform grid (k_nn_search_grid)
+    bool grid_ok = false;
+    int grid_mode = -1;              // OA_NN_GRID: -1 auto, 0 never, 1 whenever possible
+    oa::GridParams gp;
+    int n_cells = 0;
+    int *d_cell_start = nullptr;
+    float4 *d_sorted = nullptr;
+    int *d_todo_list = nullptr, *d_todo_count = nullptr;
     bool filter_ok = false;
     float tc[3] = { 0, 0, 0 };
     double qmax = 0.0;
@@ -159,6 +169,9 @@ int check_ready(oa_ctx *c)
     return OA_OK;
 }
 
+bool grid_active(const oa_ctx *c);
+int build_grid(oa_ctx *c);
+
 int launch_nn(oa_ctx *c)
 {
     if (c->ns <= 0) return OA_OK;
@@ -166,22 +179,35 @@ int launch_nn(oa_ctx *c)
         return fail(OA_E_BAD_ARG, "shard of %d points exceeds the launch grid (use more shards or OA_NN_R=8)", c->ns);
     dim3 grid(c->n_splits, c->ns_pad / (oa::NN_THREADS * c->R));
     dim3 block(oa::NN_THREADS);
+    const int *list = nullptr, *list_count = nullptr;
+    if (grid_active(c)) {
+        // grid search settles (almost) every point; the rest go through the brute-force kernel in list mode
+        HIPCHK(hipMemsetAsync(c->d_todo_count, 0, sizeof(int), c->stream));
+        hipLaunchKernelGGL(oa::k_nn_search_grid, dim3((c->ns + 255) / 256), dim3(256), 0, c->stream, c->d_state, c->d_src4,
+                           c->ns, c->gp, c->d_cell_start, c->d_sorted, c->d_tgt_xyz, c->d_prev, c->d_keys,
+                           c->d_todo_list, c->d_todo_count);
+        HIPCHK(hipGetLastError());
+        list = c->d_todo_list; list_count = c->d_todo_count;
+        grid.y = std::min<unsigned>((unsigned)((c->ns + 1023) / 1024), 32u);
+    }
 #define OA_NN_ARGS c->d_state, c->d_src4, c->d_tg, c->groups_per_split, c->n_groups_pad, c->d_keys
-#define OA_NNF_ARGS c->d_state, c->d_src4, c->d_tg, c->d_tf, c->d_tgt_xyz, c->d_prev, c->groups_per_split, c->n_groups_pad, c->d_keys
-    if (c->filter_ok && c->use_filter) {
+#define OA_NNF_ARGS c->d_state, c->d_src4, c->d_tg, c->d_tf, c->d_tgt_xyz, c->d_prev, c->groups_per_split, c->n_groups_pad, c->d_keys, list, list_count
+    if (list) {
+        hipLaunchKernelGGL((oa::k_nn_search_filtered<4, true, true>), grid, block, 0, c->stream, OA_NNF_ARGS);
+    } else if (c->filter_ok && c->use_filter) {
         if (c->use_pk) {
             switch (c->R) {
-            case 1: hipLaunchKernelGGL((oa::k_nn_search_filtered<1, true>), grid, block, 0, c->stream, OA_NNF_ARGS); break;
-            case 2: hipLaunchKernelGGL((oa::k_nn_search_filtered<2, true>), grid, block, 0, c->stream, OA_NNF_ARGS); break;
-            case 8: hipLaunchKernelGGL((oa::k_nn_search_filtered<8, true>), grid, block, 0, c->stream, OA_NNF_ARGS); break;
-            default: hipLaunchKernelGGL((oa::k_nn_search_filtered<4, true>), grid, block, 0, c->stream, OA_NNF_ARGS); break;
+            case 1: hipLaunchKernelGGL((oa::k_nn_search_filtered<1, true, false>), grid, block, 0, c->stream, OA_NNF_ARGS); break;
+            case 2: hipLaunchKernelGGL((oa::k_nn_search_filtered<2, true, false>), grid, block, 0, c->stream, OA_NNF_ARGS); break;
+            case 8: hipLaunchKernelGGL((oa::k_nn_search_filtered<8, true, false>), grid, block, 0, c->stream, OA_NNF_ARGS); break;
+            default: hipLaunchKernelGGL((oa::k_nn_search_filtered<4, true, false>), grid, block, 0, c->stream, OA_NNF_ARGS); break;
             }
         } else {
             switch (c->R) {
-            case 1: hipLaunchKernelGGL((oa::k_nn_search_filtered<1, false>), grid, block, 0, c->stream, OA_NNF_ARGS); break;
-            case 2: hipLaunchKernelGGL((oa::k_nn_search_filtered<2, false>), grid, block, 0, c->stream, OA_NNF_ARGS); break;
-            case 8: hipLaunchKernelGGL((oa::k_nn_search_filtered<8, false>), grid, block, 0, c->stream, OA_NNF_ARGS); break;
-            default: hipLaunchKernelGGL((oa::k_nn_search_filtered<4, false>), grid, block, 0, c->stream, OA_NNF_ARGS); break;
+            case 1: hipLaunchKernelGGL((oa::k_nn_search_filtered<1, false, false>), grid, block, 0, c->stream, OA_NNF_ARGS); break;
+            case 2: hipLaunchKernelGGL((oa::k_nn_search_filtered<2, false, false>), grid, block, 0, c->stream, OA_NNF_ARGS); break;
+            case 8: hipLaunchKernelGGL((oa::k_nn_search_filtered<8, false, false>), grid, block, 0, c->stream, OA_NNF_ARGS); break;
+            default: hipLaunchKernelGGL((oa::k_nn_search_filtered<4, false, false>), grid, block, 0, c->stream, OA_NNF_ARGS); break;
             }
         }
     } else {
@@ -356,6 +382,7 @@ OA_EXPORT int oa_create(oa_ctx **out, int device)
     if (c->R != 1 && c->R != 2 && c->R != 4 && c->R != 8) c->R = 4;
     c->use_filter = env_int("OA_NN_FILTER", 1) != 0;
     c->use_pk = env_int("OA_NN_PK", 1) != 0;
+    c->grid_mode = env_int("OA_NN_GRID", -1);
     *out = c;
     return OA_OK;
 }
@@ -365,7 +392,7 @@ OA_EXPORT void oa_destroy(oa_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    dev_free(c->d_tgt_xyz); dev_free(c->d_tg); dev_free(c->d_tf); dev_free(c->d_prev); dev_free(c->d_src4); dev_free(c->d_keys); dev_free(c->d_state);
+    dev_free(c->d_tgt_xyz); dev_free(c->d_tg); dev_free(c->d_tf); dev_free(c->d_prev); dev_free(c->d_cell_start); dev_free(c->d_sorted); dev_free(c->d_todo_list); dev_free(c->d_todo_count); dev_free(c->d_src4); dev_free(c->d_keys); dev_free(c->d_state);
     dev_free(c->d_hist); dev_free(c->d_partials); dev_free(c->d_sums); dev_free(c->d_solve);
     dev_free(c->d_valid); dev_free(c->d_b); dev_free(c->d_dist); dev_free(c->d_counts); dev_free(c->d_offsets);
     dev_free(c->d_A); dev_free(c->d_B);
@@ -374,6 +401,20 @@ OA_EXPORT void oa_destroy(oa_ctx *c)
     if (c->ev_loop1) (void)hipEventDestroy(c->ev_loop1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
+}
+
+OA_EXPORT int oa_set_search_mode(oa_ctx *c, int mode)
+{
+    if (!c) return fail(OA_E_BAD_ARG, "null context");
+    if (mode < -1 || mode > 1) return fail(OA_E_BAD_ARG, "search mode %d (use OA_SEARCH_AUTO/BRUTE/GRID)", mode);
+    const bool rebuild = (c->grid_mode == 0 && mode != 0 && c->nt > 0 && !c->grid_ok);
+    c->grid_mode = mode;
+    if (rebuild) {                                   // the grid was skipped when the target was uploaded
+        int rc = use_device(c);
+        if (rc) return rc;
+        return build_grid(c);
+    }
+    return OA_OK;
 }
 
 OA_EXPORT int oa_set_stream(oa_ctx *c, void *stream)
@@ -414,7 +455,7 @@ int build_filter(oa_ctx *c)
         }
     for (int a = 0; a < 3; ++a) if (!(lo[a] <= hi[a]) || !(fabs(lo[a]) < 1e18) || !(fabs(hi[a]) < 1e18)) finite = false;
     if (!finite) return OA_OK;                                   // exact kernel only
-    for (int a = 0; a < 3; ++a) c->tc[a] = (float)(0.5 * (lo[a] + hi[a]));
+    for (int a = 0; a < 3; ++a) { c->tc[a] = (float)(0.5 * (lo[a] + hi[a])); c->bb_lo[a] = lo[a]; c->bb_hi[a] = hi[a]; }
     const int blocks = (c->n_groups_pad + 255) / 256;
     HIPCHK(hipMalloc(&c->d_tf, sizeof(float4) * 4 * (size_t)c->n_groups_pad));
     e = hipMalloc(&d_mx, sizeof(double) * (size_t)blocks);
@@ -431,6 +472,86 @@ int build_filter(oa_ctx *c)
     c->qmax = sqrt(m) * (1.0 + 1e-6);
     c->filter_ok = (c->qmax < 1e18);
     return OA_OK;
+}
+
+// uniform grid over the target for k_nn_search_grid (needs the finite bbox build_filter found)
+int build_grid(oa_ctx *c)
+{
+    c->grid_ok = false;
+    dev_free(c->d_cell_start); dev_free(c->d_sorted);
+    if (!c->filter_ok || c->grid_mode == 0 || c->nt < 2) return OA_OK;
+    double ext[3], vol = 1.0, scale = 0.0;
+    int nz = 0;
+    for (int a = 0; a < 3; ++a) {
+        ext[a] = c->bb_hi[a] - c->bb_lo[a];
+        if (ext[a] > 0.0) { vol *= ext[a]; ++nz; }
+        scale = std::max(scale, std::max(fabs(c->bb_lo[a]), fabs(c->bb_hi[a])));
+    }
+    const double ppc = 2.0;
+    double h = nz ? pow(vol * ppc / (double)c->nt, 1.0 / nz) : 1.0;
+    if (!(h > 0.0) || !(h < INFINITY)) return OA_OK;
+    const long long max_cells = 1ll << 24;
+    int *d_cell_of = nullptr, *d_counts = nullptr, *d_nz = nullptr;
+    long long *d_off = nullptr;
+    HIPCHK(hipMalloc(&d_cell_of, sizeof(int) * (size_t)c->nt));
+    hipError_t e = hipMalloc(&d_nz, sizeof(int));
+    oa::GridParams gp{};
+    int n_cells = 0;
+    for (int attempt = 0; attempt < 6 && e == hipSuccess; ++attempt) {
+        long long total = 1;
+        for (int a = 0; a < 3; ++a) {
+            long long n = ext[a] > 0.0 ? (long long)floor(ext[a] / h) + 1 : 1;
+            n = std::max(1ll, std::min(n, 1024ll));
+            gp.n[a] = (int)n;
+            total *= n;
+            gp.lo[a] = c->bb_lo[a]; gp.hi[a] = c->bb_hi[a];
+        }
+        if (total > max_cells) { h *= 1.3; continue; }
+        // a clamped axis (1024 cells) needs a cell edge that still covers the extent
+        for (int a = 0; a < 3; ++a) if (ext[a] > 0.0 && ext[a] / h >= gp.n[a]) h = std::max(h, ext[a] / (gp.n[a] - 0.5));
+        gp.h = h; gp.inv_h = 1.0 / h;
+        gp.r_max = env_int("OA_GRID_RMAX", 3);
+        gp.slack = 1e-10 * scale + 1e-300;
+        n_cells = (int)total;
+        dev_free(d_counts); dev_free(d_off);
+        e = hipMalloc(&d_counts, sizeof(int) * (size_t)n_cells);
+        if (e == hipSuccess) e = hipMalloc(&d_off, sizeof(long long) * (size_t)(n_cells + 1));
+        if (e == hipSuccess) e = hipMemsetAsync(d_counts, 0, sizeof(int) * (size_t)n_cells, c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_nz, 0, sizeof(int), c->stream);
+        if (e != hipSuccess) break;
+        hipLaunchKernelGGL(oa::k_grid_count, dim3((c->nt + 255) / 256), dim3(256), 0, c->stream, c->d_tgt_xyz, c->nt, gp, d_cell_of, d_counts);
+        hipLaunchKernelGGL(oa::k_count_nonzero, dim3((n_cells + 255) / 256), dim3(256), 0, c->stream, d_counts, n_cells, d_nz);
+        int occupied = 0;
+        e = hipMemcpyAsync(&occupied, d_nz, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) break;
+        const double avg = occupied > 0 ? (double)c->nt / occupied : 0.0;
+        // surfaces fill few cells: refine until occupied cells hold a handful of vertices each
+        if (avg > 6.0 && total * 8 <= max_cells && attempt < 5) { h *= 0.5; continue; }
+        break;
+    }
+    if (e == hipSuccess && n_cells > 0) {
+        e = hipMalloc(&c->d_cell_start, sizeof(int) * (size_t)(n_cells + 1));
+        if (e == hipSuccess) e = hipMalloc(&c->d_sorted, sizeof(float4) * (size_t)c->nt);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(oa::k_scan_counts, dim3(1), dim3(1024), 0, c->stream, d_counts, n_cells, d_off);
+            hipLaunchKernelGGL(oa::k_grid_starts, dim3((n_cells + 256) / 256), dim3(256), 0, c->stream, d_off, n_cells, c->d_cell_start, d_counts);
+            hipLaunchKernelGGL(oa::k_grid_scatter, dim3((c->nt + 255) / 256), dim3(256), 0, c->stream, c->d_tgt_xyz, c->nt, d_cell_of, c->d_cell_start, d_counts, c->d_sorted);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        }
+    }
+    dev_free(d_cell_of); dev_free(d_counts); dev_free(d_off); dev_free(d_nz);
+    if (e != hipSuccess) return fail(OA_E_HIP, "build_grid: %s", hipGetErrorString(e));
+    if (n_cells > 0) { c->gp = gp; c->n_cells = n_cells; c->grid_ok = true; }
+    return OA_OK;
+}
+
+bool grid_active(const oa_ctx *c)
+{
+    if (!c->grid_ok || !c->filter_ok || !c->use_filter || c->grid_mode == 0) return false;
+    if (c->grid_mode == 1) return true;
+    return c->nt >= 8192 && (double)c->nt * (double)c->ns >= 1e9;     // auto: small problems stay on the brute-force kernel
 }
 }  // namespace
 OA_EXPORT int oa_set_target(oa_ctx *c, const float *xyz, int64_t n, int on_device)
@@ -463,6 +584,7 @@ OA_EXPORT int oa_set_target(oa_ctx *c, const float *xyz, int64_t n, int on_devic
     HIPCHK(hipStreamSynchronize(c->stream));
     int rcf = build_filter(c);
     if (rcf) return rcf;
+    if ((rcf = build_grid(c))) return rcf;
     plan_geometry(c);
     return OA_OK;
 }
@@ -500,6 +622,10 @@ OA_EXPORT int oa_set_source(oa_ctx *c, const float *xyz, int64_t n_verts, int on
     HIPCHK(hipMalloc(&c->d_src4, sizeof(float4) * (size_t)c->ns_pad));
     HIPCHK(hipMalloc(&c->d_keys, sizeof(unsigned long long) * (size_t)c->ns_pad));
     HIPCHK(hipMalloc(&c->d_prev, sizeof(int) * (size_t)c->ns_pad));
+    dev_free(c->d_todo_list); dev_free(c->d_todo_count);
+    HIPCHK(hipMalloc(&c->d_todo_list, sizeof(int) * (size_t)c->ns_pad));
+    HIPCHK(hipMalloc(&c->d_todo_count, sizeof(int)));
+    HIPCHK(hipMemsetAsync(c->d_todo_count, 0, sizeof(int), c->stream));
     hipLaunchKernelGGL(oa::k_fill_int, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, c->d_prev, c->ns_pad, -1);
     c->pivot[0] = c->pivot[1] = c->pivot[2] = 0.0;
     if (n_sel > 0) {

@@ -496,7 +496,7 @@ __global__ void k_bbox_partial(const float *__restrict__ xyz, int nt, float *__r
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-template <int R, bool PK>
+template <int R, bool PK, bool LIST>
 __global__ __launch_bounds__(NN_THREADS) void k_nn_search_filtered(const DevState *__restrict__ st,
                                                                    const float4 *__restrict__ src4,
                                                                    const float4 *__restrict__ tg,
@@ -504,20 +504,31 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_search_filtered(const DevStat
                                                                    const float *__restrict__ tgt_xyz,
                                                                    const int *__restrict__ prev, int groups_per_split,
                                                                    int n_groups_pad,
-                                                                   unsigned long long *__restrict__ keys)
+                                                                   unsigned long long *__restrict__ keys,
+                                                                   const int *__restrict__ list,
+                                                                   const int *__restrict__ list_count)
 {
+    // list mode (LIST): finish the source points the grid search could not settle.  `list` holds
+    // their indices, `*list_count` how many; their running best sits in keys[] and seeds the scan.
     if (st->halt) return;
     __shared__ float4 tile[2][FTILE_GROUPS * 4];
     const int tid = threadIdx.x;
-    const int base = blockIdx.y * (NN_THREADS * R);
     const double qmax = st->qmax;
     const float cx = st->tc[0], cy = st->tc[1], cz = st->tc[2];
+    const long long n_items = LIST ? (long long)*list_count : (long long)gridDim.y * (NN_THREADS * R);
 
+  for (int chunk = blockIdx.y; (long long)chunk * (NN_THREADS * R) < n_items; chunk += gridDim.y) {
+    const int base = chunk * (NN_THREADS * R);
     float px[R], py[R], pz[R], hx[R], hy[R], hz[R], best[R], thr[R];
     uint32_t bidx[R];
+    int item[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int i = base + r * NN_THREADS + tid;
+        const int slot = base + r * NN_THREADS + tid;
+        int i = slot;
+        if (LIST) { i = (slot < n_items) ? list[slot] : -1; }
+        item[r] = i;
+        if (LIST && i < 0) i = list[0];                                  // inactive lane of the last chunk: harmless duplicate
         const float4 p = src4[i];
         float wx, wy, wz;
         m4_mul_v3(st->mx1, p.x, p.y, p.z, wx, wy, wz);
@@ -527,10 +538,17 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_search_filtered(const DevStat
         hz[r] = (float)((double)pz[r] - (double)cz);
         best[r] = INFINITY;
         bidx[r] = IDX_NONE;
-        const int s = prev ? prev[i] : -1;
-        if (s >= 0) {                                           // seed: last iteration's nearest vertex
-            const float d = d2_metric(px[r], py[r], pz[r], tgt_xyz[3ll * s], tgt_xyz[3ll * s + 1], tgt_xyz[3ll * s + 2]);
-            if (d < INFINITY) { best[r] = d; bidx[r] = (uint32_t)s; }
+        if (LIST) {                                             // seed: what the grid search found so far
+            const unsigned long long k0 = keys[i];
+            best[r] = __uint_as_float((uint32_t)(k0 >> 32));
+            bidx[r] = (uint32_t)k0;
+            if (!(best[r] < INFINITY)) { best[r] = INFINITY; bidx[r] = IDX_NONE; }
+        } else {
+            const int s = prev ? prev[i] : -1;
+            if (s >= 0) {                                       // seed: last iteration's nearest vertex
+                const float d = d2_metric(px[r], py[r], pz[r], tgt_xyz[3ll * s], tgt_xyz[3ll * s + 1], tgt_xyz[3ll * s + 2]);
+                if (d < INFINITY) { best[r] = d; bidx[r] = (uint32_t)s; }
+            }
         }
         thr[r] = filter_threshold(best[r], hx[r], hy[r], hz[r], qmax);
     }
@@ -609,10 +627,13 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_search_filtered(const DevStat
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const unsigned long long key = ((unsigned long long)__float_as_uint(best[r]) << 32) | bidx[r];
-        unsigned long long *dst = keys + base + r * NN_THREADS + tid;
-        if (gridDim.x == 1) *dst = key;
+        if (LIST && item[r] < 0) continue;
+        unsigned long long *dst = keys + item[r];
+        if (gridDim.x == 1 && !LIST) *dst = key;
         else atomicMin(dst, key);
     }
+    if (!LIST) break;                                            // single pass: lets the compiler drop the loop
+  }   // chunk loop (list mode only)
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -81,6 +81,12 @@ class IcpEngine:
         h = C.c_void_p(-1) if stream_handle is None else C.c_void_p(int(stream_handle))
         capi.check(self._L.oa_set_stream(self._h, h))
 
+    def set_search_mode(self, mode):
+        """'auto' (default), 'brute' (north-star LDS-tiled brute force) or 'grid' (uniform-grid exact search).
+        All modes return identical correspondences."""
+        code = {"auto": -1, "brute": 0, "grid": 1}[mode] if isinstance(mode, str) else int(mode)
+        capi.check(self._L.oa_set_search_mode(self._h, code))
+
     # ---- uploads
     def set_target(self, xyz):
         p, on_dev, keep, n = _device_ptr(xyz)

@@ -178,6 +178,54 @@ def test_nn_filter_adversarial(orc, case):
     assert np.array_equal(d2, rd2)
 
 
+@pytest.mark.parametrize("case", ["volume", "surface", "far_apart", "lattice_ties", "flat", "one_cell", "outside_box"])
+def test_grid_search_identical_to_brute_force(orc, case):
+    """k_nn_search_grid (+ list-mode finish) must return exactly what the brute-force kernel and the oracle return."""
+    from object_alignment_amd import synth
+    from object_alignment_amd.engine import IcpEngine
+    rng = np.random.default_rng(len(case) * 1009)
+    eye = np.identity(4, dtype=np.float32)
+    mxa = eye.copy()
+    if case == "volume":
+        tgt = rng.uniform(-1, 1, size=(60000, 3)).astype(np.float32)
+        src = (tgt[rng.permutation(60000)[:20000]] + rng.normal(0, 2e-3, size=(20000, 3))).astype(np.float32)
+    elif case == "surface":
+        src, tgt, mxa, _ = synth.c2_bunny_pair(40000)
+        src = src[:15000]
+    elif case == "far_apart":                     # most queries cannot be settled within r_max rings -> list mode
+        tgt = rng.uniform(-1, 1, size=(30000, 3)).astype(np.float32)
+        src = (rng.uniform(-1, 1, size=(5000, 3)) + [6.0, -3.0, 2.0]).astype(np.float32)
+        tgt[:100] += np.float32(7.0)              # a far cluster stretches the grid
+    elif case == "lattice_ties":
+        tgt = rng.integers(-10, 11, size=(50000, 3)).astype(np.float32) * np.float32(0.1)
+        src = (rng.integers(-10, 10, size=(8000, 3)) * 0.1 + 0.05).astype(np.float32)
+    elif case == "flat":
+        tgt = rng.uniform(-1, 1, size=(30000, 3)).astype(np.float32)
+        tgt[:, 1] = -0.5
+        src = rng.uniform(-1, 1, size=(6000, 3)).astype(np.float32)
+    elif case == "one_cell":                      # all target vertices identical
+        tgt = np.tile(np.array([[0.3, -0.2, 0.9]], np.float32), (9000, 1))
+        src = rng.uniform(-1, 1, size=(3000, 3)).astype(np.float32)
+    else:
+        tgt = rng.uniform(-1, 1, size=(30000, 3)).astype(np.float32)
+        src = (rng.normal(size=(6000, 3)) * 3.0).astype(np.float32)
+    ref_idx, ref_d2 = orc.nn_brute(_cofind(orc, src, mxa, eye), tgt)
+    for mode in ("brute", "grid"):
+        with IcpEngine(0) as e:
+            e.set_search_mode(mode)
+            e.set_target(tgt)
+            e.set_source(src)
+            e.set_matrices(mxa, eye)
+            idx, d2, _ = e.nn_search()
+            assert np.array_equal(idx, ref_idx), (case, mode)
+            assert np.array_equal(d2, ref_d2), (case, mode)
+            e.iterate(thresh=100.0)                    # seeds + moved pose: search again
+            m2 = e.matrix_world()
+            idx2, d22, _ = e.nn_search()
+        r2, rd2 = orc.nn_brute(_cofind(orc, src, m2, eye), tgt)
+        assert np.array_equal(idx2, r2) and np.array_equal(d22, rd2), (case, mode, "seeded")
+
+
 def test_nn_search_full_size_self_match(eng):
     """BASELINE config 3 size (1M <-> 1M): every point finds itself (property test, no oracle needed)."""
     rng = np.random.default_rng(1234)
@@ -265,12 +313,16 @@ def _settings_from(g):
                        align_meth=str(int(meth)))
 
 
+@pytest.mark.parametrize("mode", ["brute", "grid"])
 @pytest.mark.parametrize("name", LOOPS)
-def test_icp_align_run_golden(golden_dir, name):
+def test_icp_align_run_golden(golden_dir, name, mode):
     """IcpAlign.run reproduces what the reference's execute() produced, iteration by iteration."""
+    from object_alignment_amd.engine import IcpEngine
     from object_alignment_amd.operators import IcpAlign
     g = _load(golden_dir, name)
-    res = IcpAlign(_settings_from(g)).run(g["src"], g["tgt"], g["mx_align"], g["mx_base"], vlist=g["vlist"])
+    with IcpEngine(0) as e:
+        e.set_search_mode(mode)
+        res = IcpAlign(_settings_from(g), engine=e).run(g["src"], g["tgt"], g["mx_align"], g["mx_base"], vlist=g["vlist"])
     assert res.iters_done == int(g["iters_done"])
     assert res.converged == bool(g["converged"])
     assert np.array_equal(res.step_K, g["step_K"])
@@ -371,6 +423,7 @@ def test_c2_bunny_100k_50_iters(orc):
     from object_alignment_amd.engine import IcpEngine
     src, tgt, mxa, mxb = synth.c2_bunny_pair(100_000)
     with IcpEngine(0) as e:
+        e.set_search_mode("brute")
         e.set_target(tgt)
         e.set_source(src, stride=1)
         e.set_matrices(mxa, mxb)
@@ -382,6 +435,13 @@ def test_c2_bunny_100k_50_iters(orc):
     err = np.linalg.norm(res.matrix_world.astype(np.float64) - ref["matrix_world"].astype(np.float64))
     assert err <= FROB_TOL, err
     assert np.abs(res.step_M - ref["step_M"]).max() < 1e-9
+    with IcpEngine(0) as e:                              # grid search: bitwise the same run
+        e.set_search_mode("grid")
+        e.set_target(tgt)
+        e.set_source(src, stride=1)
+        e.set_matrices(mxa, mxb)
+        res_g = e.run(iters=50, thresh=0.5, target_d=0.01, use_target=True, early_exit=False)
+    assert np.array_equal(res_g.matrix_world, res.matrix_world) and np.array_equal(res_g.step_M, res.step_M)
 
 
 def test_c3_random_1m_few_iters(orc):
@@ -389,11 +449,17 @@ def test_c3_random_1m_few_iters(orc):
     from object_alignment_amd import synth
     from object_alignment_amd.engine import IcpEngine
     src, tgt, mxa, mxb = synth.c3_random_pair(1_000_000)
-    with IcpEngine(0) as e:
-        e.set_target(tgt)
-        e.set_source(src, stride=1)
-        e.set_matrices(mxa, mxb)
-        res = e.run(iters=3, thresh=0.5, target_d=0.01, use_target=True, early_exit=False)
+    runs = {}
+    for mode in ("brute", "grid"):
+        with IcpEngine(0) as e:
+            e.set_search_mode(mode)
+            e.set_target(tgt)
+            e.set_source(src, stride=1)
+            e.set_matrices(mxa, mxb)
+            runs[mode] = e.run(iters=3, thresh=0.5, target_d=0.01, use_target=True, early_exit=False)
+    res = runs["brute"]
+    assert np.array_equal(runs["grid"].matrix_world, res.matrix_world)
+    assert np.array_equal(runs["grid"].step_M, res.step_M)
     ref = orc.icp_run(src, tgt, mxa, mxb, iters=3, sample=1, thresh=0.5, target_d=1e-300, use_target=True,
                       kd=orc.KDTree(tgt))
     assert np.array_equal(res.step_K, ref["step_K"])
