@@ -89,10 +89,17 @@ def main():
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the oa_icp engine has no CPU fallback")
+    # test hooks (not used by the driver): run N ranks on ONE GPU over gloo to exercise the sharded path end to end
+    backend = os.environ.get("OA_BENCH_BACKEND", "nccl")
+    if os.environ.get("OA_BENCH_SAME_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from object_alignment_amd import synth
     from object_alignment_amd.distributed import EngineShard, new_sums_tensor, run_sharded

@@ -241,7 +241,7 @@ int launch_accumulate(oa_ctx *c, bool emit, int *nn_idx, float *nn_d2)
 
 int launch_reduce(oa_ctx *c, double *d_sums)
 {
-    hipLaunchKernelGGL(oa::k_reduce_partials, dim3(1), dim3(256), 0, c->stream, c->d_partials, c->acc_blocks, d_sums);
+    hipLaunchKernelGGL(oa::k_reduce_partials, dim3(1), dim3(1024), 0, c->stream, c->d_partials, c->acc_blocks, d_sums);
     HIPCHK(hipGetLastError());
     return OA_OK;
 }
@@ -846,7 +846,7 @@ OA_EXPORT int oa_kabsch(oa_ctx *c, const double *A, const double *B, int64_t K, 
     if (e == hipSuccess) {
         hipLaunchKernelGGL(oa::k_accumulate_pairs, dim3(blocks), dim3(oa::ACC_THREADS), 0, c->stream, dA, dB,
                            (long long)K, (long long)K, pv[0], pv[1], pv[2], c->d_partials);
-        hipLaunchKernelGGL(oa::k_reduce_partials, dim3(1), dim3(256), 0, c->stream, c->d_partials, blocks, c->d_sums);
+        hipLaunchKernelGGL(oa::k_reduce_partials, dim3(1), dim3(1024), 0, c->stream, c->d_partials, blocks, c->d_sums);
         e = hipGetLastError();
     }
     if (e == hipSuccess) rc = solve_on_device(c, c->d_sums, pv, with_scale, M);

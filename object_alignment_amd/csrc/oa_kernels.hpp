@@ -136,7 +136,7 @@ __host__ __device__ inline void rotation_from_covariance(const double H[9], doub
                 const double npp = g[0][p] * g[0][p] + g[1][p] * g[1][p] + g[2][p] * g[2][p];
                 const double nqq = g[0][q] * g[0][q] + g[1][q] * g[1][q] + g[2][q] * g[2][q];
                 const double dpq = g[0][p] * g[0][q] + g[1][p] * g[1][q] + g[2][p] * g[2][q];
-                if (dpq == 0.0 || fabs(dpq) <= 1e-17 * sqrt(npp * nqq)) continue;
+                if (dpq == 0.0 || fabs(dpq) <= 1e-15 * sqrt(npp * nqq)) continue;   // ~4.5 eps: R good to 1e-15
                 any = true;
                 const double zeta = (nqq - npp) / (2.0 * dpq);
                 const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
@@ -728,20 +728,20 @@ __global__ __launch_bounds__(ACC_THREADS) void k_pair_accumulate(const DevState 
     }
 }
 
-// fixed-order reduction of the per-block partials: 8 interleaved slices, then slice 0..7 in order
-__global__ __launch_bounds__(256) void k_reduce_partials(const double *__restrict__ partials, int n_blocks,
-                                                         double *__restrict__ sums)
+// fixed-order reduction of the per-block partials: 32 interleaved slices, then slices 0..31 in order
+__global__ __launch_bounds__(1024) void k_reduce_partials(const double *__restrict__ partials, int n_blocks,
+                                                          double *__restrict__ sums)
 {
-    __shared__ double red[8][32];
+    __shared__ double red[32][32];
     const int j = threadIdx.x & 31, s = threadIdx.x >> 5;
     double v = 0.0;
     if (j < NSUMS)
-        for (int b = s; b < n_blocks; b += 8) v += partials[(long long)b * NSUMS + j];
+        for (int b = s; b < n_blocks; b += 32) v += partials[(long long)b * NSUMS + j];
     red[s][j] = v;
     __syncthreads();
     if (threadIdx.x < NSUMS) {
         double t = red[0][threadIdx.x];
-        for (int k = 1; k < 8; ++k) t += red[k][threadIdx.x];
+        for (int k = 1; k < 32; ++k) t += red[k][threadIdx.x];
         sums[threadIdx.x] = t;
     }
 }
