@@ -36,6 +36,15 @@ __device__ __forceinline__ int grid_cell_coord(double q, double lo, double inv_h
     return k >= n ? n - 1 : k;
 }
 
+// distance from coordinate v to the slab [lo + k h, lo + (k+1) h] of cell k (0 inside), shrunk by `slack`
+__device__ __forceinline__ double grid_axis_gap(double v, double lo, double h, int k, double slack)
+{
+    const double a = lo + (double)k * h, b = lo + (double)(k + 1) * h;
+    double g = v < a ? a - v : (v > b ? v - b : 0.0);
+    g -= slack;
+    return g > 0.0 ? g : 0.0;
+}
+
 __global__ void k_grid_count(const float *__restrict__ xyz, int nt, GridParams gp, int *__restrict__ cell_of,
                              int *__restrict__ counts)
 {
@@ -113,18 +122,31 @@ __global__ __launch_bounds__(256) void k_nn_search_grid(const DevState *__restri
             const int x0 = max(c[0] - r, 0), x1 = min(c[0] + r, gp.n[0] - 1);
             const int y0 = max(c[1] - r, 0), y1 = min(c[1] + r, gp.n[1] - 1);
             const int z0 = max(c[2] - r, 0), z1 = min(c[2] + r, gp.n[2] - 1);
-            for (int z = z0; z <= z1; ++z)
+            for (int z = z0; z <= z1; ++z) {
+                const double dz = grid_axis_gap(pc[2], gp.lo[2], gp.h, z, gp.slack);
                 for (int y = y0; y <= y1; ++y) {
+                    // every vertex of this row of cells is at real distance^2 >= off2 + dy^2 + dz^2 from the query
+                    const double dy = grid_axis_gap(pc[1], gp.lo[1], gp.h, y, gp.slack);
+                    const double row2 = off2 + dz * dz + dy * dy;
+                    if (row2 * (1.0 - 1e-5) - 1e-30 > (double)best) continue;      // cannot beat or tie
+                    // cells of the row that can still matter: |x - pc.x| <= sqrt(best' - row2)
+                    int xa = x0, xb = x1;
+                    if (best < INFINITY) {
+                        double w2 = (double)best * (1.0 + 1e-5) + 1e-30 - row2 * (1.0 - 1e-5);
+                        const double w = sqrt(w2 > 0.0 ? w2 : 0.0) * (1.0 + 1e-6) + gp.slack;
+                        xa = max(xa, grid_cell_coord(pc[0] - w, gp.lo[0], gp.inv_h, gp.n[0]));
+                        xb = min(xb, grid_cell_coord(pc[0] + w, gp.lo[0], gp.inv_h, gp.n[0]));
+                    }
                     // interior rows were fully covered by ring r-1: only their two end cells are new
                     const bool shell_row = (r == 0) || z == c[2] - r || z == c[2] + r || y == c[1] - r || y == c[1] + r;
                     const int row = (z * gp.n[1] + y) * gp.n[0];
                     int segs[2][2];
-                    int n_seg;
-                    if (shell_row) { segs[0][0] = x0; segs[0][1] = x1; n_seg = 1; }
+                    int n_seg = 0;
+                    if (shell_row) { if (xa <= xb) { segs[0][0] = xa; segs[0][1] = xb; n_seg = 1; } }
                     else {
-                        n_seg = 0;
-                        if (c[0] - r >= 0) { segs[n_seg][0] = c[0] - r; segs[n_seg][1] = c[0] - r; ++n_seg; }
-                        if (c[0] + r < gp.n[0]) { segs[n_seg][0] = c[0] + r; segs[n_seg][1] = c[0] + r; ++n_seg; }
+                        const int xl = c[0] - r, xr = c[0] + r;
+                        if (xl >= xa && xl <= xb) { segs[n_seg][0] = xl; segs[n_seg][1] = xl; ++n_seg; }
+                        if (xr >= xa && xr <= xb) { segs[n_seg][0] = xr; segs[n_seg][1] = xr; ++n_seg; }
                     }
                     for (int sg = 0; sg < n_seg; ++sg) {
                         const int j0 = cell_start[row + segs[sg][0]], j1 = cell_start[row + segs[sg][1] + 1];
@@ -136,6 +158,7 @@ __global__ __launch_bounds__(256) void k_nn_search_grid(const DevState *__restri
                         }
                     }
                 }
+            }
             // lower bound for everything outside the cube of radius r
             double m = INFINITY;
             for (int a = 0; a < 3; ++a) {

@@ -45,6 +45,18 @@ template <typename T> void dev_free(T *&p)
     if (p) { (void)hipFree(p); p = nullptr; }
 }
 
+// temporary device buffer, released on every exit path
+template <typename T> struct DevTmp {
+    T *p = nullptr;
+    DevTmp() = default;
+    DevTmp(const DevTmp &) = delete;
+    DevTmp &operator=(const DevTmp &) = delete;
+    ~DevTmp() { reset(); }
+    hipError_t alloc(size_t n) { reset(); return hipMalloc(&p, sizeof(T) * (n ? n : 1)); }
+    void reset() { if (p) { (void)hipFree(p); p = nullptr; } }
+    operator T *() const { return p; }
+};
+
 int env_int(const char *name, int dflt)
 {
     const char *v = getenv(name);
@@ -435,15 +447,13 @@ int build_filter(oa_ctx *c)
 {
     c->filter_ok = false;
     const int nb = 256;
-    float *d_bb = nullptr;
-    double *d_mx = nullptr;
-    HIPCHK(hipMalloc(&d_bb, sizeof(float) * 6 * nb));
-    hipLaunchKernelGGL(oa::k_bbox_partial, dim3(nb), dim3(256), 0, c->stream, c->d_tgt_xyz, c->nt, d_bb);
+    DevTmp<float> d_bb;
+    HIPCHK(d_bb.alloc(6 * nb));
+    hipLaunchKernelGGL(oa::k_bbox_partial, dim3(nb), dim3(256), 0, c->stream, c->d_tgt_xyz, c->nt, d_bb.p);
+    HIPCHK(hipGetLastError());
     std::vector<float> bb(6 * nb);
-    hipError_t e = hipMemcpyAsync(bb.data(), d_bb, sizeof(float) * 6 * nb, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    dev_free(d_bb);
-    if (e != hipSuccess) return fail(OA_E_HIP, "build_filter: %s", hipGetErrorString(e));
+    HIPCHK(hipMemcpyAsync(bb.data(), d_bb, sizeof(float) * 6 * nb, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     double lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
     bool finite = true;
     for (int b = 0; b < nb; ++b)
@@ -457,16 +467,15 @@ int build_filter(oa_ctx *c)
     if (!finite) return OA_OK;                                   // exact kernel only
     for (int a = 0; a < 3; ++a) { c->tc[a] = (float)(0.5 * (lo[a] + hi[a])); c->bb_lo[a] = lo[a]; c->bb_hi[a] = hi[a]; }
     const int blocks = (c->n_groups_pad + 255) / 256;
+    DevTmp<double> d_mx;
     HIPCHK(hipMalloc(&c->d_tf, sizeof(float4) * 4 * (size_t)c->n_groups_pad));
-    e = hipMalloc(&d_mx, sizeof(double) * (size_t)blocks);
-    if (e != hipSuccess) return fail(OA_E_HIP, "build_filter: %s", hipGetErrorString(e));
+    HIPCHK(d_mx.alloc((size_t)blocks));
     hipLaunchKernelGGL(oa::k_pack_filter, dim3(blocks), dim3(256), 0, c->stream, c->d_tgt_xyz, c->nt, c->n_groups_pad,
-                       c->tc[0], c->tc[1], c->tc[2], c->d_tf, d_mx);
+                       c->tc[0], c->tc[1], c->tc[2], c->d_tf, d_mx.p);
+    HIPCHK(hipGetLastError());
     std::vector<double> mx((size_t)blocks);
-    e = hipMemcpyAsync(mx.data(), d_mx, sizeof(double) * (size_t)blocks, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    dev_free(d_mx);
-    if (e != hipSuccess) return fail(OA_E_HIP, "build_filter: %s", hipGetErrorString(e));
+    HIPCHK(hipMemcpyAsync(mx.data(), d_mx, sizeof(double) * (size_t)blocks, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     double m = 0.0;
     for (double v : mx) if (v > m) m = v;
     c->qmax = sqrt(m) * (1.0 + 1e-6);
@@ -487,17 +496,17 @@ int build_grid(oa_ctx *c)
         if (ext[a] > 0.0) { vol *= ext[a]; ++nz; }
         scale = std::max(scale, std::max(fabs(c->bb_lo[a]), fabs(c->bb_hi[a])));
     }
-    const double ppc = 2.0;
+    const double ppc = 2.0;                                          // target vertices per cell
     double h = nz ? pow(vol * ppc / (double)c->nt, 1.0 / nz) : 1.0;
     if (!(h > 0.0) || !(h < INFINITY)) return OA_OK;
     const long long max_cells = 1ll << 24;
-    int *d_cell_of = nullptr, *d_counts = nullptr, *d_nz = nullptr;
-    long long *d_off = nullptr;
-    HIPCHK(hipMalloc(&d_cell_of, sizeof(int) * (size_t)c->nt));
-    hipError_t e = hipMalloc(&d_nz, sizeof(int));
+    DevTmp<int> d_cell_of, d_counts, d_nz;
+    DevTmp<long long> d_off;
+    HIPCHK(d_cell_of.alloc((size_t)c->nt));
+    HIPCHK(d_nz.alloc(1));
     oa::GridParams gp{};
     int n_cells = 0;
-    for (int attempt = 0; attempt < 6 && e == hipSuccess; ++attempt) {
+    for (int attempt = 0; attempt < 6; ++attempt) {
         long long total = 1;
         for (int a = 0; a < 3; ++a) {
             long long n = ext[a] > 0.0 ? (long long)floor(ext[a] / h) + 1 : 1;
@@ -506,44 +515,37 @@ int build_grid(oa_ctx *c)
             total *= n;
             gp.lo[a] = c->bb_lo[a]; gp.hi[a] = c->bb_hi[a];
         }
-        if (total > max_cells) { h *= 1.3; continue; }
+        if (total > max_cells) { h *= 1.3; n_cells = 0; continue; }
         // a clamped axis (1024 cells) needs a cell edge that still covers the extent
         for (int a = 0; a < 3; ++a) if (ext[a] > 0.0 && ext[a] / h >= gp.n[a]) h = std::max(h, ext[a] / (gp.n[a] - 0.5));
         gp.h = h; gp.inv_h = 1.0 / h;
         gp.r_max = env_int("OA_GRID_RMAX", 3);
         gp.slack = 1e-10 * scale + 1e-300;
         n_cells = (int)total;
-        dev_free(d_counts); dev_free(d_off);
-        e = hipMalloc(&d_counts, sizeof(int) * (size_t)n_cells);
-        if (e == hipSuccess) e = hipMalloc(&d_off, sizeof(long long) * (size_t)(n_cells + 1));
-        if (e == hipSuccess) e = hipMemsetAsync(d_counts, 0, sizeof(int) * (size_t)n_cells, c->stream);
-        if (e == hipSuccess) e = hipMemsetAsync(d_nz, 0, sizeof(int), c->stream);
-        if (e != hipSuccess) break;
-        hipLaunchKernelGGL(oa::k_grid_count, dim3((c->nt + 255) / 256), dim3(256), 0, c->stream, c->d_tgt_xyz, c->nt, gp, d_cell_of, d_counts);
-        hipLaunchKernelGGL(oa::k_count_nonzero, dim3((n_cells + 255) / 256), dim3(256), 0, c->stream, d_counts, n_cells, d_nz);
+        HIPCHK(d_counts.alloc((size_t)n_cells));
+        HIPCHK(d_off.alloc((size_t)n_cells + 1));
+        HIPCHK(hipMemsetAsync(d_counts, 0, sizeof(int) * (size_t)n_cells, c->stream));
+        HIPCHK(hipMemsetAsync(d_nz, 0, sizeof(int), c->stream));
+        hipLaunchKernelGGL(oa::k_grid_count, dim3((c->nt + 255) / 256), dim3(256), 0, c->stream, c->d_tgt_xyz, c->nt, gp, d_cell_of.p, d_counts.p);
+        hipLaunchKernelGGL(oa::k_count_nonzero, dim3((n_cells + 255) / 256), dim3(256), 0, c->stream, d_counts.p, n_cells, d_nz.p);
+        HIPCHK(hipGetLastError());
         int occupied = 0;
-        e = hipMemcpyAsync(&occupied, d_nz, sizeof(int), hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) break;
+        HIPCHK(hipMemcpyAsync(&occupied, d_nz, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
         const double avg = occupied > 0 ? (double)c->nt / occupied : 0.0;
         // surfaces fill few cells: refine until occupied cells hold a handful of vertices each
         if (avg > 6.0 && total * 8 <= max_cells && attempt < 5) { h *= 0.5; continue; }
         break;
     }
-    if (e == hipSuccess && n_cells > 0) {
-        e = hipMalloc(&c->d_cell_start, sizeof(int) * (size_t)(n_cells + 1));
-        if (e == hipSuccess) e = hipMalloc(&c->d_sorted, sizeof(float4) * (size_t)c->nt);
-        if (e == hipSuccess) {
-            hipLaunchKernelGGL(oa::k_scan_counts, dim3(1), dim3(1024), 0, c->stream, d_counts, n_cells, d_off);
-            hipLaunchKernelGGL(oa::k_grid_starts, dim3((n_cells + 256) / 256), dim3(256), 0, c->stream, d_off, n_cells, c->d_cell_start, d_counts);
-            hipLaunchKernelGGL(oa::k_grid_scatter, dim3((c->nt + 255) / 256), dim3(256), 0, c->stream, c->d_tgt_xyz, c->nt, d_cell_of, c->d_cell_start, d_counts, c->d_sorted);
-            e = hipGetLastError();
-            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        }
-    }
-    dev_free(d_cell_of); dev_free(d_counts); dev_free(d_off); dev_free(d_nz);
-    if (e != hipSuccess) return fail(OA_E_HIP, "build_grid: %s", hipGetErrorString(e));
-    if (n_cells > 0) { c->gp = gp; c->n_cells = n_cells; c->grid_ok = true; }
+    if (n_cells <= 0) return OA_OK;
+    HIPCHK(hipMalloc(&c->d_cell_start, sizeof(int) * (size_t)(n_cells + 1)));
+    HIPCHK(hipMalloc(&c->d_sorted, sizeof(float4) * (size_t)c->nt));
+    hipLaunchKernelGGL(oa::k_scan_counts, dim3(1), dim3(1024), 0, c->stream, d_counts.p, n_cells, d_off.p);
+    hipLaunchKernelGGL(oa::k_grid_starts, dim3((n_cells + 256) / 256), dim3(256), 0, c->stream, d_off.p, n_cells, c->d_cell_start, d_counts.p);
+    hipLaunchKernelGGL(oa::k_grid_scatter, dim3((c->nt + 255) / 256), dim3(256), 0, c->stream, c->d_tgt_xyz, c->nt, d_cell_of.p, c->d_cell_start, d_counts.p, c->d_sorted);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->gp = gp; c->n_cells = n_cells; c->grid_ok = true;
     return OA_OK;
 }
 
@@ -630,15 +632,15 @@ OA_EXPORT int oa_set_source(oa_ctx *c, const float *xyz, int64_t n_verts, int on
     c->pivot[0] = c->pivot[1] = c->pivot[2] = 0.0;
     if (n_sel > 0) {
         const float *d_xyz = xyz;
-        float *tmp_xyz = nullptr;
-        long long *d_vlist = nullptr;
+        DevTmp<float> tmp_xyz;
+        DevTmp<long long> d_vlist;
         if (!on_device) {
-            HIPCHK(hipMalloc(&tmp_xyz, sizeof(float) * 3 * (size_t)n_verts));
+            HIPCHK(tmp_xyz.alloc(3 * (size_t)n_verts));
             HIPCHK(hipMemcpyAsync(tmp_xyz, xyz, sizeof(float) * 3 * (size_t)n_verts, hipMemcpyHostToDevice, c->stream));
             d_xyz = tmp_xyz;
         }
         if (vlist) {
-            HIPCHK(hipMalloc(&d_vlist, sizeof(long long) * (size_t)n_vlist));
+            HIPCHK(d_vlist.alloc((size_t)n_vlist));
             HIPCHK(hipMemcpyAsync(d_vlist, vlist, sizeof(long long) * (size_t)n_vlist, hipMemcpyHostToDevice, c->stream));
         }
         // pivot = first selected vertex of the WHOLE selection (identical on every shard)
@@ -646,13 +648,11 @@ OA_EXPORT int oa_set_source(oa_ctx *c, const float *xyz, int64_t n_verts, int on
         float p0[3];
         if (on_device) HIPCHK(hipMemcpyAsync(p0, xyz + 3 * v0, sizeof p0, hipMemcpyDeviceToHost, c->stream));
         else memcpy(p0, xyz + 3 * v0, sizeof p0);
-        hipLaunchKernelGGL(oa::k_pack_source, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, d_xyz, d_vlist,
-                           step, begin, c->ns, c->ns_pad, c->d_src4);
+        hipLaunchKernelGGL(oa::k_pack_source, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, d_xyz,
+                           (const long long *)d_vlist.p, step, begin, c->ns, c->ns_pad, c->d_src4);
         hipLaunchKernelGGL(oa::k_fill_keys, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, c->d_keys, c->ns_pad);
-        hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        dev_free(tmp_xyz); dev_free(d_vlist);
-        if (e != hipSuccess) return fail(OA_E_HIP, "oa_set_source: %s", hipGetErrorString(e));
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(c->stream));
         for (int k = 0; k < 3; ++k) c->pivot[k] = (double)p0[k];
     } else {
         HIPCHK(hipMemsetAsync(c->d_src4, 0, sizeof(float4) * (size_t)c->ns_pad, c->stream));
@@ -721,24 +721,19 @@ OA_EXPORT int oa_nn_search(oa_ctx *c, int64_t *idx, float *d2, double *kernel_ms
     if ((rc = push_state_for_oneshot(c, 1.0))) return rc;
     if (kernel_ms) *kernel_ms = 0.0;
     if (c->ns <= 0) return OA_OK;
-    long long *d_idx = nullptr;
-    float *d_d2 = nullptr;
-    hipError_t e = hipSuccess;
-    if (idx) e = hipMalloc(&d_idx, sizeof(long long) * (size_t)c->ns);
-    if (e == hipSuccess && d2) e = hipMalloc(&d_d2, sizeof(float) * (size_t)c->ns);
-    if (e == hipSuccess) e = hipEventRecord(c->ev[0], c->stream);
-    if (e == hipSuccess) { rc = launch_nn(c); if (rc) { dev_free(d_idx); dev_free(d_d2); return rc; } }
-    if (e == hipSuccess) e = hipEventRecord(c->ev[1], c->stream);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(oa::k_decode_keys, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, c->d_keys,
-                           c->ns_pad, c->ns, d_idx, d_d2);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess && idx) e = hipMemcpyAsync(idx, d_idx, sizeof(long long) * (size_t)c->ns, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess && d2) e = hipMemcpyAsync(d2, d_d2, sizeof(float) * (size_t)c->ns, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    dev_free(d_idx); dev_free(d_d2);
-    if (e != hipSuccess) return fail(OA_E_HIP, "oa_nn_search: %s", hipGetErrorString(e));
+    DevTmp<long long> d_idx;
+    DevTmp<float> d_d2;
+    if (idx) HIPCHK(d_idx.alloc((size_t)c->ns));
+    if (d2) HIPCHK(d_d2.alloc((size_t)c->ns));
+    HIPCHK(hipEventRecord(c->ev[0], c->stream));
+    if ((rc = launch_nn(c))) return rc;
+    HIPCHK(hipEventRecord(c->ev[1], c->stream));
+    hipLaunchKernelGGL(oa::k_decode_keys, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, c->d_keys,
+                       c->ns_pad, c->ns, d_idx.p, d_d2.p);
+    HIPCHK(hipGetLastError());
+    if (idx) HIPCHK(hipMemcpyAsync(idx, d_idx, sizeof(long long) * (size_t)c->ns, hipMemcpyDeviceToHost, c->stream));
+    if (d2) HIPCHK(hipMemcpyAsync(d2, d_d2, sizeof(float) * (size_t)c->ns, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     if (kernel_ms) {
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
@@ -832,27 +827,21 @@ OA_EXPORT int oa_kabsch(oa_ctx *c, const double *A, const double *B, int64_t K, 
     int rc = use_device(c);
     if (rc) return rc;
     if ((rc = ensure_common(c))) return rc;
-    double *dA = nullptr, *dB = nullptr;
-    HIPCHK(hipMalloc(&dA, sizeof(double) * 3 * (size_t)K));
-    hipError_t e = hipMalloc(&dB, sizeof(double) * 3 * (size_t)K);
-    if (e != hipSuccess) { dev_free(dA); return fail(OA_E_HIP, "oa_kabsch: %s", hipGetErrorString(e)); }
-    for (int a = 0; a < 3 && e == hipSuccess; ++a) {
-        e = hipMemcpyAsync(dA + (size_t)a * K, A + (size_t)a * ld, sizeof(double) * (size_t)K, hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess)
-            e = hipMemcpyAsync(dB + (size_t)a * K, B + (size_t)a * ld, sizeof(double) * (size_t)K, hipMemcpyHostToDevice, c->stream);
+    DevTmp<double> dA, dB;
+    HIPCHK(dA.alloc(3 * (size_t)K));
+    HIPCHK(dB.alloc(3 * (size_t)K));
+    for (int a = 0; a < 3; ++a) {
+        HIPCHK(hipMemcpyAsync(dA.p + (size_t)a * K, A + (size_t)a * ld, sizeof(double) * (size_t)K, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(dB.p + (size_t)a * K, B + (size_t)a * ld, sizeof(double) * (size_t)K, hipMemcpyHostToDevice, c->stream));
     }
     const double pv[3] = { A[0], A[ld], A[2 * ld] };
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(oa::ACC_MAX_BLOCKS, (K + oa::ACC_THREADS - 1) / oa::ACC_THREADS));
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(oa::k_accumulate_pairs, dim3(blocks), dim3(oa::ACC_THREADS), 0, c->stream, dA, dB,
-                           (long long)K, (long long)K, pv[0], pv[1], pv[2], c->d_partials);
-        hipLaunchKernelGGL(oa::k_reduce_partials, dim3(1), dim3(1024), 0, c->stream, c->d_partials, blocks, c->d_sums);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) rc = solve_on_device(c, c->d_sums, pv, with_scale, M);
-    else rc = fail(OA_E_HIP, "oa_kabsch: %s", hipGetErrorString(e));
-    (void)hipStreamSynchronize(c->stream);
-    dev_free(dA); dev_free(dB);
+    hipLaunchKernelGGL(oa::k_accumulate_pairs, dim3(blocks), dim3(oa::ACC_THREADS), 0, c->stream, (const double *)dA.p,
+                       (const double *)dB.p, (long long)K, (long long)K, pv[0], pv[1], pv[2], c->d_partials);
+    hipLaunchKernelGGL(oa::k_reduce_partials, dim3(1), dim3(1024), 0, c->stream, c->d_partials, blocks, c->d_sums);
+    HIPCHK(hipGetLastError());
+    rc = solve_on_device(c, c->d_sums, pv, with_scale, M);      // synchronises the stream
+    if (rc) (void)hipStreamSynchronize(c->stream);
     return rc;
 }
 

@@ -1,1 +1,2 @@
 from .icp_align import IcpAlign, IcpSettings, OBJECT_OT_icp_align, build_vlist, get_addon_preferences  # noqa: F401
+from .icp_align_feedback import OBJECT_OT_icp_align_feedback  # noqa: F401

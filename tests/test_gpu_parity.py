@@ -378,6 +378,35 @@ def test_operator_execute_duck_typed(golden_dir, orc, name):
         setattr(icp_align.get_addon_preferences(), k, v)
 
 
+def test_modal_operator_ticks(golden_dir, orc):
+    """OBJECT_OT_icp_align_feedback: timer ticks of `redraw_frequency` iterations reach the reference's final matrix."""
+    from object_alignment_amd.operators import OBJECT_OT_icp_align_feedback, icp_align
+    g = _load(golden_dir, "icp_loop_bumpy_converge")
+    st = _settings_from(g)
+    st.redraw_frequency = 3
+    for k, v in st.__dict__.items():
+        setattr(icp_align.get_addon_preferences(), k, v)
+    align = orc.MeshObject(g["src"], g["mx_align"], "align")
+    base = orc.MeshObject(g["tgt"], g["mx_base"], "base")
+    align.type = base.type = "MESH"
+    ctx = types.SimpleNamespace(object=align, selected_objects=[base, align], scene=types.SimpleNamespace(objects=[]))
+    op = OBJECT_OT_icp_align_feedback()
+    assert OBJECT_OT_icp_align_feedback.bl_idname == "object.align_icp_redraw"
+    assert op.poll(ctx)
+    assert op.invoke(ctx, None) == {"RUNNING_MODAL"}
+    tick = types.SimpleNamespace(type="TIMER")
+    assert op.modal(ctx, types.SimpleNamespace(type="MOUSEMOVE")) == {"PASS_THROUGH"}
+    n_ticks = 0
+    while op.modal(ctx, tick) == {"RUNNING_MODAL"}:
+        n_ticks += 1
+        assert n_ticks < 50
+    assert op.converged and op.total_iters == int(g["iters_done"])
+    got = np.array([[align.matrix_world[r][c] for c in range(4)] for r in range(4)], np.float32)
+    assert np.abs(got - g["final_world"]).max() <= F32_ULP
+    for k, v in icp_align.IcpSettings().__dict__.items():
+        setattr(icp_align.get_addon_preferences(), k, v)
+
+
 def test_step_mode_equals_fused_loop(golden_dir):
     from object_alignment_amd.engine import IcpEngine
     g = _load(golden_dir, "icp_loop_bumpy_converge")
@@ -466,6 +495,51 @@ def test_c3_random_1m_few_iters(orc):
     err = np.linalg.norm(res.matrix_world.astype(np.float64) - ref["matrix_world"].astype(np.float64))
     assert err <= FROB_TOL, err
     assert np.abs(res.step_M - ref["step_M"]).max() < 1e-9
+
+
+def test_c5_shaped_masked_sharded(orc):
+    """BASELINE config 5's shape at 1/10 scale: 1M source on a surface, 200k target, a 10 % cap of the source excluded
+    (icp_exclude semantics -> vlist), source split over two contexts; against the oracle's KD-tree loop."""
+    import torch
+    from object_alignment_amd import synth, _capi
+    from object_alignment_amd.engine import IcpEngine
+    from object_alignment_amd.operators.icp_align import vlist_from_weights
+    src = synth.bunny_surface(1_000_000, 0.5)
+    tgt = synth.bunny_surface(200_000, 0.0)
+    R = synth.rotation_from_rotvec([0.03, -0.02, 0.04])
+    mxa = synth.rigid4(R, [0.02, -0.01, 0.015])
+    eye = np.identity(4, dtype=np.float32)
+    cap = np.nonzero(src[:, 2] > np.quantile(src[:, 2], 0.9))[0]
+    vlist = np.array(vlist_from_weights(len(src), exclude=[(int(v), 1.0) for v in cap]), dtype=np.int64)
+    assert len(vlist) == len(src) - len(cap)
+    iters = 4
+    dev = torch.device("cuda:0")
+    engs = [IcpEngine(0) for _ in range(2)]
+    try:
+        sums = [torch.zeros(_capi.OA_NSUMS, dtype=torch.float64, device=dev) for _ in range(2)]
+        for r, e in enumerate(engs):
+            e.set_stream(torch.cuda.current_stream().cuda_stream)
+            e.set_target(tgt)
+            e.set_source(src, vlist=vlist, stride=1, shard_index=r, shard_count=2)
+            e.set_matrices(mxa, eye)
+            e.run_begin(iters=iters, thresh=0.5, target_d=0.01, use_target=True, early_exit=False)
+        for _ in range(iters):
+            for r, e in enumerate(engs):
+                e.iter_partial(sums[r].data_ptr())
+            total = sums[0] + sums[1]
+            for e in engs:
+                e.iter_finish(total.data_ptr())
+        res = [e.run_end() for e in engs]
+    finally:
+        for e in engs:
+            e.close()
+    ref = orc.icp_run(src, tgt, mxa, eye, iters=iters, sample=1, thresh=0.5, target_d=1e-300, use_target=True,
+                      vlist=vlist, kd=orc.KDTree(tgt))
+    assert np.array_equal(res[0].matrix_world, res[1].matrix_world)
+    assert np.array_equal(res[0].step_K, ref["step_K"])
+    err = np.linalg.norm(res[0].matrix_world.astype(np.float64) - ref["matrix_world"].astype(np.float64))
+    assert err <= FROB_TOL, err
+    assert np.abs(res[0].step_M - ref["step_M"]).max() < 1e-9
 
 
 # ------------------------------------------------------------------ sharded (split-phase) path on one GPU
