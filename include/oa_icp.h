@@ -99,6 +99,13 @@ int oa_set_search_mode(oa_ctx *ctx, int mode);
  *      walk over align_obj.data.vertices, functions/general.py:280-284) ------------------------ */
 /* target (base object) vertices, base-LOCAL, n x 3 float32.  on_device != 0: xyz is a device pointer. */
 int oa_set_target(oa_ctx *ctx, const float *xyz, int64_t n, int on_device);
+/* SURFACE mode (the BVHTree.find_nearest semantics of functions/general.py:297): the base object's vertices plus
+ * its triangles (n_tris x 3 vertex indices, host int32; quads/ngons triangulated by the caller, e.g. Blender's
+ * loop_triangles).  The correspondence of a source point is then the closest point on the nearest triangle
+ * (Ericson's closest-point-on-triangle in float32, lowest triangle index on ties) instead of the nearest vertex;
+ * everything else (threshold, pair mapping, solve, loop) is unchanged.  oa_set_target() returns to vertex mode. */
+int oa_set_target_mesh(oa_ctx *ctx, const float *xyz, int64_t n_verts, int on_device,
+                       const int32_t *tris, int64_t n_tris);
 /* source (align object) vertices, align-LOCAL, n_verts x 3 float32.
  * vlist (host, may be NULL = all vertices) is the operator's vertex list; stride > 1 applies
  * vlist[0::stride] (functions/general.py:274-275).  The selected list is then cut into
@@ -116,8 +123,8 @@ int64_t oa_num_selected(oa_ctx *ctx);     /* selected source points held by this
  * dstats = [mean, population std] of the world-space pair distances when calc_stats. */
 int oa_make_pairs(oa_ctx *ctx, double thresh, int calc_stats,
                   double *A, double *B, int64_t cap, int64_t *K, double dstats[2]);
-/* the correspondence search alone: nearest target vertex index and fp32 squared distance
- * (base-local) for every selected source point of this shard.  idx/d2 may be NULL (timing). */
+/* the correspondence search alone: nearest target vertex index (surface mode: nearest triangle index) and fp32
+ * squared distance (base-local) for every selected source point of this shard.  idx/d2 may be NULL (timing). */
 int oa_nn_search(oa_ctx *ctx, int64_t *idx, float *d2, double *kernel_ms);
 
 /* ---- contract 2: affine_matrix_from_points(v0=A, v1=B, shear=False, scale, usesvd=True)

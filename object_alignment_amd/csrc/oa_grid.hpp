@@ -25,6 +25,7 @@ struct GridParams {
     int    n[3];             // cells per axis
     int    r_max;            // rings searched before handing the query to the brute-force kernel
     double slack;            // absolute slack subtracted from face distances (1e-10 x largest |coordinate|)
+    double scale;            // largest |coordinate| of the box
 };
 
 #if defined(__HIPCC__)

@@ -5,6 +5,7 @@
 // compute entry point needs a usable HIP device and fails loudly otherwise.
 #include "oa_kernels.hpp"
 #include "oa_grid.hpp"
+#include "oa_tri.hpp"
 #include "../../include/oa_icp.h"
 
 #include <algorithm>
@@ -83,6 +84,12 @@ struct oa_ctx {
     int *d_cell_start = nullptr;
     float4 *d_sorted = nullptr;
     int *d_todo_list = nullptr, *d_todo_count = nullptr;
+    // surface mode (closest point on triangle, oa_tri.hpp)
+    bool surface = false, tri_grid_ok = false;
+    int n_tris = 0;
+    float4 *d_tri9 = nullptr;
+    oa::GridParams tgp;
+    int *d_tcell_start = nullptr, *d_tcell_tris = nullptr;
     bool filter_ok = false;
     float tc[3] = { 0, 0, 0 };
     double qmax = 0.0;
@@ -183,10 +190,12 @@ int check_ready(oa_ctx *c)
 
 bool grid_active(const oa_ctx *c);
 int build_grid(oa_ctx *c);
+int launch_tri_search(oa_ctx *c);
 
 int launch_nn(oa_ctx *c)
 {
     if (c->ns <= 0) return OA_OK;
+    if (c->surface) return launch_tri_search(c);
     if (c->ns_pad / (oa::NN_THREADS * c->R) > 65535)
         return fail(OA_E_BAD_ARG, "shard of %d points exceeds the launch grid (use more shards or OA_NN_R=8)", c->ns);
     dim3 grid(c->n_splits, c->ns_pad / (oa::NN_THREADS * c->R));
@@ -242,10 +251,12 @@ int launch_accumulate(oa_ctx *c, bool emit, int *nn_idx, float *nn_d2)
     if (emit) {
         po.valid = c->d_valid; po.b = c->d_b; po.dist = c->d_dist; po.nn_idx = nn_idx; po.nn_d2 = nn_d2;
         hipLaunchKernelGGL(oa::k_pair_accumulate<true>, dim3(c->acc_blocks), dim3(oa::ACC_THREADS), 0, c->stream,
-                           c->d_state, c->d_src4, c->ns, c->d_tgt_xyz, c->d_keys, c->d_prev, c->d_partials, po);
+                           c->d_state, c->d_src4, c->ns, c->d_tgt_xyz, c->d_keys, c->d_prev,
+                           c->surface ? (const float4 *)c->d_tri9 : (const float4 *)nullptr, c->d_partials, po);
     } else {
         hipLaunchKernelGGL(oa::k_pair_accumulate<false>, dim3(c->acc_blocks), dim3(oa::ACC_THREADS), 0, c->stream,
-                           c->d_state, c->d_src4, c->ns, c->d_tgt_xyz, c->d_keys, c->d_prev, c->d_partials, po);
+                           c->d_state, c->d_src4, c->ns, c->d_tgt_xyz, c->d_keys, c->d_prev,
+                           c->surface ? (const float4 *)c->d_tri9 : (const float4 *)nullptr, c->d_partials, po);
     }
     HIPCHK(hipGetLastError());
     return OA_OK;
@@ -408,6 +419,7 @@ OA_EXPORT void oa_destroy(oa_ctx *c)
     dev_free(c->d_hist); dev_free(c->d_partials); dev_free(c->d_sums); dev_free(c->d_solve);
     dev_free(c->d_valid); dev_free(c->d_b); dev_free(c->d_dist); dev_free(c->d_counts); dev_free(c->d_offsets);
     dev_free(c->d_A); dev_free(c->d_B);
+    dev_free(c->d_tri9); dev_free(c->d_tcell_start); dev_free(c->d_tcell_tris);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->ev_loop0) (void)hipEventDestroy(c->ev_loop0);
     if (c->ev_loop1) (void)hipEventDestroy(c->ev_loop1);
@@ -521,6 +533,7 @@ int build_grid(oa_ctx *c)
         gp.h = h; gp.inv_h = 1.0 / h;
         gp.r_max = env_int("OA_GRID_RMAX", 3);
         gp.slack = 1e-10 * scale + 1e-300;
+        gp.scale = scale;
         n_cells = (int)total;
         HIPCHK(d_counts.alloc((size_t)n_cells));
         HIPCHK(d_off.alloc((size_t)n_cells + 1));
@@ -565,6 +578,8 @@ OA_EXPORT int oa_set_target(oa_ctx *c, const float *xyz, int64_t n, int on_devic
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
     dev_free(c->d_tgt_xyz); dev_free(c->d_tg); dev_free(c->d_tf);
+    dev_free(c->d_tri9); dev_free(c->d_tcell_start); dev_free(c->d_tcell_tris);
+    c->surface = false; c->tri_grid_ok = false; c->n_tris = 0;
     c->filter_ok = false;
     c->nt = (int)n;
     c->n_groups_pad = 0;
@@ -589,6 +604,133 @@ OA_EXPORT int oa_set_target(oa_ctx *c, const float *xyz, int64_t n, int on_devic
     if ((rcf = build_grid(c))) return rcf;
     plan_geometry(c);
     return OA_OK;
+}
+
+namespace {
+// uniform grid over the triangles' bounding boxes
+int build_tri_grid(oa_ctx *c)
+{
+    c->tri_grid_ok = false;
+    dev_free(c->d_tcell_start); dev_free(c->d_tcell_tris);
+    if (!c->filter_ok || c->grid_mode == 0 || c->n_tris < 64) return OA_OK;
+    DevTmp<double> d_sum;
+    HIPCHK(d_sum.alloc(1));
+    HIPCHK(hipMemsetAsync(d_sum, 0, sizeof(double), c->stream));
+    hipLaunchKernelGGL(oa::k_tri_diag_sum, dim3((c->n_tris + 255) / 256), dim3(256), 0, c->stream, c->d_tri9, c->n_tris, d_sum.p);
+    HIPCHK(hipGetLastError());
+    double diag_sum = 0.0;
+    HIPCHK(hipMemcpyAsync(&diag_sum, d_sum, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    double ext[3], scale = 0.0, max_ext = 0.0;
+    for (int a = 0; a < 3; ++a) {
+        ext[a] = c->bb_hi[a] - c->bb_lo[a];
+        max_ext = std::max(max_ext, ext[a]);
+        scale = std::max(scale, std::max(fabs(c->bb_lo[a]), fabs(c->bb_hi[a])));
+    }
+    double h = 1.5 * diag_sum / (double)c->n_tris;                  // ~1.5 mean triangle bbox diagonals per cell
+    if (!(h > 0.0) || !(h < INFINITY)) h = max_ext > 0.0 ? max_ext / 64.0 : 1.0;
+    h = std::max(h, max_ext / 512.0);
+    const long long max_cells = 1ll << 24;
+    DevTmp<int> d_counts;
+    DevTmp<long long> d_off;
+    DevTmp<unsigned long long> d_total;
+    HIPCHK(d_total.alloc(1));
+    oa::GridParams gp{};
+    int n_cells = 0;
+    unsigned long long entries = 0;
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        long long total = 1;
+        for (int a = 0; a < 3; ++a) {
+            long long n = ext[a] > 0.0 ? (long long)floor(ext[a] / h) + 1 : 1;
+            n = std::max(1ll, std::min(n, 512ll));
+            gp.n[a] = (int)n;
+            total *= n;
+            gp.lo[a] = c->bb_lo[a]; gp.hi[a] = c->bb_hi[a];
+        }
+        if (total > max_cells) { h *= 1.3; n_cells = 0; continue; }
+        gp.h = h; gp.inv_h = 1.0 / h;
+        gp.r_max = env_int("OA_GRID_RMAX", 3);
+        gp.scale = scale;
+        gp.slack = 1e-10 * scale + 1e-300;
+        n_cells = (int)total;
+        HIPCHK(d_counts.alloc((size_t)n_cells));
+        HIPCHK(hipMemsetAsync(d_counts, 0, sizeof(int) * (size_t)n_cells, c->stream));
+        HIPCHK(hipMemsetAsync(d_total, 0, sizeof(unsigned long long), c->stream));
+        hipLaunchKernelGGL(oa::k_tri_grid_bin<false>, dim3((c->n_tris + 255) / 256), dim3(256), 0, c->stream, c->d_tri9,
+                           c->n_tris, gp, d_counts.p, (const int *)nullptr, (int *)nullptr, d_total.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(&entries, d_total, sizeof(entries), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        // triangles much larger than a cell explode the lists: coarsen
+        if (entries > 32ull * (unsigned long long)c->n_tris + (1ull << 20) || entries > 0x7FFFFFF0ull) { h *= 2.0; n_cells = 0; continue; }
+        break;
+    }
+    if (n_cells <= 0 || entries == 0) return OA_OK;
+    HIPCHK(d_off.alloc((size_t)n_cells + 1));
+    HIPCHK(hipMalloc(&c->d_tcell_start, sizeof(int) * (size_t)(n_cells + 1)));
+    HIPCHK(hipMalloc(&c->d_tcell_tris, sizeof(int) * (size_t)entries));
+    hipLaunchKernelGGL(oa::k_scan_counts, dim3(1), dim3(1024), 0, c->stream, d_counts.p, n_cells, d_off.p);
+    hipLaunchKernelGGL(oa::k_grid_starts, dim3((n_cells + 256) / 256), dim3(256), 0, c->stream, d_off.p, n_cells, c->d_tcell_start, d_counts.p);
+    hipLaunchKernelGGL(oa::k_tri_grid_bin<true>, dim3((c->n_tris + 255) / 256), dim3(256), 0, c->stream, c->d_tri9, c->n_tris,
+                       gp, d_counts.p, (const int *)c->d_tcell_start, c->d_tcell_tris, (unsigned long long *)nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->tgp = gp;
+    c->tri_grid_ok = true;
+    return OA_OK;
+}
+
+int launch_tri_search(oa_ctx *c)
+{
+    const bool use_grid = c->tri_grid_ok && c->grid_mode != 0 &&
+                          (c->grid_mode == 1 || (double)c->n_tris * (double)c->ns >= 2e7);
+    if (getenv("OA_DEBUG"))
+        fprintf(stderr, "[oa] tri search: grid=%d ns=%d n_tris=%d state=%p src4=%p tri9=%p prev=%p keys=%p todo=%p/%p cells=%p/%p\n",
+                (int)use_grid, c->ns, c->n_tris, (void *)c->d_state, (void *)c->d_src4, (void *)c->d_tri9, (void *)c->d_prev,
+                (void *)c->d_keys, (void *)c->d_todo_list, (void *)c->d_todo_count, (void *)c->d_tcell_start, (void *)c->d_tcell_tris);
+    if (use_grid) {
+        HIPCHK(hipMemsetAsync(c->d_todo_count, 0, sizeof(int), c->stream));
+        hipLaunchKernelGGL(oa::k_tri_search_grid, dim3((c->ns + 255) / 256), dim3(256), 0, c->stream, c->d_state, c->d_src4,
+                           c->ns, c->tgp, c->d_tcell_start, c->d_tcell_tris, c->d_tri9, c->d_prev, c->d_keys,
+                           c->d_todo_list, c->d_todo_count);
+        hipLaunchKernelGGL(oa::k_tri_search_all, dim3(std::min((c->ns + 255) / 256, 2048)), dim3(256), 0, c->stream,
+                           c->d_state, c->d_src4, c->ns, c->d_tri9, c->n_tris, c->d_prev, c->d_keys,
+                           (const int *)c->d_todo_list, (const int *)c->d_todo_count);
+    } else {
+        hipLaunchKernelGGL(oa::k_tri_search_all, dim3(std::min((c->ns + 255) / 256, 65535)), dim3(256), 0, c->stream,
+                           c->d_state, c->d_src4, c->ns, c->d_tri9, c->n_tris, c->d_prev, c->d_keys,
+                           (const int *)nullptr, (const int *)nullptr);
+    }
+    HIPCHK(hipGetLastError());
+    return OA_OK;
+}
+}  // namespace
+
+OA_EXPORT int oa_set_target_mesh(oa_ctx *c, const float *xyz, int64_t n_verts, int on_device, const int32_t *tris,
+                                 int64_t n_tris)
+{
+    if (!c) return fail(OA_E_BAD_ARG, "null context");
+    if (n_tris < 1 || !tris) return fail(OA_E_BAD_ARG, "oa_set_target_mesh: no triangles");
+    if (n_tris > 0x2AAAAAA0ll) return fail(OA_E_BAD_ARG, "too many triangles");
+    int rc = oa_set_target(c, xyz, n_verts, on_device);             // vertex images + bbox + filter (and vertex grid)
+    if (rc) return rc;
+    if (n_verts < 1) return fail(OA_E_BAD_ARG, "oa_set_target_mesh: no vertices");
+    DevTmp<int> d_tris, d_bad;
+    HIPCHK(d_tris.alloc(3 * (size_t)n_tris));
+    HIPCHK(d_bad.alloc(1));
+    HIPCHK(hipMemcpyAsync(d_tris, tris, sizeof(int) * 3 * (size_t)n_tris, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(int), c->stream));
+    HIPCHK(hipMalloc(&c->d_tri9, sizeof(float4) * 3 * (size_t)n_tris));
+    hipLaunchKernelGGL(oa::k_pack_tris, dim3((unsigned)((n_tris + 255) / 256)), dim3(256), 0, c->stream, c->d_tgt_xyz,
+                       (int)n_verts, (const int *)d_tris.p, (int)n_tris, c->d_tri9, d_bad.p);
+    HIPCHK(hipGetLastError());
+    int bad = 0;
+    HIPCHK(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (bad) { dev_free(c->d_tri9); return fail(OA_E_BAD_ARG, "oa_set_target_mesh: %d triangle corners index outside 0..%lld", bad, (long long)n_verts - 1); }
+    c->n_tris = (int)n_tris;
+    c->surface = true;
+    return build_tri_grid(c);
 }
 
 OA_EXPORT int oa_set_source(oa_ctx *c, const float *xyz, int64_t n_verts, int on_device, const int64_t *vlist,

@@ -223,7 +223,69 @@ __host__ __device__ inline double rotation_angle_3x3(const double M[16])
     return acos(x);
 }
 
+// ------------------------------------------------------------------------------------------------
+// closest point on a triangle (surface mode, oa_tri.hpp): Blender's closest_on_tri_to_point_v3 restated in float32
+// with explicit operation order and no fma; bit-identical to oracle/oa_oracle.c: oo_closest_on_tri
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ inline float dot3f(const float *a, const float *b)
+{
+    float s = a[0] * b[0];
+    s = s + a[1] * b[1];
+    s = s + a[2] * b[2];
+    return s;
+}
+
+// Blender math_geom.c closest_on_tri_to_point_v3, float32, same operation order as the oracle
+__host__ __device__ inline void closest_on_tri(const float *p, const float *a, const float *b, const float *c, float *r)
+{
+    float ab[3], ac[3], ap[3], bp[3], cp[3];
+    for (int i = 0; i < 3; ++i) { ab[i] = b[i] - a[i]; ac[i] = c[i] - a[i]; ap[i] = p[i] - a[i]; }
+    const float d1 = dot3f(ab, ap), d2 = dot3f(ac, ap);
+    if (d1 <= 0.0f && d2 <= 0.0f) { r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; return; }
+    for (int i = 0; i < 3; ++i) bp[i] = p[i] - b[i];
+    const float d3 = dot3f(ab, bp), d4 = dot3f(ac, bp);
+    if (d3 >= 0.0f && d4 <= d3) { r[0] = b[0]; r[1] = b[1]; r[2] = b[2]; return; }
+    const float vc = d1 * d4 - d3 * d2;
+    if (vc <= 0.0f && d1 >= 0.0f && d3 <= 0.0f) {
+        const float v = d1 / (d1 - d3);
+        for (int i = 0; i < 3; ++i) r[i] = a[i] + ab[i] * v;
+        return;
+    }
+    for (int i = 0; i < 3; ++i) cp[i] = p[i] - c[i];
+    const float d5 = dot3f(ab, cp), d6 = dot3f(ac, cp);
+    if (d6 >= 0.0f && d5 <= d6) { r[0] = c[0]; r[1] = c[1]; r[2] = c[2]; return; }
+    const float vb = d5 * d2 - d1 * d6;
+    if (vb <= 0.0f && d2 >= 0.0f && d6 <= 0.0f) {
+        const float w = d2 / (d2 - d6);
+        for (int i = 0; i < 3; ++i) r[i] = a[i] + ac[i] * w;
+        return;
+    }
+    const float va = d3 * d6 - d5 * d4;
+    if (va <= 0.0f && (d4 - d3) >= 0.0f && (d5 - d6) >= 0.0f) {
+        const float w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+        for (int i = 0; i < 3; ++i) { float t = c[i] - b[i]; t = t * w; r[i] = t + b[i]; }
+        return;
+    }
+    const float denom = 1.0f / ((va + vb) + vc);
+    const float v = vb * denom, w = vc * denom;
+    for (int i = 0; i < 3; ++i) { const float acw = ac[i] * w; const float t = a[i] + ab[i] * v; r[i] = t + acw; }
+}
+
+__host__ __device__ inline float tri_dist2(const float *p, const float *r)
+{
+    const float d[3] = { r[0] - p[0], r[1] - p[1], r[2] - p[2] };
+    return dot3f(d, d);
+}
+
+
 #if defined(__HIPCC__)
+
+// triangle image: 3 x float4 per triangle {ax,ay,az,bx} {by,bz,cx,cy} {cz,-,-,-}
+__device__ __forceinline__ void load_tri(const float4 *__restrict__ tri9, long long t, float *a, float *b, float *c)
+{
+    const float4 u = tri9[3 * t], v = tri9[3 * t + 1], w = tri9[3 * t + 2];
+    a[0] = u.x; a[1] = u.y; a[2] = u.z; b[0] = u.w; b[1] = v.x; b[2] = v.y; c[0] = v.z; c[1] = v.w; c[2] = w.x;
+}
 
 // ------------------------------------------------------------------------------------------------
 // packing kernels (one-time)
@@ -660,6 +722,7 @@ __global__ __launch_bounds__(ACC_THREADS) void k_pair_accumulate(const DevState 
                                                                  const float *__restrict__ tgt_xyz,
                                                                  unsigned long long *__restrict__ keys,
                                                                  int *__restrict__ prev,
+                                                                 const float4 *__restrict__ tri9,
                                                                  double *__restrict__ partials, PairOut out)
 {
     __shared__ double red[ACC_THREADS / 64][NSUMS];
@@ -684,7 +747,16 @@ __global__ __launch_bounds__(ACC_THREADS) void k_pair_accumulate(const DevState 
                 float wx, wy, wz, cx, cy, cz;
                 m4_mul_v3(st->mx1, p.x, p.y, p.z, wx, wy, wz);
                 m4_mul_v3(st->imx2, wx, wy, wz, cx, cy, cz);       // co_find                   (general.py:287)
-                const float qx = tgt_xyz[3ll * idx], qy = tgt_xyz[3ll * idx + 1], qz = tgt_xyz[3ll * idx + 2];
+                float qx, qy, qz;                                    // co1 (general.py:297)
+                if (tri9) {                                          // surface mode: closest point on triangle `idx`
+                    float ta[3], tb[3], tc[3], rr[3];
+                    const float cf[3] = { cx, cy, cz };
+                    load_tri(tri9, idx, ta, tb, tc);
+                    closest_on_tri(cf, ta, tb, tc, rr);
+                    qx = rr[0]; qy = rr[1]; qz = rr[2];
+                } else {                                             // vertex mode: target vertex `idx`
+                    qx = tgt_xyz[3ll * idx]; qy = tgt_xyz[3ll * idx + 1]; qz = tgt_xyz[3ll * idx + 2];
+                }
                 float ax, ay, az, wbx, wby, wbz;
                 m4_mul_v3(st->mx2, cx, cy, cz, ax, ay, az);         // mx2 @ co_find             (general.py:299)
                 m4_mul_v3(st->mx2, qx, qy, qz, wbx, wby, wbz);      // mx2 @ co1                 (general.py:299)

@@ -1,0 +1,221 @@
+// oa_tri.hpp -- closest point on the target's triangle SURFACE (closes discrepancy D2).
+//
+// This is what Blender's BVHTree.find_nearest (functions/general.py:297) returns: the nearest point of the nearest
+// triangle of the evaluated base mesh.  The per-triangle arithmetic restates Blender's closest_on_tri_to_point_v3
+// (Ericson, "Real-Time Collision Detection" 5.1.5) in float32 with explicit operation order and no fma -- identical,
+// bit for bit, to the CPU oracle (oracle/oa_oracle.c: oo_closest_on_tri).  Nearest triangle wins, lowest triangle
+// index on ties.  Blender API knowledge: PARITY UNPINNED against Blender itself (not installed, not vendored).
+//
+// Search: triangles are binned into every cell of a uniform grid their bounding box overlaps; a query scans rings of
+// cells around its (box-projected) position exactly like k_nn_search_grid.  A triangle that has not been seen after
+// ring r has a bounding box disjoint from the searched cube, so all of it is at real distance >= sqrt(|p-pc|^2 + m^2);
+// the float32 evaluation can undershoot the real distance by at most delta = 64 u (|coords|), hence the stop rule
+// (sqrt(|p-pc|^2 + m^2) - delta)^2 (1 - 1e-5) > best.  Unsettled queries are finished by brute force over all
+// triangles (k_tri_search_all in list mode), which is also the whole search for small meshes.
+#pragma once
+#include "oa_grid.hpp"
+
+namespace oa {
+
+#if defined(__HIPCC__)
+
+__global__ void k_pack_tris(const float *__restrict__ xyz, int n_verts, const int *__restrict__ tris, int n_tris,
+                            float4 *__restrict__ tri9, int *__restrict__ bad)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tris) return;
+    float q[9];
+    for (int k = 0; k < 3; ++k) {
+        const int v = tris[3ll * t + k];
+        if (v < 0 || v >= n_verts) { atomicAdd(bad, 1); for (int j = 0; j < 3; ++j) q[3 * k + j] = NAN; continue; }
+        for (int j = 0; j < 3; ++j) q[3 * k + j] = xyz[3ll * v + j];
+    }
+    tri9[3ll * t] = make_float4(q[0], q[1], q[2], q[3]);
+    tri9[3ll * t + 1] = make_float4(q[4], q[5], q[6], q[7]);
+    tri9[3ll * t + 2] = make_float4(q[8], 0.f, 0.f, 0.f);
+}
+
+// sum of triangle bounding-box diagonals (for the cell size) -- double atomics are fine here (one-time, not a result)
+__global__ void k_tri_diag_sum(const float4 *__restrict__ tri9, int n_tris, double *__restrict__ out)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    double d = 0.0;
+    if (t < n_tris) {
+        float a[3], b[3], c[3];
+        load_tri(tri9, t, a, b, c);
+        double s = 0.0;
+        for (int i = 0; i < 3; ++i) {
+            const double lo = fmin(fmin((double)a[i], (double)b[i]), (double)c[i]);
+            const double hi = fmax(fmax((double)a[i], (double)b[i]), (double)c[i]);
+            s += (hi - lo) * (hi - lo);
+        }
+        d = sqrt(s);
+        if (!(d < INFINITY)) d = 0.0;
+    }
+    d = wave_sum(d);
+    if ((threadIdx.x & 63) == 0 && d > 0.0) atomicAdd(out, d);
+}
+
+__device__ __forceinline__ void tri_cell_range(const float4 *__restrict__ tri9, int t, const GridParams &gp, int lo[3], int hi[3], bool &ok)
+{
+    float a[3], b[3], c[3];
+    load_tri(tri9, t, a, b, c);
+    ok = true;
+    for (int i = 0; i < 3; ++i) {
+        const double mn = fmin(fmin((double)a[i], (double)b[i]), (double)c[i]);
+        const double mx = fmax(fmax((double)a[i], (double)b[i]), (double)c[i]);
+        if (!(mn <= mx)) ok = false;                                 // NaN vertex: the triangle can never be selected
+        lo[i] = grid_cell_coord(mn, gp.lo[i], gp.inv_h, gp.n[i]);
+        hi[i] = grid_cell_coord(mx, gp.lo[i], gp.inv_h, gp.n[i]);
+    }
+}
+
+// pass 0: counts[cell] += 1 for every cell overlapped; pass 1: write the triangle id at cell_start[cell] + cursor++
+template <bool FILL>
+__global__ void k_tri_grid_bin(const float4 *__restrict__ tri9, int n_tris, GridParams gp, int *__restrict__ counts,
+                               const int *__restrict__ cell_start, int *__restrict__ cell_tris,
+                               unsigned long long *__restrict__ total)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tris) return;
+    int lo[3], hi[3];
+    bool ok;
+    tri_cell_range(tri9, t, gp, lo, hi, ok);
+    if (!ok) return;
+    unsigned long long n = 0;
+    for (int z = lo[2]; z <= hi[2]; ++z)
+        for (int y = lo[1]; y <= hi[1]; ++y)
+            for (int x = lo[0]; x <= hi[0]; ++x) {
+                const int cidx = (z * gp.n[1] + y) * gp.n[0] + x;
+                if (FILL) cell_tris[cell_start[cidx] + atomicAdd(&counts[cidx], 1)] = t;
+                else atomicAdd(&counts[cidx], 1);
+                ++n;
+            }
+    if (!FILL && total) atomicAdd(total, n);
+}
+
+__device__ __forceinline__ void tri_eval(const float *p, const float4 *__restrict__ tri9, uint32_t t, float &best, uint32_t &bidx)
+{
+    float a[3], b[3], c[3], r[3];
+    load_tri(tri9, t, a, b, c);
+    closest_on_tri(p, a, b, c, r);
+    const float d = tri_dist2(p, r);
+    if (d < best || (d == best && t < bidx)) { best = d; bidx = t; }
+}
+
+__global__ __launch_bounds__(256) void k_tri_search_grid(const DevState *__restrict__ st,
+                                                         const float4 *__restrict__ src4, int ns, GridParams gp,
+                                                         const int *__restrict__ cell_start,
+                                                         const int *__restrict__ cell_tris,
+                                                         const float4 *__restrict__ tri9,
+                                                         const int *__restrict__ prev,
+                                                         unsigned long long *__restrict__ keys,
+                                                         int *__restrict__ todo_list, int *__restrict__ todo_count)
+{
+    if (st->halt) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ns) return;
+    const float4 p4 = src4[i];
+    float wx, wy, wz, pf[3];
+    m4_mul_v3(st->mx1, p4.x, p4.y, p4.z, wx, wy, wz);
+    m4_mul_v3(st->imx2, wx, wy, wz, pf[0], pf[1], pf[2]);          // co_find (general.py:287)
+
+    float best = INFINITY;
+    uint32_t bidx = IDX_NONE;
+    const int s = prev ? prev[i] : -1;
+    if (s >= 0) tri_eval(pf, tri9, (uint32_t)s, best, bidx);
+
+    const double p[3] = { (double)pf[0], (double)pf[1], (double)pf[2] };
+    double pc[3], off2 = 0.0, pabs = 0.0;
+    int c[3];
+    bool finite = true;
+    for (int a = 0; a < 3; ++a) {
+        if (!(fabs(p[a]) < INFINITY)) finite = false;
+        pabs += fabs(p[a]);
+        pc[a] = p[a] < gp.lo[a] ? gp.lo[a] : (p[a] > gp.hi[a] ? gp.hi[a] : p[a]);
+        const double d = p[a] - pc[a];
+        off2 += d * d;
+        c[a] = grid_cell_coord(pc[a], gp.lo[a], gp.inv_h, gp.n[a]);
+    }
+    // float32 closest-point evaluation can undershoot the real distance by at most delta
+    const double delta = 64.0 * 5.9604644775390625e-08 * (gp.scale + pabs) + gp.slack;
+    bool settled = false;
+    if (finite) {
+        for (int r = 0; r <= gp.r_max && !settled; ++r) {
+            const int x0 = max(c[0] - r, 0), x1 = min(c[0] + r, gp.n[0] - 1);
+            const int y0 = max(c[1] - r, 0), y1 = min(c[1] + r, gp.n[1] - 1);
+            const int z0 = max(c[2] - r, 0), z1 = min(c[2] + r, gp.n[2] - 1);
+            for (int z = z0; z <= z1; ++z) {
+                const double dz = grid_axis_gap(pc[2], gp.lo[2], gp.h, z, gp.slack);
+                for (int y = y0; y <= y1; ++y) {
+                    const double dy = grid_axis_gap(pc[1], gp.lo[1], gp.h, y, gp.slack);
+                    double lb = sqrt(off2 + dz * dz + dy * dy) - delta;
+                    lb = lb > 0.0 ? lb : 0.0;
+                    if (lb * lb * (1.0 - 1e-5) - 1e-30 > (double)best) continue;
+                    const bool shell_row = (r == 0) || z == c[2] - r || z == c[2] + r || y == c[1] - r || y == c[1] + r;
+                    const int row = (z * gp.n[1] + y) * gp.n[0];
+                    int segs[2][2];
+                    int n_seg = 0;
+                    if (shell_row) { segs[0][0] = x0; segs[0][1] = x1; n_seg = 1; }
+                    else {
+                        if (c[0] - r >= 0) { segs[n_seg][0] = c[0] - r; segs[n_seg][1] = c[0] - r; ++n_seg; }
+                        if (c[0] + r < gp.n[0]) { segs[n_seg][0] = c[0] + r; segs[n_seg][1] = c[0] + r; ++n_seg; }
+                    }
+                    for (int sg = 0; sg < n_seg; ++sg) {
+                        const int j0 = cell_start[row + segs[sg][0]], j1 = cell_start[row + segs[sg][1] + 1];
+                        for (int j = j0; j < j1; ++j) tri_eval(pf, tri9, (uint32_t)cell_tris[j], best, bidx);
+                    }
+                }
+            }
+            double m = INFINITY;
+            for (int a = 0; a < 3; ++a) {
+                if (c[a] - r > 0) { const double f = pc[a] - (gp.lo[a] + (double)(c[a] - r) * gp.h); m = f < m ? f : m; }
+                if (c[a] + r + 1 < gp.n[a]) { const double f = (gp.lo[a] + (double)(c[a] + r + 1) * gp.h) - pc[a]; m = f < m ? f : m; }
+            }
+            if (!(m < INFINITY)) settled = true;
+            else {
+                m -= gp.slack;
+                m = m > 0.0 ? m : 0.0;
+                double lb = sqrt(off2 + m * m) - delta;
+                lb = lb > 0.0 ? lb : 0.0;
+                if (lb * lb * (1.0 - 1e-5) - 1e-30 > (double)best) settled = true;
+            }
+        }
+    }
+    keys[i] = ((unsigned long long)__float_as_uint(best) << 32) | bidx;
+    if (!settled) todo_list[atomicAdd(todo_count, 1)] = i;
+}
+
+// brute force over all triangles: every source point (list == nullptr) or the points the grid could not settle
+__global__ __launch_bounds__(256) void k_tri_search_all(const DevState *__restrict__ st,
+                                                        const float4 *__restrict__ src4, int ns,
+                                                        const float4 *__restrict__ tri9, int n_tris,
+                                                        const int *__restrict__ prev,
+                                                        unsigned long long *__restrict__ keys,
+                                                        const int *__restrict__ list, const int *__restrict__ list_count)
+{
+    if (st->halt) return;
+    const int n_items = list ? *list_count : ns;
+    for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n_items; slot += gridDim.x * blockDim.x) {
+        const int i = list ? list[slot] : slot;
+        const float4 p4 = src4[i];
+        float wx, wy, wz, pf[3];
+        m4_mul_v3(st->mx1, p4.x, p4.y, p4.z, wx, wy, wz);
+        m4_mul_v3(st->imx2, wx, wy, wz, pf[0], pf[1], pf[2]);
+        float best = INFINITY;
+        uint32_t bidx = IDX_NONE;
+        if (list) {
+            const unsigned long long k0 = keys[i];
+            best = __uint_as_float((uint32_t)(k0 >> 32));
+            bidx = (uint32_t)k0;
+            if (!(best < INFINITY)) { best = INFINITY; bidx = IDX_NONE; }
+        } else if (prev && prev[i] >= 0) {
+            tri_eval(pf, tri9, (uint32_t)prev[i], best, bidx);
+        }
+        for (int t = 0; t < n_tris; ++t) tri_eval(pf, tri9, (uint32_t)t, best, bidx);
+        keys[i] = ((unsigned long long)__float_as_uint(best) << 32) | bidx;
+    }
+}
+
+#endif  // __HIPCC__
+}  // namespace oa

@@ -94,6 +94,15 @@ class IcpEngine:
         self.n_target = n
         del keep
 
+    def set_target_mesh(self, xyz, tris):
+        """Surface mode: closest point on the base mesh's triangles (BVHTree.find_nearest semantics).
+        tris: (n, 3) vertex indices (triangulate quads/ngons first)."""
+        p, on_dev, keep, n = _device_ptr(xyz)
+        t = np.ascontiguousarray(tris, dtype=np.int32).reshape(-1, 3)
+        capi.check(self._L.oa_set_target_mesh(self._h, p, n, on_dev, t.ctypes.data_as(C.POINTER(C.c_int32)), len(t)))
+        self.n_target = n
+        del keep
+
     def set_source(self, xyz, vlist=None, stride=0, shard_index=0, shard_count=1):
         p, on_dev, keep, n = _device_ptr(xyz)
         if vlist is not None:

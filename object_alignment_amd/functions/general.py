@@ -54,10 +54,40 @@ def _coords_of(obj) -> np.ndarray:
     return xyz
 
 
-class AlignObject:
-    """Blender-free stand-in for an object: local coordinates + matrix_world (float32 4x4)."""
+def _tris_of(obj):
+    """(n, 3) int32 triangles of a Blender-like object / AlignObject, or None when it has no faces."""
+    t = getattr(obj, "tris", None)
+    if t is not None:
+        return np.ascontiguousarray(t, dtype=np.int32).reshape(-1, 3)
+    data = getattr(obj, "data", None)
+    if data is None:
+        return None
+    lt = getattr(data, "loop_triangles", None)
+    if lt is not None:                                        # real bpy mesh
+        if hasattr(data, "calc_loop_triangles"):
+            data.calc_loop_triangles()
+        if len(lt) == 0:
+            return None
+        if hasattr(lt, "foreach_get"):
+            flat = np.empty(len(lt) * 3, dtype=np.int32)
+            lt.foreach_get("vertices", flat)
+            return flat.reshape(-1, 3)
+        return np.array([[int(v) for v in t.vertices] for t in lt], dtype=np.int32).reshape(-1, 3)
+    polys = getattr(data, "polygons", None)
+    if polys is not None and len(polys):                      # duck-typed faces: fan triangulation
+        out = []
+        for p in polys:
+            v = [int(i) for i in p.vertices]
+            out += [(v[0], v[k], v[k + 1]) for k in range(1, len(v) - 1)]
+        return np.array(out, dtype=np.int32).reshape(-1, 3) if out else None
+    return None
 
-    def __init__(self, xyz, matrix_world=None, name="object"):
+
+class AlignObject:
+    """Blender-free stand-in for an object: local coordinates + matrix_world (float32 4x4) (+ optional triangles)."""
+
+    def __init__(self, xyz, matrix_world=None, name="object", tris=None):
+        self.tris = None if tris is None else np.ascontiguousarray(tris, dtype=np.int32).reshape(-1, 3)
         self.xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
         self.matrix_world = (np.identity(4, dtype=np.float32) if matrix_world is None
                              else np.ascontiguousarray(matrix_world, dtype=np.float32).reshape(4, 4))
@@ -72,15 +102,21 @@ class GpuBVH:
     serves is nearest target VERTEX, not closest point on the triangle surface.
     """
 
-    def __init__(self, target_xyz, engine: IcpEngine | None = None):
+    def __init__(self, target_xyz, engine: IcpEngine | None = None, tris=None):
         self.engine = engine if engine is not None else default_engine()
         self.target = np.ascontiguousarray(target_xyz, dtype=np.float32).reshape(-1, 3)
-        self.engine.set_target(self.target)
+        self.tris = tris
+        if tris is not None:        # surface mode: closest point on the triangles, as BVHTree.find_nearest does
+            self.engine.set_target_mesh(self.target, tris)
+        else:                       # no faces (point cloud): nearest vertex
+            self.engine.set_target(self.target)
         self._src_key = None
 
     @classmethod
-    def FromObject(cls, base_obj, depsgraph=None, engine: IcpEngine | None = None):
-        return cls(_coords_of(base_obj), engine)
+    def FromObject(cls, base_obj, depsgraph=None, engine: IcpEngine | None = None, surface=True):
+        """Like BVHTree.FromObject: when the object has faces the tree answers with the closest SURFACE point;
+        an object without faces (or surface=False) is searched as a vertex cloud."""
+        return cls(_coords_of(base_obj), engine, _tris_of(base_obj) if surface else None)
 
     def _bind_source(self, xyz, vlist, sample):
         key = (id(xyz), xyz.shape, None if vlist is None else (len(vlist), hash(bytes(memoryview(vlist)))), sample)

@@ -12,7 +12,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from ..engine import IcpEngine, RunResult
-from ..functions.general import _coords_of, _matrix_to_np, default_engine
+from ..functions.general import _coords_of, _matrix_to_np, _tris_of, default_engine
 
 try:                                              # inside Blender the operator registers as usual
     import bpy as _bpy                            # noqa: F401
@@ -90,7 +90,10 @@ class IcpAlign:
         self.settings = settings if settings is not None else get_addon_preferences()
         self.engine = engine if engine is not None else default_engine()
 
-    def run(self, source_xyz, target_xyz, mx_align, mx_base, vlist=None, early_exit=True) -> RunResult:
+    def run(self, source_xyz, target_xyz, mx_align, mx_base, vlist=None, early_exit=True,
+            target_tris=None) -> RunResult:
+        """target_tris: (n, 3) triangles of the base mesh -> closest point on the surface (the reference's BVH
+        semantics); None -> nearest target vertex (point-cloud targets, BASELINE's configurations)."""
         s = self.settings
         thresh = s.min_start                                   # :83
         factor = round(1 / s.sample_fraction)                  # :89  (ZeroDivisionError at 0, as the reference)
@@ -98,7 +101,10 @@ class IcpAlign:
             # make_pairs returns None and `(A, B, d_stats) = None` raises   (:101, general.py:277)
             raise TypeError("cannot unpack non-iterable NoneType object")
         eng = self.engine
-        eng.set_target(target_xyz)
+        if target_tris is not None:
+            eng.set_target_mesh(target_xyz, target_tris)
+        else:
+            eng.set_target(target_xyz)
         eng.set_source(source_xyz, vlist=vlist, stride=factor)
         eng.set_matrices(mx_align, mx_base)
         return eng.run(iters=s.icp_iterations, thresh=thresh, target_d=s.target_d, use_target=s.use_target,
@@ -139,7 +145,7 @@ class OBJECT_OT_icp_align(_OperatorBase):
         vlist = build_vlist(align_obj)
         res = IcpAlign(settings).run(_coords_of(align_obj), _coords_of(base_obj),
                                      _matrix_to_np(align_obj.matrix_world), _matrix_to_np(base_obj.matrix_world),
-                                     vlist=vlist)
+                                     vlist=vlist, target_tris=_tris_of(base_obj))
         _assign_matrix(align_obj, res.matrix_world)
         if settings.take_m_with:                                # :123-127, replayed in iteration order
             from .. import _hostmath

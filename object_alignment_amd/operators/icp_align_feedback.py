@@ -13,7 +13,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from ..functions.general import _coords_of, _matrix_to_np, default_engine
+from ..functions.general import _coords_of, _matrix_to_np, _tris_of, default_engine
 from .icp_align import _OperatorBase, _assign_matrix, _bpy, build_vlist, get_addon_preferences
 
 
@@ -62,7 +62,11 @@ class OBJECT_OT_icp_align_feedback(_OperatorBase):
         if not self.thresh > 0:
             raise TypeError("cannot unpack non-iterable NoneType object")   # make_pairs would return None (:252)
         self.engine = default_engine()
-        self.engine.set_target(_coords_of(self.base_obj))
+        tris = _tris_of(self.base_obj)
+        if tris is not None:
+            self.engine.set_target_mesh(_coords_of(self.base_obj), tris)
+        else:
+            self.engine.set_target(_coords_of(self.base_obj))
         self.engine.set_source(_coords_of(self.align_obj), vlist=self.vlist, stride=self.sample_factor)
         self.engine.set_matrices(_matrix_to_np(self.align_obj.matrix_world), _matrix_to_np(self.base_obj.matrix_world))
         return {'RUNNING_MODAL'}

@@ -38,6 +38,11 @@ def rot_z(deg: float) -> np.ndarray:
 
 def icosphere(subdivisions: int = 4, radius: float = 1.0) -> np.ndarray:
     """Vertices of a subdivided icosahedron (10*4**s + 2 points; s=4 -> 2562), float32."""
+    return icosphere_mesh(subdivisions, radius)[0]
+
+
+def icosphere_mesh(subdivisions: int = 4, radius: float = 1.0):
+    """(vertices float32 [n,3], triangles int32 [20*4**s, 3]) of a subdivided icosahedron."""
     t = (1.0 + math.sqrt(5.0)) / 2.0
     verts = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t),
              (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
@@ -62,7 +67,31 @@ def icosphere(subdivisions: int = 4, radius: float = 1.0) -> np.ndarray:
             ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
             new_faces += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
         faces = new_faces
-    return (np.array(verts) * radius).astype(np.float32)
+    return (np.array(verts) * radius).astype(np.float32), np.array(faces, dtype=np.int32)
+
+
+def bumpy_icosphere_mesh(subdivisions: int = 4):
+    """bumpy_icosphere() with its triangles."""
+    v, f = icosphere_mesh(subdivisions)
+    v = v.astype(np.float64)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    return (v * _bunny_radius(v)[:, None]).astype(np.float32), f
+
+
+def lattice_surface_mesh(nu: int, nv: int):
+    """Triangulated (nu x nv) lat-long grid of the bunny surface: (vertices [nu*nv,3], triangles [2(nu-1)(nv-1),3])."""
+    th = np.linspace(0.02, math.pi - 0.02, nu)
+    ph = np.linspace(0.0, 2.0 * math.pi, nv, endpoint=False)
+    T, P = np.meshgrid(th, ph, indexing="ij")
+    u = np.stack([np.sin(T) * np.cos(P), np.sin(T) * np.sin(P), np.cos(T)], axis=-1).reshape(-1, 3)
+    verts = (u * _bunny_radius(u)[:, None]).astype(np.float32)
+    i, j = np.meshgrid(np.arange(nu - 1), np.arange(nv), indexing="ij")
+    a = (i * nv + j).ravel()
+    b = (i * nv + (j + 1) % nv).ravel()
+    c = ((i + 1) * nv + j).ravel()
+    d = ((i + 1) * nv + (j + 1) % nv).ravel()
+    tris = np.concatenate([np.stack([a, b, c], 1), np.stack([b, d, c], 1)]).astype(np.int32)
+    return verts, tris
 
 
 def _bunny_radius(u: np.ndarray) -> np.ndarray:

@@ -350,6 +350,86 @@ OO_API int oo_max_threads(void)
 }
 
 /* ------------------------------------------------------------------ */
+/* closest point on the triangle surface -- what BVHTree.find_nearest  */
+/* (functions/general.py:297) actually returns in Blender.  The tree    */
+/* itself is Blender C code outside /root/reference; this restates its  */
+/* per-triangle callback (closest_on_tri_to_point_v3: Ericson,          */
+/* "Real-Time Collision Detection" 5.1.5) in float32 with explicit      */
+/* operation order and no fma, squared distance = |p - r|^2 in float32, */
+/* nearest triangle wins, lowest triangle index on ties.                */
+/* Blender API knowledge -- PARITY UNPINNED (no Blender here).          */
+/* ------------------------------------------------------------------ */
+static inline float dot3f(const float *a, const float *b)
+{
+    float s = a[0] * b[0];
+    s = s + a[1] * b[1];
+    s = s + a[2] * b[2];
+    return s;
+}
+
+OO_API void oo_closest_on_tri(const float *p, const float *a, const float *b, const float *c, float *r)
+{
+    float ab[3], ac[3], ap[3], bp[3], cp[3];
+    for (int i = 0; i < 3; ++i) { ab[i] = b[i] - a[i]; ac[i] = c[i] - a[i]; ap[i] = p[i] - a[i]; }
+    const float d1 = dot3f(ab, ap), d2 = dot3f(ac, ap);
+    if (d1 <= 0.0f && d2 <= 0.0f) { r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; return; }          /* vertex A */
+    for (int i = 0; i < 3; ++i) bp[i] = p[i] - b[i];
+    const float d3 = dot3f(ab, bp), d4 = dot3f(ac, bp);
+    if (d3 >= 0.0f && d4 <= d3) { r[0] = b[0]; r[1] = b[1]; r[2] = b[2]; return; }            /* vertex B */
+    const float vc = d1 * d4 - d3 * d2;
+    if (vc <= 0.0f && d1 >= 0.0f && d3 <= 0.0f) {                                             /* edge AB */
+        const float v = d1 / (d1 - d3);
+        for (int i = 0; i < 3; ++i) r[i] = a[i] + ab[i] * v;
+        return;
+    }
+    for (int i = 0; i < 3; ++i) cp[i] = p[i] - c[i];
+    const float d5 = dot3f(ab, cp), d6 = dot3f(ac, cp);
+    if (d6 >= 0.0f && d5 <= d6) { r[0] = c[0]; r[1] = c[1]; r[2] = c[2]; return; }            /* vertex C */
+    const float vb = d5 * d2 - d1 * d6;
+    if (vb <= 0.0f && d2 >= 0.0f && d6 <= 0.0f) {                                             /* edge AC */
+        const float w = d2 / (d2 - d6);
+        for (int i = 0; i < 3; ++i) r[i] = a[i] + ac[i] * w;
+        return;
+    }
+    const float va = d3 * d6 - d5 * d4;
+    if (va <= 0.0f && (d4 - d3) >= 0.0f && (d5 - d6) >= 0.0f) {                               /* edge BC */
+        const float w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+        for (int i = 0; i < 3; ++i) { float t = c[i] - b[i]; t = t * w; r[i] = t + b[i]; }
+        return;
+    }
+    const float denom = 1.0f / ((va + vb) + vc);                                              /* face interior */
+    const float v = vb * denom, w = vc * denom;
+    for (int i = 0; i < 3; ++i) { const float acw = ac[i] * w; float t = a[i] + ab[i] * v; r[i] = t + acw; }
+}
+
+static inline float tri_dist2(const float *p, const float *r)
+{
+    float d[3] = { r[0] - p[0], r[1] - p[1], r[2] - p[2] };
+    return dot3f(d, d);
+}
+
+/* definitional brute force over all triangles; face = -1 and d2 = +inf when there is no usable triangle */
+OO_API void oo_nn_tri_brute(const float *q, int64_t nq, const float *verts, const int32_t *tris, int64_t ntris,
+                            int64_t *face, float *co1, float *d2out)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < nq; ++i) {
+        float best = INFINITY, br[3] = { 0, 0, 0 };
+        int64_t bf = -1;
+        for (int64_t t = 0; t < ntris; ++t) {
+            float r[3];
+            oo_closest_on_tri(q + 3 * i, verts + 3 * (int64_t)tris[3 * t], verts + 3 * (int64_t)tris[3 * t + 1],
+                              verts + 3 * (int64_t)tris[3 * t + 2], r);
+            const float d = tri_dist2(q + 3 * i, r);
+            if (d < best) { best = d; bf = t; br[0] = r[0]; br[1] = r[1]; br[2] = r[2]; }
+        }
+        if (face) face[i] = bf;
+        if (co1) { co1[3 * i] = br[0]; co1[3 * i + 1] = br[1]; co1[3 * i + 2] = br[2]; }
+        if (d2out) d2out[i] = best;
+    }
+}
+
+/* ------------------------------------------------------------------ */
 /* make_pairs  (functions/general.py:257-329)                          */
 /* ------------------------------------------------------------------ */
 /*
@@ -357,6 +437,8 @@ OO_API int oo_max_threads(void)
  * vlist    : vertex indices to use (NULL => 0..n_verts-1), :259
  * sample   : stride, applied only when > 1 (:274-275)
  * kd       : tree over tgt (NULL => brute force); tgt is base-LOCAL
+ * tris     : NULL => nearest target VERTEX; else n_tris x 3 vertex indices and the closest point on the
+ *            triangle SURFACE is used (the BVHTree.find_nearest semantics)
  * mx1, mx2 : align / base matrix_world, row-major float32 (:262-263)
  * A, B     : caller-allocated 3 x cap row-major doubles (row = axis, :313-321)
  * returns K >= 0, or -1 if thresh <= 0 (reference falls through and returns
@@ -365,6 +447,7 @@ OO_API int oo_max_threads(void)
 OO_API int64_t oo_make_pairs(const float *src, int64_t n_verts,
                              const int64_t *vlist, int64_t n_vlist, int sample,
                              const float *tgt, int64_t nt, const void *kd,
+                             const int32_t *tris, int64_t n_tris,
                              const float *mx1, const float *mx2,
                              double thresh, int calc_stats, int nthreads,
                              double *A, double *B, int64_t cap,
@@ -389,8 +472,15 @@ OO_API int64_t oo_make_pairs(const float *src, int64_t n_verts,
         oo_mat4_mul_vec3(mx1, src + 3 * vi, w);
         oo_mat4_mul_vec3(imx2, w, cof + 3 * s);
     }
-    if (kd) oo_kd_query(kd, cof, n_sel, nn, NULL, nthreads);
-    else oo_nn_brute(cof, n_sel, tgt, nt, nn, NULL);
+    float *co1buf = (float *)malloc((size_t)n_sel * 3 * sizeof(float));
+    if (tris) {
+        oo_nn_tri_brute(cof, n_sel, tgt, tris, n_tris, nn, co1buf, NULL);
+    } else {
+        if (kd) oo_kd_query(kd, cof, n_sel, nn, NULL, nthreads);
+        else oo_nn_brute(cof, n_sel, tgt, nt, nn, NULL);
+        for (int64_t s = 0; s < n_sel; ++s)
+            for (int a = 0; a < 3; ++a) co1buf[3 * s + a] = nn[s] >= 0 ? tgt[3 * nn[s] + a] : 0.f;
+    }
 
     int64_t K = 0;
     double sd = 0.0, sd2 = 0.0;
@@ -398,14 +488,14 @@ OO_API int64_t oo_make_pairs(const float *src, int64_t n_verts,
         int64_t vi = vlist ? vlist[s * step] : s * step;
         if (nn_idx_out) nn_idx_out[s] = nn[s];
         if (nn[s] < 0) continue;
-        const float *co1 = tgt + 3 * nn[s];
+        const float *co1 = co1buf + 3 * s;
         float wa[3], wb[3], df[3];
         oo_mat4_mul_vec3(mx2, cof + 3 * s, wa);       /* mx2 @ co_find  :299 */
         oo_mat4_mul_vec3(mx2, co1, wb);               /* mx2 @ co1      :299 */
         df[0] = wa[0] - wb[0]; df[1] = wa[1] - wb[1]; df[2] = wa[2] - wb[2];
         double dist = oo_vec3_length(df);
         if (dist < thresh) {                           /* :302 */
-            if (K >= cap) { free(cof); free(nn); return -3; }
+            if (K >= cap) { free(cof); free(nn); free(co1buf); return -3; }
             float b[3];
             oo_mat4_mul_vec3(imx1, wb, b);             /* imx1 @ (mx2 @ co1)  :304 */
             for (int a = 0; a < 3; ++a) {
@@ -427,7 +517,7 @@ OO_API int64_t oo_make_pairs(const float *src, int64_t n_verts,
             int64_t k = 0;
             for (int64_t s = 0; s < n_sel && k < K; ++s) {
                 if (nn[s] < 0) continue;
-                const float *co1 = tgt + 3 * nn[s];
+                const float *co1 = co1buf + 3 * s;
                 float wa[3], wb[3], df[3];
                 oo_mat4_mul_vec3(mx2, cof + 3 * s, wa);
                 oo_mat4_mul_vec3(mx2, co1, wb);
@@ -439,7 +529,7 @@ OO_API int64_t oo_make_pairs(const float *src, int64_t n_verts,
         } else { dstats[0] = NAN; dstats[1] = NAN; }
     }
     (void)sd2;
-    free(cof); free(nn);
+    free(cof); free(nn); free(co1buf);
     return K;
 }
 
@@ -587,6 +677,7 @@ typedef struct {
 OO_API int oo_icp_run(const float *src, int64_t n_verts,
                       const int64_t *vlist, int64_t n_vlist,
                       const float *tgt, int64_t nt, const void *kd,
+                      const int32_t *tris, int64_t n_tris,
                       float *mx1, const float *mx2, const oo_settings *st, int nthreads,
                       oo_report *rep, double *step_M, float *step_new,
                       int64_t *step_K, double *step_stats, double *step_trans)
@@ -603,7 +694,7 @@ OO_API int oo_icp_run(const float *src, int64_t n_verts,
     memset(rep, 0, sizeof *rep);
     while (n < st->iters && !converged) {                        /* :96 */
         double ds[2] = { NAN, NAN };
-        int64_t K = oo_make_pairs(src, n_verts, vlist, n_vlist, st->sample, tgt, nt, kd,
+        int64_t K = oo_make_pairs(src, n_verts, vlist, n_vlist, st->sample, tgt, nt, kd, tris, n_tris,
                                   mx1, mx2, st->thresh, st->use_target, nthreads,
                                   A, B, cap, ds, NULL);           /* :101 */
         if (K < 0) { rep->status = (int32_t)K; break; }

@@ -75,12 +75,15 @@ def lib():
         L.oo_kd_free.argtypes = [vp]
         L.oo_kd_query.argtypes = [vp, fp, C.c_int64, ip, fp, C.c_int]
         L.oo_max_threads.restype = C.c_int
-        L.oo_make_pairs.argtypes = [fp, C.c_int64, ip, C.c_int64, C.c_int, fp, C.c_int64, vp, fp, fp,
+        i32p = C.POINTER(C.c_int32)
+        L.oo_closest_on_tri.argtypes = [fp, fp, fp, fp, fp]
+        L.oo_nn_tri_brute.argtypes = [fp, C.c_int64, fp, i32p, C.c_int64, ip, fp, fp]
+        L.oo_make_pairs.argtypes = [fp, C.c_int64, ip, C.c_int64, C.c_int, fp, C.c_int64, vp, i32p, C.c_int64, fp, fp,
                                     C.c_double, C.c_int, C.c_int, dp, dp, C.c_int64, dp, ip]
         L.oo_make_pairs.restype = C.c_int64
         L.oo_kabsch.argtypes = [dp, dp, C.c_int64, C.c_int64, C.c_int, dp]
         L.oo_kabsch.restype = C.c_int
-        L.oo_icp_run.argtypes = [fp, C.c_int64, ip, C.c_int64, fp, C.c_int64, vp, fp, fp,
+        L.oo_icp_run.argtypes = [fp, C.c_int64, ip, C.c_int64, fp, C.c_int64, vp, i32p, C.c_int64, fp, fp,
                                  C.POINTER(Settings), C.c_int, C.POINTER(Report), dp, fp, ip, dp, dp]
         L.oo_icp_run.restype = C.c_int
         _lib = L
@@ -173,8 +176,26 @@ def max_threads():
 
 # ---------------------------------------------------------------- make_pairs / kabsch / loop (C)
 
+def _tris(tris):
+    if tris is None:
+        return None, None, 0
+    t = np.ascontiguousarray(tris, dtype=np.int32).reshape(-1, 3)
+    return t, t.ctypes.data_as(C.POINTER(C.c_int32)), len(t)
+
+
+def nn_tri_brute(queries, verts, tris):
+    """Closest point on the triangle surface (BVHTree.find_nearest semantics): (face, co1, d2)."""
+    q, v = _f32(queries).reshape(-1, 3), _f32(verts).reshape(-1, 3)
+    t, tp, nt = _tris(tris)
+    face = np.empty(len(q), np.int64)
+    co1 = np.empty((len(q), 3), np.float32)
+    d2 = np.empty(len(q), np.float32)
+    lib().oo_nn_tri_brute(_f(q), len(q), _f(v), tp, nt, _i(face), _f(co1), _f(d2))
+    return face, co1, d2
+
+
 def make_pairs(src, target, mx_align, mx_base, thresh, vlist=None, sample=0, calc_stats=False,
-               kd: KDTree | None = None, nthreads=0, return_nn=False):
+               kd: KDTree | None = None, nthreads=0, return_nn=False, tris=None):
     """Restates /root/reference/functions/general.py:257-329 with a nearest-vertex provider.
 
     Returns (A, B, d_stats) with A, B float64[3, K]; raises TypeError-equivalent
@@ -194,8 +215,9 @@ def make_pairs(src, target, mx_align, mx_base, thresh, vlist=None, sample=0, cal
     B = np.zeros((3, cap), np.float64)
     ds = np.zeros(2, np.float64)
     nn = np.empty(cap, np.int64)
+    tk, tp, ntri = _tris(tris)
     K = lib().oo_make_pairs(_f(src), len(src), _i(vl) if vl is not None else None, n_all, int(sample),
-                            _f(tgt), len(tgt), kd._h if kd is not None else None, _f(m1), _f(m2),
+                            _f(tgt), len(tgt), kd._h if kd is not None else None, tp, ntri, _f(m1), _f(m2),
                             float(thresh), int(bool(calc_stats)), int(nthreads), _d(A), _d(B), cap, _d(ds), _i(nn))
     if K == -1:
         raise ValueError("make_pairs: thresh must be > 0 (the reference returns None here)")
@@ -255,7 +277,7 @@ def affine_matrix_from_points(v0, v1, shear=False, scale=False, usesvd=True):
 
 
 def icp_run(src, target, mx_align, mx_base, *, iters=50, sample=2, thresh=0.5, target_d=0.01,
-            use_target=True, with_scale=False, vlist=None, kd: KDTree | None = None, nthreads=0):
+            use_target=True, with_scale=False, vlist=None, kd: KDTree | None = None, nthreads=0, tris=None):
     """Restates /root/reference/operators/icp_align.py:91-151.  Returns a dict."""
     src = _f32(src).reshape(-1, 3)
     tgt = _f32(target).reshape(-1, 3)
@@ -270,8 +292,9 @@ def icp_run(src, target, mx_align, mx_base, *, iters=50, sample=2, thresh=0.5, t
     step_K = np.zeros(n, np.int64)
     step_stats = np.zeros((n, 2), np.float64)
     step_trans = np.zeros(n, np.float64)
+    tk, tp, ntri = _tris(tris)
     rc = lib().oo_icp_run(_f(src), len(src), _i(vl) if vl is not None else None, len(vl) if vl is not None else 0,
-                          _f(tgt), len(tgt), kd._h if kd is not None else None, _f(m1), _f(m2),
+                          _f(tgt), len(tgt), kd._h if kd is not None else None, tp, ntri, _f(m1), _f(m2),
                           C.byref(st), int(nthreads), C.byref(rep), _d(step_M), _f(step_new), _i(step_K),
                           _d(step_stats), _d(step_trans))
     d = rep.iters_done

@@ -580,6 +580,44 @@ def test_two_shards_on_one_gpu_equal_unsharded(golden_dir):
     assert np.abs(res[0].matrix_world - g["final_world"]).max() <= F32_ULP
 
 
+def test_more_shards_than_points(orc):
+    """Empty shards (shard_count > selected points) contribute zero sums and do not disturb the others."""
+    import torch
+    from object_alignment_amd.engine import IcpEngine
+    from object_alignment_amd import _capi
+    rng = np.random.default_rng(4)
+    tgt = rng.uniform(-1, 1, size=(500, 3)).astype(np.float32)
+    src = (tgt[:10] + np.float32(0.01)).astype(np.float32)
+    eye = np.identity(4, dtype=np.float32)
+    world = 16                                   # 10 points over 16 shards: 6 contexts hold nothing
+    dev = torch.device("cuda:0")
+    engs = [IcpEngine(0) for _ in range(world)]
+    try:
+        sums = [torch.zeros(_capi.OA_NSUMS, dtype=torch.float64, device=dev) for _ in range(world)]
+        for r, e in enumerate(engs):
+            e.set_stream(torch.cuda.current_stream().cuda_stream)
+            e.set_target(tgt)
+            e.set_source(src, shard_index=r, shard_count=world)
+            e.set_matrices(eye, eye)
+            e.run_begin(iters=3, thresh=0.5, use_target=True, early_exit=False)
+        assert sum(e.n_selected for e in engs) == 10 and min(e.n_selected for e in engs) == 0
+        for _ in range(3):
+            for r, e in enumerate(engs):
+                e.iter_partial(sums[r].data_ptr())
+            total = torch.stack(sums).sum(0)
+            for e in engs:
+                e.iter_finish(total.data_ptr())
+        res = [e.run_end() for e in engs]
+    finally:
+        for e in engs:
+            e.close()
+    ref = orc.icp_run(src, tgt, eye, eye, iters=3, sample=1, thresh=0.5, target_d=1e-300, use_target=True)
+    for r in res:
+        assert np.array_equal(r.matrix_world, res[0].matrix_world)
+    assert np.array_equal(res[0].step_K, ref["step_K"])
+    assert np.abs(res[0].step_M - ref["step_M"]).max() < 1e-9
+
+
 def test_run_sharded_world1_torch_stream(golden_dir):
     """distributed.run_sharded with world_size 1 (no collective) on torch's current stream."""
     import torch
@@ -595,3 +633,80 @@ def test_run_sharded_world1_torch_stream(golden_dir):
                           30, sums, world_size=1)
     assert res.iters_done == int(g["iters_done"]) and res.converged
     assert np.abs(res.matrix_world - g["final_world"]).max() <= F32_ULP
+
+
+# ------------------------------------------------------------------ surface mode (closest point on triangles, D2)
+
+def _surface_cases():
+    from object_alignment_amd import synth
+    rng = np.random.default_rng(77)
+    v1, t1 = synth.bumpy_icosphere_mesh(4)                       # 2562 vertices, 5120 triangles
+    q1 = (synth.bumpy_icosphere(4)[::2] * np.float32(1.03) + np.float32(0.01)).astype(np.float32)
+    v2, t2 = synth.lattice_surface_mesh(120, 240)                # 28800 vertices, 57120 triangles
+    q2 = (synth.bunny_surface(12000, 0.5) + rng.normal(0, 0.01, size=(12000, 3))).astype(np.float32)
+    q3 = (rng.normal(size=(3000, 3)) * 3.0).astype(np.float32)   # far outside: list-mode finish
+    v4 = rng.integers(-5, 6, size=(400, 3)).astype(np.float32)   # integer lattice: exact ties, degenerate triangles
+    t4 = rng.integers(0, 400, size=(3000, 3)).astype(np.int32)
+    q4 = (rng.integers(-5, 5, size=(2000, 3)) + 0.5).astype(np.float32)
+    return {"ico": (v1, t1, q1), "lattice": (v2, t2, q2), "far": (v2, t2, q3), "ties": (v4, t4, q4)}
+
+
+@pytest.mark.parametrize("mode", ["brute", "grid"])
+@pytest.mark.parametrize("case", ["ico", "lattice", "far", "ties"])
+def test_surface_search_bit_exact(orc, case, mode):
+    """Nearest triangle index and float32 squared distance equal the oracle's brute force over all triangles."""
+    from object_alignment_amd.engine import IcpEngine
+    verts, tris, q = _surface_cases()[case]
+    eye = np.identity(4, dtype=np.float32)
+    face, co1, d2 = orc.nn_tri_brute(q, verts, tris)
+    with IcpEngine(0) as e:
+        e.set_search_mode(mode)
+        e.set_target_mesh(verts, tris)
+        e.set_source(q)
+        e.set_matrices(eye, eye)
+        idx, gd2, _ = e.nn_search()
+        assert np.array_equal(gd2, d2), (case, mode)
+        assert np.array_equal(idx, face), (case, mode)
+        e.iterate(thresh=100.0)                                   # seeds (previous triangle) + new pose
+        m2 = e.matrix_world()
+        idx2, gd22, _ = e.nn_search()
+    f2, _, d22 = orc.nn_tri_brute(_cofind(orc, q, m2, eye), verts, tris)
+    assert np.array_equal(idx2, f2) and np.array_equal(gd22, d22), (case, mode, "seeded")
+
+
+def test_surface_make_pairs_and_loop(orc):
+    """make_pairs / the ICP loop in surface mode against the oracle's mesh-mode restatement."""
+    from object_alignment_amd import synth
+    from object_alignment_amd.functions import make_pairs, GpuBVH, AlignObject
+    from object_alignment_amd.operators import IcpAlign, IcpSettings
+    verts, tris = synth.lattice_surface_mesh(80, 160)
+    src = synth.bunny_surface(20000, 0.5)
+    mxa = synth.rigid4(synth.rotation_from_rotvec([0.05, -0.04, 0.06]), [0.03, -0.02, 0.02])
+    mxb = synth.rigid4(synth.rotation_from_rotvec([0.2, 0.1, -0.3]) @ np.diag([1.2, 0.9, 1.1]), [0.1, 0.0, -0.1])
+    align = AlignObject(src, mxb @ mxa)
+    base = AlignObject(verts, mxb, tris=tris)
+    bvh = GpuBVH.FromObject(base, None)
+    assert bvh.tris is not None
+    A, B, ds = make_pairs(align, base, bvh, list(range(len(src))), 0.3, 2, calc_stats=True)
+    rA, rB, rds = orc.make_pairs(src, verts, mxb @ mxa, mxb, 0.3, sample=2, calc_stats=True, tris=tris)
+    assert np.array_equal(A, rA) and np.array_equal(B, rB)
+    assert np.allclose(ds, rds, rtol=1e-9, atol=1e-13)
+    # the surface is at most as far as the nearest vertex
+    Av, Bv, dsv = make_pairs(align, base, GpuBVH.FromObject(base, None, surface=False), list(range(len(src))), 0.3, 2,
+                             calc_stats=True)
+    assert ds[0] < dsv[0]
+    res = IcpAlign(IcpSettings(icp_iterations=12, sample_fraction=1.0)).run(src, verts, mxb @ mxa, mxb, target_tris=tris)
+    ref = orc.icp_run(src, verts, mxb @ mxa, mxb, iters=12, sample=1, tris=tris)
+    assert res.iters_done == ref["iters_done"] and res.converged == ref["converged"]
+    assert np.array_equal(res.step_K, ref["step_K"])
+    assert np.abs(res.step_M - ref["step_M"]).max() < 1e-9
+    assert np.abs(res.matrix_world - ref["matrix_world"]).max() <= F32_ULP
+
+
+def test_surface_bad_triangle_index(eng):
+    from object_alignment_amd import _capi
+    v = np.zeros((4, 3), np.float32)
+    with pytest.raises(_capi.OaError) as ei:
+        eng.set_target_mesh(v, np.array([[0, 1, 4]], np.int32))
+    assert ei.value.code == _capi.OA_E_BAD_ARG
+    eng.set_target(np.random.default_rng(0).normal(size=(10, 3)).astype(np.float32))   # back to vertex mode
