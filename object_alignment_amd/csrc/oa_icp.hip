@@ -101,7 +101,7 @@ struct oa_ctx {
     double pivot[3] = { 0, 0, 0 };
     // launch geometry for k_nn_search
     int n_splits = 1, groups_per_split = 0, acc_blocks = 1;
-    bool use_filter = true, use_pk = true;
+    bool use_filter = true, use_pk = false;
     // device state
     oa::DevState h_state;
     oa::DevState *d_state = nullptr;
@@ -214,7 +214,7 @@ int launch_nn(oa_ctx *c)
 #define OA_NN_ARGS c->d_state, c->d_src4, c->d_tg, c->groups_per_split, c->n_groups_pad, c->d_keys
 #define OA_NNF_ARGS c->d_state, c->d_src4, c->d_tg, c->d_tf, c->d_tgt_xyz, c->d_prev, c->groups_per_split, c->n_groups_pad, c->d_keys, list, list_count
     if (list) {
-        hipLaunchKernelGGL((oa::k_nn_search_filtered<4, true, true>), grid, block, 0, c->stream, OA_NNF_ARGS);
+        hipLaunchKernelGGL((oa::k_nn_search_filtered<4, false, true>), grid, block, 0, c->stream, OA_NNF_ARGS);
     } else if (c->filter_ok && c->use_filter) {
         if (c->use_pk) {
             switch (c->R) {
@@ -404,7 +404,7 @@ OA_EXPORT int oa_create(oa_ctx **out, int device)
     c->R = env_int("OA_NN_R", 4);
     if (c->R != 1 && c->R != 2 && c->R != 4 && c->R != 8) c->R = 4;
     c->use_filter = env_int("OA_NN_FILTER", 1) != 0;
-    c->use_pk = env_int("OA_NN_PK", 1) != 0;
+    c->use_pk = env_int("OA_NN_PK", 0) != 0;
     c->grid_mode = env_int("OA_NN_GRID", -1);
     *out = c;
     return OA_OK;

@@ -559,7 +559,7 @@ __global__ void k_bbox_partial(const float *__restrict__ xyz, int nt, float *__r
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 template <int R, bool PK, bool LIST>
-__global__ __launch_bounds__(NN_THREADS) void k_nn_search_filtered(const DevState *__restrict__ st,
+__global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_filtered(const DevState *__restrict__ st,
                                                                    const float4 *__restrict__ src4,
                                                                    const float4 *__restrict__ tg,
                                                                    const float4 *__restrict__ tf,
@@ -633,49 +633,64 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_search_filtered(const DevStat
             s0 = nsrc[tid]; s1 = nsrc[NN_THREADS + tid]; s2 = nsrc[2 * NN_THREADS + tid]; s3 = nsrc[3 * NN_THREADS + tid];
         }
         const int gbase = g_begin + t * FTILE_GROUPS;
-        // register double-buffer of the broadcast LDS reads: group g+1 is in flight while group g is evaluated
-        float4 nAX = tile[cur][0], nAY = tile[cur][1], nAZ = tile[cur][2], nW = tile[cur][3];
-#pragma unroll 2
-        for (int g = 0; g < FTILE_GROUPS; ++g) {
-            const float4 AX = nAX, AY = nAY, AZ = nAZ, W = nW;
-            {
-                const int gn = (g + 1) & (FTILE_GROUPS - 1);      // wraps on the last group (value unused)
-                nAX = tile[cur][4 * gn]; nAY = tile[cur][4 * gn + 1]; nAZ = tile[cur][4 * gn + 2]; nW = tile[cur][4 * gn + 3];
+        // GW groups (4*GW targets) per skip test: one branch per GW groups, all fma chains of the R points in one block
+        constexpr int GW = 2;
+        for (int g = 0; g < FTILE_GROUPS; g += GW) {
+            float4 AX[GW], AY[GW], AZ[GW], W[GW];
+#pragma unroll
+            for (int k = 0; k < GW; ++k) {
+                AX[k] = tile[cur][4 * (g + k)]; AY[k] = tile[cur][4 * (g + k) + 1];
+                AZ[k] = tile[cur][4 * (g + k) + 2]; W[k] = tile[cur][4 * (g + k) + 3];
             }
+            float gm[R];
+            bool hit = false;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                float c0, c1, c2, c3;
-                if (PK) {      // two targets per v_pk_fma_f32 (same per-lane IEEE fma; fewer issue slots' worth of power)
-                    const v2f X = { hx[r], hx[r] }, Y = { hy[r], hy[r] }, Z = { hz[r], hz[r] };
-                    const v2f q0 = __builtin_elementwise_fma(X, v2f{ AX.x, AX.y }, __builtin_elementwise_fma(Y, v2f{ AY.x, AY.y },
-                                   __builtin_elementwise_fma(Z, v2f{ AZ.x, AZ.y }, v2f{ W.x, W.y })));
-                    const v2f q1 = __builtin_elementwise_fma(X, v2f{ AX.z, AX.w }, __builtin_elementwise_fma(Y, v2f{ AY.z, AY.w },
-                                   __builtin_elementwise_fma(Z, v2f{ AZ.z, AZ.w }, v2f{ W.z, W.w })));
-                    c0 = q0.x; c1 = q0.y; c2 = q1.x; c3 = q1.y;
-                } else {
-                    c0 = __builtin_fmaf(hx[r], AX.x, __builtin_fmaf(hy[r], AY.x, __builtin_fmaf(hz[r], AZ.x, W.x)));
-                    c1 = __builtin_fmaf(hx[r], AX.y, __builtin_fmaf(hy[r], AY.y, __builtin_fmaf(hz[r], AZ.y, W.y)));
-                    c2 = __builtin_fmaf(hx[r], AX.z, __builtin_fmaf(hy[r], AY.z, __builtin_fmaf(hz[r], AZ.z, W.z)));
-                    c3 = __builtin_fmaf(hx[r], AX.w, __builtin_fmaf(hy[r], AY.w, __builtin_fmaf(hz[r], AZ.w, W.w)));
+                float m = INFINITY;
+#pragma unroll
+                for (int k = 0; k < GW; ++k) {
+                    float c0, c1, c2, c3;
+                    if (PK) {  // two targets per v_pk_fma_f32 (same per-lane IEEE fma)
+                        const v2f X = { hx[r], hx[r] }, Y = { hy[r], hy[r] }, Z = { hz[r], hz[r] };
+                        const v2f q0 = __builtin_elementwise_fma(X, v2f{ AX[k].x, AX[k].y }, __builtin_elementwise_fma(Y, v2f{ AY[k].x, AY[k].y },
+                                       __builtin_elementwise_fma(Z, v2f{ AZ[k].x, AZ[k].y }, v2f{ W[k].x, W[k].y })));
+                        const v2f q1 = __builtin_elementwise_fma(X, v2f{ AX[k].z, AX[k].w }, __builtin_elementwise_fma(Y, v2f{ AY[k].z, AY[k].w },
+                                       __builtin_elementwise_fma(Z, v2f{ AZ[k].z, AZ[k].w }, v2f{ W[k].z, W[k].w })));
+                        c0 = q0.x; c1 = q0.y; c2 = q1.x; c3 = q1.y;
+                    } else {
+                        c0 = __builtin_fmaf(hx[r], AX[k].x, __builtin_fmaf(hy[r], AY[k].x, __builtin_fmaf(hz[r], AZ[k].x, W[k].x)));
+                        c1 = __builtin_fmaf(hx[r], AX[k].y, __builtin_fmaf(hy[r], AY[k].y, __builtin_fmaf(hz[r], AZ[k].y, W[k].y)));
+                        c2 = __builtin_fmaf(hx[r], AX[k].z, __builtin_fmaf(hy[r], AY[k].z, __builtin_fmaf(hz[r], AZ[k].z, W[k].z)));
+                        c3 = __builtin_fmaf(hx[r], AX[k].w, __builtin_fmaf(hy[r], AY[k].w, __builtin_fmaf(hz[r], AZ[k].w, W[k].w)));
+                    }
+                    m = __builtin_fminf(m, __builtin_fminf(__builtin_fminf(c0, c1), __builtin_fminf(c2, c3)));
                 }
-                const float m = __builtin_fminf(__builtin_fminf(c0, c1), __builtin_fminf(c2, c3));
-                if (!(m > thr[r])) {                              // cannot be ruled out: exact path
-                    const float4 *eg = tg + 3ll * (gbase + g);
-                    const float4 X = eg[0], Y = eg[1], Z = eg[2];
-                    const uint32_t j = (uint32_t)(gbase + g) * 4u;
-                    const float e0 = d2_metric(px[r], py[r], pz[r], X.x, Y.x, Z.x);
-                    const float e1 = d2_metric(px[r], py[r], pz[r], X.y, Y.y, Z.y);
-                    const float e2 = d2_metric(px[r], py[r], pz[r], X.z, Y.z, Z.z);
-                    const float e3 = d2_metric(px[r], py[r], pz[r], X.w, Y.w, Z.w);
-                    float b = best[r];
-                    uint32_t bi = bidx[r];
-                    if (e0 < b || (e0 == b && j < bi)) { b = e0; bi = j; }
-                    if (e1 < b || (e1 == b && j + 1u < bi)) { b = e1; bi = j + 1u; }
-                    if (e2 < b || (e2 == b && j + 2u < bi)) { b = e2; bi = j + 2u; }
-                    if (e3 < b || (e3 == b && j + 3u < bi)) { b = e3; bi = j + 3u; }
-                    if (b < best[r]) thr[r] = filter_threshold(b, hx[r], hy[r], hz[r], qmax);
-                    best[r] = b;
-                    bidx[r] = bi;
+                gm[r] = m;
+                hit = hit || !(m > thr[r]);
+            }
+            if (hit) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if (!(gm[r] > thr[r])) {                          // cannot be ruled out: exact path on these 4*GW targets
+                        float b = best[r];
+                        uint32_t bi = bidx[r];
+                        for (int k = 0; k < GW; ++k) {
+                            const float4 *eg = tg + 3ll * (gbase + g + k);
+                            const float4 X = eg[0], Y = eg[1], Z = eg[2];
+                            const uint32_t j = (uint32_t)(gbase + g + k) * 4u;
+                            const float e0 = d2_metric(px[r], py[r], pz[r], X.x, Y.x, Z.x);
+                            const float e1 = d2_metric(px[r], py[r], pz[r], X.y, Y.y, Z.y);
+                            const float e2 = d2_metric(px[r], py[r], pz[r], X.z, Y.z, Z.z);
+                            const float e3 = d2_metric(px[r], py[r], pz[r], X.w, Y.w, Z.w);
+                            if (e0 < b || (e0 == b && j < bi)) { b = e0; bi = j; }
+                            if (e1 < b || (e1 == b && j + 1u < bi)) { b = e1; bi = j + 1u; }
+                            if (e2 < b || (e2 == b && j + 2u < bi)) { b = e2; bi = j + 2u; }
+                            if (e3 < b || (e3 == b && j + 3u < bi)) { b = e3; bi = j + 3u; }
+                        }
+                        if (b < best[r]) thr[r] = filter_threshold(b, hx[r], hy[r], hz[r], qmax);
+                        best[r] = b;
+                        bidx[r] = bi;
+                    }
                 }
             }
         }
