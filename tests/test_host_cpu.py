@@ -136,3 +136,12 @@ def test_synthetic_configs_are_deterministic():
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
     s, t, _, _ = synth.c2_bunny_pair(5000)
     assert s.shape == t.shape == (5000, 3) and s.dtype == np.float32
+
+
+def test_blender_addon_shell_imports_without_bpy():
+    from object_alignment_amd import blender_addon
+    assert blender_addon.bl_info["blender"] == (3, 2, 2)
+    if blender_addon.bpy is None:
+        with pytest.raises(RuntimeError):
+            blender_addon.register()
+        blender_addon.unregister()
