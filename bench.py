@@ -74,15 +74,15 @@ def cpu_baseline(src, tgt, mxa, mxb, iters, gpu_step_M):
 
 def main():
     args = parse()
-    import torch
-    import torch.distributed as dist
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1:                          # before the HIP runtime comes up: RCCL needs dmabuf IPC on this host driver
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if world == 1 and args.gpus > 1:
@@ -170,7 +170,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32 search / f64 accumulate+solve",
+            "dtype": "f32", "accumulate_dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "1M<->1M uniform [-1,1]^3 clouds, sigma = 5%% of mean spacing, seed 1234, "
                                    "thresh 0.5, stride 1, %d iterations, early-exit off" % args.steps,

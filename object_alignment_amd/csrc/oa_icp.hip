@@ -102,6 +102,7 @@ struct oa_ctx {
     // launch geometry for k_nn_search
     int n_splits = 1, groups_per_split = 0, acc_blocks = 1;
     bool use_filter = true, use_pk = false;
+    double d_pivot0 = 0.0;           // initial distance pivot for the next loop / one-shot (see DevState::d_pivot)
     // device state
     oa::DevState h_state;
     oa::DevState *d_state = nullptr;
@@ -190,6 +191,7 @@ int check_ready(oa_ctx *c)
 
 bool grid_active(const oa_ctx *c);
 int build_grid(oa_ctx *c);
+int build_tri_grid(oa_ctx *c);
 int launch_tri_search(oa_ctx *c);
 
 int launch_nn(oa_ctx *c)
@@ -285,6 +287,7 @@ void init_loop_state(oa_ctx *c, const oa_settings *st, int iters)
     for (int k = 0; k < 3; ++k) s.tc[k] = c->tc[k];
     s.pad1 = 0.f;
     s.qmax = c->qmax;
+    s.d_pivot = c->d_pivot0;
 }
 
 int begin_loop(oa_ctx *c, const oa_settings *st, int iters)
@@ -431,12 +434,13 @@ OA_EXPORT int oa_set_search_mode(oa_ctx *c, int mode)
 {
     if (!c) return fail(OA_E_BAD_ARG, "null context");
     if (mode < -1 || mode > 1) return fail(OA_E_BAD_ARG, "search mode %d (use OA_SEARCH_AUTO/BRUTE/GRID)", mode);
-    const bool rebuild = (c->grid_mode == 0 && mode != 0 && c->nt > 0 && !c->grid_ok);
+    const bool rebuild = (c->grid_mode == 0 && mode != 0 && c->nt > 0);
     c->grid_mode = mode;
-    if (rebuild) {                                   // the grid was skipped when the target was uploaded
+    if (rebuild) {                                   // the grids were skipped when the target was uploaded
         int rc = use_device(c);
         if (rc) return rc;
-        return build_grid(c);
+        if (!c->grid_ok && (rc = build_grid(c))) return rc;
+        if (c->surface && !c->tri_grid_ok && (rc = build_tri_grid(c))) return rc;
     }
     return OA_OK;
 }
@@ -912,10 +916,26 @@ OA_EXPORT int oa_make_pairs(oa_ctx *c, double thresh, int calc_stats, double *A,
         HIPCHK(hipMalloc(&c->d_B, sizeof(double) * 3 * (size_t)c->ns));
         c->emit_cap = c->ns;
     }
+    c->d_pivot0 = 0.0;
     if ((rc = push_state_for_oneshot(c, thresh))) return rc;
     if ((rc = launch_nn(c))) return rc;
     if ((rc = launch_accumulate(c, true, nullptr, nullptr))) return rc;
     if ((rc = launch_reduce(c, c->d_sums))) return rc;
+    if (calc_stats) {
+        // np.std is two-pass; redo the (cheap) accumulation around the mean of the first pass so that the
+        // population std is accurate even when it is tiny compared with the mean
+        double s1[oa::NSUMS];
+        HIPCHK(hipMemcpyAsync(s1, c->d_sums, sizeof s1, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (s1[oa::S_K] > 0.0) {
+            c->d_pivot0 = s1[oa::S_D] / s1[oa::S_K];
+            if ((rc = push_state_for_oneshot(c, thresh))) { c->d_pivot0 = 0.0; return rc; }
+            rc = launch_nn(c);
+            if (!rc) rc = launch_accumulate(c, true, nullptr, nullptr);
+            if (!rc) rc = launch_reduce(c, c->d_sums);
+            if (rc) { c->d_pivot0 = 0.0; return rc; }
+        }
+    }
     hipLaunchKernelGGL(oa::k_block_counts, dim3(n_blocks), dim3(256), 0, c->stream, c->d_valid, c->ns, c->d_counts);
     hipLaunchKernelGGL(oa::k_scan_counts, dim3(1), dim3(1024), 0, c->stream, c->d_counts, n_blocks, c->d_offsets);
     hipLaunchKernelGGL(oa::k_scatter_pairs, dim3(n_blocks), dim3(256), 0, c->stream, c->d_valid, c->ns, c->d_src4,
@@ -935,12 +955,13 @@ OA_EXPORT int oa_make_pairs(oa_ctx *c, double thresh, int calc_stats, double *A,
     *K = total;
     if (calc_stats && dstats && total > 0) {
         const double kk = sums[oa::S_K];
-        const double mean = sums[oa::S_D] / kk;
-        double var = sums[oa::S_DD] / kk - mean * mean;
+        const double mean_dd = sums[oa::S_D] / kk;                  // relative to the pivot of the second pass
+        double var = sums[oa::S_DD] / kk - mean_dd * mean_dd;
         if (var < 0.0) var = 0.0;
-        dstats[0] = mean;                                           // np.mean(dists)  (general.py:324)
+        dstats[0] = mean_dd + c->d_pivot0;                          // np.mean(dists)  (general.py:324)
         dstats[1] = sqrt(var);                                      // np.std(dists)   (general.py:325)
     }
+    c->d_pivot0 = 0.0;
     return OA_OK;
 }
 

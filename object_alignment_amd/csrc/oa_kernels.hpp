@@ -20,7 +20,7 @@ namespace oa {
 constexpr int NSUMS = 24;
 // layout of the per-iteration sums (all relative to `pivot`, a' = a - pivot, b' = b - pivot):
 //   [0..2] sum a'   [3..5] sum b'   [6..14] sum b'_i a'_j (row i, col j)   [15] sum |a'|^2   [16] sum |b'|^2
-//   [17] K          [18] sum d      [19] sum d^2        [20..23] reserved (0)
+//   [17] K          [18] sum (d - d_pivot)      [19] sum (d - d_pivot)^2        [20..23] reserved (0)
 constexpr int S_A = 0, S_B = 3, S_H = 6, S_AA = 15, S_BB = 16, S_K = 17, S_D = 18, S_DD = 19;
 
 constexpr unsigned long long KEY_EMPTY = ~0ull;
@@ -48,6 +48,8 @@ struct DevState {
     // conservative-filter data (k_nn_search_filtered): target bbox centre and max |q - centre|
     float  tc[3], pad1;
     double qmax;
+    double d_pivot;      // subtracted from the pair distances before summing (previous iteration's mean): keeps
+                         // the one-pass variance sum d^2 - K mean^2 free of cancellation
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -747,6 +749,7 @@ __global__ __launch_bounds__(ACC_THREADS) void k_pair_accumulate(const DevState 
     const bool halted = st->halt != 0;
     const double thresh = st->thresh;
     const double pvx = st->pivot[0], pvy = st->pivot[1], pvz = st->pivot[2];
+    const double d_pivot = st->d_pivot;
 
     if (!halted) {
         for (int i = blockIdx.x * ACC_THREADS + threadIdx.x; i < ns; i += gridDim.x * ACC_THREADS) {
@@ -796,8 +799,9 @@ __global__ __launch_bounds__(ACC_THREADS) void k_pair_accumulate(const DevState 
                 acc[S_AA] += (a0 * a0 + a1 * a1) + a2 * a2;
                 acc[S_BB] += (b0 * b0 + b1 * b1) + b2 * b2;
                 acc[S_K] += 1.0;
-                acc[S_D] += dist;
-                acc[S_DD] += dist * dist;
+                const double dd = dist - d_pivot;
+                acc[S_D] += dd;
+                acc[S_DD] += dd * dd;
             }
         }
     }
@@ -907,8 +911,9 @@ __global__ void k_solve_update(DevState *__restrict__ st, const double *__restri
     const double trans = v3_length(new_mat[3], new_mat[7], new_mat[11]);   // new_mat.to_translation().length (:129,:138)
     const double angle = rotation_angle_3x3(M);
     const double K = s[S_K];
-    const double mean_d = s[S_D] / K;
-    double var = s[S_DD] / K - mean_d * mean_d;
+    const double mean_dd = s[S_D] / K;                               // mean of (d - d_pivot)
+    const double mean_d = mean_dd + st->d_pivot;
+    double var = s[S_DD] / K - mean_dd * mean_dd;
     if (var < 0.0) var = 0.0;
     const int n = st->n;
     if (hist && st->max_records > 0) {
@@ -923,6 +928,7 @@ __global__ void k_solve_update(DevState *__restrict__ st, const double *__restri
         for (int k = 0; k < 5; ++k) all = all && (st->ring_t[k] < st->target_d);   // (:141)
         if (all) st->converged = 1;
     }
+    st->d_pivot = mean_d;                                           // next iteration sums d relative to this mean
     st->n = n + 1;                                                  // n += 1                        (:151)
     if ((st->converged && st->early_exit) || st->n >= st->iters) st->halt = 1;
 }

@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""GPU box: randomized differential test of the HIP path against the CPU oracle.
+
+Every trial draws a cloud family, sizes, scales, offsets and two (possibly non-uniformly scaled) matrix_world
+matrices, then checks, for search modes brute and grid:
+  * oa_nn_search == oracle brute force (index and float32 d2, bit exact) -- vertex mode and surface mode;
+  * oa_make_pairs == oracle make_pairs (A, B bit exact; d_stats to 1e-9).
+Usage: python tools/fuzz_parity.py [trials] [seed]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def cloud(rng, kind, n):
+    if kind == "uniform":
+        return rng.uniform(-1, 1, size=(n, 3))
+    if kind == "gauss":
+        return rng.normal(size=(n, 3))
+    if kind == "sphere":
+        v = rng.normal(size=(n, 3))
+        return v / np.maximum(1e-9, np.linalg.norm(v, axis=1, keepdims=True))
+    if kind == "lattice":
+        return rng.integers(-6, 7, size=(n, 3)) * 0.25
+    if kind == "clusters":
+        c = rng.normal(size=(8, 3)) * 2
+        return c[rng.integers(0, 8, size=n)] + rng.normal(size=(n, 3)) * 0.01
+    if kind == "line":
+        t = rng.uniform(-1, 1, size=(n, 1))
+        return t * np.array([[1.0, 0.5, -0.25]]) + rng.normal(size=(n, 3)) * 1e-4
+    if kind == "plane":
+        p = rng.uniform(-1, 1, size=(n, 3))
+        p[:, 2] = 0.125
+        return p
+    raise ValueError(kind)
+
+
+def rand_matrix(rng, scaled):
+    from object_alignment_amd import synth
+    R = synth.rotation_from_rotvec(rng.normal(size=3) * rng.choice([0.01, 0.3, 2.0]))
+    S = np.diag(rng.uniform(0.5, 2.0, size=3)) if scaled else np.identity(3)
+    M = np.identity(4)
+    M[:3, :3] = R @ S
+    M[:3, 3] = rng.normal(size=3) * rng.choice([0.0, 0.05, 1.0])
+    return M.astype(np.float32)
+
+
+def main():
+    from object_alignment_amd.engine import IcpEngine
+    from oracle import oracle as orc
+    trials = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    rng = np.random.default_rng(seed)
+    kinds = ["uniform", "gauss", "sphere", "lattice", "clusters", "line", "plane"]
+    engines = {m: IcpEngine(0) for m in ("brute", "grid")}
+    for m, e in engines.items():
+        e.set_search_mode(m)
+    bad = 0
+    t0 = time.time()
+    for t in range(trials):
+        kt, ks = rng.choice(kinds), rng.choice(kinds)
+        nt = int(rng.choice([1, 3, 17, 500, 4096, 12000, 30000]))
+        ns = int(rng.choice([1, 5, 300, 2500, 9000]))
+        scale = float(rng.choice([1e-6, 1e-2, 1.0, 1.0, 50.0, 1e5]))
+        offset = rng.normal(size=3) * float(rng.choice([0.0, 0.0, 10.0, 1e3])) * scale
+        tgt = (cloud(rng, kt, nt) * scale + offset).astype(np.float32)
+        src = (cloud(rng, ks, ns) * scale * rng.uniform(0.5, 1.5) + offset).astype(np.float32)
+        mxb = rand_matrix(rng, scaled=bool(rng.integers(0, 2)))
+        mxa = (mxb.astype(np.float64) @ rand_matrix(rng, False).astype(np.float64)).astype(np.float32)
+        surface = nt >= 3 and bool(rng.integers(0, 2))
+        tris = rng.integers(0, nt, size=(int(rng.choice([1, 50, 2000, 20000])), 3)).astype(np.int32) if surface else None
+        imx2 = orc.mat4_inverted(mxb)
+        cof = np.array([orc.mat4_mul_vec3(imx2, orc.mat4_mul_vec3(mxa, p)) for p in src], np.float32)
+        if surface:
+            ridx, _, rd2 = orc.nn_tri_brute(cof, tgt, tris)
+        else:
+            ridx, rd2 = orc.nn_brute(cof, tgt)
+        thresh = float(np.sqrt(np.median(rd2[np.isfinite(rd2)])) * rng.uniform(0.5, 3.0)) if np.isfinite(rd2).any() else 1.0
+        thresh = max(thresh, 1e-30) * float(np.abs(mxb[:3, :3]).max())
+        stride = int(rng.choice([0, 1, 2, 5]))
+        vlist = None if rng.integers(0, 2) else np.sort(rng.choice(ns, size=max(1, ns // 2), replace=False)).astype(np.int64)
+        rA, rB, rds = orc.make_pairs(src, tgt, mxa, mxb, thresh, vlist=vlist, sample=stride, calc_stats=True, tris=tris)
+        for mode, e in engines.items():
+            if surface:
+                e.set_target_mesh(tgt, tris)
+            else:
+                e.set_target(tgt)
+            e.set_source(src)
+            e.set_matrices(mxa, mxb)
+            idx, d2, _ = e.nn_search()
+            ok = np.array_equal(idx, ridx) and np.array_equal(d2, rd2)
+            e.set_source(src, vlist=vlist, stride=stride)
+            A, B, ds = e.make_pairs(thresh, calc_stats=True)
+            ok_p = A.shape == rA.shape and np.array_equal(A, rA) and np.array_equal(B, rB)
+            detail = "A/B differ" if not ok_p else ""
+            if ok_p and rA.shape[1]:
+                # population std: accumulated around the first pass's mean on the GPU, two-pass in the oracle
+                ok_p = abs(ds[0] - rds[0]) <= 1e-9 * abs(rds[0]) and abs(ds[1] - rds[1]) <= 1e-8 * abs(rds[1]) + 1e-13 * abs(rds[0])
+                detail = "d_stats %r vs %r" % (ds, rds) if not ok_p else ""
+            if not (ok and ok_p):
+                bad += 1
+                nd = int(np.count_nonzero(idx != ridx))
+                print("MISMATCH trial %d mode %s surface %s kinds %s/%s ns %d nt %d scale %g: nn ok %s (%d idx differ) "
+                      "pairs ok %s (K %d vs %d) %s" % (t, mode, surface, ks, kt, ns, nt, scale, ok, nd, ok_p, A.shape[1],
+                                                        rA.shape[1], detail), flush=True)
+        if (t + 1) % 10 == 0:
+            print("trial %d/%d  mismatches %d  (%.0f s)" % (t + 1, trials, bad, time.time() - t0), flush=True)
+    for e in engines.values():
+        e.close()
+    print("FUZZ DONE: %d trials, %d mismatches" % (trials, bad))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
