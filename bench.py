@@ -72,6 +72,33 @@ def cpu_baseline(src, tgt, mxa, mxb, iters, gpu_step_M):
     }
 
 
+def cpu_tiers(src, tgt, mxa, mxb):
+    """T1 = the reference's cost structure (per-vertex interpreter loop), T3 = like-for-like
+    brute force in C/OpenMP.  Both on bounded samples; the `cpu_baseline` object above is tier T2."""
+    from oracle import oracle as orc
+    out = {}
+    kd = orc.KDTree(tgt)
+    n1 = 4000
+    t0 = time.perf_counter()
+    A, B, _ = orc.make_pairs_python_loop(src[:n1], tgt, mxa, mxb, 0.5, kd, calc_stats=True)
+    t1 = time.perf_counter() - t0
+    A2, B2, _ = orc.make_pairs(src[:n1], tgt, mxa, mxb, 0.5, calc_stats=True, kd=kd)
+    out["T1_reference_style_python_loop"] = {
+        "us_per_vertex": 1e6 * t1 / n1, "cores": 1, "sample": "%d source vertices of the workload" % n1,
+        "extrapolated_s_per_iteration": t1 / n1 * len(src), "same_pairs_as_vectorised_oracle": bool(np.array_equal(A, A2) and np.array_equal(B, B2)),
+        "note": "interpreter loop + float32 4x4 transforms on Python objects + one tree query per vertex, as "
+                "functions/general.py:280-321 does (its per-vertex print omitted)"}
+    n3 = min(len(src), 20000)
+    t0 = time.perf_counter()
+    orc.nn_brute(src[:n3], tgt)
+    t3 = time.perf_counter() - t0
+    out["T3_bruteforce_c_openmp"] = {
+        "gpairs_per_s": n3 * len(tgt) / t3 / 1e9, "cores": orc.max_threads(),
+        "sample": "%d x %d pairs, same fp32 metric" % (n3, len(tgt)),
+        "extrapolated_s_per_iteration": t3 / n3 * len(src)}
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -218,6 +245,10 @@ def main():
                 pass
         if world == 1 and not args.no_cpu_baseline and args.cpu_iters > 0:
             out["cpu_baseline"] = cpu_baseline(src, tgt, mxa, mxb, min(args.cpu_iters, args.steps), res.step_M)
+            try:
+                out["cpu_baseline_tiers"] = cpu_tiers(src, tgt, mxa, mxb)
+            except Exception as exc:
+                out["cpu_baseline_tiers"] = {"error": repr(exc)}
         print(json.dumps(out), flush=True)
     eng.close()
     if world > 1:

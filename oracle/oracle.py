@@ -429,3 +429,33 @@ class NearestVertexBVH:
         idx, d2 = (nn_brute(q, self.t) if self.kd is None else self.kd.query(q, nthreads=1))
         i = int(idx[0])
         return Vector(self.t[i]), None, i, math.sqrt(float(d2[0]))
+
+
+# ---------------------------------------------------------------- reference-style cost structure (bench tier T1)
+
+def make_pairs_python_loop(src, target, mx_align, mx_base, thresh, kd: KDTree, vlist=None, calc_stats=False):
+    """The reference's make_pairs COST STRUCTURE (functions/general.py:280-321): an interpreter-level loop with
+    float32 4x4 transforms on Python objects and one tree query per vertex (stdout writes omitted).  Same results as
+    :func:`make_pairs`; used only to time what a per-vertex Python loop costs (tier T1)."""
+    align, base = MeshObject(src, mx_align), MeshObject(target, mx_base)
+    mx1, mx2 = align.matrix_world, base.matrix_world
+    imx1, imx2 = mx1.inverted(), mx2.inverted()
+    tgt = _f32(target).reshape(-1, 3)
+    verts1, verts2, dists = [], [], []
+    for vert_ind in (range(len(align.data.vertices)) if vlist is None else vlist):
+        vert = align.data.vertices[vert_ind]
+        co_find = imx2 @ (mx1 @ vert.co)
+        idx, _ = kd.query(co_find.v.reshape(1, 3), nthreads=1)
+        co1 = Vector(tgt[int(idx[0])])
+        dist = (mx2 @ co_find - mx2 @ co1).length
+        if dist < thresh:
+            verts1.append(vert.co)
+            verts2.append(imx1 @ (mx2 @ co1))
+            if calc_stats:
+                dists.append(dist)
+    A = np.zeros((3, len(verts1)))
+    B = np.zeros((3, len(verts1)))
+    for i in range(len(verts1)):
+        A[0][i], A[1][i], A[2][i] = verts1[i][0], verts1[i][1], verts1[i][2]
+        B[0][i], B[1][i], B[2][i] = verts2[i][0], verts2[i][1], verts2[i][2]
+    return A, B, ([float(np.mean(dists)), float(np.std(dists))] if calc_stats else None)

@@ -580,6 +580,47 @@ def test_two_shards_on_one_gpu_equal_unsharded(golden_dir):
     assert np.abs(res[0].matrix_world - g["final_world"]).max() <= F32_ULP
 
 
+def test_c4_shaped_eight_shards_one_gpu(orc):
+    """BASELINE config 4's shape: 1M <-> 1M with the source cut into 8 shards of 125k (here 8 contexts on one GPU,
+    brute-force kernel, the all-reduce replaced by a tensor sum), 2 iterations, against the oracle's KD-tree loop."""
+    import torch
+    from object_alignment_amd import synth, _capi
+    from object_alignment_amd.engine import IcpEngine
+    src, tgt, mxa, mxb = synth.c3_random_pair(1_000_000)
+    world, iters = 8, 2
+    dev = torch.device("cuda:0")
+    engs = [IcpEngine(0) for _ in range(world)]
+    try:
+        sums = [torch.zeros(_capi.OA_NSUMS, dtype=torch.float64, device=dev) for _ in range(world)]
+        tgt_dev = torch.from_numpy(tgt).to(dev)
+        for r, e in enumerate(engs):
+            e.set_search_mode("brute")
+            e.set_stream(torch.cuda.current_stream().cuda_stream)
+            e.set_target(tgt_dev)
+            e.set_source(src, stride=1, shard_index=r, shard_count=world)
+            assert e.n_selected == 125_000
+            e.set_matrices(mxa, mxb)
+            e.run_begin(iters=iters, thresh=0.5, target_d=0.01, use_target=True, early_exit=False)
+        for _ in range(iters):
+            for r, e in enumerate(engs):
+                e.iter_partial(sums[r].data_ptr())
+            total = torch.stack(sums).sum(0)
+            for e in engs:
+                e.iter_finish(total.data_ptr())
+        res = [e.run_end() for e in engs]
+    finally:
+        for e in engs:
+            e.close()
+    ref = orc.icp_run(src, tgt, mxa, mxb, iters=iters, sample=1, thresh=0.5, target_d=1e-300, use_target=True,
+                      kd=orc.KDTree(tgt))
+    for r in res[1:]:
+        assert np.array_equal(r.matrix_world, res[0].matrix_world)
+    assert np.array_equal(res[0].step_K, ref["step_K"])
+    assert np.abs(res[0].step_M - ref["step_M"]).max() < 1e-9
+    err = np.linalg.norm(res[0].matrix_world.astype(np.float64) - ref["matrix_world"].astype(np.float64))
+    assert err <= FROB_TOL, err
+
+
 def test_more_shards_than_points(orc):
     """Empty shards (shard_count > selected points) contribute zero sums and do not disturb the others."""
     import torch
