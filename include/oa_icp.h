@@ -113,6 +113,13 @@ int oa_set_target_mesh(oa_ctx *ctx, const float *xyz, int64_t n_verts, int on_de
 int oa_set_source(oa_ctx *ctx, const float *xyz, int64_t n_verts, int on_device,
                   const int64_t *vlist, int64_t n_vlist, int32_t stride,
                   int32_t shard_index, int32_t shard_count);
+/* EXTENSION (no counterpart in the reference): reject a pair when the angle between the world-space
+ * normals of the source vertex and of its correspondence exceeds max_angle_deg.  src_normals: n_verts x 3 (align-
+ * local, host); tgt_normals: nt x 3 per target vertex (vertex mode; ignored in surface mode, where the geometric
+ * normal of the nearest triangle is used).  Call after oa_set_source / oa_set_target; passing src_normals == NULL
+ * or an angle outside (0, 180) switches the test off; a new source or target upload switches it off too. */
+int oa_set_normals(oa_ctx *ctx, const float *src_normals, int64_t n_verts, const float *tgt_normals, int64_t nt,
+                   double max_angle_deg);
 /* matrix_world of the align and base objects (functions/general.py:262-263) */
 int oa_set_matrices(oa_ctx *ctx, const float mx_align[16], const float mx_base[16]);
 int oa_get_matrix_world(oa_ctx *ctx, float mx_align[16]);

@@ -27,7 +27,7 @@ OA_NSUMS = 24
 SYMBOLS = [
     "oa_device_count", "oa_create", "oa_destroy", "oa_last_error", "oa_version", "oa_set_stream",
     "oa_set_search_mode",
-    "oa_set_target", "oa_set_target_mesh", "oa_set_source", "oa_set_matrices", "oa_get_matrix_world", "oa_num_selected",
+    "oa_set_target", "oa_set_target_mesh", "oa_set_source", "oa_set_normals", "oa_set_matrices", "oa_get_matrix_world", "oa_num_selected",
     "oa_make_pairs", "oa_nn_search", "oa_kabsch", "oa_kabsch_from_sums", "oa_get_pivot",
     "oa_iterate", "oa_run", "oa_get_history", "oa_run_begin", "oa_iter_partial", "oa_iter_finish", "oa_run_end",
 ]
@@ -84,6 +84,7 @@ def load():
     L.oa_set_target.argtypes = [vp, vp, C.c_int64, C.c_int]
     L.oa_set_target_mesh.argtypes = [vp, vp, C.c_int64, C.c_int, C.POINTER(C.c_int32), C.c_int64]
     L.oa_set_source.argtypes = [vp, vp, C.c_int64, C.c_int, ip, C.c_int64, C.c_int32, C.c_int32, C.c_int32]
+    L.oa_set_normals.argtypes = [vp, fp, C.c_int64, fp, C.c_int64, C.c_double]
     L.oa_set_matrices.argtypes = [vp, fp, fp]
     L.oa_get_matrix_world.argtypes = [vp, fp]
     L.oa_num_selected.argtypes = [vp]

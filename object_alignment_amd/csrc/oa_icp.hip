@@ -98,6 +98,12 @@ struct oa_ctx {
     float4 *d_src4 = nullptr;
     unsigned long long *d_keys = nullptr;
     int *d_prev = nullptr;           // nearest index of the previous search (seed), -1 = none
+    int *d_sel = nullptr;            // vertex index held by each source slot
+    long long src_n_verts = 0;
+    // normal-angle rejection (extension)
+    float *d_src_n = nullptr, *d_tgt_n = nullptr;
+    double cos_min = -2.0;
+    bool normals_on = false;
     double pivot[3] = { 0, 0, 0 };
     // launch geometry for k_nn_search
     int n_splits = 1, groups_per_split = 0, acc_blocks = 1;
@@ -250,15 +256,17 @@ int launch_nn(oa_ctx *c)
 int launch_accumulate(oa_ctx *c, bool emit, int *nn_idx, float *nn_d2)
 {
     oa::PairOut po{};
+    oa::NormalTest nrm{};
+    if (c->normals_on) { nrm.src_n = c->d_src_n; nrm.tgt_n = c->surface ? nullptr : c->d_tgt_n; nrm.cos_min = c->cos_min; }
     if (emit) {
         po.valid = c->d_valid; po.b = c->d_b; po.dist = c->d_dist; po.nn_idx = nn_idx; po.nn_d2 = nn_d2;
         hipLaunchKernelGGL(oa::k_pair_accumulate<true>, dim3(c->acc_blocks), dim3(oa::ACC_THREADS), 0, c->stream,
                            c->d_state, c->d_src4, c->ns, c->d_tgt_xyz, c->d_keys, c->d_prev,
-                           c->surface ? (const float4 *)c->d_tri9 : (const float4 *)nullptr, c->d_partials, po);
+                           c->surface ? (const float4 *)c->d_tri9 : (const float4 *)nullptr, nrm, c->d_partials, po);
     } else {
         hipLaunchKernelGGL(oa::k_pair_accumulate<false>, dim3(c->acc_blocks), dim3(oa::ACC_THREADS), 0, c->stream,
                            c->d_state, c->d_src4, c->ns, c->d_tgt_xyz, c->d_keys, c->d_prev,
-                           c->surface ? (const float4 *)c->d_tri9 : (const float4 *)nullptr, c->d_partials, po);
+                           c->surface ? (const float4 *)c->d_tri9 : (const float4 *)nullptr, nrm, c->d_partials, po);
     }
     HIPCHK(hipGetLastError());
     return OA_OK;
@@ -423,6 +431,7 @@ OA_EXPORT void oa_destroy(oa_ctx *c)
     dev_free(c->d_valid); dev_free(c->d_b); dev_free(c->d_dist); dev_free(c->d_counts); dev_free(c->d_offsets);
     dev_free(c->d_A); dev_free(c->d_B);
     dev_free(c->d_tri9); dev_free(c->d_tcell_start); dev_free(c->d_tcell_tris);
+    dev_free(c->d_sel); dev_free(c->d_src_n); dev_free(c->d_tgt_n);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->ev_loop0) (void)hipEventDestroy(c->ev_loop0);
     if (c->ev_loop1) (void)hipEventDestroy(c->ev_loop1);
@@ -584,6 +593,8 @@ OA_EXPORT int oa_set_target(oa_ctx *c, const float *xyz, int64_t n, int on_devic
     dev_free(c->d_tgt_xyz); dev_free(c->d_tg); dev_free(c->d_tf);
     dev_free(c->d_tri9); dev_free(c->d_tcell_start); dev_free(c->d_tcell_tris);
     c->surface = false; c->tri_grid_ok = false; c->n_tris = 0;
+    dev_free(c->d_tgt_n);
+    c->normals_on = false;
     c->filter_ok = false;
     c->nt = (int)n;
     c->n_groups_pad = 0;
@@ -759,7 +770,9 @@ OA_EXPORT int oa_set_source(oa_ctx *c, const float *xyz, int64_t n_verts, int on
     int rc = use_device(c);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
-    dev_free(c->d_src4); dev_free(c->d_keys); dev_free(c->d_prev);
+    dev_free(c->d_src4); dev_free(c->d_keys); dev_free(c->d_prev); dev_free(c->d_sel); dev_free(c->d_src_n);
+    c->normals_on = false;
+    c->src_n_verts = n_verts;
     dev_free(c->d_valid); dev_free(c->d_b); dev_free(c->d_dist); dev_free(c->d_counts); dev_free(c->d_offsets);
     dev_free(c->d_A); dev_free(c->d_B);
     c->emit_cap = 0;
@@ -770,6 +783,8 @@ OA_EXPORT int oa_set_source(oa_ctx *c, const float *xyz, int64_t n_verts, int on
     HIPCHK(hipMalloc(&c->d_src4, sizeof(float4) * (size_t)c->ns_pad));
     HIPCHK(hipMalloc(&c->d_keys, sizeof(unsigned long long) * (size_t)c->ns_pad));
     HIPCHK(hipMalloc(&c->d_prev, sizeof(int) * (size_t)c->ns_pad));
+    HIPCHK(hipMalloc(&c->d_sel, sizeof(int) * (size_t)c->ns_pad));
+    HIPCHK(hipMemsetAsync(c->d_sel, 0, sizeof(int) * (size_t)c->ns_pad, c->stream));
     dev_free(c->d_todo_list); dev_free(c->d_todo_count);
     HIPCHK(hipMalloc(&c->d_todo_list, sizeof(int) * (size_t)c->ns_pad));
     HIPCHK(hipMalloc(&c->d_todo_count, sizeof(int)));
@@ -795,7 +810,7 @@ OA_EXPORT int oa_set_source(oa_ctx *c, const float *xyz, int64_t n_verts, int on
         if (on_device) HIPCHK(hipMemcpyAsync(p0, xyz + 3 * v0, sizeof p0, hipMemcpyDeviceToHost, c->stream));
         else memcpy(p0, xyz + 3 * v0, sizeof p0);
         hipLaunchKernelGGL(oa::k_pack_source, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, d_xyz,
-                           (const long long *)d_vlist.p, step, begin, c->ns, c->ns_pad, c->d_src4);
+                           (const long long *)d_vlist.p, step, begin, c->ns, c->ns_pad, c->d_src4, c->d_sel);
         hipLaunchKernelGGL(oa::k_fill_keys, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, c->d_keys, c->ns_pad);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -806,6 +821,37 @@ OA_EXPORT int oa_set_source(oa_ctx *c, const float *xyz, int64_t n_verts, int on
         HIPCHK(hipStreamSynchronize(c->stream));
     }
     plan_geometry(c);
+    return OA_OK;
+}
+
+OA_EXPORT int oa_set_normals(oa_ctx *c, const float *src_normals, int64_t n_verts, const float *tgt_normals, int64_t nt,
+                             double max_angle_deg)
+{
+    if (!c) return fail(OA_E_BAD_ARG, "null context");
+    c->normals_on = false;
+    if (!src_normals || !(max_angle_deg > 0.0) || !(max_angle_deg < 180.0)) return OA_OK;       // switched off
+    if (!c->d_src4 || !c->d_sel) return fail(OA_E_STATE, "oa_set_normals: call oa_set_source first");
+    if (c->nt <= 0) return fail(OA_E_STATE, "oa_set_normals: call oa_set_target first");
+    if (n_verts != c->src_n_verts) return fail(OA_E_BAD_ARG, "oa_set_normals: %lld source normals for %lld vertices", (long long)n_verts, c->src_n_verts);
+    if (!c->surface && (!tgt_normals || nt != c->nt)) return fail(OA_E_BAD_ARG, "oa_set_normals: vertex mode needs one normal per target vertex");
+    int rc = use_device(c);
+    if (rc) return rc;
+    DevTmp<float> tmp;
+    HIPCHK(tmp.alloc(3 * (size_t)n_verts));
+    HIPCHK(hipMemcpyAsync(tmp, src_normals, sizeof(float) * 3 * (size_t)n_verts, hipMemcpyHostToDevice, c->stream));
+    dev_free(c->d_src_n); dev_free(c->d_tgt_n);
+    HIPCHK(hipMalloc(&c->d_src_n, sizeof(float) * 3 * (size_t)std::max(1, c->ns)));
+    if (c->ns > 0)
+        hipLaunchKernelGGL(oa::k_gather_rows3, dim3((c->ns + 255) / 256), dim3(256), 0, c->stream, (const float *)tmp.p,
+                           (const int *)c->d_sel, c->ns, c->d_src_n);
+    HIPCHK(hipGetLastError());
+    if (!c->surface) {
+        HIPCHK(hipMalloc(&c->d_tgt_n, sizeof(float) * 3 * (size_t)nt));
+        HIPCHK(hipMemcpyAsync(c->d_tgt_n, tgt_normals, sizeof(float) * 3 * (size_t)nt, hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->cos_min = cos(max_angle_deg * 3.14159265358979323846 / 180.0);
+    c->normals_on = true;
     return OA_OK;
 }
 

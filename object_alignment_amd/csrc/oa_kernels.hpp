@@ -294,7 +294,8 @@ __device__ __forceinline__ void load_tri(const float4 *__restrict__ tri9, long l
 // ------------------------------------------------------------------------------------------------
 // source: gather xyz[vlist[(begin + i) * stride]] -> float4; the tail up to ns_pad repeats the last point
 __global__ void k_pack_source(const float *__restrict__ xyz, const long long *__restrict__ vlist, long long stride,
-                              long long begin, int ns, int ns_pad, float4 *__restrict__ src4)
+                              long long begin, int ns, int ns_pad, float4 *__restrict__ src4,
+                              int *__restrict__ sel_vertex)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ns_pad) return;
@@ -303,6 +304,15 @@ __global__ void k_pack_source(const float *__restrict__ xyz, const long long *__
     float4 p;
     p.x = xyz[3 * v]; p.y = xyz[3 * v + 1]; p.z = xyz[3 * v + 2]; p.w = 0.f;
     src4[i] = p;
+    sel_vertex[i] = (int)v;                       // which vertex this slot holds (normals are gathered with it)
+}
+
+__global__ void k_gather_rows3(const float *__restrict__ rows, const int *__restrict__ sel, int n, float *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long long v = sel[i];
+    out[3ll * i] = rows[3 * v]; out[3ll * i + 1] = rows[3 * v + 1]; out[3ll * i + 2] = rows[3 * v + 2];
 }
 
 // target: groups of 4 vertices as [x0..x3][y0..y3][z0..z3]; vertices past nt are +INF (never selected)
@@ -725,6 +735,30 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+// Optional normal-angle rejection (an EXTENSION: the reference has no such test -- SURVEY.md D3).  A pair is kept
+// only if the angle between the world-space normals of the source vertex and of its correspondence is at most
+// max_angle.  Normals are carried to world space with the inverse-transpose of the object matrices (imx1 / imx2).
+struct NormalTest {
+    const float *src_n;     // ns x 3, align-local, same slot order as src4 (nullptr = test disabled)
+    const float *tgt_n;     // nt x 3 per target vertex (vertex mode); nullptr in surface mode = geometric face normal
+    double cos_min;
+};
+
+__device__ __forceinline__ bool normal_angle_ok(const float *imx1, const float *imx2, const float *ns, const float *nt,
+                                                double cos_min)
+{
+    double a[3], b[3];
+    for (int k = 0; k < 3; ++k) {      // (M^-1)^T n : column k of the inverse dotted with n
+        a[k] = (double)imx1[k] * (double)ns[0] + (double)imx1[4 + k] * (double)ns[1] + (double)imx1[8 + k] * (double)ns[2];
+        b[k] = (double)imx2[k] * (double)nt[0] + (double)imx2[4 + k] * (double)nt[1] + (double)imx2[8 + k] * (double)nt[2];
+    }
+    const double ab = (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2];
+    const double aa = (a[0] * a[0] + a[1] * a[1]) + a[2] * a[2];
+    const double bb = (b[0] * b[0] + b[1] * b[1]) + b[2] * b[2];
+    const double c = ab / sqrt(aa * bb);
+    return c >= cos_min;               // NaN (zero normal) -> rejected
+}
+
 struct PairOut {            // optional per-point outputs for the make_pairs contract
     unsigned char *valid;   // ns
     float  *b;              // ns x 3  (imx1 @ (mx2 @ co1))
@@ -739,7 +773,7 @@ __global__ __launch_bounds__(ACC_THREADS) void k_pair_accumulate(const DevState 
                                                                  const float *__restrict__ tgt_xyz,
                                                                  unsigned long long *__restrict__ keys,
                                                                  int *__restrict__ prev,
-                                                                 const float4 *__restrict__ tri9,
+                                                                 const float4 *__restrict__ tri9, NormalTest nrm,
                                                                  double *__restrict__ partials, PairOut out)
 {
     __shared__ double red[ACC_THREADS / 64][NSUMS];
@@ -766,20 +800,33 @@ __global__ __launch_bounds__(ACC_THREADS) void k_pair_accumulate(const DevState 
                 m4_mul_v3(st->mx1, p.x, p.y, p.z, wx, wy, wz);
                 m4_mul_v3(st->imx2, wx, wy, wz, cx, cy, cz);       // co_find                   (general.py:287)
                 float qx, qy, qz;                                    // co1 (general.py:297)
+                float tn[3] = { 0.f, 0.f, 0.f };                     // correspondence normal (only for the extension)
                 if (tri9) {                                          // surface mode: closest point on triangle `idx`
                     float ta[3], tb[3], tc[3], rr[3];
                     const float cf[3] = { cx, cy, cz };
                     load_tri(tri9, idx, ta, tb, tc);
                     closest_on_tri(cf, ta, tb, tc, rr);
                     qx = rr[0]; qy = rr[1]; qz = rr[2];
+                    if (nrm.src_n) {                                 // geometric face normal (Blender normal_tri_v3 order)
+                        const float e1[3] = { ta[0] - tb[0], ta[1] - tb[1], ta[2] - tb[2] };
+                        const float e2[3] = { tb[0] - tc[0], tb[1] - tc[1], tb[2] - tc[2] };
+                        tn[0] = e1[1] * e2[2] - e1[2] * e2[1];
+                        tn[1] = e1[2] * e2[0] - e1[0] * e2[2];
+                        tn[2] = e1[0] * e2[1] - e1[1] * e2[0];
+                    }
                 } else {                                             // vertex mode: target vertex `idx`
                     qx = tgt_xyz[3ll * idx]; qy = tgt_xyz[3ll * idx + 1]; qz = tgt_xyz[3ll * idx + 2];
+                    if (nrm.src_n) { tn[0] = nrm.tgt_n[3ll * idx]; tn[1] = nrm.tgt_n[3ll * idx + 1]; tn[2] = nrm.tgt_n[3ll * idx + 2]; }
                 }
                 float ax, ay, az, wbx, wby, wbz;
                 m4_mul_v3(st->mx2, cx, cy, cz, ax, ay, az);         // mx2 @ co_find             (general.py:299)
                 m4_mul_v3(st->mx2, qx, qy, qz, wbx, wby, wbz);      // mx2 @ co1                 (general.py:299)
                 dist = v3_length(ax - wbx, ay - wby, az - wbz);
                 valid = dist < thresh;                             // face_index != -1 always holds (general.py:302)
+                if (valid && nrm.src_n) {
+                    const float sn[3] = { nrm.src_n[3ll * i], nrm.src_n[3ll * i + 1], nrm.src_n[3ll * i + 2] };
+                    valid = normal_angle_ok(st->imx1, st->imx2, sn, tn, nrm.cos_min);
+                }
                 if (valid) m4_mul_v3(st->imx1, wbx, wby, wbz, bx, by, bz);   // imx1 @ (mx2 @ co1)  (general.py:304)
             }
             if (EMIT) {

@@ -114,6 +114,17 @@ class IcpEngine:
         self.n_selected = int(self._L.oa_num_selected(self._h))
         del keep, vl
 
+    def set_normals(self, src_normals, tgt_normals=None, max_angle_deg=45.0):
+        """Extension (not in the reference): drop pairs whose world-space normals differ by more than max_angle_deg.
+        Call after set_source / set_target*; src_normals=None switches the test off."""
+        if src_normals is None:
+            capi.check(self._L.oa_set_normals(self._h, None, 0, None, 0, 0.0))
+            return
+        sn = capi.as_f32(src_normals).reshape(-1, 3)
+        tn = capi.as_f32(tgt_normals).reshape(-1, 3) if tgt_normals is not None else None
+        capi.check(self._L.oa_set_normals(self._h, capi.fptr(sn), len(sn), capi.fptr(tn) if tn is not None else None,
+                                          len(tn) if tn is not None else 0, float(max_angle_deg)))
+
     def set_matrices(self, mx_align, mx_base):
         a, b = capi.as_f32(mx_align, (4, 4)), capi.as_f32(mx_base, (4, 4))
         capi.check(self._L.oa_set_matrices(self._h, capi.fptr(a), capi.fptr(b)))

@@ -90,7 +90,7 @@ def lattice_surface_mesh(nu: int, nv: int):
     b = (i * nv + (j + 1) % nv).ravel()
     c = ((i + 1) * nv + j).ravel()
     d = ((i + 1) * nv + (j + 1) % nv).ravel()
-    tris = np.concatenate([np.stack([a, b, c], 1), np.stack([b, d, c], 1)]).astype(np.int32)
+    tris = np.concatenate([np.stack([a, c, b], 1), np.stack([b, c, d], 1)]).astype(np.int32)   # outward winding
     return verts, tris
 
 
@@ -114,6 +114,25 @@ def bunny_surface(n: int, offset: float = 0.0) -> np.ndarray:
     """'Synthetic bunny' (SURVEY.md 8d C2): a bumpy star-shaped surface sampled on a Fibonacci lattice."""
     u = fibonacci_dirs(n, offset)
     return (u * _bunny_radius(u)[:, None]).astype(np.float32)
+
+
+def bunny_surface_with_normals(n: int, offset: float = 0.0):
+    """bunny_surface() plus outward unit normals (central differences of the (theta, phi) parametrisation)."""
+    u = fibonacci_dirs(n, offset)
+    theta = np.arccos(np.clip(u[:, 2], -1.0, 1.0))
+    phi = np.arctan2(u[:, 1], u[:, 0])
+
+    def P(t, p):
+        d = np.stack([np.sin(t) * np.cos(p), np.sin(t) * np.sin(p), np.cos(t)], axis=1)
+        return d * _bunny_radius(d)[:, None]
+
+    e = 1e-5
+    pt = (P(theta + e, phi) - P(theta - e, phi)) / (2 * e)
+    pp = (P(theta, phi + e) - P(theta, phi - e)) / (2 * e)
+    nrm = np.cross(pt, pp)
+    nrm /= np.maximum(1e-30, np.linalg.norm(nrm, axis=1, keepdims=True))
+    nrm *= np.sign(np.sum(nrm * u, axis=1, keepdims=True) + 1e-30)
+    return (u * _bunny_radius(u)[:, None]).astype(np.float32), nrm.astype(np.float32)
 
 
 def bumpy_icosphere(subdivisions: int = 4) -> np.ndarray:

@@ -444,10 +444,39 @@ OO_API void oo_nn_tri_brute(const float *q, int64_t nq, const float *verts, cons
  * returns K >= 0, or -1 if thresh <= 0 (reference falls through and returns
  *         None, :277), -2 singular matrix, -3 cap too small
  */
+/* EXTENSION (not in the reference): angle between world-space normals, carried with the
+ * inverse-transpose of the object matrices; same arithmetic as normal_angle_ok in oa_kernels.hpp */
+static int normal_angle_ok(const float *imx1, const float *imx2, const float *ns, const float *nt, double cos_min)
+{
+    double a[3], b[3];
+    for (int k = 0; k < 3; ++k) {
+        a[k] = (double)imx1[k] * (double)ns[0] + (double)imx1[4 + k] * (double)ns[1] + (double)imx1[8 + k] * (double)ns[2];
+        b[k] = (double)imx2[k] * (double)nt[0] + (double)imx2[4 + k] * (double)nt[1] + (double)imx2[8 + k] * (double)nt[2];
+    }
+    const double ab = (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2];
+    const double aa = (a[0] * a[0] + a[1] * a[1]) + a[2] * a[2];
+    const double bb = (b[0] * b[0] + b[1] * b[1]) + b[2] * b[2];
+    const double c = ab / sqrt(aa * bb);
+    return c >= cos_min;
+}
+
+static void pair_normal(const float *tgt, const int32_t *tris, const float *tgt_n, int64_t idx, float *tn)
+{
+    if (tris) {                                  /* geometric face normal, Blender normal_tri_v3 operand order */
+        const float *a = tgt + 3 * (int64_t)tris[3 * idx], *b = tgt + 3 * (int64_t)tris[3 * idx + 1], *c = tgt + 3 * (int64_t)tris[3 * idx + 2];
+        const float e1[3] = { a[0] - b[0], a[1] - b[1], a[2] - b[2] };
+        const float e2[3] = { b[0] - c[0], b[1] - c[1], b[2] - c[2] };
+        tn[0] = e1[1] * e2[2] - e1[2] * e2[1];
+        tn[1] = e1[2] * e2[0] - e1[0] * e2[2];
+        tn[2] = e1[0] * e2[1] - e1[1] * e2[0];
+    } else { tn[0] = tgt_n[3 * idx]; tn[1] = tgt_n[3 * idx + 1]; tn[2] = tgt_n[3 * idx + 2]; }
+}
+
 OO_API int64_t oo_make_pairs(const float *src, int64_t n_verts,
                              const int64_t *vlist, int64_t n_vlist, int sample,
                              const float *tgt, int64_t nt, const void *kd,
                              const int32_t *tris, int64_t n_tris,
+                             const float *src_n, const float *tgt_n, double cos_min,
                              const float *mx1, const float *mx2,
                              double thresh, int calc_stats, int nthreads,
                              double *A, double *B, int64_t cap,
@@ -494,7 +523,9 @@ OO_API int64_t oo_make_pairs(const float *src, int64_t n_verts,
         oo_mat4_mul_vec3(mx2, co1, wb);               /* mx2 @ co1      :299 */
         df[0] = wa[0] - wb[0]; df[1] = wa[1] - wb[1]; df[2] = wa[2] - wb[2];
         double dist = oo_vec3_length(df);
-        if (dist < thresh) {                           /* :302 */
+        int keep = dist < thresh;                      /* :302 */
+        if (keep && src_n) { float tn[3]; pair_normal(tgt, tris, tgt_n, nn[s], tn); keep = normal_angle_ok(imx1, imx2, src_n + 3 * vi, tn, cos_min); }
+        if (keep) {
             if (K >= cap) { free(cof); free(nn); free(co1buf); return -3; }
             float b[3];
             oo_mat4_mul_vec3(imx1, wb, b);             /* imx1 @ (mx2 @ co1)  :304 */
@@ -523,7 +554,13 @@ OO_API int64_t oo_make_pairs(const float *src, int64_t n_verts,
                 oo_mat4_mul_vec3(mx2, co1, wb);
                 df[0] = wa[0] - wb[0]; df[1] = wa[1] - wb[1]; df[2] = wa[2] - wb[2];
                 double dist = oo_vec3_length(df);
-                if (dist < thresh) { acc += (dist - mean) * (dist - mean); ++k; }
+                int keep = dist < thresh;
+                if (keep && src_n) {
+                    int64_t vi2 = vlist ? vlist[s * step] : s * step;
+                    float tn[3]; pair_normal(tgt, tris, tgt_n, nn[s], tn);
+                    keep = normal_angle_ok(imx1, imx2, src_n + 3 * vi2, tn, cos_min);
+                }
+                if (keep) { acc += (dist - mean) * (dist - mean); ++k; }
             }
             dstats[1] = sqrt(acc / (double)K);
         } else { dstats[0] = NAN; dstats[1] = NAN; }
@@ -678,6 +715,7 @@ OO_API int oo_icp_run(const float *src, int64_t n_verts,
                       const int64_t *vlist, int64_t n_vlist,
                       const float *tgt, int64_t nt, const void *kd,
                       const int32_t *tris, int64_t n_tris,
+                      const float *src_n, const float *tgt_n, double cos_min,
                       float *mx1, const float *mx2, const oo_settings *st, int nthreads,
                       oo_report *rep, double *step_M, float *step_new,
                       int64_t *step_K, double *step_stats, double *step_trans)
@@ -694,7 +732,7 @@ OO_API int oo_icp_run(const float *src, int64_t n_verts,
     memset(rep, 0, sizeof *rep);
     while (n < st->iters && !converged) {                        /* :96 */
         double ds[2] = { NAN, NAN };
-        int64_t K = oo_make_pairs(src, n_verts, vlist, n_vlist, st->sample, tgt, nt, kd, tris, n_tris,
+        int64_t K = oo_make_pairs(src, n_verts, vlist, n_vlist, st->sample, tgt, nt, kd, tris, n_tris, src_n, tgt_n, cos_min,
                                   mx1, mx2, st->thresh, st->use_target, nthreads,
                                   A, B, cap, ds, NULL);           /* :101 */
         if (K < 0) { rep->status = (int32_t)K; break; }

@@ -78,12 +78,12 @@ def lib():
         i32p = C.POINTER(C.c_int32)
         L.oo_closest_on_tri.argtypes = [fp, fp, fp, fp, fp]
         L.oo_nn_tri_brute.argtypes = [fp, C.c_int64, fp, i32p, C.c_int64, ip, fp, fp]
-        L.oo_make_pairs.argtypes = [fp, C.c_int64, ip, C.c_int64, C.c_int, fp, C.c_int64, vp, i32p, C.c_int64, fp, fp,
+        L.oo_make_pairs.argtypes = [fp, C.c_int64, ip, C.c_int64, C.c_int, fp, C.c_int64, vp, i32p, C.c_int64, fp, fp, C.c_double, fp, fp,
                                     C.c_double, C.c_int, C.c_int, dp, dp, C.c_int64, dp, ip]
         L.oo_make_pairs.restype = C.c_int64
         L.oo_kabsch.argtypes = [dp, dp, C.c_int64, C.c_int64, C.c_int, dp]
         L.oo_kabsch.restype = C.c_int
-        L.oo_icp_run.argtypes = [fp, C.c_int64, ip, C.c_int64, fp, C.c_int64, vp, i32p, C.c_int64, fp, fp,
+        L.oo_icp_run.argtypes = [fp, C.c_int64, ip, C.c_int64, fp, C.c_int64, vp, i32p, C.c_int64, fp, fp, C.c_double, fp, fp,
                                  C.POINTER(Settings), C.c_int, C.POINTER(Report), dp, fp, ip, dp, dp]
         L.oo_icp_run.restype = C.c_int
         _lib = L
@@ -183,6 +183,15 @@ def _tris(tris):
     return t, t.ctypes.data_as(C.POINTER(C.c_int32)), len(t)
 
 
+def _normals(normals, max_angle_deg):
+    """normals = (source normals [n_verts,3], target vertex normals [nt,3] or None in surface mode) or None."""
+    if normals is None:
+        return None, None, -2.0
+    sn = _f32(normals[0]).reshape(-1, 3)
+    tn = _f32(normals[1]).reshape(-1, 3) if normals[1] is not None else None
+    return sn, tn, math.cos(max_angle_deg * 3.14159265358979323846 / 180.0)
+
+
 def nn_tri_brute(queries, verts, tris):
     """Closest point on the triangle surface (BVHTree.find_nearest semantics): (face, co1, d2)."""
     q, v = _f32(queries).reshape(-1, 3), _f32(verts).reshape(-1, 3)
@@ -195,7 +204,7 @@ def nn_tri_brute(queries, verts, tris):
 
 
 def make_pairs(src, target, mx_align, mx_base, thresh, vlist=None, sample=0, calc_stats=False,
-               kd: KDTree | None = None, nthreads=0, return_nn=False, tris=None):
+               kd: KDTree | None = None, nthreads=0, return_nn=False, tris=None, normals=None, max_angle_deg=45.0):
     """Restates /root/reference/functions/general.py:257-329 with a nearest-vertex provider.
 
     Returns (A, B, d_stats) with A, B float64[3, K]; raises TypeError-equivalent
@@ -216,8 +225,10 @@ def make_pairs(src, target, mx_align, mx_base, thresh, vlist=None, sample=0, cal
     ds = np.zeros(2, np.float64)
     nn = np.empty(cap, np.int64)
     tk, tp, ntri = _tris(tris)
+    sn, tn, cmin = _normals(normals, max_angle_deg)
     K = lib().oo_make_pairs(_f(src), len(src), _i(vl) if vl is not None else None, n_all, int(sample),
-                            _f(tgt), len(tgt), kd._h if kd is not None else None, tp, ntri, _f(m1), _f(m2),
+                            _f(tgt), len(tgt), kd._h if kd is not None else None, tp, ntri,
+                            _f(sn) if sn is not None else None, _f(tn) if tn is not None else None, cmin, _f(m1), _f(m2),
                             float(thresh), int(bool(calc_stats)), int(nthreads), _d(A), _d(B), cap, _d(ds), _i(nn))
     if K == -1:
         raise ValueError("make_pairs: thresh must be > 0 (the reference returns None here)")
@@ -277,7 +288,8 @@ def affine_matrix_from_points(v0, v1, shear=False, scale=False, usesvd=True):
 
 
 def icp_run(src, target, mx_align, mx_base, *, iters=50, sample=2, thresh=0.5, target_d=0.01,
-            use_target=True, with_scale=False, vlist=None, kd: KDTree | None = None, nthreads=0, tris=None):
+            use_target=True, with_scale=False, vlist=None, kd: KDTree | None = None, nthreads=0, tris=None,
+            normals=None, max_angle_deg=45.0):
     """Restates /root/reference/operators/icp_align.py:91-151.  Returns a dict."""
     src = _f32(src).reshape(-1, 3)
     tgt = _f32(target).reshape(-1, 3)
@@ -293,8 +305,10 @@ def icp_run(src, target, mx_align, mx_base, *, iters=50, sample=2, thresh=0.5, t
     step_stats = np.zeros((n, 2), np.float64)
     step_trans = np.zeros(n, np.float64)
     tk, tp, ntri = _tris(tris)
+    sn, tn, cmin = _normals(normals, max_angle_deg)
     rc = lib().oo_icp_run(_f(src), len(src), _i(vl) if vl is not None else None, len(vl) if vl is not None else 0,
-                          _f(tgt), len(tgt), kd._h if kd is not None else None, tp, ntri, _f(m1), _f(m2),
+                          _f(tgt), len(tgt), kd._h if kd is not None else None, tp, ntri,
+                          _f(sn) if sn is not None else None, _f(tn) if tn is not None else None, cmin, _f(m1), _f(m2),
                           C.byref(st), int(nthreads), C.byref(rep), _d(step_M), _f(step_new), _i(step_K),
                           _d(step_stats), _d(step_trans))
     d = rep.iters_done

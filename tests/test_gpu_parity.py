@@ -751,3 +751,52 @@ def test_surface_bad_triangle_index(eng):
         eng.set_target_mesh(v, np.array([[0, 1, 4]], np.int32))
     assert ei.value.code == _capi.OA_E_BAD_ARG
     eng.set_target(np.random.default_rng(0).normal(size=(10, 3)).astype(np.float32))   # back to vertex mode
+
+
+# ------------------------------------------------------------------ normal-angle rejection (extension)
+
+@pytest.mark.parametrize("surface", [False, True])
+def test_normal_angle_rejection_extension(orc, surface):
+    """BASELINE config 5 names a normal-angle outlier rejection the reference does not have; the build's extension is
+    pinned against the oracle's restatement of the same test (parity unpinned against the reference by construction)."""
+    from object_alignment_amd import synth
+    from object_alignment_amd.engine import IcpEngine
+    rng = np.random.default_rng(5)
+    src, src_n = synth.bunny_surface_with_normals(20000, 0.5)
+    flip = rng.random(len(src)) < 0.2
+    src_n[flip] = -src_n[flip]                                   # 20 % of the source normals point inwards
+    src_n += rng.normal(0, 0.2, size=src_n.shape).astype(np.float32)
+    mxb = synth.rigid4(synth.rotation_from_rotvec([0.2, 0.1, -0.3]) @ np.diag([1.2, 0.9, 1.1]), [0.1, 0.0, -0.1])
+    mxa = (mxb.astype(np.float64) @ synth.rigid4(synth.rotation_from_rotvec([0.05, -0.04, 0.06]), [0.03, -0.02, 0.02],
+                                                  np.float64)).astype(np.float32)
+    if surface:
+        tgt, tris = synth.lattice_surface_mesh(80, 160)
+        tgt_n = None
+    else:
+        tgt, tgt_n = synth.bunny_surface_with_normals(30000, 0.0)
+        tris = None
+    kw = dict(tris=tris, normals=(src_n, tgt_n), max_angle_deg=50.0)
+    rA, rB, rds = orc.make_pairs(src, tgt, mxa, mxb, 0.3, sample=1, calc_stats=True, **kw)
+    rA0, _, _ = orc.make_pairs(src, tgt, mxa, mxb, 0.3, sample=1, calc_stats=True, tris=tris)
+    assert 0.5 * rA0.shape[1] < rA.shape[1] < 0.9 * rA0.shape[1]          # the test really rejects (~20-25 %)
+    with IcpEngine(0) as e:
+        if surface:
+            e.set_target_mesh(tgt, tris)
+        else:
+            e.set_target(tgt)
+        e.set_source(src, stride=1)
+        e.set_normals(src_n, tgt_n, 50.0)
+        e.set_matrices(mxa, mxb)
+        A, B, ds = e.make_pairs(0.3, calc_stats=True)
+        assert np.array_equal(A, rA) and np.array_equal(B, rB)
+        assert np.allclose(ds, rds, rtol=1e-9, atol=1e-13)
+        res = e.run(iters=8, thresh=0.3, use_target=True, early_exit=False)
+        ref = orc.icp_run(src, tgt, mxa, mxb, iters=8, sample=1, thresh=0.3, target_d=1e-300, **kw)
+        assert np.array_equal(res.step_K, ref["step_K"])
+        assert np.abs(res.step_M - ref["step_M"]).max() < 1e-9
+        assert np.abs(res.matrix_world - ref["matrix_world"]).max() <= F32_ULP
+        e.set_normals(None)                                       # switched off again
+        A2, _, _ = e.make_pairs(0.3)
+        e.set_matrices(mxa, mxb)
+    rA2, _, _ = orc.make_pairs(src, tgt, res.matrix_world, mxb, 0.3, sample=1, tris=tris)
+    assert A2.shape == rA2.shape
