@@ -497,6 +497,27 @@ def test_c3_random_1m_few_iters(orc):
     assert np.abs(res.step_M - ref["step_M"]).max() < 1e-9
 
 
+def test_c5_full_size_property():
+    """BASELINE config 5's sizes (10M source, 2M target) on one GPU with the grid search: every source point is an
+    exact copy of a target vertex, so it must find distance 0 and an index <= its own (lowest index on duplicates)."""
+    from object_alignment_amd.engine import IcpEngine
+    rng = np.random.default_rng(500)
+    nt, ns = 2_000_000, 10_000_000
+    tgt = rng.uniform(-1, 1, size=(nt, 3)).astype(np.float32)
+    own = rng.integers(0, nt, size=ns)
+    src = tgt[own]
+    eye = np.identity(4, dtype=np.float32)
+    with IcpEngine(0) as e:
+        e.set_search_mode("grid")
+        e.set_target(tgt)
+        e.set_source(src)
+        e.set_matrices(eye, eye)
+        idx, d2, ms = e.nn_search()
+    assert np.all(d2 == 0.0)
+    assert np.all(idx <= own)
+    assert np.array_equal(tgt[idx], src)
+
+
 def test_c5_shaped_masked_sharded(orc):
     """BASELINE config 5's shape at 1/10 scale: 1M source on a surface, 200k target, a 10 % cap of the source excluded
     (icp_exclude semantics -> vlist), source split over two contexts; against the oracle's KD-tree loop."""
