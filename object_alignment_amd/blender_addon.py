@@ -40,28 +40,26 @@ if bpy is not None:
 
         icp_iterations: IntProperty(name="ICP Iterations", default=50)
         redraw_frequency: IntProperty(
-            name="Redraw Iterations",
-            description="Number of iterations between redraw, bigger = less redraw but faster completion", default=10)
-        use_sample: BoolProperty(name="Use Sample", description="Use a sample of verts to align", default=False)
+            name="Redraw Iterations", description="Iterations per viewport redraw in the modal operator", default=10)
+        use_sample: BoolProperty(name="Use Sample", description="Kept for compatibility; not read by the loop", default=False)
         sample_fraction: FloatProperty(
-            name="Sample Fraction", description="Only fraction of mesh verts for alignment. Less accurate, faster",
+            name="Sample Fraction", description="Stride through the vertex list is round(1 / fraction)",
             default=0.5, min=0, max=1)
         min_start: FloatProperty(
-            name="Minimum Starting Dist",
-            description="Only verts closer than this distance will be used in each iteration", default=0.5, min=0, max=20)
+            name="Minimum Starting Dist", description="World-space distance above which a pair is ignored",
+            default=0.5, min=0, max=20)
         target_d: FloatProperty(
             name="Target Translation",
-            description="If translation of 3 iterations is < target, ICP is considered sucessful", default=0.01, min=0,
-            max=10)
+            description="Converged once the last five iterations all moved the object by less than this", default=0.01,
+            min=0, max=10)
         use_target: BoolProperty(
-            name="Use Target",
-            description="Calc alignment stats at each iteration to assess convergence. SLower per step, may result in "
-                        "less steps", default=True)
+            name="Use Target", description="Compute pair-distance statistics and test convergence every iteration",
+            default=True)
         take_m_with: BoolProperty(
-            name="Take m_ Objects with",
-            description="Applies the same Transformation Matrix to all Objects which start with 'm_'", default=False)
+            name="Take m_ Objects with", description="Also move every scene object whose name starts with 'm_'",
+            default=False)
         align_meth: EnumProperty(items=[("0", "RIGID", "0"), ("1", "ROT_LOC_SCALE", "1")], name="Alignment Method",
-                                 description="Changes how picked points registration aligns object", default="0")
+                                 description="Rigid, or rotation + translation + uniform scale", default="0")
 
         def draw(self, context):
             col = self.layout.column()

@@ -45,32 +45,32 @@ def get_addon_preferences() -> IcpSettings:
 
 
 def build_vlist(align_obj):
-    """The vertex list `execute` builds from the icp_include / icp_exclude groups (operators/icp_align.py:56-80)."""
-    groups = getattr(align_obj, "vertex_groups", None)
-    verts = align_obj.data.vertices if hasattr(align_obj, "data") else None
-    if verts is None:
+    """Vertex indices the operator aligns with, from the object's `icp_include` / `icp_exclude` vertex groups
+    (semantics of operators/icp_align.py:56-80): an include group wins and keeps memberships heavier than 0.9;
+    otherwise an exclude group drops every vertex whose membership weighs 0.1 or more; no group = every vertex."""
+    mesh = getattr(align_obj, "data", None)
+    if mesh is None:
         return list(range(len(_coords_of(align_obj))))
-    vlist = []
-    group_lookup = {g.name: g.index for g in groups} if groups is not None else {}
-    if "icp_include" in group_lookup:
-        group = group_lookup["icp_include"]
-        for v in verts:
-            for g in v.groups:
-                if g.group == group and g.weight > 0.9:
-                    vlist.append(v.index)
-    elif "icp_exclude" in group_lookup:
-        group = group_lookup["icp_exclude"]
-        for v in verts:
-            v_groups = [g.group for g in v.groups]
-            if group not in v_groups:
-                vlist.append(v.index)
+    group_index = {g.name: g.index for g in (getattr(align_obj, "vertex_groups", None) or ())}
+
+    def weights_in(vertex, gi):
+        return [m.weight for m in vertex.groups if m.group == gi]
+
+    if "icp_include" in group_index:
+        gi = group_index["icp_include"]
+        # one entry per qualifying membership, exactly as the reference appends inside its inner loop
+        return [v.index for v in mesh.vertices for w in weights_in(v, gi) if w > 0.9]
+    if "icp_exclude" in group_index:
+        gi = group_index["icp_exclude"]
+        keep = []
+        for v in mesh.vertices:
+            ws = weights_in(v, gi)
+            if not ws:
+                keep.append(v.index)
             else:
-                for g in v.groups:
-                    if g.group == group and g.weight < 0.1:
-                        vlist.append(v.index)
-    else:
-        vlist = [v.index for v in verts]
-    return vlist
+                keep.extend(v.index for w in ws if w < 0.1)
+        return keep
+    return [v.index for v in mesh.vertices]
 
 
 def vlist_from_weights(n_verts, include=None, exclude=None):
@@ -123,21 +123,20 @@ def _assign_matrix(obj, new_np):
 
 
 class OBJECT_OT_icp_align(_OperatorBase):
-    """Uses ICP alignment to iteratevely aligne two objects"""
+    """Iterative-closest-point alignment of the active object onto the other selected object"""
     bl_idname = "object.align_icp"
     bl_label = "ICP Align"
     bl_options = {'REGISTER', 'UNDO'}
 
     @classmethod
     def poll(cls, context):
-        condition_1 = len(context.selected_objects) == 2
-        condition_2 = context.object.type == 'MESH'
-        return condition_1 and condition_2
+        # exactly two selected objects, the active one a mesh (operators/icp_align.py:41-45)
+        return len(context.selected_objects) == 2 and context.object.type == 'MESH'
 
     def execute(self, context):
         settings = get_addon_preferences()
         align_obj = context.object
-        base_obj = [obj for obj in context.selected_objects if obj != align_obj][0]
+        base_obj = next(o for o in context.selected_objects if o != align_obj)
         try:
             align_obj.rotation_mode = 'QUATERNION'
         except Exception:
