@@ -3,6 +3,9 @@
 // Host side of the drop-in boundary: context lifetime, uploads/packing, launch geometry, the device-resident
 // iterate loop and its split-phase form for one-process-per-GPU sharding.  No CPU fallback lives here: every
 // compute entry point needs a usable HIP device and fails loudly otherwise.
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
 #include "oa_kernels.hpp"
 #include "oa_grid.hpp"
 #include "oa_tri.hpp"
@@ -99,6 +102,8 @@ struct oa_ctx {
     unsigned long long *d_keys = nullptr;
     int *d_prev = nullptr;           // nearest index of the previous search (seed), -1 = none
     int *d_sel = nullptr;            // vertex index held by each source slot
+    float4 *d_src4o = nullptr;       // the same points in the caller's (vlist) order -- only oa_make_pairs needs it
+    int *d_perm = nullptr;           // sorted slot -> caller-order slot (nullptr: not sorted)
     long long src_n_verts = 0;
     // normal-angle rejection (extension)
     float *d_src_n = nullptr, *d_tgt_n = nullptr;
@@ -259,7 +264,7 @@ int launch_accumulate(oa_ctx *c, bool emit, int *nn_idx, float *nn_d2)
     oa::NormalTest nrm{};
     if (c->normals_on) { nrm.src_n = c->d_src_n; nrm.tgt_n = c->surface ? nullptr : c->d_tgt_n; nrm.cos_min = c->cos_min; }
     if (emit) {
-        po.valid = c->d_valid; po.b = c->d_b; po.dist = c->d_dist; po.nn_idx = nn_idx; po.nn_d2 = nn_d2;
+        po.valid = c->d_valid; po.b = c->d_b; po.dist = c->d_dist; po.nn_idx = nn_idx; po.nn_d2 = nn_d2; po.perm = c->d_perm;
         hipLaunchKernelGGL(oa::k_pair_accumulate<true>, dim3(c->acc_blocks), dim3(oa::ACC_THREADS), 0, c->stream,
                            c->d_state, c->d_src4, c->ns, c->d_tgt_xyz, c->d_keys, c->d_prev,
                            c->surface ? (const float4 *)c->d_tri9 : (const float4 *)nullptr, nrm, c->d_partials, po);
@@ -431,7 +436,7 @@ OA_EXPORT void oa_destroy(oa_ctx *c)
     dev_free(c->d_valid); dev_free(c->d_b); dev_free(c->d_dist); dev_free(c->d_counts); dev_free(c->d_offsets);
     dev_free(c->d_A); dev_free(c->d_B);
     dev_free(c->d_tri9); dev_free(c->d_tcell_start); dev_free(c->d_tcell_tris);
-    dev_free(c->d_sel); dev_free(c->d_src_n); dev_free(c->d_tgt_n);
+    dev_free(c->d_sel); dev_free(c->d_src_n); dev_free(c->d_tgt_n); dev_free(c->d_src4o); dev_free(c->d_perm);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->ev_loop0) (void)hipEventDestroy(c->ev_loop0);
     if (c->ev_loop1) (void)hipEventDestroy(c->ev_loop1);
@@ -622,6 +627,56 @@ OA_EXPORT int oa_set_target(oa_ctx *c, const float *xyz, int64_t n, int on_devic
 }
 
 namespace {
+// Spatial (Morton) order of the source slots: the points a wave owns are neighbours in space, so the grid search's
+// reads are shared instead of scattered and the brute-force filter's slow path fires for fewer waves.  The caller-
+// order copy and the permutation stay around for the entry points that return per-point data in vlist order.
+int sort_source_slots(oa_ctx *c, const float *d_xyz, long long n_verts)
+{
+    const int nb = 256;
+    DevTmp<float> d_bb;
+    HIPCHK(d_bb.alloc(6 * nb));
+    hipLaunchKernelGGL(oa::k_bbox_partial, dim3(nb), dim3(256), 0, c->stream, d_xyz, (int)n_verts, d_bb.p);
+    HIPCHK(hipGetLastError());
+    std::vector<float> bb(6 * nb);
+    HIPCHK(hipMemcpyAsync(bb.data(), d_bb, sizeof(float) * 6 * nb, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (int b = 0; b < nb; ++b)
+        for (int a = 0; a < 3; ++a) {
+            const float l = bb[6 * b + a], h = bb[6 * b + 3 + a];
+            if (l != l || h != h) return OA_OK;                     // non-finite coordinates: keep the caller's order
+            lo[a] = std::min(lo[a], l); hi[a] = std::max(hi[a], h);
+        }
+    float sc[3];
+    for (int a = 0; a < 3; ++a) {
+        if (!(lo[a] <= hi[a]) || !(fabsf(lo[a]) < 1e18f) || !(fabsf(hi[a]) < 1e18f)) return OA_OK;
+        sc[a] = hi[a] > lo[a] ? 1023.0f / (hi[a] - lo[a]) : 0.f;
+    }
+    DevTmp<unsigned> k_in, k_out;
+    DevTmp<int> v_in;
+    HIPCHK(k_in.alloc((size_t)c->ns)); HIPCHK(k_out.alloc((size_t)c->ns)); HIPCHK(v_in.alloc((size_t)c->ns));
+    HIPCHK(hipMalloc(&c->d_perm, sizeof(int) * (size_t)c->ns));
+    hipLaunchKernelGGL(oa::k_morton_keys, dim3((c->ns + 255) / 256), dim3(256), 0, c->stream, (const float4 *)c->d_src4, c->ns,
+                       lo[0], lo[1], lo[2], sc[0], sc[1], sc[2], k_in.p, v_in.p);
+    HIPCHK(hipGetLastError());
+    size_t bytes = 0;
+    HIPCHK(rocprim::radix_sort_pairs(nullptr, bytes, k_in.p, k_out.p, v_in.p, c->d_perm, (size_t)c->ns, 0, 30, c->stream));
+    DevTmp<char> tmp;
+    HIPCHK(tmp.alloc(bytes));
+    HIPCHK(rocprim::radix_sort_pairs((void *)tmp.p, bytes, k_in.p, k_out.p, v_in.p, c->d_perm, (size_t)c->ns, 0, 30, c->stream));
+    // d_src4 / d_sel become the sorted images; the packed originals move to d_src4o / a temporary
+    DevTmp<int> selo;
+    HIPCHK(selo.alloc((size_t)c->ns_pad));
+    HIPCHK(hipMalloc(&c->d_src4o, sizeof(float4) * (size_t)c->ns_pad));
+    HIPCHK(hipMemcpyAsync(c->d_src4o, c->d_src4, sizeof(float4) * (size_t)c->ns_pad, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(selo, c->d_sel, sizeof(int) * (size_t)c->ns_pad, hipMemcpyDeviceToDevice, c->stream));
+    hipLaunchKernelGGL(oa::k_apply_perm, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, (const float4 *)c->d_src4o,
+                       (const int *)selo.p, (const int *)c->d_perm, c->ns, c->ns_pad, c->d_src4, c->d_sel);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return OA_OK;
+}
+
 // uniform grid over the triangles' bounding boxes
 int build_tri_grid(oa_ctx *c)
 {
@@ -771,6 +826,7 @@ OA_EXPORT int oa_set_source(oa_ctx *c, const float *xyz, int64_t n_verts, int on
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
     dev_free(c->d_src4); dev_free(c->d_keys); dev_free(c->d_prev); dev_free(c->d_sel); dev_free(c->d_src_n);
+    dev_free(c->d_src4o); dev_free(c->d_perm);
     c->normals_on = false;
     c->src_n_verts = n_verts;
     dev_free(c->d_valid); dev_free(c->d_b); dev_free(c->d_dist); dev_free(c->d_counts); dev_free(c->d_offsets);
@@ -815,6 +871,10 @@ OA_EXPORT int oa_set_source(oa_ctx *c, const float *xyz, int64_t n_verts, int on
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(c->stream));
         for (int k = 0; k < 3; ++k) c->pivot[k] = (double)p0[k];
+        if (c->ns > 1 && env_int("OA_SORT_SOURCE", 1)) {
+            int rcs = sort_source_slots(c, d_xyz, n_verts);
+            if (rcs) return rcs;
+        }
     } else {
         HIPCHK(hipMemsetAsync(c->d_src4, 0, sizeof(float4) * (size_t)c->ns_pad, c->stream));
         hipLaunchKernelGGL(oa::k_fill_keys, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, c->d_keys, c->ns_pad);
@@ -921,7 +981,7 @@ OA_EXPORT int oa_nn_search(oa_ctx *c, int64_t *idx, float *d2, double *kernel_ms
     if ((rc = launch_nn(c))) return rc;
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
     hipLaunchKernelGGL(oa::k_decode_keys, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, c->d_keys,
-                       c->ns_pad, c->ns, d_idx.p, d_d2.p);
+                       c->ns_pad, c->ns, (const int *)c->d_perm, d_idx.p, d_d2.p);
     HIPCHK(hipGetLastError());
     if (idx) HIPCHK(hipMemcpyAsync(idx, d_idx, sizeof(long long) * (size_t)c->ns, hipMemcpyDeviceToHost, c->stream));
     if (d2) HIPCHK(hipMemcpyAsync(d2, d_d2, sizeof(float) * (size_t)c->ns, hipMemcpyDeviceToHost, c->stream));
@@ -984,7 +1044,8 @@ OA_EXPORT int oa_make_pairs(oa_ctx *c, double thresh, int calc_stats, double *A,
     }
     hipLaunchKernelGGL(oa::k_block_counts, dim3(n_blocks), dim3(256), 0, c->stream, c->d_valid, c->ns, c->d_counts);
     hipLaunchKernelGGL(oa::k_scan_counts, dim3(1), dim3(1024), 0, c->stream, c->d_counts, n_blocks, c->d_offsets);
-    hipLaunchKernelGGL(oa::k_scatter_pairs, dim3(n_blocks), dim3(256), 0, c->stream, c->d_valid, c->ns, c->d_src4,
+    hipLaunchKernelGGL(oa::k_scatter_pairs, dim3(n_blocks), dim3(256), 0, c->stream, c->d_valid, c->ns,
+                       c->d_perm ? c->d_src4o : c->d_src4,
                        c->d_b, c->d_offsets, (long long)c->ns, c->d_A, c->d_B);
     HIPCHK(hipGetLastError());
     double sums[oa::NSUMS];

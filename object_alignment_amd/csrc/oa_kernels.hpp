@@ -315,6 +315,41 @@ __global__ void k_gather_rows3(const float *__restrict__ rows, const int *__rest
     out[3ll * i] = rows[3 * v]; out[3ll * i + 1] = rows[3 * v + 1]; out[3ll * i + 2] = rows[3 * v + 2];
 }
 
+// 30-bit Morton key of a source point inside the source bounding box (spatial sort of the source slots: lanes of a
+// wave then work on neighbouring points, which turns the grid search's scattered reads into mostly shared lines)
+__device__ __forceinline__ unsigned spread10(unsigned v)
+{
+    v &= 1023u;
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+__global__ void k_morton_keys(const float4 *__restrict__ src4, int ns, float lx, float ly, float lz, float sx, float sy,
+                              float sz, unsigned *__restrict__ keys, int *__restrict__ slots)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ns) return;
+    const float4 p = src4[i];
+    const float fx = fminf(fmaxf((p.x - lx) * sx, 0.f), 1023.f), fy = fminf(fmaxf((p.y - ly) * sy, 0.f), 1023.f),
+                fz = fminf(fmaxf((p.z - lz) * sz, 0.f), 1023.f);      // NaN -> 0 through fmaxf
+    keys[i] = spread10((unsigned)fx) | (spread10((unsigned)fy) << 1) | (spread10((unsigned)fz) << 2);
+    slots[i] = i;
+}
+
+// sorted slot i takes original slot perm[i]; the padding repeats the last sorted point
+__global__ void k_apply_perm(const float4 *__restrict__ src4o, const int *__restrict__ selo, const int *__restrict__ perm,
+                             int ns, int ns_pad, float4 *__restrict__ src4, int *__restrict__ sel)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ns_pad) return;
+    const int o = perm[i < ns ? i : (ns > 0 ? ns - 1 : 0)];
+    src4[i] = src4o[o];
+    sel[i] = selo[o];
+}
+
 // target: groups of 4 vertices as [x0..x3][y0..y3][z0..z3]; vertices past nt are +INF (never selected)
 __global__ void k_pack_target(const float *__restrict__ xyz, int nt, int n_groups_pad, float4 *__restrict__ tg)
 {
@@ -341,17 +376,18 @@ __global__ void k_fill_int(int *a, int n, int v)
 }
 
 // (d2, idx) keys -> separate arrays (first n_out entries); resets all n keys for the next search
-__global__ void k_decode_keys(unsigned long long *__restrict__ keys, int n, int n_out, long long *__restrict__ idx,
-                              float *__restrict__ d2)
+__global__ void k_decode_keys(unsigned long long *__restrict__ keys, int n, int n_out, const int *__restrict__ perm,
+                              long long *__restrict__ idx, float *__restrict__ d2)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const unsigned long long key = keys[i];
     keys[i] = KEY_EMPTY;
     if (i >= n_out) return;
+    const int o = perm ? perm[i] : i;                 // outputs are in the caller's (vlist) order
     const uint32_t j = (uint32_t)key;
-    if (idx) idx[i] = (j == IDX_NONE) ? -1ll : (long long)j;
-    if (d2) d2[i] = __uint_as_float((uint32_t)(key >> 32));
+    if (idx) idx[o] = (j == IDX_NONE) ? -1ll : (long long)j;
+    if (d2) d2[o] = __uint_as_float((uint32_t)(key >> 32));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -765,6 +801,7 @@ struct PairOut {            // optional per-point outputs for the make_pairs con
     double *dist;           // ns
     int    *nn_idx;         // ns
     float  *nn_d2;          // ns
+    const int *perm;        // sorted slot -> caller-order slot (nullptr = identity); outputs are in caller order
 };
 
 template <bool EMIT>
@@ -830,10 +867,11 @@ __global__ __launch_bounds__(ACC_THREADS) void k_pair_accumulate(const DevState 
                 if (valid) m4_mul_v3(st->imx1, wbx, wby, wbz, bx, by, bz);   // imx1 @ (mx2 @ co1)  (general.py:304)
             }
             if (EMIT) {
-                out.valid[i] = valid ? 1 : 0;
-                out.b[3ll * i] = bx; out.b[3ll * i + 1] = by; out.b[3ll * i + 2] = bz;
-                out.dist[i] = dist;
-                if (out.nn_idx) { out.nn_idx[i] = (int)idx; out.nn_d2[i] = __uint_as_float((uint32_t)(key >> 32)); }
+                const long long o = out.perm ? out.perm[i] : i;
+                out.valid[o] = valid ? 1 : 0;
+                out.b[3 * o] = bx; out.b[3 * o + 1] = by; out.b[3 * o + 2] = bz;
+                out.dist[o] = dist;
+                if (out.nn_idx) { out.nn_idx[o] = (int)idx; out.nn_d2[o] = __uint_as_float((uint32_t)(key >> 32)); }
             }
             if (valid) {
                 const double a0 = (double)p.x - pvx, a1 = (double)p.y - pvy, a2 = (double)p.z - pvz;
