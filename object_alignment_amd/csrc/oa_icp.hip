@@ -215,8 +215,9 @@ int launch_nn(oa_ctx *c)
     dim3 block(oa::NN_THREADS);
     const int *list = nullptr, *list_count = nullptr;
     if (grid_active(c)) {
-        // grid search settles (almost) every point; the rest go through the brute-force kernel in list mode
-        HIPCHK(hipMemsetAsync(c->d_todo_count, 0, sizeof(int), c->stream));
+        // grid search settles (almost) every point; the rest go through the brute-force kernel in list mode.
+        // Inside the loop k_solve_update leaves the counter at zero; one-shot calls clear it here.
+        if (!c->loop_active) HIPCHK(hipMemsetAsync(c->d_todo_count, 0, sizeof(int), c->stream));
         hipLaunchKernelGGL(oa::k_nn_search_grid, dim3((c->ns + 255) / 256), dim3(256), 0, c->stream, c->d_state, c->d_src4,
                            c->ns, c->gp, c->d_cell_start, c->d_sorted, c->d_tgt_xyz, c->d_prev, c->d_keys,
                            c->d_todo_list, c->d_todo_count);
@@ -315,6 +316,7 @@ int begin_loop(oa_ctx *c, const oa_settings *st, int iters)
     c->settings = *st;
     init_loop_state(c, st, iters);
     HIPCHK(hipMemcpyAsync(c->d_state, &c->h_state, sizeof(oa::DevState), hipMemcpyHostToDevice, c->stream));
+    if (c->d_todo_count) HIPCHK(hipMemsetAsync(c->d_todo_count, 0, sizeof(int), c->stream));   // kept at zero by k_solve_update
     c->ev_used = 0;
     c->loop_active = true;
     return OA_OK;
@@ -338,7 +340,7 @@ int iter_partial(oa_ctx *c, double *d_sums, bool timed)
 
 int iter_finish(oa_ctx *c, const double *d_sums)
 {
-    hipLaunchKernelGGL(oa::k_solve_update, dim3(1), dim3(64), 0, c->stream, c->d_state, d_sums, c->d_hist);
+    hipLaunchKernelGGL(oa::k_solve_update, dim3(1), dim3(64), 0, c->stream, c->d_state, d_sums, c->d_hist, c->d_todo_count);
     HIPCHK(hipGetLastError());
     return OA_OK;
 }
@@ -759,7 +761,7 @@ int launch_tri_search(oa_ctx *c)
                 (int)use_grid, c->ns, c->n_tris, (void *)c->d_state, (void *)c->d_src4, (void *)c->d_tri9, (void *)c->d_prev,
                 (void *)c->d_keys, (void *)c->d_todo_list, (void *)c->d_todo_count, (void *)c->d_tcell_start, (void *)c->d_tcell_tris);
     if (use_grid) {
-        HIPCHK(hipMemsetAsync(c->d_todo_count, 0, sizeof(int), c->stream));
+        if (!c->loop_active) HIPCHK(hipMemsetAsync(c->d_todo_count, 0, sizeof(int), c->stream));
         hipLaunchKernelGGL(oa::k_tri_search_grid, dim3((c->ns + 255) / 256), dim3(256), 0, c->stream, c->d_state, c->d_src4,
                            c->ns, c->tgp, c->d_tcell_start, c->d_tcell_tris, c->d_tri9, c->d_prev, c->d_keys,
                            c->d_todo_list, c->d_todo_count);

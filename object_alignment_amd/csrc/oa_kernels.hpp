@@ -974,9 +974,11 @@ __global__ void k_solve_only(const double *__restrict__ sums, double pvx, double
 // ------------------------------------------------------------------------------------------------
 // k_solve_update : operators/icp_align.py:106-149, one thread
 // ------------------------------------------------------------------------------------------------
-__global__ void k_solve_update(DevState *__restrict__ st, const double *__restrict__ sums, StepRecord *__restrict__ hist)
+__global__ void k_solve_update(DevState *__restrict__ st, const double *__restrict__ sums, StepRecord *__restrict__ hist,
+                               int *__restrict__ todo_count)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (todo_count) *todo_count = 0;                                // the grid search's unsettled list restarts empty
     if (st->halt) return;
     double s[NSUMS], M[16];
     for (int k = 0; k < NSUMS; ++k) s[k] = sums[k];
