@@ -39,3 +39,13 @@ def test_bench_two_ranks_gloo_same_gpu():
     assert one["result"]["last_K"] == two["result"]["last_K"]
     assert abs(one["result"]["final_translation"] - two["result"]["final_translation"]) < 1e-12
     assert abs(one["result"]["mean_dist"] - two["result"]["mean_dist"]) < 1e-12
+
+
+def test_c_program_drives_the_library_on_the_gpu(tmp_path):
+    """tests/c/abi_smoke.c: a pure C consumer of include/oa_icp.h aligns a small cloud on the GPU."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_host_cpu import _build_abi_smoke
+    exe = _build_abi_smoke(tmp_path)
+    p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout
+    assert "ABI_SMOKE_OK device" in p.stdout, p.stdout

@@ -145,3 +145,23 @@ def test_blender_addon_shell_imports_without_bpy():
         with pytest.raises(RuntimeError):
             blender_addon.register()
         blender_addon.unregister()
+
+
+def _build_abi_smoke(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "abi_smoke")
+    libdir = os.path.join(ROOT, "object_alignment_amd")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "c", "abi_smoke.c"), "-L", libdir, "-loa_icp", "-lm",
+           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    subprocess.check_call(cmd)
+    return exe
+
+
+def test_header_is_plain_c_and_library_links(built, tmp_path):
+    """include/oa_icp.h compiles as pedantic C99 and a C program links against liboa_icp.so and runs."""
+    import subprocess
+    exe = _build_abi_smoke(tmp_path)
+    p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout
+    assert "ABI_SMOKE_OK" in p.stdout
