@@ -407,6 +407,25 @@ def test_modal_operator_ticks(golden_dir, orc):
         setattr(icp_align.get_addon_preferences(), k, v)
 
 
+@pytest.mark.parametrize("mode", ["brute", "grid"])
+def test_runs_are_bitwise_reproducible(mode):
+    """No float atomics anywhere on the result path: repeated runs (fresh contexts, fresh grid builds whose
+    in-cell order is scheduling dependent) give bit-identical matrices, sums and statistics."""
+    from object_alignment_amd import synth
+    from object_alignment_amd.engine import IcpEngine
+    src, tgt, mxa, mxb = synth.c2_bunny_pair(60_000)
+    outs = []
+    for _ in range(3):
+        with IcpEngine(0) as e:
+            e.set_search_mode(mode)
+            e.set_target(tgt)
+            e.set_source(src, stride=1)
+            e.set_matrices(mxa, mxb)
+            r = e.run(iters=12, thresh=0.5, early_exit=False)
+            outs.append((r.matrix_world.tobytes(), r.step_M.tobytes(), r.step_stats.tobytes(), r.step_K.tobytes()))
+    assert outs[0] == outs[1] == outs[2]
+
+
 def test_step_mode_equals_fused_loop(golden_dir):
     from object_alignment_amd.engine import IcpEngine
     g = _load(golden_dir, "icp_loop_bumpy_converge")
