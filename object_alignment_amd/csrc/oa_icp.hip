@@ -77,7 +77,9 @@ struct oa_ctx {
     int nt = 0, n_groups_pad = 0;
     float *d_tgt_xyz = nullptr;
     float4 *d_tg = nullptr;
-    float4 *d_tf = nullptr;          // filter image (k_nn_search_filtered)
+    float4 *d_tf = nullptr;          // filter image, level 1: 3 float4 per group (k_nn_search_filtered)
+    float4 *d_tf3 = nullptr;         // filter image, level 2: 2 float4 per group
+    int fax[3] = { 0, 1, 2 };
     double bb_lo[3] = { 0, 0, 0 }, bb_hi[3] = { 0, 0, 0 };
     // uniform grid (k_nn_search_grid)
     bool grid_ok = false;
@@ -226,7 +228,7 @@ int launch_nn(oa_ctx *c)
         grid.y = std::min<unsigned>((unsigned)((c->ns + 1023) / 1024), 32u);
     }
 #define OA_NN_ARGS c->d_state, c->d_src4, c->d_tg, c->groups_per_split, c->n_groups_pad, c->d_keys
-#define OA_NNF_ARGS c->d_state, c->d_src4, c->d_tg, c->d_tf, c->d_tgt_xyz, c->d_prev, c->groups_per_split, c->n_groups_pad, c->d_keys, list, list_count
+#define OA_NNF_ARGS c->d_state, c->d_src4, c->d_tg, c->d_tf, c->d_tf3, c->d_tgt_xyz, c->d_prev, c->groups_per_split, c->n_groups_pad, c->d_keys, list, list_count
     if (list) {
         hipLaunchKernelGGL((oa::k_nn_search_filtered<4, false, true>), grid, block, 0, c->stream, OA_NNF_ARGS);
     } else if (c->filter_ok && c->use_filter) {
@@ -298,8 +300,8 @@ void init_loop_state(oa_ctx *c, const oa_settings *st, int iters)
     s.early_exit = st->early_exit ? 1 : 0;
     s.n = 0; s.converged = 0; s.status = 0; s.halt = (iters <= 0) ? 1 : 0;
     s.max_records = c->max_records; s.pad0 = 0;
-    for (int k = 0; k < 3; ++k) s.tc[k] = c->tc[k];
-    s.pad1 = 0.f;
+    for (int k = 0; k < 3; ++k) { s.tc[k] = c->tc[k]; s.fax[k] = c->fax[k]; }
+    s.pad1 = 0.f; s.pad2 = 0;
     s.qmax = c->qmax;
     s.d_pivot = c->d_pivot0;
 }
@@ -433,7 +435,7 @@ OA_EXPORT void oa_destroy(oa_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    dev_free(c->d_tgt_xyz); dev_free(c->d_tg); dev_free(c->d_tf); dev_free(c->d_prev); dev_free(c->d_cell_start); dev_free(c->d_sorted); dev_free(c->d_todo_list); dev_free(c->d_todo_count); dev_free(c->d_src4); dev_free(c->d_keys); dev_free(c->d_state);
+    dev_free(c->d_tgt_xyz); dev_free(c->d_tg); dev_free(c->d_tf); dev_free(c->d_tf3); dev_free(c->d_prev); dev_free(c->d_cell_start); dev_free(c->d_sorted); dev_free(c->d_todo_list); dev_free(c->d_todo_count); dev_free(c->d_src4); dev_free(c->d_keys); dev_free(c->d_state);
     dev_free(c->d_hist); dev_free(c->d_partials); dev_free(c->d_sums); dev_free(c->d_solve);
     dev_free(c->d_valid); dev_free(c->d_b); dev_free(c->d_dist); dev_free(c->d_counts); dev_free(c->d_offsets);
     dev_free(c->d_A); dev_free(c->d_B);
@@ -498,12 +500,18 @@ int build_filter(oa_ctx *c)
     for (int a = 0; a < 3; ++a) if (!(lo[a] <= hi[a]) || !(fabs(lo[a]) < 1e18) || !(fabs(hi[a]) < 1e18)) finite = false;
     if (!finite) return OA_OK;                                   // exact kernel only
     for (int a = 0; a < 3; ++a) { c->tc[a] = (float)(0.5 * (lo[a] + hi[a])); c->bb_lo[a] = lo[a]; c->bb_hi[a] = hi[a]; }
+    // the first-level score drops the axis along which the cloud is thinnest (fewest vertices share a projection)
+    int ad = 0;
+    for (int a = 1; a < 3; ++a) if (hi[a] - lo[a] < hi[ad] - lo[ad]) ad = a;
+    c->fax[2] = ad; c->fax[0] = (ad + 1) % 3; c->fax[1] = (ad + 2) % 3;
+    if (c->fax[0] > c->fax[1]) std::swap(c->fax[0], c->fax[1]);
     const int blocks = (c->n_groups_pad + 255) / 256;
     DevTmp<double> d_mx;
-    HIPCHK(hipMalloc(&c->d_tf, sizeof(float4) * 4 * (size_t)c->n_groups_pad));
+    HIPCHK(hipMalloc(&c->d_tf, sizeof(float4) * 3 * (size_t)c->n_groups_pad));
+    HIPCHK(hipMalloc(&c->d_tf3, sizeof(float4) * 2 * (size_t)c->n_groups_pad));
     HIPCHK(d_mx.alloc((size_t)blocks));
     hipLaunchKernelGGL(oa::k_pack_filter, dim3(blocks), dim3(256), 0, c->stream, c->d_tgt_xyz, c->nt, c->n_groups_pad,
-                       c->tc[0], c->tc[1], c->tc[2], c->d_tf, d_mx.p);
+                       c->tc[0], c->tc[1], c->tc[2], c->fax[0], c->fax[1], c->fax[2], c->d_tf, c->d_tf3, d_mx.p);
     HIPCHK(hipGetLastError());
     std::vector<double> mx((size_t)blocks);
     HIPCHK(hipMemcpyAsync(mx.data(), d_mx, sizeof(double) * (size_t)blocks, hipMemcpyDeviceToHost, c->stream));
@@ -597,7 +605,7 @@ OA_EXPORT int oa_set_target(oa_ctx *c, const float *xyz, int64_t n, int on_devic
     int rc = use_device(c);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
-    dev_free(c->d_tgt_xyz); dev_free(c->d_tg); dev_free(c->d_tf);
+    dev_free(c->d_tgt_xyz); dev_free(c->d_tg); dev_free(c->d_tf); dev_free(c->d_tf3);
     dev_free(c->d_tri9); dev_free(c->d_tcell_start); dev_free(c->d_tcell_tris);
     c->surface = false; c->tri_grid_ok = false; c->n_tris = 0;
     dev_free(c->d_tgt_n);

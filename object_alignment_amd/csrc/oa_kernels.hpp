@@ -48,6 +48,7 @@ struct DevState {
     // conservative-filter data (k_nn_search_filtered): target bbox centre and max |q - centre|
     float  tc[3], pad1;
     double qmax;
+    int32_t fax[3], pad2;    // filter axes: fax[0], fax[1] kept by the 2-D score, fax[2] (smallest extent) dropped
     double d_pivot;      // subtracted from the pair distances before summing (previous iteration's mean): keeps
                          // the one-pass variance sum d^2 - K mean^2 free of cancellation
 };
@@ -488,7 +489,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_search(const DevState *__rest
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_nn_search_filtered : same answers as k_nn_search, ~4 VALU ops per pair instead of ~6.8
+// k_nn_search_filtered : same answers as k_nn_search, ~3 VALU ops per pair instead of ~6.8
 // ------------------------------------------------------------------------------------------------
 // Idea: a cheap score that can only be used to PROVE "this target cannot win or tie", never to pick a winner.
 //   centred coordinates   qh = fl32(q - c),  ph = fl32(p - c)          (c = centre of the target bbox)
@@ -523,40 +524,54 @@ __device__ __forceinline__ float round_up_to_float(double x)
     return f;
 }
 
-__device__ __forceinline__ float filter_threshold(float best, float phx, float phy, float phz, double qmax)
+// thr3 bounds the 3-D score, thr2 the 2-D score (the kept-plane distance can only be smaller than the 3-D one, the
+// rounding analysis is the same with one fma less, and G bounds the 2-D norms as well)
+__device__ __forceinline__ void filter_thresholds(float best, float hu, float hv, float hd, double qmax, float &thr2,
+                                                  float &thr3)
 {
-    if (!(best < INFINITY)) return INFINITY;                  // nothing known yet: nothing can be skipped
-    const double P = (double)phx * (double)phx + (double)phy * (double)phy + (double)phz * (double)phz;
-    const double G = sqrt(P) * (1.0 + 1e-12) + qmax;
-    const double T = (double)best * (1.0 + FILTER_K) + FILTER_K * G * G - P + FILTER_ABS;
-    return round_up_to_float(T);
+    if (!(best < INFINITY)) { thr2 = INFINITY; thr3 = INFINITY; return; }   // nothing known yet: nothing can be skipped
+    const double P2 = (double)hu * (double)hu + (double)hv * (double)hv;
+    const double P3 = P2 + (double)hd * (double)hd;
+    const double G = sqrt(P3) * (1.0 + 1e-12) + qmax;
+    const double base = (double)best * (1.0 + FILTER_K) + FILTER_K * G * G + FILTER_ABS;
+    thr2 = round_up_to_float(base - P2);
+    thr3 = round_up_to_float(base - P3);
 }
 
-// filter image of the target: per group of 4 vertices [ax0..3][ay0..3][az0..3][w0..3]; padding can never pass
+// filter images of the target, per group of 4 vertices.  (u, v, d) = fax: the axis of smallest extent is dropped by
+// the first-level score.   tf2: [-2qu][-2qv][qu^2+qv^2]  (tiled through LDS)     tf3: [-2qd][|q|^2]  (rare path, global)
+// Padding can never pass: its W2 / W3 are 3e38.
 __global__ void k_pack_filter(const float *__restrict__ xyz, int nt, int n_groups_pad, float cx, float cy, float cz,
-                              float4 *__restrict__ tf, double *__restrict__ block_max_q2)
+                              int au, int av, int ad, float4 *__restrict__ tf2, float4 *__restrict__ tf3,
+                              double *__restrict__ block_max_q2)
 {
     __shared__ double red[4];
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     double mx = 0.0;
     if (g < n_groups_pad) {
-        float a[3][4], w[4];
+        float a[3][4], w2[4], w3[4];
         for (int k = 0; k < 4; ++k) {
             const long long v = 4ll * g + k;
             if (v < nt) {
-                const float qx = (float)((double)xyz[3 * v] - (double)cx);
-                const float qy = (float)((double)xyz[3 * v + 1] - (double)cy);
-                const float qz = (float)((double)xyz[3 * v + 2] - (double)cz);
-                const double q2 = (double)qx * (double)qx + (double)qy * (double)qy + (double)qz * (double)qz;
-                a[0][k] = -2.0f * qx; a[1][k] = -2.0f * qy; a[2][k] = -2.0f * qz;
-                w[k] = (float)q2;
+                float q[3];
+                q[0] = (float)((double)xyz[3 * v] - (double)cx);
+                q[1] = (float)((double)xyz[3 * v + 1] - (double)cy);
+                q[2] = (float)((double)xyz[3 * v + 2] - (double)cz);
+                const double p2 = (double)q[au] * (double)q[au] + (double)q[av] * (double)q[av];
+                const double q2 = p2 + (double)q[ad] * (double)q[ad];
+                a[0][k] = -2.0f * q[au]; a[1][k] = -2.0f * q[av]; a[2][k] = -2.0f * q[ad];
+                w2[k] = (float)p2;
+                w3[k] = (float)q2;
                 if (q2 > mx) mx = q2;
             } else {
-                a[0][k] = 0.f; a[1][k] = 0.f; a[2][k] = 0.f; w[k] = 3.0e38f;   // score = 3e38 > any threshold
+                a[0][k] = 0.f; a[1][k] = 0.f; a[2][k] = 0.f; w2[k] = 3.0e38f; w3[k] = 3.0e38f;
             }
         }
-        for (int c = 0; c < 3; ++c) tf[4ll * g + c] = make_float4(a[c][0], a[c][1], a[c][2], a[c][3]);
-        tf[4ll * g + 3] = make_float4(w[0], w[1], w[2], w[3]);
+        tf2[3ll * g] = make_float4(a[0][0], a[0][1], a[0][2], a[0][3]);
+        tf2[3ll * g + 1] = make_float4(a[1][0], a[1][1], a[1][2], a[1][3]);
+        tf2[3ll * g + 2] = make_float4(w2[0], w2[1], w2[2], w2[3]);
+        tf3[2ll * g] = make_float4(a[2][0], a[2][1], a[2][2], a[2][3]);
+        tf3[2ll * g + 1] = make_float4(w3[0], w3[1], w3[2], w3[3]);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_down(mx, off, 64); mx = o > mx ? o : mx; }
@@ -610,7 +625,8 @@ template <int R, bool PK, bool LIST>
 __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_filtered(const DevState *__restrict__ st,
                                                                    const float4 *__restrict__ src4,
                                                                    const float4 *__restrict__ tg,
-                                                                   const float4 *__restrict__ tf,
+                                                                   const float4 *__restrict__ tf2,
+                                                                   const float4 *__restrict__ tf3,
                                                                    const float *__restrict__ tgt_xyz,
                                                                    const int *__restrict__ prev, int groups_per_split,
                                                                    int n_groups_pad,
@@ -620,16 +636,18 @@ __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_filt
 {
     // list mode (LIST): finish the source points the grid search could not settle.  `list` holds
     // their indices, `*list_count` how many; their running best sits in keys[] and seeds the scan.
+    // PK is kept as a template slot for A/B experiments; the shipped instantiations use scalar v_fma_f32.
     if (st->halt) return;
-    __shared__ float4 tile[2][FTILE_GROUPS * 4];
+    __shared__ float4 tile[2][FTILE_GROUPS * 3];
     const int tid = threadIdx.x;
     const double qmax = st->qmax;
     const float cx = st->tc[0], cy = st->tc[1], cz = st->tc[2];
+    const int au = st->fax[0], av = st->fax[1];
     const long long n_items = LIST ? (long long)*list_count : (long long)gridDim.y * (NN_THREADS * R);
 
   for (int chunk = blockIdx.y; (long long)chunk * (NN_THREADS * R) < n_items; chunk += gridDim.y) {
     const int base = chunk * (NN_THREADS * R);
-    float px[R], py[R], pz[R], hx[R], hy[R], hz[R], best[R], thr[R];
+    float px[R], py[R], pz[R], hu[R], hv[R], hd[R], best[R], thr2[R], thr3[R];
     uint32_t bidx[R];
     int item[R];
 #pragma unroll
@@ -638,14 +656,17 @@ __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_filt
         int i = slot;
         if (LIST) { i = (slot < n_items) ? list[slot] : -1; }
         item[r] = i;
-        if (LIST && i < 0) i = list[0];                                  // inactive lane of the last chunk: harmless duplicate
+        if (LIST && i < 0) i = list[0];                          // inactive lane of the last chunk: harmless duplicate
         const float4 p = src4[i];
         float wx, wy, wz;
         m4_mul_v3(st->mx1, p.x, p.y, p.z, wx, wy, wz);
         m4_mul_v3(st->imx2, wx, wy, wz, px[r], py[r], pz[r]);    // co_find (general.py:287)
-        hx[r] = (float)((double)px[r] - (double)cx);
-        hy[r] = (float)((double)py[r] - (double)cy);
-        hz[r] = (float)((double)pz[r] - (double)cz);
+        const float h0 = (float)((double)px[r] - (double)cx);
+        const float h1 = (float)((double)py[r] - (double)cy);
+        const float h2 = (float)((double)pz[r] - (double)cz);
+        hu[r] = au == 0 ? h0 : (au == 1 ? h1 : h2);               // kept axes of the 2-D score
+        hv[r] = av == 0 ? h0 : (av == 1 ? h1 : h2);
+        hd[r] = (au + av == 1) ? h2 : ((au + av == 2) ? h1 : h0); // the dropped axis is the remaining one
         best[r] = INFINITY;
         bidx[r] = IDX_NONE;
         if (LIST) {                                             // seed: what the grid search found so far
@@ -660,35 +681,35 @@ __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_filt
                 if (d < INFINITY) { best[r] = d; bidx[r] = (uint32_t)s; }
             }
         }
-        thr[r] = filter_threshold(best[r], hx[r], hy[r], hz[r], qmax);
+        filter_thresholds(best[r], hu[r], hv[r], hd[r], qmax, thr2[r], thr3[r]);
     }
 
     const int g_begin = blockIdx.x * groups_per_split;
     int g_end = g_begin + groups_per_split;
     if (g_end > n_groups_pad) g_end = n_groups_pad;
     const int n_tiles = (g_end - g_begin) / FTILE_GROUPS;
-    const float4 *tsrc = tf + 4ll * g_begin;
+    const float4 *tsrc = tf2 + 3ll * g_begin;
 
-    float4 s0 = tsrc[tid], s1 = tsrc[NN_THREADS + tid], s2 = tsrc[2 * NN_THREADS + tid], s3 = tsrc[3 * NN_THREADS + tid];
-    tile[0][tid] = s0; tile[0][NN_THREADS + tid] = s1; tile[0][2 * NN_THREADS + tid] = s2; tile[0][3 * NN_THREADS + tid] = s3;
+    float4 s0 = tsrc[tid], s1 = tsrc[NN_THREADS + tid], s2 = tsrc[2 * NN_THREADS + tid];
+    tile[0][tid] = s0; tile[0][NN_THREADS + tid] = s1; tile[0][2 * NN_THREADS + tid] = s2;
     __syncthreads();
 
     for (int t = 0; t < n_tiles; ++t) {
         const int cur = t & 1;
         const bool more = (t + 1 < n_tiles);
         if (more) {
-            const float4 *nsrc = tsrc + 4ll * FTILE_GROUPS * (t + 1);
-            s0 = nsrc[tid]; s1 = nsrc[NN_THREADS + tid]; s2 = nsrc[2 * NN_THREADS + tid]; s3 = nsrc[3 * NN_THREADS + tid];
+            const float4 *nsrc = tsrc + 3ll * FTILE_GROUPS * (t + 1);
+            s0 = nsrc[tid]; s1 = nsrc[NN_THREADS + tid]; s2 = nsrc[2 * NN_THREADS + tid];
         }
         const int gbase = g_begin + t * FTILE_GROUPS;
-        // GW groups (4*GW targets) per skip test: one branch per GW groups, all fma chains of the R points in one block
+        // GW groups (4*GW targets) per skip test.  Level 1 (hot): 2 fma + min per pair in the kept plane; level 2 (rare):
+        // the dropped axis is added for the points that passed; level 3 (rarer): the exact metric.
         constexpr int GW = 2;
         for (int g = 0; g < FTILE_GROUPS; g += GW) {
-            float4 AX[GW], AY[GW], AZ[GW], W[GW];
+            float4 AU[GW], AV[GW], W2[GW];
 #pragma unroll
             for (int k = 0; k < GW; ++k) {
-                AX[k] = tile[cur][4 * (g + k)]; AY[k] = tile[cur][4 * (g + k) + 1];
-                AZ[k] = tile[cur][4 * (g + k) + 2]; W[k] = tile[cur][4 * (g + k) + 3];
+                AU[k] = tile[cur][3 * (g + k)]; AV[k] = tile[cur][3 * (g + k) + 1]; W2[k] = tile[cur][3 * (g + k) + 2];
             }
             float gm[R];
             bool hit = false;
@@ -697,54 +718,54 @@ __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_filt
                 float m = INFINITY;
 #pragma unroll
                 for (int k = 0; k < GW; ++k) {
-                    float c0, c1, c2, c3;
-                    if (PK) {  // two targets per v_pk_fma_f32 (same per-lane IEEE fma)
-                        const v2f X = { hx[r], hx[r] }, Y = { hy[r], hy[r] }, Z = { hz[r], hz[r] };
-                        const v2f q0 = __builtin_elementwise_fma(X, v2f{ AX[k].x, AX[k].y }, __builtin_elementwise_fma(Y, v2f{ AY[k].x, AY[k].y },
-                                       __builtin_elementwise_fma(Z, v2f{ AZ[k].x, AZ[k].y }, v2f{ W[k].x, W[k].y })));
-                        const v2f q1 = __builtin_elementwise_fma(X, v2f{ AX[k].z, AX[k].w }, __builtin_elementwise_fma(Y, v2f{ AY[k].z, AY[k].w },
-                                       __builtin_elementwise_fma(Z, v2f{ AZ[k].z, AZ[k].w }, v2f{ W[k].z, W[k].w })));
-                        c0 = q0.x; c1 = q0.y; c2 = q1.x; c3 = q1.y;
-                    } else {
-                        c0 = __builtin_fmaf(hx[r], AX[k].x, __builtin_fmaf(hy[r], AY[k].x, __builtin_fmaf(hz[r], AZ[k].x, W[k].x)));
-                        c1 = __builtin_fmaf(hx[r], AX[k].y, __builtin_fmaf(hy[r], AY[k].y, __builtin_fmaf(hz[r], AZ[k].y, W[k].y)));
-                        c2 = __builtin_fmaf(hx[r], AX[k].z, __builtin_fmaf(hy[r], AY[k].z, __builtin_fmaf(hz[r], AZ[k].z, W[k].z)));
-                        c3 = __builtin_fmaf(hx[r], AX[k].w, __builtin_fmaf(hy[r], AY[k].w, __builtin_fmaf(hz[r], AZ[k].w, W[k].w)));
-                    }
+                    const float c0 = __builtin_fmaf(hu[r], AU[k].x, __builtin_fmaf(hv[r], AV[k].x, W2[k].x));
+                    const float c1 = __builtin_fmaf(hu[r], AU[k].y, __builtin_fmaf(hv[r], AV[k].y, W2[k].y));
+                    const float c2 = __builtin_fmaf(hu[r], AU[k].z, __builtin_fmaf(hv[r], AV[k].z, W2[k].z));
+                    const float c3 = __builtin_fmaf(hu[r], AU[k].w, __builtin_fmaf(hv[r], AV[k].w, W2[k].w));
                     m = __builtin_fminf(m, __builtin_fminf(__builtin_fminf(c0, c1), __builtin_fminf(c2, c3)));
                 }
                 gm[r] = m;
-                hit = hit || !(m > thr[r]);
+                hit = hit || !(m > thr2[r]);
             }
             if (hit) {
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    if (!(gm[r] > thr[r])) {                          // cannot be ruled out: exact path on these 4*GW targets
-                        float b = best[r];
-                        uint32_t bi = bidx[r];
+                    if (!(gm[r] > thr2[r])) {                         // level 2: full 3-D score for these 4*GW targets
+                        float m3 = INFINITY;
                         for (int k = 0; k < GW; ++k) {
-                            const float4 *eg = tg + 3ll * (gbase + g + k);
-                            const float4 X = eg[0], Y = eg[1], Z = eg[2];
-                            const uint32_t j = (uint32_t)(gbase + g + k) * 4u;
-                            const float e0 = d2_metric(px[r], py[r], pz[r], X.x, Y.x, Z.x);
-                            const float e1 = d2_metric(px[r], py[r], pz[r], X.y, Y.y, Z.y);
-                            const float e2 = d2_metric(px[r], py[r], pz[r], X.z, Y.z, Z.z);
-                            const float e3 = d2_metric(px[r], py[r], pz[r], X.w, Y.w, Z.w);
-                            if (e0 < b || (e0 == b && j < bi)) { b = e0; bi = j; }
-                            if (e1 < b || (e1 == b && j + 1u < bi)) { b = e1; bi = j + 1u; }
-                            if (e2 < b || (e2 == b && j + 2u < bi)) { b = e2; bi = j + 2u; }
-                            if (e3 < b || (e3 == b && j + 3u < bi)) { b = e3; bi = j + 3u; }
+                            const float4 AD = tf3[2ll * (gbase + g + k)], W3 = tf3[2ll * (gbase + g + k) + 1];
+                            const float c0 = __builtin_fmaf(hu[r], AU[k].x, __builtin_fmaf(hv[r], AV[k].x, __builtin_fmaf(hd[r], AD.x, W3.x)));
+                            const float c1 = __builtin_fmaf(hu[r], AU[k].y, __builtin_fmaf(hv[r], AV[k].y, __builtin_fmaf(hd[r], AD.y, W3.y)));
+                            const float c2 = __builtin_fmaf(hu[r], AU[k].z, __builtin_fmaf(hv[r], AV[k].z, __builtin_fmaf(hd[r], AD.z, W3.z)));
+                            const float c3 = __builtin_fmaf(hu[r], AU[k].w, __builtin_fmaf(hv[r], AV[k].w, __builtin_fmaf(hd[r], AD.w, W3.w)));
+                            m3 = __builtin_fminf(m3, __builtin_fminf(__builtin_fminf(c0, c1), __builtin_fminf(c2, c3)));
                         }
-                        if (b < best[r]) thr[r] = filter_threshold(b, hx[r], hy[r], hz[r], qmax);
-                        best[r] = b;
-                        bidx[r] = bi;
+                        if (!(m3 > thr3[r])) {                        // level 3: cannot be ruled out, exact metric
+                            float b = best[r];
+                            uint32_t bi = bidx[r];
+                            for (int k = 0; k < GW; ++k) {
+                                const float4 *eg = tg + 3ll * (gbase + g + k);
+                                const float4 X = eg[0], Y = eg[1], Z = eg[2];
+                                const uint32_t j = (uint32_t)(gbase + g + k) * 4u;
+                                const float e0 = d2_metric(px[r], py[r], pz[r], X.x, Y.x, Z.x);
+                                const float e1 = d2_metric(px[r], py[r], pz[r], X.y, Y.y, Z.y);
+                                const float e2 = d2_metric(px[r], py[r], pz[r], X.z, Y.z, Z.z);
+                                const float e3 = d2_metric(px[r], py[r], pz[r], X.w, Y.w, Z.w);
+                                if (e0 < b || (e0 == b && j < bi)) { b = e0; bi = j; }
+                                if (e1 < b || (e1 == b && j + 1u < bi)) { b = e1; bi = j + 1u; }
+                                if (e2 < b || (e2 == b && j + 2u < bi)) { b = e2; bi = j + 2u; }
+                                if (e3 < b || (e3 == b && j + 3u < bi)) { b = e3; bi = j + 3u; }
+                            }
+                            if (b < best[r]) filter_thresholds(b, hu[r], hv[r], hd[r], qmax, thr2[r], thr3[r]);
+                            best[r] = b;
+                            bidx[r] = bi;
+                        }
                     }
                 }
             }
         }
         if (more) {
-            tile[cur ^ 1][tid] = s0; tile[cur ^ 1][NN_THREADS + tid] = s1;
-            tile[cur ^ 1][2 * NN_THREADS + tid] = s2; tile[cur ^ 1][3 * NN_THREADS + tid] = s3;
+            tile[cur ^ 1][tid] = s0; tile[cur ^ 1][NN_THREADS + tid] = s1; tile[cur ^ 1][2 * NN_THREADS + tid] = s2;
         }
         __syncthreads();
     }
