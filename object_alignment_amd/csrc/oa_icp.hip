@@ -114,6 +114,8 @@ struct oa_ctx {
     double pivot[3] = { 0, 0, 0 };
     // launch geometry for k_nn_search
     int n_splits = 1, groups_per_split = 0, acc_blocks = 1;
+    int tile_groups = oa::FTILE_GROUPS;   // LDS tile of k_nn_search_filtered: 256 groups, 64 for small targets
+    int R_env = 0;                      // OA_NN_R override (0 = choose from the shard size)
     bool use_filter = true, use_pk = false;
     double d_pivot0 = 0.0;           // initial distance pivot for the next loop / one-shot (see DevState::d_pivot)
     // device state
@@ -150,7 +152,9 @@ void plan_geometry(oa_ctx *c)
 {
     if (c->ns <= 0 || c->nt <= 0) return;
     const int src_blocks = c->ns_pad / (oa::NN_THREADS * c->R);
-    const int tiles_total = c->n_groups_pad / oa::TILE_GROUPS;
+    // small targets: quarter-size tiles give 4x more (and 4x shorter) workgroups; the unfiltered kernel keeps 256
+    c->tile_groups = (c->filter_ok && c->use_filter && c->nt <= 65536 && !env_int("OA_NN_BIGTILE", 0)) ? 64 : oa::FTILE_GROUPS;
+    const int tiles_total = c->n_groups_pad / c->tile_groups;
     const int want = env_int("OA_NN_TARGET_BLOCKS", c->n_cu * 64);
     int splits = (want + src_blocks - 1) / src_blocks;
     splits = std::max(1, std::min(splits, tiles_total));
@@ -158,7 +162,7 @@ void plan_geometry(oa_ctx *c)
     const int forced = env_int("OA_NN_SPLITS", 0);
     if (forced > 0) splits = std::min(forced, tiles_total);
     const int tiles_per_split = (tiles_total + splits - 1) / splits;
-    c->groups_per_split = tiles_per_split * oa::TILE_GROUPS;
+    c->groups_per_split = tiles_per_split * c->tile_groups;
     c->n_splits = (tiles_total + tiles_per_split - 1) / tiles_per_split;
     c->acc_blocks = std::max(1, std::min(oa::ACC_MAX_BLOCKS, (c->ns + oa::ACC_THREADS - 1) / oa::ACC_THREADS));
 }
@@ -230,23 +234,22 @@ int launch_nn(oa_ctx *c)
 #define OA_NN_ARGS c->d_state, c->d_src4, c->d_tg, c->groups_per_split, c->n_groups_pad, c->d_keys
 #define OA_NNF_ARGS c->d_state, c->d_src4, c->d_tg, c->d_tf, c->d_tf3, c->d_tgt_xyz, c->d_prev, c->groups_per_split, c->n_groups_pad, c->d_keys, list, list_count
     if (list) {
-        hipLaunchKernelGGL((oa::k_nn_search_filtered<4, false, true>), grid, block, 0, c->stream, OA_NNF_ARGS);
+        if (c->tile_groups == 64) hipLaunchKernelGGL((oa::k_nn_search_filtered<4, false, true, 64>), grid, block, 0, c->stream, OA_NNF_ARGS);
+        else hipLaunchKernelGGL((oa::k_nn_search_filtered<4, false, true, oa::FTILE_GROUPS>), grid, block, 0, c->stream, OA_NNF_ARGS);
     } else if (c->filter_ok && c->use_filter) {
-        if (c->use_pk) {
-            switch (c->R) {
-            case 1: hipLaunchKernelGGL((oa::k_nn_search_filtered<1, true, false>), grid, block, 0, c->stream, OA_NNF_ARGS); break;
-            case 2: hipLaunchKernelGGL((oa::k_nn_search_filtered<2, true, false>), grid, block, 0, c->stream, OA_NNF_ARGS); break;
-            case 8: hipLaunchKernelGGL((oa::k_nn_search_filtered<8, true, false>), grid, block, 0, c->stream, OA_NNF_ARGS); break;
-            default: hipLaunchKernelGGL((oa::k_nn_search_filtered<4, true, false>), grid, block, 0, c->stream, OA_NNF_ARGS); break;
-            }
-        } else {
-            switch (c->R) {
-            case 1: hipLaunchKernelGGL((oa::k_nn_search_filtered<1, false, false>), grid, block, 0, c->stream, OA_NNF_ARGS); break;
-            case 2: hipLaunchKernelGGL((oa::k_nn_search_filtered<2, false, false>), grid, block, 0, c->stream, OA_NNF_ARGS); break;
-            case 8: hipLaunchKernelGGL((oa::k_nn_search_filtered<8, false, false>), grid, block, 0, c->stream, OA_NNF_ARGS); break;
-            default: hipLaunchKernelGGL((oa::k_nn_search_filtered<4, false, false>), grid, block, 0, c->stream, OA_NNF_ARGS); break;
-            }
+        const bool small = (c->tile_groups == 64);
+#define OA_LAUNCH_F(RR)                                                                                              \
+        do {                                                                                                         \
+            if (small) hipLaunchKernelGGL((oa::k_nn_search_filtered<RR, false, false, 64>), grid, block, 0, c->stream, OA_NNF_ARGS); \
+            else hipLaunchKernelGGL((oa::k_nn_search_filtered<RR, false, false, oa::FTILE_GROUPS>), grid, block, 0, c->stream, OA_NNF_ARGS); \
+        } while (0)
+        switch (c->R) {
+        case 1: OA_LAUNCH_F(1); break;
+        case 2: OA_LAUNCH_F(2); break;
+        case 8: OA_LAUNCH_F(8); break;
+        default: OA_LAUNCH_F(4); break;
         }
+#undef OA_LAUNCH_F
     } else {
         switch (c->R) {
         case 1: hipLaunchKernelGGL(oa::k_nn_search<1>, grid, block, 0, c->stream, OA_NN_ARGS); break;
@@ -421,8 +424,9 @@ OA_EXPORT int oa_create(oa_ctx **out, int device)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fail(OA_E_HIP, "oa_create: %s", hipGetErrorString(e)); }
     c->stream = c->own_stream;
-    c->R = env_int("OA_NN_R", 4);
-    if (c->R != 1 && c->R != 2 && c->R != 4 && c->R != 8) c->R = 4;
+    c->R_env = env_int("OA_NN_R", 0);
+    if (c->R_env != 1 && c->R_env != 2 && c->R_env != 4 && c->R_env != 8) c->R_env = 0;
+    c->R = c->R_env ? c->R_env : 4;
     c->use_filter = env_int("OA_NN_FILTER", 1) != 0;
     c->use_pk = env_int("OA_NN_PK", 0) != 0;
     c->grid_mode = env_int("OA_NN_GRID", -1);
@@ -843,6 +847,8 @@ OA_EXPORT int oa_set_source(oa_ctx *c, const float *xyz, int64_t n_verts, int on
     dev_free(c->d_A); dev_free(c->d_B);
     c->emit_cap = 0;
     c->ns = (int)count;
+    // points per thread: 4 for big shards; small shards take 2 or 1 so that the launch still has enough workgroups
+    c->R = c->R_env ? c->R_env : (count >= 131072 ? 4 : (count >= 32768 ? 2 : 1));
     const int chunk = oa::NN_THREADS * c->R;
     c->ns_pad = (int)(((count + chunk - 1) / chunk) * chunk);
     if (c->ns_pad == 0) c->ns_pad = chunk;

@@ -621,7 +621,7 @@ __global__ void k_bbox_partial(const float *__restrict__ xyz, int nt, float *__r
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-template <int R, bool PK, bool LIST>
+template <int R, bool PK, bool LIST, int TG = FTILE_GROUPS>
 __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_filtered(const DevState *__restrict__ st,
                                                                    const float4 *__restrict__ src4,
                                                                    const float4 *__restrict__ tg,
@@ -638,7 +638,9 @@ __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_filt
     // their indices, `*list_count` how many; their running best sits in keys[] and seeds the scan.
     // PK is kept as a template slot for A/B experiments; the shipped instantiations use scalar v_fma_f32.
     if (st->halt) return;
-    __shared__ float4 tile[2][FTILE_GROUPS * 3];
+    // TG = groups of 4 targets per LDS tile: 256 for large targets, 64 for small ones (more, shorter workgroups)
+    constexpr int TILE_F4 = TG * 3, LOADS = (TILE_F4 + NN_THREADS - 1) / NN_THREADS;
+    __shared__ float4 tile[2][TILE_F4];
     const int tid = threadIdx.x;
     const double qmax = st->qmax;
     const float cx = st->tc[0], cy = st->tc[1], cz = st->tc[2];
@@ -687,25 +689,29 @@ __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_filt
     const int g_begin = blockIdx.x * groups_per_split;
     int g_end = g_begin + groups_per_split;
     if (g_end > n_groups_pad) g_end = n_groups_pad;
-    const int n_tiles = (g_end - g_begin) / FTILE_GROUPS;
+    const int n_tiles = (g_end - g_begin) / TG;
     const float4 *tsrc = tf2 + 3ll * g_begin;
 
-    float4 s0 = tsrc[tid], s1 = tsrc[NN_THREADS + tid], s2 = tsrc[2 * NN_THREADS + tid];
-    tile[0][tid] = s0; tile[0][NN_THREADS + tid] = s1; tile[0][2 * NN_THREADS + tid] = s2;
+    float4 stg[LOADS];
+#pragma unroll
+    for (int k = 0; k < LOADS; ++k)
+        if (k * NN_THREADS + tid < TILE_F4) { stg[k] = tsrc[k * NN_THREADS + tid]; tile[0][k * NN_THREADS + tid] = stg[k]; }
     __syncthreads();
 
     for (int t = 0; t < n_tiles; ++t) {
         const int cur = t & 1;
         const bool more = (t + 1 < n_tiles);
-        if (more) {
-            const float4 *nsrc = tsrc + 3ll * FTILE_GROUPS * (t + 1);
-            s0 = nsrc[tid]; s1 = nsrc[NN_THREADS + tid]; s2 = nsrc[2 * NN_THREADS + tid];
+        if (more) {                                               // next tile: global -> registers, hidden under compute
+            const float4 *nsrc = tsrc + 3ll * TG * (t + 1);
+#pragma unroll
+            for (int k = 0; k < LOADS; ++k)
+                if (k * NN_THREADS + tid < TILE_F4) stg[k] = nsrc[k * NN_THREADS + tid];
         }
-        const int gbase = g_begin + t * FTILE_GROUPS;
+        const int gbase = g_begin + t * TG;
         // GW groups (4*GW targets) per skip test.  Level 1 (hot): 2 fma + min per pair in the kept plane; level 2 (rare):
         // the dropped axis is added for the points that passed; level 3 (rarer): the exact metric.
         constexpr int GW = 2;
-        for (int g = 0; g < FTILE_GROUPS; g += GW) {
+        for (int g = 0; g < TG; g += GW) {
             float4 AU[GW], AV[GW], W2[GW];
 #pragma unroll
             for (int k = 0; k < GW; ++k) {
@@ -765,7 +771,9 @@ __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_filt
             }
         }
         if (more) {
-            tile[cur ^ 1][tid] = s0; tile[cur ^ 1][NN_THREADS + tid] = s1; tile[cur ^ 1][2 * NN_THREADS + tid] = s2;
+#pragma unroll
+            for (int k = 0; k < LOADS; ++k)
+                if (k * NN_THREADS + tid < TILE_F4) tile[cur ^ 1][k * NN_THREADS + tid] = stg[k];
         }
         __syncthreads();
     }
