@@ -848,7 +848,7 @@ OA_EXPORT int oa_set_source(oa_ctx *c, const float *xyz, int64_t n_verts, int on
     c->emit_cap = 0;
     c->ns = (int)count;
     // points per thread: 4 for big shards; small shards take 2 or 1 so that the launch still has enough workgroups
-    c->R = c->R_env ? c->R_env : (count >= 131072 ? 4 : (count >= 32768 ? 2 : 1));
+    c->R = c->R_env ? c->R_env : (count >= 65536 ? 4 : (count >= 16384 ? 2 : 1));
     const int chunk = oa::NN_THREADS * c->R;
     c->ns_pad = (int)(((count + chunk - 1) / chunk) * chunk);
     if (c->ns_pad == 0) c->ns_pad = chunk;
