@@ -55,6 +55,10 @@ def test_affine_matrix_from_points_golden(golden_dir):
         assert np.array_equal(calc_target_matrix(A, B, scale=sc), got)
     with pytest.raises(ValueError, match=str(g["valueerror_msg"])):
         affine_matrix_from_points(np.zeros((3, 2)), np.zeros((3, 2)), shear=False, scale=False)
+    for i in range(int(g["n_horn"])):                       # usesvd=False: the reference's Horn-branch results
+        p = "h%02d_" % i
+        got = affine_matrix_from_points(g[p + "A"], g[p + "B"], shear=False, scale=bool(g[p + "scale"]), usesvd=False)
+        assert np.abs(got - g[p + "M"]).max() < 1e-9
 
 
 def test_kabsch_properties(eng):
