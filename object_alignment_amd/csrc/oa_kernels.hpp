@@ -824,6 +824,36 @@ __device__ __forceinline__ bool normal_angle_ok(const float *imx1, const float *
     return c >= cos_min;               // NaN (zero normal) -> rejected
 }
 
+// Wave-level sum of the 24 running sums: a reduce-scatter butterfly.  Each exchange step halves the number of values
+// a lane still carries (24 -> 12 -> 6 -> 3, partner = lane ^ 32, ^ 16, ^ 8), then the remaining 3 values are summed
+// over the 8 lanes that share bits 5..3 (^ 4, ^ 2, ^ 1): 30 double shuffles instead of 24 x 6 = 144.  Afterwards every
+// lane holds, in out[0..2], the wave totals of sums number first .. first + 2.  Fixed pattern => bitwise reproducible.
+__device__ __forceinline__ void wave_reduce_sums(const double (&acc)[NSUMS], int lane, double (&out)[3], int &first)
+{
+    double a12[12], a6[6];
+    const bool b5 = (lane & 32) != 0, b4 = (lane & 16) != 0, b3 = (lane & 8) != 0;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        const double keep = b5 ? acc[12 + k] : acc[k], send = b5 ? acc[k] : acc[12 + k];
+        a12[k] = keep + __shfl_xor(send, 32, 64);
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const double keep = b4 ? a12[6 + k] : a12[k], send = b4 ? a12[k] : a12[6 + k];
+        a6[k] = keep + __shfl_xor(send, 16, 64);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double keep = b3 ? a6[3 + k] : a6[k], send = b3 ? a6[k] : a6[3 + k];
+        double v = keep + __shfl_xor(send, 8, 64);
+        v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 1, 64);
+        out[k] = v;
+    }
+    first = (b5 ? 12 : 0) + (b4 ? 6 : 0) + (b3 ? 3 : 0);
+}
+
 struct PairOut {            // optional per-point outputs for the make_pairs contract
     unsigned char *valid;   // ns
     float  *b;              // ns x 3  (imx1 @ (mx2 @ co1))
@@ -920,10 +950,11 @@ __global__ __launch_bounds__(ACC_THREADS) void k_pair_accumulate(const DevState 
         }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < NSUMS; ++k) {
-        const double v = wave_sum(acc[k]);
-        if (lane == 0) red[wave][k] = v;
+    {
+        double tot[3];
+        int first;
+        wave_reduce_sums(acc, lane, tot, first);
+        if ((lane & 7) == 0) { red[wave][first] = tot[0]; red[wave][first + 1] = tot[1]; red[wave][first + 2] = tot[2]; }
     }
     __syncthreads();
     if (threadIdx.x < NSUMS) {
@@ -974,10 +1005,11 @@ __global__ __launch_bounds__(ACC_THREADS) void k_accumulate_pairs(const double *
         acc[S_K] += 1.0;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < NSUMS; ++k) {
-        const double v = wave_sum(acc[k]);
-        if (lane == 0) red[wave][k] = v;
+    {
+        double tot[3];
+        int first;
+        wave_reduce_sums(acc, lane, tot, first);
+        if ((lane & 7) == 0) { red[wave][first] = tot[0]; red[wave][first + 1] = tot[1]; red[wave][first + 2] = tot[2]; }
     }
     __syncthreads();
     if (threadIdx.x < NSUMS) {
