@@ -350,6 +350,26 @@ int iter_finish(oa_ctx *c, const double *d_sums)
     return OA_OK;
 }
 
+// single-GPU iteration: search, accumulate, then reduce + solve in one launch
+int iter_fused(oa_ctx *c, bool timed)
+{
+    int rc;
+    if (timed) {
+        if ((rc = ensure_events(c, c->ev_used + 1))) return rc;
+        HIPCHK(hipEventRecord(c->ev[2 * c->ev_used], c->stream));
+    }
+    if ((rc = launch_nn(c))) return rc;
+    if (timed) {
+        HIPCHK(hipEventRecord(c->ev[2 * c->ev_used + 1], c->stream));
+        c->ev_used++;
+    }
+    if ((rc = launch_accumulate(c, false, nullptr, nullptr))) return rc;
+    hipLaunchKernelGGL(oa::k_reduce_solve_update, dim3(1), dim3(1024), 0, c->stream, c->d_state, (const double *)c->d_partials,
+                       c->acc_blocks, c->d_sums, c->d_hist, c->d_todo_count);
+    HIPCHK(hipGetLastError());
+    return OA_OK;
+}
+
 int fetch_state(oa_ctx *c)
 {
     HIPCHK(hipMemcpyAsync(&c->h_state, c->d_state, sizeof(oa::DevState), hipMemcpyDeviceToHost, c->stream));
@@ -1194,10 +1214,8 @@ OA_EXPORT int oa_run(oa_ctx *c, const oa_settings *st, oa_report *rep)
     if (!c || !st || !rep) return fail(OA_E_BAD_ARG, "oa_run: null argument");
     int rc = oa_run_begin(c, st);
     if (rc) return rc;
-    for (int it = 0; it < st->iters; ++it) {
-        if ((rc = iter_partial(c, c->d_sums, true))) return rc;
-        if ((rc = iter_finish(c, c->d_sums))) return rc;
-    }
+    for (int it = 0; it < st->iters; ++it)
+        if ((rc = iter_fused(c, true))) return rc;
     return oa_run_end(c, rep);
 }
 
@@ -1210,8 +1228,7 @@ OA_EXPORT int oa_iterate(oa_ctx *c, const oa_settings *st, double M_step[16], do
     }
     if ((rc = use_device(c))) return rc;
     c->ev_used = 0;
-    if ((rc = iter_partial(c, c->d_sums, false))) return rc;
-    if ((rc = iter_finish(c, c->d_sums))) return rc;
+    if ((rc = iter_fused(c, false))) return rc;
     if ((rc = fetch_state(c))) return rc;
     const oa::DevState &s = c->h_state;
     if (s.status == OA_E_TOO_FEW_PAIRS) { c->loop_active = false; return fail(OA_E_TOO_FEW_PAIRS, "input arrays are of wrong shape or type"); }

@@ -964,9 +964,9 @@ __global__ __launch_bounds__(ACC_THREADS) void k_pair_accumulate(const DevState 
     }
 }
 
-// fixed-order reduction of the per-block partials: 32 interleaved slices, then slices 0..31 in order
-__global__ __launch_bounds__(1024) void k_reduce_partials(const double *__restrict__ partials, int n_blocks,
-                                                          double *__restrict__ sums)
+// fixed-order reduction of the per-block partials: 32 interleaved slices, then slices 0..31 in order.
+// Called by all 1024 threads of a block; the totals land in out[0..NSUMS) (shared or global memory).
+__device__ __forceinline__ void reduce_partials_block(const double *__restrict__ partials, int n_blocks, double *out)
 {
     __shared__ double red[32][32];
     const int j = threadIdx.x & 31, s = threadIdx.x >> 5;
@@ -978,8 +978,14 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const double *__restri
     if (threadIdx.x < NSUMS) {
         double t = red[0][threadIdx.x];
         for (int k = 1; k < 32; ++k) t += red[k][threadIdx.x];
-        sums[threadIdx.x] = t;
+        out[threadIdx.x] = t;
     }
+}
+
+__global__ __launch_bounds__(1024) void k_reduce_partials(const double *__restrict__ partials, int n_blocks,
+                                                          double *__restrict__ sums)
+{
+    reduce_partials_block(partials, n_blocks, sums);
 }
 
 // sums over explicit pairs (contract 2: oa_kabsch).  A, B: 3 x K row-major with leading dimension ld.
@@ -1035,10 +1041,9 @@ __global__ void k_solve_only(const double *__restrict__ sums, double pvx, double
 // ------------------------------------------------------------------------------------------------
 // k_solve_update : operators/icp_align.py:106-149, one thread
 // ------------------------------------------------------------------------------------------------
-__global__ void k_solve_update(DevState *__restrict__ st, const double *__restrict__ sums, StepRecord *__restrict__ hist,
-                               int *__restrict__ todo_count)
+__device__ __forceinline__ void solve_update_body(DevState *__restrict__ st, const double *sums, StepRecord *__restrict__ hist,
+                                                  int *__restrict__ todo_count)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (todo_count) *todo_count = 0;                                // the grid search's unsettled list restarts empty
     if (st->halt) return;
     double s[NSUMS], M[16];
@@ -1079,6 +1084,26 @@ __global__ void k_solve_update(DevState *__restrict__ st, const double *__restri
     st->d_pivot = mean_d;                                           // next iteration sums d relative to this mean
     st->n = n + 1;                                                  // n += 1                        (:151)
     if ((st->converged && st->early_exit) || st->n >= st->iters) st->halt = 1;
+}
+
+// split-phase form (one process per GPU): the sums come back from the all-reduce
+__global__ void k_solve_update(DevState *__restrict__ st, const double *__restrict__ sums, StepRecord *__restrict__ hist,
+                               int *__restrict__ todo_count)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    solve_update_body(st, sums, hist, todo_count);
+}
+
+// single-GPU form: the fixed-order reduction and the solve in one launch (same arithmetic, one boundary less)
+__global__ __launch_bounds__(1024) void k_reduce_solve_update(DevState *__restrict__ st, const double *__restrict__ partials,
+                                                              int n_blocks, double *__restrict__ sums_out,
+                                                              StepRecord *__restrict__ hist, int *__restrict__ todo_count)
+{
+    __shared__ double sums[NSUMS];
+    reduce_partials_block(partials, n_blocks, sums);
+    __syncthreads();
+    if (threadIdx.x < NSUMS && sums_out) sums_out[threadIdx.x] = sums[threadIdx.x];
+    if (threadIdx.x == 0) solve_update_body(st, sums, hist, todo_count);
 }
 
 // ------------------------------------------------------------------------------------------------
