@@ -230,6 +230,54 @@ def test_grid_search_identical_to_brute_force(orc, case):
         assert np.array_equal(idx2, r2) and np.array_equal(d22, rd2), (case, mode, "seeded")
 
 
+@pytest.mark.parametrize("mode", ["brute", "grid"])
+def test_non_finite_coordinates(orc, mode):
+    """NaN / Inf vertices never win and never poison their neighbours: same answers as the oracle (index -1 and
+    d2 = +inf for a query that has no finite distance)."""
+    from object_alignment_amd.engine import IcpEngine
+    rng = np.random.default_rng(8)
+    tgt = rng.uniform(-1, 1, size=(20000, 3)).astype(np.float32)
+    src = rng.uniform(-1, 1, size=(5000, 3)).astype(np.float32)
+    eye = np.identity(4, dtype=np.float32)
+    src_bad = src.copy()
+    src_bad[::97, 0] = np.nan
+    src_bad[5::131, 2] = np.inf
+    tgt_bad = tgt.copy()
+    tgt_bad[::53, 1] = np.nan
+    tgt_bad[7::211] = np.inf
+    for s_, t_ in ((src_bad, tgt), (src, tgt_bad), (src_bad, tgt_bad)):
+        ridx, rd2 = orc.nn_brute(s_, t_)
+        with IcpEngine(0) as e:
+            e.set_search_mode(mode)
+            e.set_target(t_)
+            e.set_source(s_)
+            e.set_matrices(eye, eye)
+            idx, d2, _ = e.nn_search()
+            assert np.array_equal(idx, ridx)
+            assert np.array_equal(d2, rd2)
+            A, B, ds = e.make_pairs(0.5, calc_stats=True)
+        rA, rB, rds = orc.make_pairs(s_, t_, eye, eye, 0.5, calc_stats=True)
+        assert np.array_equal(A, rA) and np.array_equal(B, rB)
+
+
+def test_device_resident_inputs_with_vlist(orc):
+    """Source / target given as device tensors (on_device = 1) together with a host vlist and a stride."""
+    import torch
+    from object_alignment_amd.engine import IcpEngine
+    rng = np.random.default_rng(12)
+    tgt = rng.uniform(-1, 1, size=(9000, 3)).astype(np.float32)
+    src = rng.uniform(-1, 1, size=(7000, 3)).astype(np.float32)
+    vlist = np.sort(rng.choice(7000, size=4000, replace=False)).astype(np.int64)[::-1].copy()   # descending order
+    eye = np.identity(4, dtype=np.float32)
+    with IcpEngine(0) as e:
+        e.set_target(torch.from_numpy(tgt).cuda())
+        e.set_source(torch.from_numpy(src).cuda(), vlist=vlist, stride=3)
+        e.set_matrices(eye, eye)
+        A, B, ds = e.make_pairs(0.2, calc_stats=True)
+    rA, rB, rds = orc.make_pairs(src, tgt, eye, eye, 0.2, vlist=vlist, sample=3, calc_stats=True)
+    assert np.array_equal(A, rA) and np.array_equal(B, rB) and np.allclose(ds, rds, rtol=1e-9)
+
+
 def test_nn_search_full_size_self_match(eng):
     """BASELINE config 3 size (1M <-> 1M): every point finds itself (property test, no oracle needed)."""
     rng = np.random.default_rng(1234)
