@@ -155,7 +155,10 @@ void plan_geometry(oa_ctx *c)
     // small targets: quarter-size tiles give 4x more (and 4x shorter) workgroups; the unfiltered kernel keeps 256
     c->tile_groups = (c->filter_ok && c->use_filter && c->nt <= 65536 && !env_int("OA_NN_BIGTILE", 0)) ? 64 : oa::FTILE_GROUPS;
     const int tiles_total = c->n_groups_pad / c->tile_groups;
-    const int want = env_int("OA_NN_TARGET_BLOCKS", c->n_cu * 64);
+    // workgroups wanted: ~2e5 pairs each (below that the prologue and the atomicMin merge dominate), at most 64 per CU
+    const double pairs = (double)c->ns * (double)c->nt;
+    const int want_auto = (int)std::min((double)c->n_cu * 64.0, std::max((double)c->n_cu * 2.0, pairs / 2e5));
+    const int want = env_int("OA_NN_TARGET_BLOCKS", want_auto);
     int splits = (want + src_blocks - 1) / src_blocks;
     splits = std::max(1, std::min(splits, tiles_total));
     if (splits > 8) splits = std::min(tiles_total, ((splits + 7) / 8) * 8);   // multiple of 8: one XCD per split residue
