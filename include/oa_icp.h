@@ -87,12 +87,15 @@ int         oa_set_stream(oa_ctx *ctx, void *stream);
 /* Correspondence-search strategy.  Every mode returns the same (index, d2) per source point, bit for bit:
  *   OA_SEARCH_BRUTE  k_nn_search_filtered: LDS-tiled brute force over all target vertices (the north-star kernel)
  *   OA_SEARCH_GRID   k_nn_search_grid: exact search through a uniform grid; points it cannot settle within a few
- *                    rings are finished by the brute-force kernel
- *   OA_SEARCH_AUTO   grid for large problems (>= 8192 target vertices and >= 1e9 pairs), brute force otherwise
- * Default: OA_SEARCH_AUTO (env OA_NN_GRID = 0 / 1 overrides at oa_create). */
+ *                    rings (far from the target: partial overlaps, holes) are finished by the tree search
+ *   OA_SEARCH_BVH    k_bvh_search: every query through the 64-ary bounding-box tree, one wavefront per query
+ *   OA_SEARCH_AUTO   grid (+ tree) for large problems (>= 8192 target vertices and >= 1e9 pairs), brute force otherwise
+ * The same modes apply to surface targets (oa_set_target_mesh) with triangles in place of vertices.
+ * Default: OA_SEARCH_AUTO (env OA_NN_GRID = 0 / 1 / 2 overrides at oa_create). */
 #define OA_SEARCH_AUTO  (-1)
 #define OA_SEARCH_BRUTE 0
 #define OA_SEARCH_GRID  1
+#define OA_SEARCH_BVH   2
 int oa_set_search_mode(oa_ctx *ctx, int mode);
 
 /* ---- one-time uploads (replaces BVHTree.FromObject, operators/icp_align.py:53, and the vlist

@@ -1,0 +1,319 @@
+// oa_bvh.hpp -- exact nearest vertex / nearest triangle through a 64-ary bounding-box tree, one WAVE per query.
+//
+// Why it exists: the uniform-grid searches (oa_grid.hpp, oa_tri.hpp) settle a query only when its nearest
+// primitive lies within `r_max` rings of cells.  Partial overlaps, holes and the first iterations of a badly
+// aligned pair leave queries far from the surface; finishing those by brute force costs O(N_target) each.  This tree
+// finishes them in O(log) steps and is exact for any input.  (The reference leaves all of this to Blender's BVHTree,
+// functions/general.py:297; this is the wave64 restatement of that idea, not of Blender's code.)
+//
+// Layout: primitives sorted by the 30-bit Morton code of their centre; leaf j = sorted primitives [64 j, 64 j + 64);
+// level-1 box j = bounds of leaf j, level-(l+1) box k = bounds of level-l boxes [64 k, 64 k + 64), up to a top level
+// of <= 64 boxes.  A wave handles one query: its 64 lanes test the 64 children of a node (or the 64 primitives of a
+// leaf) in ONE step with coalesced loads and no divergence; the running best (d2, index) is wave-uniform.  Children
+// are visited nearest-first; the per-level candidate masks and bounds live in LDS (6 levels x 64 lanes per wave).
+//
+// Exactness: candidates are evaluated with the same float32 arithmetic as the brute-force kernels on the ORIGINAL
+// coordinates and merged lexicographically on (d2, original index); a box is skipped only if no primitive inside
+// can beat OR tie the best: lb (1 - 1e-5) - 1e-30 > best, where lb is a lower bound of the squared distance to the
+// box (vertex mode: float32 gaps, relative error < 6u, metric >= D (1 - 5.01u); triangle mode: double, minus
+// delta = 64u(|coords|) for the float32 closest-point evaluation, as in oa_tri.hpp).
+#pragma once
+#include "oa_grid.hpp"
+
+namespace oa {
+
+constexpr int BVH_W = 64;
+constexpr int BVH_MAX_LEVELS = 6;
+
+struct BvhParams {
+    int n_prims;                          // real primitives
+    int levels;                           // box levels L >= 1: level 1 = leaf boxes ... level L = top (<= 64 boxes)
+    int cnt[BVH_MAX_LEVELS + 1];          // boxes at level l (1..L)
+    int off[BVH_MAX_LEVELS + 1];          // offset of level l in the box array, in boxes (each level padded to 64)
+    double scale, slack;                  // largest |coordinate| and absolute slack (triangle mode's delta)
+};
+
+#if defined(__HIPCC__)
+
+constexpr unsigned long long KEY_NONE = 0x7F800000FFFFFFFFull;     // (d2 = +inf, no index)
+
+// ---- wave-wide unsigned minimum, result uniform (DPP inside rows of 16, readlane across the 4 rows)
+__device__ __forceinline__ uint32_t dpp_min_step(uint32_t v, const int ctrl_sel)
+{
+    uint32_t o;
+    switch (ctrl_sel) {
+    case 0:  o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false); break;   // quad_perm [1,0,3,2]
+    case 1:  o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false); break;   // quad_perm [2,3,0,1]
+    case 2:  o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false); break;  // row_half_mirror
+    default: o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false); break;  // row_mirror
+    }
+    return o < v ? o : v;
+}
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+    v = dpp_min_step(v, 0);
+    v = dpp_min_step(v, 1);
+    v = dpp_min_step(v, 2);
+    v = dpp_min_step(v, 3);
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    const uint32_t ab = a < b ? a : b, cd = c < d ? c : d;
+    return ab < cd ? ab : cd;
+}
+
+// ---- build ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned bvh_spread10(unsigned v)
+{
+    v &= 1023u;
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+// Morton key of a primitive's centre (vertex: the point; triangle: centre of its bounding box)
+template <bool TRI>
+__global__ void k_bvh_keys(const float *__restrict__ xyz, const float4 *__restrict__ tri9, int n, float lx, float ly,
+                           float lz, float sx, float sy, float sz, unsigned *__restrict__ keys, int *__restrict__ ids)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float cx, cy, cz;
+    if (TRI) {
+        float a[3], b[3], c[3];
+        load_tri(tri9, i, a, b, c);
+        cx = 0.5f * (fminf(fminf(a[0], b[0]), c[0]) + fmaxf(fmaxf(a[0], b[0]), c[0]));
+        cy = 0.5f * (fminf(fminf(a[1], b[1]), c[1]) + fmaxf(fmaxf(a[1], b[1]), c[1]));
+        cz = 0.5f * (fminf(fminf(a[2], b[2]), c[2]) + fmaxf(fmaxf(a[2], b[2]), c[2]));
+    } else {
+        cx = xyz[3ll * i]; cy = xyz[3ll * i + 1]; cz = xyz[3ll * i + 2];
+    }
+    const float fx = fminf(fmaxf((cx - lx) * sx, 0.f), 1023.f), fy = fminf(fmaxf((cy - ly) * sy, 0.f), 1023.f),
+                fz = fminf(fmaxf((cz - lz) * sz, 0.f), 1023.f);      // NaN -> 0 through fmaxf
+    keys[i] = bvh_spread10((unsigned)fx) | (bvh_spread10((unsigned)fy) << 1) | (bvh_spread10((unsigned)fz) << 2);
+    ids[i] = i;
+}
+
+// sorted primitive images.  vertex: float4 {x, y, z, bits(original index)}; triangle: the tri9 image with the original
+// index in the second lane of its third float4.  Slots past n are NaN (never selected) with index IDX_NONE.
+template <bool TRI>
+__global__ void k_bvh_gather(const float *__restrict__ xyz, const float4 *__restrict__ tri9, const int *__restrict__ order,
+                             int n, int n_pad, float4 *__restrict__ prims)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_pad) return;
+    if (TRI) {
+        if (j < n) {
+            const int t = order[j];
+            float4 w = tri9[3ll * t + 2];
+            w.y = __uint_as_float((uint32_t)t);
+            prims[3ll * j] = tri9[3ll * t]; prims[3ll * j + 1] = tri9[3ll * t + 1]; prims[3ll * j + 2] = w;
+        } else {
+            const float4 bad = make_float4(NAN, NAN, NAN, NAN);
+            prims[3ll * j] = bad; prims[3ll * j + 1] = bad;
+            prims[3ll * j + 2] = make_float4(NAN, __uint_as_float(IDX_NONE), 0.f, 0.f);
+        }
+    } else {
+        if (j < n) {
+            const int v = order[j];
+            prims[j] = make_float4(xyz[3ll * v], xyz[3ll * v + 1], xyz[3ll * v + 2], __uint_as_float((uint32_t)v));
+        } else {
+            prims[j] = make_float4(NAN, NAN, NAN, __uint_as_float(IDX_NONE));
+        }
+    }
+}
+
+// level-1 boxes: bounds of 64 consecutive primitives (NaN coordinates are ignored by fminf/fmaxf; an all-NaN leaf gets
+// the empty box lo = +inf, hi = -inf).  One thread per box; the build runs once per target.
+template <bool TRI>
+__global__ void k_bvh_leaf_boxes(const float4 *__restrict__ prims, int n_pad, int n_boxes, float4 *__restrict__ boxes)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_boxes) return;
+    float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (int k = 0; k < BVH_W; ++k) {
+        const long long j = (long long)b * BVH_W + k;
+        if (j >= n_pad) break;
+        if (TRI) {
+            float p[3][3];
+            load_tri(prims, j, p[0], p[1], p[2]);
+            for (int v = 0; v < 3; ++v)
+                for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], p[v][a]); hi[a] = fmaxf(hi[a], p[v][a]); }
+        } else {
+            const float4 q = prims[j];
+            lo[0] = fminf(lo[0], q.x); lo[1] = fminf(lo[1], q.y); lo[2] = fminf(lo[2], q.z);
+            hi[0] = fmaxf(hi[0], q.x); hi[1] = fmaxf(hi[1], q.y); hi[2] = fmaxf(hi[2], q.z);
+        }
+    }
+    boxes[2ll * b] = make_float4(lo[0], lo[1], lo[2], 0.f);
+    boxes[2ll * b + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
+}
+
+__global__ void k_bvh_upper_boxes(const float4 *__restrict__ child, int n_child, int n_boxes, float4 *__restrict__ boxes)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_boxes) return;
+    float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (int k = 0; k < BVH_W; ++k) {
+        const long long j = (long long)b * BVH_W + k;
+        if (j >= n_child) break;
+        const float4 l = child[2 * j], h = child[2 * j + 1];
+        lo[0] = fminf(lo[0], l.x); lo[1] = fminf(lo[1], l.y); lo[2] = fminf(lo[2], l.z);
+        hi[0] = fmaxf(hi[0], h.x); hi[1] = fmaxf(hi[1], h.y); hi[2] = fmaxf(hi[2], h.z);
+    }
+    boxes[2ll * b] = make_float4(lo[0], lo[1], lo[2], 0.f);
+    boxes[2ll * b + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
+}
+
+// ---- query ---------------------------------------------------------------------------------------------------------
+// lower bound of the squared distance from p to anything inside the box, as a float that never exceeds the real bound
+// by more than the (1 - 1e-5) factor of the prune test absorbs
+template <bool TRI>
+__device__ __forceinline__ float bvh_box_bound(const float *p, const float4 lo, const float4 hi, double delta)
+{
+    if (TRI) {
+        const double gx = fmax(fmax((double)lo.x - (double)p[0], (double)p[0] - (double)hi.x), 0.0);
+        const double gy = fmax(fmax((double)lo.y - (double)p[1], (double)p[1] - (double)hi.y), 0.0);
+        const double gz = fmax(fmax((double)lo.z - (double)p[2], (double)p[2] - (double)hi.z), 0.0);
+        double lb = sqrt(gx * gx + gy * gy + gz * gz) - delta;
+        lb = lb > 0.0 ? lb : 0.0;
+        return (float)(lb * lb * (1.0 - 1e-6));                  // the float rounding stays below the 1e-6
+    } else {
+        const float gx = fmaxf(fmaxf(lo.x - p[0], p[0] - hi.x), 0.f);
+        const float gy = fmaxf(fmaxf(lo.y - p[1], p[1] - hi.y), 0.f);
+        const float gz = fmaxf(fmaxf(lo.z - p[2], p[2] - hi.z), 0.f);
+        return gx * gx + gy * gy + gz * gz;
+    }
+}
+
+__device__ __forceinline__ bool bvh_prune(float lb, float best)
+{
+    return lb * 0.99999f - 1e-30f > best;                          // cannot beat or tie
+}
+
+// One wave per query.  list == nullptr: every source point, seeded with last iteration's primitive (`prev`, original
+// index, evaluated through tgt_xyz / tri9); else the points the grid search could not settle, seeded with keys[i].
+template <bool TRI>
+__global__ __launch_bounds__(256) void k_bvh_search(const DevState *__restrict__ st, const float4 *__restrict__ src4,
+                                                    int ns, BvhParams bp, const float4 *__restrict__ boxes,
+                                                    const float4 *__restrict__ prims,
+                                                    const float *__restrict__ tgt_xyz, const float4 *__restrict__ tri9,
+                                                    const int *__restrict__ prev, unsigned long long *__restrict__ keys,
+                                                    const int *__restrict__ list, const int *__restrict__ list_count)
+{
+    if (st->halt) return;
+    __shared__ float s_lb[4][BVH_MAX_LEVELS + 1][BVH_W];
+    __shared__ unsigned long long s_mask[4][BVH_MAX_LEVELS + 1];
+    __shared__ int s_node[4][BVH_MAX_LEVELS + 1];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int n_items = list ? *list_count : ns;
+    const int n_waves = gridDim.x * 4;
+    const int top = bp.levels;
+
+    for (int slot = blockIdx.x * 4 + w; slot < n_items; slot += n_waves) {
+        const int i = list ? list[slot] : slot;
+        const float4 p4 = src4[i];
+        float wx, wy, wz, p[3];
+        m4_mul_v3(st->mx1, p4.x, p4.y, p4.z, wx, wy, wz);
+        m4_mul_v3(st->imx2, wx, wy, wz, p[0], p[1], p[2]);          // co_find (general.py:287)
+
+        float best = INFINITY;
+        uint32_t bidx = IDX_NONE;
+        if (list) {
+            const unsigned long long k0 = keys[i];
+            const float b0 = __uint_as_float((uint32_t)(k0 >> 32));
+            if (b0 < INFINITY) { best = b0; bidx = (uint32_t)k0; }
+        } else {
+            const int s = prev ? prev[i] : -1;
+            if (s >= 0) {
+                float d;
+                if (TRI) {
+                    float a[3], b[3], c[3], r[3];
+                    load_tri(tri9, s, a, b, c);
+                    closest_on_tri(p, a, b, c, r);
+                    d = tri_dist2(p, r);
+                } else {
+                    d = d2_metric(p[0], p[1], p[2], tgt_xyz[3ll * s], tgt_xyz[3ll * s + 1], tgt_xyz[3ll * s + 2]);
+                }
+                if (d < INFINITY) { best = d; bidx = (uint32_t)s; }
+            }
+        }
+        // `lim`: the best so far or the search radius (search_cutoff2), whichever is smaller -- see k_nn_search_grid
+        const float cutf = search_cutoff2(st, p[0], p[1], p[2]);
+        float lim = fminf(best, cutf);
+        const bool finite = fabsf(p[0]) < INFINITY && fabsf(p[1]) < INFINITY && fabsf(p[2]) < INFINITY;
+        const double delta = TRI ? 64.0 * 5.9604644775390625e-08 * (bp.scale + fabs((double)p[0]) + fabs((double)p[1]) + fabs((double)p[2])) + bp.slack : 0.0;
+
+        if (finite) {                                               // a non-finite query has no finite distance: stays (inf, none)
+            int level = top;
+            int node = 0;
+            bool fresh = true;                                      // `level` holds a node whose children are not tested yet
+            while (true) {
+                if (fresh) {
+                    const long long ch = (long long)node * BVH_W + lane;
+                    float lb = INFINITY;
+                    bool pass = false;
+                    if (ch < bp.cnt[level]) {
+                        const float4 lo = boxes[2 * ((long long)bp.off[level] + ch)], hi = boxes[2 * ((long long)bp.off[level] + ch) + 1];
+                        lb = bvh_box_bound<TRI>(p, lo, hi, delta);
+                        pass = lb < INFINITY && !bvh_prune(lb, lim);
+                    }
+                    s_lb[w][level][lane] = lb;
+                    const unsigned long long m = __ballot(pass);
+                    if (lane == 0) { s_mask[w][level] = m; s_node[w][level] = node; }
+                    fresh = false;
+                }
+                const unsigned long long m = s_mask[w][level];
+                if (m == 0ull) {
+                    if (level == top) break;
+                    ++level;
+                    continue;
+                }
+                const bool member = (m >> lane) & 1ull;
+                const uint32_t lbits = member ? __float_as_uint(s_lb[w][level][lane]) : 0xFFFFFFFFu;   // bounds are >= +0
+                const uint32_t mb = wave_min_u32(lbits);
+                if (bvh_prune(__uint_as_float(mb), lim)) {          // the nearest candidate is out: so are the others
+                    if (lane == 0) s_mask[w][level] = 0ull;
+                    continue;
+                }
+                const unsigned long long eq = __ballot(member && lbits == mb);
+                const int pick = __ffsll((long long)eq) - 1;
+                if (lane == 0) s_mask[w][level] = m & ~(1ull << pick);
+                const long long child = (long long)s_node[w][level] * BVH_W + pick;
+                if (level > 1) {
+                    --level;
+                    node = (int)child;
+                    fresh = true;
+                    continue;
+                }
+                // leaf: 64 primitives, one per lane
+                const long long j = child * BVH_W + lane;
+                float d;
+                uint32_t qi;
+                if (TRI) {
+                    float a[3], b[3], c[3], r[3];
+                    load_tri(prims, j, a, b, c);
+                    qi = __float_as_uint(prims[3 * j + 2].y);
+                    closest_on_tri(p, a, b, c, r);
+                    d = tri_dist2(p, r);
+                } else {
+                    const float4 q = prims[j];
+                    qi = __float_as_uint(q.w);
+                    d = d2_metric(p[0], p[1], p[2], q.x, q.y, q.z);
+                }
+                const uint32_t dbits = (d < INFINITY) ? __float_as_uint(d) : 0xFFFFFFFFu;   // d >= +0 here; NaN / inf never win
+                const uint32_t md = wave_min_u32(dbits);
+                if (md <= __float_as_uint(best) && md != 0xFFFFFFFFu) {
+                    const uint32_t mi = wave_min_u32(dbits == md ? qi : IDX_NONE);
+                    if (md < __float_as_uint(best) || mi < bidx) { best = __uint_as_float(md); bidx = mi; lim = fminf(best, cutf); }
+                }
+            }
+        }
+        if (lane == 0) keys[i] = ((unsigned long long)__float_as_uint(best) << 32) | bidx;
+    }
+}
+
+#endif  // __HIPCC__
+}  // namespace oa

@@ -26,6 +26,8 @@ struct GridParams {
     int    r_max;            // rings searched before handing the query to the brute-force kernel
     double slack;            // absolute slack subtracted from face distances (1e-10 x largest |coordinate|)
     double scale;            // largest |coordinate| of the box
+    int    budget;           // candidates one thread may look at before it hands the query to the tree search
+                             // (crowded cells -- clusters, fans of thin triangles -- would otherwise stall its wave)
 };
 
 #if defined(__HIPCC__)
@@ -117,23 +119,28 @@ __global__ __launch_bounds__(256) void k_nn_search_grid(const DevState *__restri
         off2 += d * d;
         c[a] = grid_cell_coord(pc[a], gp.lo[a], gp.inv_h, gp.n[a]);
     }
+    // `lim` = what an unseen vertex has to beat: the best so far, or the search radius beyond which the pair test
+    // (dist < thresh) fails anyway, whichever is smaller
+    const float cutf = search_cutoff2(st, px, py, pz);
+    float lim = fminf(best, cutf);
     bool settled = false;
+    int budget = gp.budget;
     if (finite) {
-        for (int r = 0; r <= gp.r_max && !settled; ++r) {
+        for (int r = 0; r <= gp.r_max && !settled && budget >= 0; ++r) {
             const int x0 = max(c[0] - r, 0), x1 = min(c[0] + r, gp.n[0] - 1);
             const int y0 = max(c[1] - r, 0), y1 = min(c[1] + r, gp.n[1] - 1);
             const int z0 = max(c[2] - r, 0), z1 = min(c[2] + r, gp.n[2] - 1);
-            for (int z = z0; z <= z1; ++z) {
+            for (int z = z0; z <= z1 && budget >= 0; ++z) {
                 const double dz = grid_axis_gap(pc[2], gp.lo[2], gp.h, z, gp.slack);
-                for (int y = y0; y <= y1; ++y) {
+                for (int y = y0; y <= y1 && budget >= 0; ++y) {
                     // every vertex of this row of cells is at real distance^2 >= off2 + dy^2 + dz^2 from the query
                     const double dy = grid_axis_gap(pc[1], gp.lo[1], gp.h, y, gp.slack);
                     const double row2 = off2 + dz * dz + dy * dy;
-                    if (row2 * (1.0 - 1e-5) - 1e-30 > (double)best) continue;      // cannot beat or tie
-                    // cells of the row that can still matter: |x - pc.x| <= sqrt(best' - row2)
+                    if (row2 * (1.0 - 1e-5) - 1e-30 > (double)lim) continue;       // cannot beat or tie
+                    // cells of the row that can still matter: |x - pc.x| <= sqrt(lim' - row2)
                     int xa = x0, xb = x1;
-                    if (best < INFINITY) {
-                        double w2 = (double)best * (1.0 + 1e-5) + 1e-30 - row2 * (1.0 - 1e-5);
+                    if (lim < INFINITY) {
+                        double w2 = (double)lim * (1.0 + 1e-5) + 1e-30 - row2 * (1.0 - 1e-5);
                         const double w = sqrt(w2 > 0.0 ? w2 : 0.0) * (1.0 + 1e-6) + gp.slack;
                         xa = max(xa, grid_cell_coord(pc[0] - w, gp.lo[0], gp.inv_h, gp.n[0]));
                         xb = min(xb, grid_cell_coord(pc[0] + w, gp.lo[0], gp.inv_h, gp.n[0]));
@@ -151,15 +158,18 @@ __global__ __launch_bounds__(256) void k_nn_search_grid(const DevState *__restri
                     }
                     for (int sg = 0; sg < n_seg; ++sg) {
                         const int j0 = cell_start[row + segs[sg][0]], j1 = cell_start[row + segs[sg][1] + 1];
+                        budget -= j1 - j0;
+                        if (budget < 0) break;                       // crowded cells: one wave of the tree search is faster
                         for (int j = j0; j < j1; ++j) {
                             const float4 q = sorted[j];
                             const float d = d2_metric(px, py, pz, q.x, q.y, q.z);
                             const uint32_t qi = (uint32_t)__float_as_int(q.w);
-                            if (d < best || (d == best && qi < bidx)) { best = d; bidx = qi; }
+                            if (d < best || (d == best && qi < bidx && d < INFINITY)) { best = d; bidx = qi; lim = fminf(best, cutf); }
                         }
                     }
                 }
             }
+            if (budget < 0) break;
             // lower bound for everything outside the cube of radius r
             double m = INFINITY;
             for (int a = 0; a < 3; ++a) {
@@ -171,12 +181,12 @@ __global__ __launch_bounds__(256) void k_nn_search_grid(const DevState *__restri
                 m -= gp.slack;
                 m = m > 0.0 ? m : 0.0;
                 const double bound = (off2 + m * m) * (1.0 - 1e-5) - 1e-30;
-                if (bound > (double)best) settled = true;        // no unseen vertex can beat or tie `best`
+                if (bound > (double)lim) settled = true;         // no unseen vertex can beat or tie `best`, or matter
             }
         }
     }
     keys[i] = ((unsigned long long)__float_as_uint(best) << 32) | bidx;
-    if (!settled) todo_list[atomicAdd(todo_count, 1)] = i;      // finished exactly by the brute-force kernel
+    if (!settled) todo_list[atomicAdd(todo_count, 1)] = i;      // finished exactly by the tree search (k_bvh_search)
 }
 
 __global__ void k_count_nonzero(const int *__restrict__ a, int n, int *__restrict__ out)

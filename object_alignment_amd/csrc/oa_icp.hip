@@ -9,6 +9,7 @@
 #include "oa_kernels.hpp"
 #include "oa_grid.hpp"
 #include "oa_tri.hpp"
+#include "oa_bvh.hpp"
 #include "../../include/oa_icp.h"
 
 #include <algorithm>
@@ -95,6 +96,10 @@ struct oa_ctx {
     float4 *d_tri9 = nullptr;
     oa::GridParams tgp;
     int *d_tcell_start = nullptr, *d_tcell_tris = nullptr;
+    // bounding-box trees (oa_bvh.hpp): over the vertices, and over the triangles in surface mode
+    bool bvh_ok = false, tbvh_ok = false;
+    oa::BvhParams bvh, tbvh;
+    float4 *d_bvh_box = nullptr, *d_bvh_prims = nullptr, *d_tbvh_box = nullptr, *d_tbvh_prims = nullptr;
     bool filter_ok = false;
     float tc[3] = { 0, 0, 0 };
     double qmax = 0.0;
@@ -210,9 +215,32 @@ int check_ready(oa_ctx *c)
 }
 
 bool grid_active(const oa_ctx *c);
+// every query through the tree: on request, and in auto mode for shards of up to `auto_max` points -- one wave per
+// query has far lower latency than the one-thread-per-query grid kernels until the waves no longer fit the chip
+// (measured crossover: ~3e4 points for vertices, ~1e5 for triangles; profiles/r01g_search_mode_crossover.txt)
+inline bool bvh_whole(const oa_ctx *c, bool ok, int auto_max)
+{
+    if (!ok) return false;
+    return c->grid_mode == 2 || (c->grid_mode == -1 && c->ns <= auto_max);
+}
 int build_grid(oa_ctx *c);
 int build_tri_grid(oa_ctx *c);
+int build_bvh(oa_ctx *c, bool tri);
+int scan_counts(oa_ctx *c, const int *d_counts, int n, long long *d_off);
 int launch_tri_search(oa_ctx *c);
+
+// one wave per query: 4 queries per workgroup, workgroups loop when there are more queries than that
+template <bool TRI>
+int launch_bvh(oa_ctx *c, const int *list, const int *list_count)
+{
+    const int items = list ? std::min(c->ns, 1 << 17) : c->ns;
+    const unsigned blocks = (unsigned)std::max(1, std::min((items + 3) / 4, c->n_cu * 64));
+    hipLaunchKernelGGL(oa::k_bvh_search<TRI>, dim3(blocks), dim3(256), 0, c->stream, c->d_state, c->d_src4, c->ns,
+                       TRI ? c->tbvh : c->bvh, TRI ? c->d_tbvh_box : c->d_bvh_box, TRI ? c->d_tbvh_prims : c->d_bvh_prims,
+                       c->d_tgt_xyz, c->d_tri9, c->d_prev, c->d_keys, list, list_count);
+    HIPCHK(hipGetLastError());
+    return OA_OK;
+}
 
 int launch_nn(oa_ctx *c)
 {
@@ -223,6 +251,7 @@ int launch_nn(oa_ctx *c)
     dim3 grid(c->n_splits, c->ns_pad / (oa::NN_THREADS * c->R));
     dim3 block(oa::NN_THREADS);
     const int *list = nullptr, *list_count = nullptr;
+    if (bvh_whole(c, c->bvh_ok, 32768)) return launch_bvh<false>(c, nullptr, nullptr);
     if (grid_active(c)) {
         // grid search settles (almost) every point; the rest go through the brute-force kernel in list mode.
         // Inside the loop k_solve_update leaves the counter at zero; one-shot calls clear it here.
@@ -232,6 +261,7 @@ int launch_nn(oa_ctx *c)
                            c->d_todo_list, c->d_todo_count);
         HIPCHK(hipGetLastError());
         list = c->d_todo_list; list_count = c->d_todo_count;
+        if (c->bvh_ok) return launch_bvh<false>(c, list, list_count);       // the far queries: tree search
         grid.y = std::min<unsigned>((unsigned)((c->ns + 1023) / 1024), 32u);
     }
 #define OA_NN_ARGS c->d_state, c->d_src4, c->d_tg, c->groups_per_split, c->n_groups_pad, c->d_keys
@@ -293,9 +323,54 @@ int launch_reduce(oa_ctx *c, double *d_sums)
     return OA_OK;
 }
 
-void init_loop_state(oa_ctx *c, const oa_settings *st, int iters)
+// smallest singular value of the upper-left 3x3 of a row-major 4x4 (cyclic Jacobi on M^T M, double)
+double min_singular_3x3(const float *M)
+{
+    double S[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double a = 0.0;
+            for (int k = 0; k < 3; ++k) a += (double)M[4 * k + i] * (double)M[4 * k + j];
+            S[i][j] = a;
+        }
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        const double off = fabs(S[0][1]) + fabs(S[0][2]) + fabs(S[1][2]);
+        if (!(off > 1e-300)) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (S[p][q] == 0.0) continue;
+                const double theta = (S[q][q] - S[p][p]) / (2.0 * S[p][q]);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+                for (int k = 0; k < 3; ++k) { const double a = S[k][p], b = S[k][q]; S[k][p] = cs * a - sn * b; S[k][q] = sn * a + cs * b; }
+                for (int k = 0; k < 3; ++k) { const double a = S[p][k], b = S[q][k]; S[p][k] = cs * a - sn * b; S[q][k] = sn * a + cs * b; }
+            }
+    }
+    double m = std::min(S[0][0], std::min(S[1][1], S[2][2]));
+    if (!(m > 0.0)) return 0.0;
+    return sqrt(m);
+}
+
+void init_loop_state(oa_ctx *c, const oa_settings *st, int iters, bool cutoff = true)
 {
     oa::DevState &s = c->h_state;
+    // search radius (DevState::cut_a / cut_b): only the grid / tree searches use it
+    s.cut_a = INFINITY; s.cut_b = 0.0;
+    if (cutoff && c->filter_ok && c->grid_mode != 0 && env_int("OA_NN_CUTOFF", 1)) {
+        const double smin = min_singular_3x3(s.mx2) * (1.0 - 1e-9);
+        double m2norm = 0.0, tmax = 0.0, tscale = 0.0;
+        for (int i = 0; i < 3; ++i) {
+            m2norm = std::max(m2norm, fabs((double)s.mx2[4 * i]) + fabs((double)s.mx2[4 * i + 1]) + fabs((double)s.mx2[4 * i + 2]));
+            tmax = std::max(tmax, fabs((double)s.mx2[4 * i + 3]));
+            tscale = std::max(tscale, std::max(fabs(c->bb_lo[i]), fabs(c->bb_hi[i])));
+        }
+        const double u64 = 64.0 * 5.9604644775390625e-08;
+        if (smin > 0.0 && st->thresh > 0.0 && st->thresh < 1e300) {
+            s.cut_a = (st->thresh + u64 * (m2norm * 3.0 * tscale + tmax)) / smin * (1.0 + 1e-5);
+            s.cut_b = u64 * m2norm / smin * (1.0 + 1e-5);
+            if (!(s.cut_a < 1e300) || !(s.cut_b < 1e300)) { s.cut_a = INFINITY; s.cut_b = 0.0; }
+        }
+    }
     for (int k = 0; k < 3; ++k) s.pivot[k] = c->pivot[k];
     s.thresh = st->thresh;
     s.target_d = st->target_d;
@@ -466,6 +541,7 @@ OA_EXPORT void oa_destroy(oa_ctx *c)
     dev_free(c->d_hist); dev_free(c->d_partials); dev_free(c->d_sums); dev_free(c->d_solve);
     dev_free(c->d_valid); dev_free(c->d_b); dev_free(c->d_dist); dev_free(c->d_counts); dev_free(c->d_offsets);
     dev_free(c->d_A); dev_free(c->d_B);
+    dev_free(c->d_bvh_box); dev_free(c->d_bvh_prims); dev_free(c->d_tbvh_box); dev_free(c->d_tbvh_prims);
     dev_free(c->d_tri9); dev_free(c->d_tcell_start); dev_free(c->d_tcell_tris);
     dev_free(c->d_sel); dev_free(c->d_src_n); dev_free(c->d_tgt_n); dev_free(c->d_src4o); dev_free(c->d_perm);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -478,14 +554,16 @@ OA_EXPORT void oa_destroy(oa_ctx *c)
 OA_EXPORT int oa_set_search_mode(oa_ctx *c, int mode)
 {
     if (!c) return fail(OA_E_BAD_ARG, "null context");
-    if (mode < -1 || mode > 1) return fail(OA_E_BAD_ARG, "search mode %d (use OA_SEARCH_AUTO/BRUTE/GRID)", mode);
+    if (mode < -1 || mode > 2) return fail(OA_E_BAD_ARG, "search mode %d (use OA_SEARCH_AUTO/BRUTE/GRID/BVH)", mode);
     const bool rebuild = (c->grid_mode == 0 && mode != 0 && c->nt > 0);
     c->grid_mode = mode;
     if (rebuild) {                                   // the grids were skipped when the target was uploaded
         int rc = use_device(c);
         if (rc) return rc;
         if (!c->grid_ok && (rc = build_grid(c))) return rc;
+        if (!c->bvh_ok && (rc = build_bvh(c, false))) return rc;
         if (c->surface && !c->tri_grid_ok && (rc = build_tri_grid(c))) return rc;
+        if (c->surface && !c->tbvh_ok && (rc = build_bvh(c, true))) return rc;
     }
     return OA_OK;
 }
@@ -587,12 +665,13 @@ int build_grid(oa_ctx *c)
         for (int a = 0; a < 3; ++a) if (ext[a] > 0.0 && ext[a] / h >= gp.n[a]) h = std::max(h, ext[a] / (gp.n[a] - 0.5));
         gp.h = h; gp.inv_h = 1.0 / h;
         gp.r_max = env_int("OA_GRID_RMAX", 3);
+        gp.budget = env_int("OA_GRID_BUDGET", 128);
         gp.slack = 1e-10 * scale + 1e-300;
         gp.scale = scale;
         n_cells = (int)total;
-        HIPCHK(d_counts.alloc((size_t)n_cells));
+        HIPCHK(d_counts.alloc((size_t)n_cells + 1));
         HIPCHK(d_off.alloc((size_t)n_cells + 1));
-        HIPCHK(hipMemsetAsync(d_counts, 0, sizeof(int) * (size_t)n_cells, c->stream));
+        HIPCHK(hipMemsetAsync(d_counts, 0, sizeof(int) * ((size_t)n_cells + 1), c->stream));
         HIPCHK(hipMemsetAsync(d_nz, 0, sizeof(int), c->stream));
         hipLaunchKernelGGL(oa::k_grid_count, dim3((c->nt + 255) / 256), dim3(256), 0, c->stream, c->d_tgt_xyz, c->nt, gp, d_cell_of.p, d_counts.p);
         hipLaunchKernelGGL(oa::k_count_nonzero, dim3((n_cells + 255) / 256), dim3(256), 0, c->stream, d_counts.p, n_cells, d_nz.p);
@@ -608,7 +687,7 @@ int build_grid(oa_ctx *c)
     if (n_cells <= 0) return OA_OK;
     HIPCHK(hipMalloc(&c->d_cell_start, sizeof(int) * (size_t)(n_cells + 1)));
     HIPCHK(hipMalloc(&c->d_sorted, sizeof(float4) * (size_t)c->nt));
-    hipLaunchKernelGGL(oa::k_scan_counts, dim3(1), dim3(1024), 0, c->stream, d_counts.p, n_cells, d_off.p);
+    { int rcs = scan_counts(c, d_counts.p, n_cells, d_off.p); if (rcs) return rcs; }
     hipLaunchKernelGGL(oa::k_grid_starts, dim3((n_cells + 256) / 256), dim3(256), 0, c->stream, d_off.p, n_cells, c->d_cell_start, d_counts.p);
     hipLaunchKernelGGL(oa::k_grid_scatter, dim3((c->nt + 255) / 256), dim3(256), 0, c->stream, c->d_tgt_xyz, c->nt, d_cell_of.p, c->d_cell_start, d_counts.p, c->d_sorted);
     HIPCHK(hipGetLastError());
@@ -620,8 +699,8 @@ int build_grid(oa_ctx *c)
 bool grid_active(const oa_ctx *c)
 {
     if (!c->grid_ok || !c->filter_ok || !c->use_filter || c->grid_mode == 0) return false;
-    if (c->grid_mode == 1) return true;
-    return c->nt >= 8192 && (double)c->nt * (double)c->ns >= 1e9;     // auto: small problems stay on the brute-force kernel
+    if (c->grid_mode == 2) return false;
+    return true;                                                      // auto: shards of <= 32768 points took the tree already
 }
 }  // namespace
 OA_EXPORT int oa_set_target(oa_ctx *c, const float *xyz, int64_t n, int on_device)
@@ -634,7 +713,8 @@ OA_EXPORT int oa_set_target(oa_ctx *c, const float *xyz, int64_t n, int on_devic
     HIPCHK(hipStreamSynchronize(c->stream));
     dev_free(c->d_tgt_xyz); dev_free(c->d_tg); dev_free(c->d_tf); dev_free(c->d_tf3);
     dev_free(c->d_tri9); dev_free(c->d_tcell_start); dev_free(c->d_tcell_tris);
-    c->surface = false; c->tri_grid_ok = false; c->n_tris = 0;
+    dev_free(c->d_bvh_box); dev_free(c->d_bvh_prims); dev_free(c->d_tbvh_box); dev_free(c->d_tbvh_prims);
+    c->surface = false; c->tri_grid_ok = false; c->n_tris = 0; c->bvh_ok = false; c->tbvh_ok = false;
     dev_free(c->d_tgt_n);
     c->normals_on = false;
     c->filter_ok = false;
@@ -659,11 +739,98 @@ OA_EXPORT int oa_set_target(oa_ctx *c, const float *xyz, int64_t n, int on_devic
     int rcf = build_filter(c);
     if (rcf) return rcf;
     if ((rcf = build_grid(c))) return rcf;
+    if ((rcf = build_bvh(c, false))) return rcf;
     plan_geometry(c);
     return OA_OK;
 }
 
 namespace {
+struct IntToLL { __host__ __device__ long long operator()(int v) const { return (long long)v; } };
+
+// offsets[0..n] = exclusive prefix sums of counts[0..n-1] (offsets[n] = total); counts must hold n + 1 ints, the last 0
+int scan_counts(oa_ctx *c, const int *d_counts, int n, long long *d_off)
+{
+    auto in = rocprim::make_transform_iterator(d_counts, IntToLL{});
+    size_t bytes = 0;
+    HIPCHK(rocprim::exclusive_scan(nullptr, bytes, in, d_off, 0ll, (size_t)n + 1, rocprim::plus<long long>(), c->stream));
+    DevTmp<char> tmp;
+    HIPCHK(tmp.alloc(bytes));
+    HIPCHK(rocprim::exclusive_scan((void *)tmp.p, bytes, in, d_off, 0ll, (size_t)n + 1, rocprim::plus<long long>(), c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));                      // tmp is released on return
+    return OA_OK;
+}
+
+// 64-ary bounding-box tree over the Morton-sorted vertices (tri = false) or triangles (tri = true), oa_bvh.hpp
+int build_bvh(oa_ctx *c, bool tri)
+{
+    bool &ok = tri ? c->tbvh_ok : c->bvh_ok;
+    float4 *&d_box = tri ? c->d_tbvh_box : c->d_bvh_box;
+    float4 *&d_prims = tri ? c->d_tbvh_prims : c->d_bvh_prims;
+    oa::BvhParams &bp = tri ? c->tbvh : c->bvh;
+    ok = false;
+    dev_free(d_box); dev_free(d_prims);
+    const int n = tri ? c->n_tris : c->nt;
+    if (!c->filter_ok || c->grid_mode == 0 || n < 1) return OA_OK;
+    bp = oa::BvhParams{};
+    bp.n_prims = n;
+    long long total = 0;
+    int level = 0;
+    for (long long cnt = ((long long)n + oa::BVH_W - 1) / oa::BVH_W;; cnt = (cnt + oa::BVH_W - 1) / oa::BVH_W) {
+        ++level;
+        if (level > oa::BVH_MAX_LEVELS) return OA_OK;
+        bp.cnt[level] = (int)cnt;
+        bp.off[level] = (int)total;
+        total += ((cnt + oa::BVH_W - 1) / oa::BVH_W) * oa::BVH_W;
+        if (cnt <= oa::BVH_W) break;
+    }
+    bp.levels = level;
+    double scale = 0.0;
+    float lo[3], sc[3];
+    for (int a = 0; a < 3; ++a) {
+        scale = std::max(scale, std::max(fabs(c->bb_lo[a]), fabs(c->bb_hi[a])));
+        lo[a] = (float)c->bb_lo[a];
+        const double ext = c->bb_hi[a] - c->bb_lo[a];
+        sc[a] = ext > 0.0 ? (float)(1023.0 / ext) : 0.f;
+    }
+    bp.scale = scale;
+    bp.slack = 1e-10 * scale + 1e-300;
+    const int n_pad = bp.cnt[1] * oa::BVH_W;
+    DevTmp<unsigned> k_in, k_out;
+    DevTmp<int> v_in, v_out;
+    HIPCHK(k_in.alloc((size_t)n)); HIPCHK(k_out.alloc((size_t)n)); HIPCHK(v_in.alloc((size_t)n)); HIPCHK(v_out.alloc((size_t)n));
+    const dim3 blk(256), grd((unsigned)((n + 255) / 256));
+    if (tri) hipLaunchKernelGGL(oa::k_bvh_keys<true>, grd, blk, 0, c->stream, (const float *)c->d_tgt_xyz, (const float4 *)c->d_tri9,
+                                n, lo[0], lo[1], lo[2], sc[0], sc[1], sc[2], k_in.p, v_in.p);
+    else hipLaunchKernelGGL(oa::k_bvh_keys<false>, grd, blk, 0, c->stream, (const float *)c->d_tgt_xyz, (const float4 *)nullptr,
+                            n, lo[0], lo[1], lo[2], sc[0], sc[1], sc[2], k_in.p, v_in.p);
+    HIPCHK(hipGetLastError());
+    size_t bytes = 0;
+    HIPCHK(rocprim::radix_sort_pairs(nullptr, bytes, k_in.p, k_out.p, v_in.p, v_out.p, (size_t)n, 0, 30, c->stream));
+    DevTmp<char> tmp;
+    HIPCHK(tmp.alloc(bytes));
+    HIPCHK(rocprim::radix_sort_pairs((void *)tmp.p, bytes, k_in.p, k_out.p, v_in.p, v_out.p, (size_t)n, 0, 30, c->stream));
+    HIPCHK(hipMalloc(&d_prims, sizeof(float4) * (tri ? 3 : 1) * (size_t)n_pad));
+    HIPCHK(hipMalloc(&d_box, sizeof(float4) * 2 * (size_t)total));
+    const dim3 grd_pad((unsigned)((n_pad + 255) / 256));
+    if (tri) hipLaunchKernelGGL(oa::k_bvh_gather<true>, grd_pad, blk, 0, c->stream, (const float *)c->d_tgt_xyz, (const float4 *)c->d_tri9,
+                                (const int *)v_out.p, n, n_pad, d_prims);
+    else hipLaunchKernelGGL(oa::k_bvh_gather<false>, grd_pad, blk, 0, c->stream, (const float *)c->d_tgt_xyz, (const float4 *)nullptr,
+                            (const int *)v_out.p, n, n_pad, d_prims);
+    HIPCHK(hipGetLastError());
+    const dim3 grd1((unsigned)((bp.cnt[1] + 255) / 256));
+    if (tri) hipLaunchKernelGGL(oa::k_bvh_leaf_boxes<true>, grd1, blk, 0, c->stream, (const float4 *)d_prims, n_pad, bp.cnt[1], d_box + 2ll * bp.off[1]);
+    else hipLaunchKernelGGL(oa::k_bvh_leaf_boxes<false>, grd1, blk, 0, c->stream, (const float4 *)d_prims, n_pad, bp.cnt[1], d_box + 2ll * bp.off[1]);
+    HIPCHK(hipGetLastError());
+    for (int l = 2; l <= bp.levels; ++l) {
+        hipLaunchKernelGGL(oa::k_bvh_upper_boxes, dim3((unsigned)((bp.cnt[l] + 255) / 256)), blk, 0, c->stream,
+                           (const float4 *)(d_box + 2ll * bp.off[l - 1]), bp.cnt[l - 1], bp.cnt[l], d_box + 2ll * bp.off[l]);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    ok = true;
+    return OA_OK;
+}
+
 // Spatial (Morton) order of the source slots: the points a wave owns are neighbours in space, so the grid search's
 // reads are shared instead of scattered and the brute-force filter's slow path fires for fewer waves.  The caller-
 // order copy and the permutation stay around for the entry points that return per-point data in vlist order.
@@ -757,11 +924,12 @@ int build_tri_grid(oa_ctx *c)
         if (total > max_cells) { h *= 1.3; n_cells = 0; continue; }
         gp.h = h; gp.inv_h = 1.0 / h;
         gp.r_max = env_int("OA_GRID_RMAX", 3);
+        gp.budget = env_int("OA_GRID_BUDGET", 128);
         gp.scale = scale;
         gp.slack = 1e-10 * scale + 1e-300;
         n_cells = (int)total;
-        HIPCHK(d_counts.alloc((size_t)n_cells));
-        HIPCHK(hipMemsetAsync(d_counts, 0, sizeof(int) * (size_t)n_cells, c->stream));
+        HIPCHK(d_counts.alloc((size_t)n_cells + 1));
+        HIPCHK(hipMemsetAsync(d_counts, 0, sizeof(int) * ((size_t)n_cells + 1), c->stream));
         HIPCHK(hipMemsetAsync(d_total, 0, sizeof(unsigned long long), c->stream));
         hipLaunchKernelGGL(oa::k_tri_grid_bin<false>, dim3((c->n_tris + 255) / 256), dim3(256), 0, c->stream, c->d_tri9,
                            c->n_tris, gp, d_counts.p, (const int *)nullptr, (int *)nullptr, d_total.p);
@@ -776,7 +944,7 @@ int build_tri_grid(oa_ctx *c)
     HIPCHK(d_off.alloc((size_t)n_cells + 1));
     HIPCHK(hipMalloc(&c->d_tcell_start, sizeof(int) * (size_t)(n_cells + 1)));
     HIPCHK(hipMalloc(&c->d_tcell_tris, sizeof(int) * (size_t)entries));
-    hipLaunchKernelGGL(oa::k_scan_counts, dim3(1), dim3(1024), 0, c->stream, d_counts.p, n_cells, d_off.p);
+    { int rcs = scan_counts(c, d_counts.p, n_cells, d_off.p); if (rcs) return rcs; }
     hipLaunchKernelGGL(oa::k_grid_starts, dim3((n_cells + 256) / 256), dim3(256), 0, c->stream, d_off.p, n_cells, c->d_tcell_start, d_counts.p);
     hipLaunchKernelGGL(oa::k_tri_grid_bin<true>, dim3((c->n_tris + 255) / 256), dim3(256), 0, c->stream, c->d_tri9, c->n_tris,
                        gp, d_counts.p, (const int *)c->d_tcell_start, c->d_tcell_tris, (unsigned long long *)nullptr);
@@ -789,8 +957,8 @@ int build_tri_grid(oa_ctx *c)
 
 int launch_tri_search(oa_ctx *c)
 {
-    const bool use_grid = c->tri_grid_ok && c->grid_mode != 0 &&
-                          (c->grid_mode == 1 || (double)c->n_tris * (double)c->ns >= 2e7);
+    if (bvh_whole(c, c->tbvh_ok, 65536)) return launch_bvh<true>(c, nullptr, nullptr);
+    const bool use_grid = c->tri_grid_ok && c->tbvh_ok && c->grid_mode != 0;
     if (getenv("OA_DEBUG"))
         fprintf(stderr, "[oa] tri search: grid=%d ns=%d n_tris=%d state=%p src4=%p tri9=%p prev=%p keys=%p todo=%p/%p cells=%p/%p\n",
                 (int)use_grid, c->ns, c->n_tris, (void *)c->d_state, (void *)c->d_src4, (void *)c->d_tri9, (void *)c->d_prev,
@@ -800,9 +968,8 @@ int launch_tri_search(oa_ctx *c)
         hipLaunchKernelGGL(oa::k_tri_search_grid, dim3((c->ns + 255) / 256), dim3(256), 0, c->stream, c->d_state, c->d_src4,
                            c->ns, c->tgp, c->d_tcell_start, c->d_tcell_tris, c->d_tri9, c->d_prev, c->d_keys,
                            c->d_todo_list, c->d_todo_count);
-        hipLaunchKernelGGL(oa::k_tri_search_all, dim3(std::min((c->ns + 255) / 256, 2048)), dim3(256), 0, c->stream,
-                           c->d_state, c->d_src4, c->ns, c->d_tri9, c->n_tris, c->d_prev, c->d_keys,
-                           (const int *)c->d_todo_list, (const int *)c->d_todo_count);
+        HIPCHK(hipGetLastError());
+        return launch_bvh<true>(c, c->d_todo_list, c->d_todo_count);       // the far queries: tree search
     } else {
         hipLaunchKernelGGL(oa::k_tri_search_all, dim3(std::min((c->ns + 255) / 256, 65535)), dim3(256), 0, c->stream,
                            c->d_state, c->d_src4, c->ns, c->d_tri9, c->n_tris, c->d_prev, c->d_keys,
@@ -837,6 +1004,7 @@ OA_EXPORT int oa_set_target_mesh(oa_ctx *c, const float *xyz, int64_t n_verts, i
     if (bad) { dev_free(c->d_tri9); return fail(OA_E_BAD_ARG, "oa_set_target_mesh: %d triangle corners index outside 0..%lld", bad, (long long)n_verts - 1); }
     c->n_tris = (int)n_tris;
     c->surface = true;
+    if ((rc = build_bvh(c, true))) return rc;
     return build_tri_grid(c);
 }
 
@@ -991,11 +1159,11 @@ OA_EXPORT int oa_get_pivot(oa_ctx *c, double pivot[3])
 // ================================================================================================
 namespace {
 // copies the host mirror (matrices, pivot) to the device with a neutral loop state
-int push_state_for_oneshot(oa_ctx *c, double thresh)
+int push_state_for_oneshot(oa_ctx *c, double thresh, bool cutoff)
 {
     oa_settings st{};
     st.iters = 1; st.use_target = 1; st.with_scale = 0; st.early_exit = 0; st.thresh = thresh; st.target_d = 0.0;
-    init_loop_state(c, &st, 1);
+    init_loop_state(c, &st, 1, cutoff);
     HIPCHK(hipMemcpyAsync(c->d_state, &c->h_state, sizeof(oa::DevState), hipMemcpyHostToDevice, c->stream));
     c->loop_active = false;
     return OA_OK;
@@ -1009,7 +1177,7 @@ OA_EXPORT int oa_nn_search(oa_ctx *c, int64_t *idx, float *d2, double *kernel_ms
     if ((rc = use_device(c))) return rc;
     if ((rc = ensure_common(c))) return rc;
     if ((rc = ensure_events(c, 1))) return rc;
-    if ((rc = push_state_for_oneshot(c, 1.0))) return rc;
+    if ((rc = push_state_for_oneshot(c, 1.0, false))) return rc;
     if (kernel_ms) *kernel_ms = 0.0;
     if (c->ns <= 0) return OA_OK;
     DevTmp<long long> d_idx;
@@ -1062,7 +1230,7 @@ OA_EXPORT int oa_make_pairs(oa_ctx *c, double thresh, int calc_stats, double *A,
         c->emit_cap = c->ns;
     }
     c->d_pivot0 = 0.0;
-    if ((rc = push_state_for_oneshot(c, thresh))) return rc;
+    if ((rc = push_state_for_oneshot(c, thresh, true))) return rc;
     if ((rc = launch_nn(c))) return rc;
     if ((rc = launch_accumulate(c, true, nullptr, nullptr))) return rc;
     if ((rc = launch_reduce(c, c->d_sums))) return rc;
@@ -1074,7 +1242,7 @@ OA_EXPORT int oa_make_pairs(oa_ctx *c, double thresh, int calc_stats, double *A,
         HIPCHK(hipStreamSynchronize(c->stream));
         if (s1[oa::S_K] > 0.0) {
             c->d_pivot0 = s1[oa::S_D] / s1[oa::S_K];
-            if ((rc = push_state_for_oneshot(c, thresh))) { c->d_pivot0 = 0.0; return rc; }
+            if ((rc = push_state_for_oneshot(c, thresh, true))) { c->d_pivot0 = 0.0; return rc; }
             rc = launch_nn(c);
             if (!rc) rc = launch_accumulate(c, true, nullptr, nullptr);
             if (!rc) rc = launch_reduce(c, c->d_sums);

@@ -51,7 +51,24 @@ struct DevState {
     int32_t fax[3], pad2;    // filter axes: fax[0], fax[1] kept by the 2-D score, fax[2] (smallest extent) dropped
     double d_pivot;      // subtracted from the pair distances before summing (previous iteration's mean): keeps
                          // the one-pass variance sum d^2 - K mean^2 free of cancellation
+    // Search radius (grid / tree searches only): a query whose nearest primitive is farther than
+    // cut_a + cut_b (|x| + |y| + |z|) in base-local space is certain to fail `dist < thresh` (general.py:300), so
+    // the search may stop there.  cut_a = +inf switches it off (oa_nn_search, brute-force mode).  See search_cutoff().
+    double cut_a, cut_b;
 };
+
+// Squared local search radius for the query p (rounded up to float).  Derivation: the pair test measures
+// |mx2 a - mx2 b| in float32; for real local distance D the real world distance is >= sigma_min(mx2) D, and the
+// float32 evaluation of the two products, the difference and the length is off by < 64u (|mx2|_inf (|a|+|b|) + |t|).
+// init_loop_state() folds thresh, sigma_min, the target's extent and those error terms into cut_a, cut_b (+1e-5).
+__host__ __device__ inline float search_cutoff2(const DevState *st, float px, float py, float pz)
+{
+    if (!(st->cut_a < 1e300)) return INFINITY;
+    const double pabs = fabs((double)px) + fabs((double)py) + fabs((double)pz);
+    const double c = st->cut_a + st->cut_b * pabs;
+    const double c2 = c * c * (1.0 + 1e-6);
+    return c2 < 3.0e38 ? (float)c2 : INFINITY;
+}
 
 // ------------------------------------------------------------------------------------------------
 // float32 "mathutils" arithmetic (host + device, identical bits)

@@ -100,7 +100,42 @@ __device__ __forceinline__ void tri_eval(const float *p, const float4 *__restric
     load_tri(tri9, t, a, b, c);
     closest_on_tri(p, a, b, c, r);
     const float d = tri_dist2(p, r);
-    if (d < best || (d == best && t < bidx)) { best = d; bidx = t; }
+    if (d < best || (d == best && t < bidx && d < INFINITY)) { best = d; bidx = t; }
+}
+
+// Squared-gap threshold above which a triangle's bounding box proves it can neither beat nor tie `best`: the float32
+// closest-point evaluation is >= (D - delta)^2 (1 - 1e-5) for real distance D, so a box at squared gap
+// > (delta + sqrt((best + 1e-30) / (1 - 1e-5)))^2 is out.  The extra 3e-6 covers the float rounding of the gap (6u) and
+// of the threshold itself.
+__device__ __forceinline__ float tri_skip_threshold(float best, double delta)
+{
+    if (!(best < INFINITY)) return INFINITY;
+    const double s = delta + sqrt(((double)best + 1e-30) / (1.0 - 1e-5));
+    return (float)(s * s * (1.0 + 3e-6));
+}
+
+// tri_eval behind the bounding-box test; `thr` follows `best` (recomputed only when the best improves)
+__device__ __forceinline__ void tri_eval_boxed(const float *p, const float4 *__restrict__ tri9, uint32_t t, float &best,
+                                               uint32_t &bidx, float &lim, float &thr, double delta, float cutf)
+{
+    if (t == bidx) return;                                         // already the best: listed in several cells
+    float a[3], b[3], c[3], r[3];
+    load_tri(tri9, t, a, b, c);
+    float lb = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float lo = fminf(fminf(a[k], b[k]), c[k]), hi = fmaxf(fmaxf(a[k], b[k]), c[k]);
+        const float g = fmaxf(fmaxf(lo - p[k], p[k] - hi), 0.f);
+        lb += g * g;
+    }
+    if (lb > thr) return;
+    closest_on_tri(p, a, b, c, r);
+    const float d = tri_dist2(p, r);
+    if (d < best || (d == best && t < bidx && d < INFINITY)) {
+        best = d; bidx = t;
+        lim = fminf(best, cutf);
+        thr = tri_skip_threshold(lim, delta);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_tri_search_grid(const DevState *__restrict__ st,
@@ -139,34 +174,53 @@ __global__ __launch_bounds__(256) void k_tri_search_grid(const DevState *__restr
     }
     // float32 closest-point evaluation can undershoot the real distance by at most delta
     const double delta = 64.0 * 5.9604644775390625e-08 * (gp.scale + pabs) + gp.slack;
+    // `lim`: the best so far or the search radius (search_cutoff2), whichever is smaller -- see k_nn_search_grid
+    const float cutf = search_cutoff2(st, pf[0], pf[1], pf[2]);
+    float lim = fminf(best, cutf);
+    float thr = tri_skip_threshold(lim, delta);
     bool settled = false;
+    int budget = gp.budget;                                        // candidates this thread may look at (see GridParams)
     if (finite) {
-        for (int r = 0; r <= gp.r_max && !settled; ++r) {
+        for (int r = 0; r <= gp.r_max && !settled && budget >= 0; ++r) {
             const int x0 = max(c[0] - r, 0), x1 = min(c[0] + r, gp.n[0] - 1);
             const int y0 = max(c[1] - r, 0), y1 = min(c[1] + r, gp.n[1] - 1);
             const int z0 = max(c[2] - r, 0), z1 = min(c[2] + r, gp.n[2] - 1);
-            for (int z = z0; z <= z1; ++z) {
+            for (int z = z0; z <= z1 && budget >= 0; ++z) {
                 const double dz = grid_axis_gap(pc[2], gp.lo[2], gp.h, z, gp.slack);
-                for (int y = y0; y <= y1; ++y) {
+                for (int y = y0; y <= y1 && budget >= 0; ++y) {
                     const double dy = grid_axis_gap(pc[1], gp.lo[1], gp.h, y, gp.slack);
-                    double lb = sqrt(off2 + dz * dz + dy * dy) - delta;
+                    const double row2 = off2 + dz * dz + dy * dy;
+                    double lb = sqrt(row2) - delta;
                     lb = lb > 0.0 ? lb : 0.0;
-                    if (lb * lb * (1.0 - 1e-5) - 1e-30 > (double)best) continue;
+                    if (lb * lb * (1.0 - 1e-5) - 1e-30 > (double)lim) continue;
+                    // cells of the row whose slab along x can still hold a triangle at distance <= sqrt(lim) + delta
+                    int xa = x0, xb = x1;
+                    if (lim < INFINITY) {
+                        const double reach = (delta + sqrt(((double)lim + 1e-30) / (1.0 - 1e-5))) * (1.0 + 1e-9);
+                        double w2 = reach * reach - row2 * (1.0 - 1e-9);
+                        const double w = sqrt(w2 > 0.0 ? w2 : 0.0) * (1.0 + 1e-6) + gp.slack;
+                        xa = max(xa, grid_cell_coord(pc[0] - w, gp.lo[0], gp.inv_h, gp.n[0]));
+                        xb = min(xb, grid_cell_coord(pc[0] + w, gp.lo[0], gp.inv_h, gp.n[0]));
+                    }
                     const bool shell_row = (r == 0) || z == c[2] - r || z == c[2] + r || y == c[1] - r || y == c[1] + r;
                     const int row = (z * gp.n[1] + y) * gp.n[0];
                     int segs[2][2];
                     int n_seg = 0;
-                    if (shell_row) { segs[0][0] = x0; segs[0][1] = x1; n_seg = 1; }
+                    if (shell_row) { if (xa <= xb) { segs[0][0] = xa; segs[0][1] = xb; n_seg = 1; } }
                     else {
-                        if (c[0] - r >= 0) { segs[n_seg][0] = c[0] - r; segs[n_seg][1] = c[0] - r; ++n_seg; }
-                        if (c[0] + r < gp.n[0]) { segs[n_seg][0] = c[0] + r; segs[n_seg][1] = c[0] + r; ++n_seg; }
+                        const int xl = c[0] - r, xr = c[0] + r;
+                        if (xl >= xa && xl <= xb) { segs[n_seg][0] = xl; segs[n_seg][1] = xl; ++n_seg; }
+                        if (xr >= xa && xr <= xb) { segs[n_seg][0] = xr; segs[n_seg][1] = xr; ++n_seg; }
                     }
                     for (int sg = 0; sg < n_seg; ++sg) {
                         const int j0 = cell_start[row + segs[sg][0]], j1 = cell_start[row + segs[sg][1] + 1];
-                        for (int j = j0; j < j1; ++j) tri_eval(pf, tri9, (uint32_t)cell_tris[j], best, bidx);
+                        budget -= j1 - j0;
+                        if (budget < 0) break;                       // crowded cells: one wave of the tree search is faster
+                        for (int j = j0; j < j1; ++j) tri_eval_boxed(pf, tri9, (uint32_t)cell_tris[j], best, bidx, lim, thr, delta, cutf);
                     }
                 }
             }
+            if (budget < 0) break;
             double m = INFINITY;
             for (int a = 0; a < 3; ++a) {
                 if (c[a] - r > 0) { const double f = pc[a] - (gp.lo[a] + (double)(c[a] - r) * gp.h); m = f < m ? f : m; }
@@ -178,7 +232,7 @@ __global__ __launch_bounds__(256) void k_tri_search_grid(const DevState *__restr
                 m = m > 0.0 ? m : 0.0;
                 double lb = sqrt(off2 + m * m) - delta;
                 lb = lb > 0.0 ? lb : 0.0;
-                if (lb * lb * (1.0 - 1e-5) - 1e-30 > (double)best) settled = true;
+                if (lb * lb * (1.0 - 1e-5) - 1e-30 > (double)lim) settled = true;
             }
         }
     }

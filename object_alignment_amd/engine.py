@@ -82,9 +82,10 @@ class IcpEngine:
         capi.check(self._L.oa_set_stream(self._h, h))
 
     def set_search_mode(self, mode):
-        """'auto' (default), 'brute' (north-star LDS-tiled brute force) or 'grid' (uniform-grid exact search).
+        """'auto' (default), 'brute' (north-star LDS-tiled brute force), 'grid' (uniform-grid exact search, far
+        queries finished by the tree) or 'bvh' (every query through the bounding-box tree).
         All modes return identical correspondences."""
-        code = {"auto": -1, "brute": 0, "grid": 1}[mode] if isinstance(mode, str) else int(mode)
+        code = {"auto": -1, "brute": 0, "grid": 1, "bvh": 2}[mode] if isinstance(mode, str) else int(mode)
         capi.check(self._L.oa_set_search_mode(self._h, code))
 
     # ---- uploads

@@ -2,7 +2,7 @@
 """GPU box: randomized differential test of the HIP path against the CPU oracle.
 
 Every trial draws a cloud family, sizes, scales, offsets and two (possibly non-uniformly scaled) matrix_world
-matrices, then checks, for search modes brute and grid:
+matrices, then checks, for search modes brute, grid and bvh:
   * oa_nn_search == oracle brute force (index and float32 d2, bit exact) -- vertex mode and surface mode;
   * oa_make_pairs == oracle make_pairs (A, B bit exact; d_stats to 1e-9).
 Usage: python tools/fuzz_parity.py [trials] [seed]
@@ -56,7 +56,7 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     rng = np.random.default_rng(seed)
     kinds = ["uniform", "gauss", "sphere", "lattice", "clusters", "line", "plane"]
-    engines = {m: IcpEngine(0) for m in ("brute", "grid")}
+    engines = {m: IcpEngine(0) for m in ("brute", "grid", "bvh")}
     for m, e in engines.items():
         e.set_search_mode(m)
     bad = 0

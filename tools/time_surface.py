@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""GPU box: surface-mode (closest point on triangles) timing at scale, next to vertex mode on the same meshes.
+Usage: python tools/time_surface.py [nu] [nv] [n_source]"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from object_alignment_amd import synth
+from object_alignment_amd.engine import IcpEngine
+
+nu = int(sys.argv[1]) if len(sys.argv) > 1 else 700
+nv = int(sys.argv[2]) if len(sys.argv) > 2 else 1400
+ns = int(sys.argv[3]) if len(sys.argv) > 3 else 1_000_000
+partial = os.environ.get("PARTIAL", "0") == "1"      # keep only the z > 0 half of the target: half the queries are far
+tgt, tris = synth.lattice_surface_mesh(nu, nv)
+if partial:
+    keep_v = tgt[:, 2] > 0.0
+    keep_t = keep_v[tris].all(axis=1)
+    remap = np.cumsum(keep_v) - 1
+    tgt, tris = tgt[keep_v], remap[tris[keep_t]].astype(np.int32)
+src = synth.bunny_surface(ns, offset=0.37)
+mxa = synth.rigid4(synth.rotation_from_rotvec([0.02, -0.015, 0.025]), [0.01, -0.008, 0.012])
+mxb = np.identity(4, dtype=np.float32)
+print("target %d vertices, %d triangles; source %d points" % (len(tgt), len(tris), ns), flush=True)
+combos = [("surface", "grid"), ("surface", "bvh"), ("vertex", "grid"), ("vertex", "bvh")]
+for mode, search in combos:
+    with IcpEngine(0) as e:
+        e.set_search_mode(search)
+        t0 = time.perf_counter()
+        if mode == "surface":
+            e.set_target_mesh(tgt, tris)
+        else:
+            e.set_target(tgt)
+        e.set_source(src, stride=1)
+        up = time.perf_counter() - t0
+        for it in (5, 30):
+            e.set_matrices(mxa, mxb)
+            t0 = time.perf_counter()
+            r = e.run(iters=it, thresh=0.05, early_exit=False)
+            wall = time.perf_counter() - t0
+            print("%-8s %-5s upload+build %.1f ms; iters %d: wall %.3f ms/iter, device loop %.3f ms/iter, nn %.3f ms/iter, K %d, "
+                  "mean dist %.3e" % (mode, search, 1e3 * up, it, 1e3 * wall / it, r.loop_ms / it, r.nn_ms_total / it, r.last_K,
+                                      r.mean_dist), flush=True)
