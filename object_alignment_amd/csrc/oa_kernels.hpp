@@ -781,7 +781,7 @@ __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_filt
                             }
                             if (b < best[r]) filter_thresholds(b, hu[r], hv[r], hd[r], qmax, thr2[r], thr3[r]);
                             best[r] = b;
-                            bidx[r] = bi;
+                            bidx[r] = (b < INFINITY) ? bi : IDX_NONE;     // overflowed distances (+inf) never win
                         }
                     }
                 }

@@ -214,7 +214,7 @@ def test_grid_search_identical_to_brute_force(orc, case):
         tgt = rng.uniform(-1, 1, size=(30000, 3)).astype(np.float32)
         src = (rng.normal(size=(6000, 3)) * 3.0).astype(np.float32)
     ref_idx, ref_d2 = orc.nn_brute(_cofind(orc, src, mxa, eye), tgt)
-    for mode in ("brute", "grid"):
+    for mode in ("brute", "grid", "bvh", "auto"):
         with IcpEngine(0) as e:
             e.set_search_mode(mode)
             e.set_target(tgt)
@@ -230,7 +230,7 @@ def test_grid_search_identical_to_brute_force(orc, case):
         assert np.array_equal(idx2, r2) and np.array_equal(d22, rd2), (case, mode, "seeded")
 
 
-@pytest.mark.parametrize("mode", ["brute", "grid"])
+@pytest.mark.parametrize("mode", ["brute", "grid", "bvh"])
 def test_non_finite_coordinates(orc, mode):
     """NaN / Inf vertices never win and never poison their neighbours: same answers as the oracle (index -1 and
     d2 = +inf for a query that has no finite distance)."""
@@ -365,7 +365,7 @@ def _settings_from(g):
                        align_meth=str(int(meth)))
 
 
-@pytest.mark.parametrize("mode", ["brute", "grid"])
+@pytest.mark.parametrize("mode", ["brute", "grid", "bvh", "auto"])
 @pytest.mark.parametrize("name", LOOPS)
 def test_icp_align_run_golden(golden_dir, name, mode):
     """IcpAlign.run reproduces what the reference's execute() produced, iteration by iteration."""
@@ -459,7 +459,7 @@ def test_modal_operator_ticks(golden_dir, orc):
         setattr(icp_align.get_addon_preferences(), k, v)
 
 
-@pytest.mark.parametrize("mode", ["brute", "grid"])
+@pytest.mark.parametrize("mode", ["brute", "grid", "bvh"])
 def test_runs_are_bitwise_reproducible(mode):
     """No float atomics anywhere on the result path: repeated runs (fresh contexts, fresh grid builds whose
     in-cell order is scheduling dependent) give bit-identical matrices, sums and statistics."""
@@ -784,7 +784,7 @@ def _surface_cases():
     return {"ico": (v1, t1, q1), "lattice": (v2, t2, q2), "far": (v2, t2, q3), "ties": (v4, t4, q4)}
 
 
-@pytest.mark.parametrize("mode", ["brute", "grid"])
+@pytest.mark.parametrize("mode", ["brute", "grid", "bvh", "auto"])
 @pytest.mark.parametrize("case", ["ico", "lattice", "far", "ties"])
 def test_surface_search_bit_exact(orc, case, mode):
     """Nearest triangle index and float32 squared distance equal the oracle's brute force over all triangles."""
@@ -892,3 +892,120 @@ def test_normal_angle_rejection_extension(orc, surface):
         e.set_matrices(mxa, mxb)
     rA2, _, _ = orc.make_pairs(src, tgt, res.matrix_world, mxb, 0.3, sample=1, tris=tris)
     assert A2.shape == rA2.shape
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("surface", [False, True])
+@pytest.mark.parametrize("mode", ["grid", "bvh", "auto"])
+def test_search_radius_does_not_change_pairs(orc, mode, surface, monkeypatch):
+    """The grid / tree searches stop at the radius beyond which `dist < thresh` (general.py:300) cannot hold
+    (DevState::cut_a): pairs, statistics and the loop must equal the oracle's exact search, for partial overlaps,
+    a non-uniformly scaled base matrix and thresholds from "almost nothing passes" to "everything passes"."""
+    from object_alignment_amd import synth
+    from object_alignment_amd.engine import IcpEngine
+    verts, tris = synth.lattice_surface_mesh(90, 180)
+    keep = verts[:, 2] > -0.2                                      # the base misses a cap: those queries are far
+    remap = np.cumsum(keep) - 1
+    tris = remap[tris[keep[tris].all(axis=1)]].astype(np.int32)
+    verts = verts[keep]
+    src = synth.bunny_surface(40000, 0.3)
+    mxb = synth.rigid4(synth.rotation_from_rotvec([0.3, -0.2, 0.1]) @ np.diag([0.4, 1.0, 2.5]), [5.0, -3.0, 1.0])
+    mxa = (mxb.astype(np.float64) @ synth.rigid4(synth.rotation_from_rotvec([0.03, 0.02, -0.04]), [0.02, 0.01, -0.015]).astype(np.float64)).astype(np.float32)
+    kw = dict(tris=tris) if surface else {}
+    with IcpEngine(0) as e:
+        e.set_search_mode(mode)
+        if surface:
+            e.set_target_mesh(verts, tris)
+        else:
+            e.set_target(verts)
+        e.set_source(src)
+        for thresh in (1e-4, 0.01, 0.08, 0.6, 50.0):
+            e.set_matrices(mxa, mxb)
+            A, B, ds = e.make_pairs(thresh, calc_stats=True)
+            rA, rB, rds = orc.make_pairs(src, verts, mxa, mxb, thresh, calc_stats=True, **kw)
+            assert A.shape == rA.shape and np.array_equal(A, rA) and np.array_equal(B, rB), (thresh, A.shape, rA.shape)
+            if rA.shape[1]:
+                assert np.allclose(ds, rds, rtol=1e-8, atol=1e-13)
+        e.set_matrices(mxa, mxb)
+        res = e.run(iters=8, thresh=0.08, target_d=1e-12)
+    ref = orc.icp_run(src, verts, mxa, mxb, iters=8, thresh=0.08, target_d=1e-12, sample=1, **kw)
+    assert np.array_equal(res.step_K, ref["step_K"])
+    assert 0 < res.step_K[-1] < len(src)                           # a real mix of kept and dropped pairs
+    assert np.abs(res.step_M - ref["step_M"]).max() < 1e-9
+    assert np.abs(res.matrix_world - ref["matrix_world"]).max() <= F32_ULP
+    # with the radius switched off the answers are the same
+    monkeypatch.setenv("OA_NN_CUTOFF", "0")
+    with IcpEngine(0) as e:
+        e.set_search_mode(mode)
+        if surface:
+            e.set_target_mesh(verts, tris)
+        else:
+            e.set_target(verts)
+        e.set_source(src)
+        e.set_matrices(mxa, mxb)
+        res0 = e.run(iters=8, thresh=0.08, target_d=1e-12)
+    assert np.array_equal(res0.matrix_world, res.matrix_world)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("surface", [False, True])
+def test_crowded_cells_are_handed_to_the_tree(orc, surface, monkeypatch):
+    """Grid cells holding more candidates than a thread's budget (a fan of 4000 thin triangles around one vertex; a
+    cluster of 5000 coincident-ish vertices) are finished by k_bvh_search: same answers, for any budget."""
+    from object_alignment_amd.engine import IcpEngine
+    rng = np.random.default_rng(77)
+    n_fan = 4000
+    ang = np.linspace(0, 2 * np.pi, n_fan, endpoint=False)
+    rim = np.stack([np.cos(ang), np.sin(ang), 0.05 * np.sin(7 * ang)], 1)
+    cloud = rng.uniform(-1, 1, size=(20000, 3)) * [1.0, 1.0, 0.2] + [0, 0, 1.5]
+    verts = np.concatenate([[[0.0, 0.0, 0.3]], rim, cloud]).astype(np.float32)
+    fan = np.stack([np.zeros(n_fan, int), 1 + np.arange(n_fan), 1 + (np.arange(n_fan) + 1) % n_fan], 1)
+    extra = rng.integers(1 + n_fan, len(verts), size=(3000, 3))
+    tris = np.concatenate([fan, extra]).astype(np.int32)
+    if not surface:
+        verts = np.concatenate([verts, (rng.normal(size=(5000, 3)) * 1e-5 + [0.2, 0.2, 0.2]).astype(np.float32)])
+    q = np.concatenate([rng.normal(size=(3000, 3)) * 0.05 + [0, 0, 0.3], rng.normal(size=(2000, 3)) * 0.01 + [0.2, 0.2, 0.2],
+                        rng.uniform(-1.5, 1.5, size=(3000, 3))]).astype(np.float32)
+    eye = np.identity(4, dtype=np.float32)
+    if surface:
+        ridx, _, rd2 = orc.nn_tri_brute(q, verts, tris)
+    else:
+        ridx, rd2 = orc.nn_brute(q, verts)
+    for budget in ("4", "128", "1000000"):
+        monkeypatch.setenv("OA_GRID_BUDGET", budget)
+        with IcpEngine(0) as e:
+            e.set_search_mode("grid")
+            if surface:
+                e.set_target_mesh(verts, tris)
+            else:
+                e.set_target(verts)
+            e.set_source(q)
+            e.set_matrices(eye, eye)
+            idx, d2, _ = e.nn_search()
+        assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2), budget
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["brute", "grid", "bvh"])
+def test_overflowing_distances_select_nothing(orc, mode):
+    """Squared distances that overflow float32 are +inf: the oracle's strict `d < best` never selects them (index -1)."""
+    from object_alignment_amd.engine import IcpEngine
+    rng = np.random.default_rng(3)
+    tgt = rng.uniform(-1, 1, size=(9000, 3)).astype(np.float32)
+    src = rng.uniform(-1, 1, size=(3000, 3)).astype(np.float32)
+    src[::3] = np.where(src[::3] < 0, np.float32(-3e19), np.float32(3e19)) * (1 + np.abs(src[::3]))   # |d|^2 > FLT_MAX
+    tris = rng.integers(0, len(tgt), size=(7000, 3)).astype(np.int32)
+    eye = np.identity(4, dtype=np.float32)
+    ridx, rd2 = orc.nn_brute(src, tgt)
+    assert (ridx[::3] == -1).all() and (ridx[1::3] >= 0).all()
+    fidx, _, fd2 = orc.nn_tri_brute(src, tgt, tris)
+    with IcpEngine(0) as e:
+        e.set_search_mode(mode)
+        e.set_target(tgt)
+        e.set_source(src)
+        e.set_matrices(eye, eye)
+        idx, d2, _ = e.nn_search()
+        assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2)
+        e.set_target_mesh(tgt, tris)
+        idx, d2, _ = e.nn_search()
+        assert np.array_equal(idx, fidx) and np.array_equal(d2, fd2)
