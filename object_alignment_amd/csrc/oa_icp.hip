@@ -250,31 +250,26 @@ int launch_nn(oa_ctx *c)
         return fail(OA_E_BAD_ARG, "shard of %d points exceeds the launch grid (use more shards or OA_NN_R=8)", c->ns);
     dim3 grid(c->n_splits, c->ns_pad / (oa::NN_THREADS * c->R));
     dim3 block(oa::NN_THREADS);
-    const int *list = nullptr, *list_count = nullptr;
     if (bvh_whole(c, c->bvh_ok, 32768)) return launch_bvh<false>(c, nullptr, nullptr);
     if (grid_active(c)) {
-        // grid search settles (almost) every point; the rest go through the brute-force kernel in list mode.
-        // Inside the loop k_solve_update leaves the counter at zero; one-shot calls clear it here.
+        // the grid search settles the queries near the target; the rest (far away, or in crowded cells) are appended
+        // to a list that the tree search finishes.  Inside the loop k_solve_update leaves the list counter at zero;
+        // one-shot calls clear it here.
         if (!c->loop_active) HIPCHK(hipMemsetAsync(c->d_todo_count, 0, sizeof(int), c->stream));
         hipLaunchKernelGGL(oa::k_nn_search_grid, dim3((c->ns + 255) / 256), dim3(256), 0, c->stream, c->d_state, c->d_src4,
                            c->ns, c->gp, c->d_cell_start, c->d_sorted, c->d_tgt_xyz, c->d_prev, c->d_keys,
                            c->d_todo_list, c->d_todo_count);
         HIPCHK(hipGetLastError());
-        list = c->d_todo_list; list_count = c->d_todo_count;
-        if (c->bvh_ok) return launch_bvh<false>(c, list, list_count);       // the far queries: tree search
-        grid.y = std::min<unsigned>((unsigned)((c->ns + 1023) / 1024), 32u);
+        return launch_bvh<false>(c, c->d_todo_list, c->d_todo_count);
     }
 #define OA_NN_ARGS c->d_state, c->d_src4, c->d_tg, c->groups_per_split, c->n_groups_pad, c->d_keys
-#define OA_NNF_ARGS c->d_state, c->d_src4, c->d_tg, c->d_tf, c->d_tf3, c->d_tgt_xyz, c->d_prev, c->groups_per_split, c->n_groups_pad, c->d_keys, list, list_count
-    if (list) {
-        if (c->tile_groups == 64) hipLaunchKernelGGL((oa::k_nn_search_filtered<4, false, true, 64>), grid, block, 0, c->stream, OA_NNF_ARGS);
-        else hipLaunchKernelGGL((oa::k_nn_search_filtered<4, false, true, oa::FTILE_GROUPS>), grid, block, 0, c->stream, OA_NNF_ARGS);
-    } else if (c->filter_ok && c->use_filter) {
+#define OA_NNF_ARGS c->d_state, c->d_src4, c->d_tg, c->d_tf, c->d_tf3, c->d_tgt_xyz, c->d_prev, c->groups_per_split, c->n_groups_pad, c->d_keys
+    if (c->filter_ok && c->use_filter) {
         const bool small = (c->tile_groups == 64);
 #define OA_LAUNCH_F(RR)                                                                                              \
         do {                                                                                                         \
-            if (small) hipLaunchKernelGGL((oa::k_nn_search_filtered<RR, false, false, 64>), grid, block, 0, c->stream, OA_NNF_ARGS); \
-            else hipLaunchKernelGGL((oa::k_nn_search_filtered<RR, false, false, oa::FTILE_GROUPS>), grid, block, 0, c->stream, OA_NNF_ARGS); \
+            if (small) hipLaunchKernelGGL((oa::k_nn_search_filtered<RR, false, 64>), grid, block, 0, c->stream, OA_NNF_ARGS); \
+            else hipLaunchKernelGGL((oa::k_nn_search_filtered<RR, false, oa::FTILE_GROUPS>), grid, block, 0, c->stream, OA_NNF_ARGS); \
         } while (0)
         switch (c->R) {
         case 1: OA_LAUNCH_F(1); break;
@@ -698,7 +693,7 @@ int build_grid(oa_ctx *c)
 
 bool grid_active(const oa_ctx *c)
 {
-    if (!c->grid_ok || !c->filter_ok || !c->use_filter || c->grid_mode == 0) return false;
+    if (!c->grid_ok || !c->bvh_ok || !c->filter_ok || !c->use_filter || c->grid_mode == 0) return false;
     if (c->grid_mode == 2) return false;
     return true;                                                      // auto: shards of <= 32768 points took the tree already
 }

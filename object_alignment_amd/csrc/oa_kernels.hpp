@@ -638,7 +638,7 @@ __global__ void k_bbox_partial(const float *__restrict__ xyz, int nt, float *__r
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-template <int R, bool PK, bool LIST, int TG = FTILE_GROUPS>
+template <int R, bool PK, int TG = FTILE_GROUPS>
 __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_filtered(const DevState *__restrict__ st,
                                                                    const float4 *__restrict__ src4,
                                                                    const float4 *__restrict__ tg,
@@ -647,12 +647,8 @@ __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_filt
                                                                    const float *__restrict__ tgt_xyz,
                                                                    const int *__restrict__ prev, int groups_per_split,
                                                                    int n_groups_pad,
-                                                                   unsigned long long *__restrict__ keys,
-                                                                   const int *__restrict__ list,
-                                                                   const int *__restrict__ list_count)
+                                                                   unsigned long long *__restrict__ keys)
 {
-    // list mode (LIST): finish the source points the grid search could not settle.  `list` holds
-    // their indices, `*list_count` how many; their running best sits in keys[] and seeds the scan.
     // PK is kept as a template slot for A/B experiments; the shipped instantiations use scalar v_fma_f32.
     if (st->halt) return;
     // TG = groups of 4 targets per LDS tile: 256 for large targets, 64 for small ones (more, shorter workgroups)
@@ -662,20 +658,12 @@ __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_filt
     const double qmax = st->qmax;
     const float cx = st->tc[0], cy = st->tc[1], cz = st->tc[2];
     const int au = st->fax[0], av = st->fax[1];
-    const long long n_items = LIST ? (long long)*list_count : (long long)gridDim.y * (NN_THREADS * R);
-
-  for (int chunk = blockIdx.y; (long long)chunk * (NN_THREADS * R) < n_items; chunk += gridDim.y) {
-    const int base = chunk * (NN_THREADS * R);
+    const int base = blockIdx.y * (NN_THREADS * R);
     float px[R], py[R], pz[R], hu[R], hv[R], hd[R], best[R], thr2[R], thr3[R];
     uint32_t bidx[R];
-    int item[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int slot = base + r * NN_THREADS + tid;
-        int i = slot;
-        if (LIST) { i = (slot < n_items) ? list[slot] : -1; }
-        item[r] = i;
-        if (LIST && i < 0) i = list[0];                          // inactive lane of the last chunk: harmless duplicate
+        const int i = base + r * NN_THREADS + tid;
         const float4 p = src4[i];
         float wx, wy, wz;
         m4_mul_v3(st->mx1, p.x, p.y, p.z, wx, wy, wz);
@@ -688,17 +676,10 @@ __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_filt
         hd[r] = (au + av == 1) ? h2 : ((au + av == 2) ? h1 : h0); // the dropped axis is the remaining one
         best[r] = INFINITY;
         bidx[r] = IDX_NONE;
-        if (LIST) {                                             // seed: what the grid search found so far
-            const unsigned long long k0 = keys[i];
-            best[r] = __uint_as_float((uint32_t)(k0 >> 32));
-            bidx[r] = (uint32_t)k0;
-            if (!(best[r] < INFINITY)) { best[r] = INFINITY; bidx[r] = IDX_NONE; }
-        } else {
-            const int s = prev ? prev[i] : -1;
-            if (s >= 0) {                                       // seed: last iteration's nearest vertex
-                const float d = d2_metric(px[r], py[r], pz[r], tgt_xyz[3ll * s], tgt_xyz[3ll * s + 1], tgt_xyz[3ll * s + 2]);
-                if (d < INFINITY) { best[r] = d; bidx[r] = (uint32_t)s; }
-            }
+        const int s = prev ? prev[i] : -1;
+        if (s >= 0) {                                           // seed: last iteration's nearest vertex
+            const float d = d2_metric(px[r], py[r], pz[r], tgt_xyz[3ll * s], tgt_xyz[3ll * s + 1], tgt_xyz[3ll * s + 2]);
+            if (d < INFINITY) { best[r] = d; bidx[r] = (uint32_t)s; }
         }
         filter_thresholds(best[r], hu[r], hv[r], hd[r], qmax, thr2[r], thr3[r]);
     }
@@ -798,13 +779,10 @@ __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_filt
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const unsigned long long key = ((unsigned long long)__float_as_uint(best[r]) << 32) | bidx[r];
-        if (LIST && item[r] < 0) continue;
-        unsigned long long *dst = keys + item[r];
-        if (gridDim.x == 1 && !LIST) *dst = key;
-        else atomicMin(dst, key);
+        unsigned long long *dst = keys + base + r * NN_THREADS + tid;
+        if (gridDim.x == 1) *dst = key;
+        else atomicMin(dst, key);                                  // (d2, idx) lexicographic: lowest index on ties
     }
-    if (!LIST) break;                                            // single pass: lets the compiler drop the loop
-  }   // chunk loop (list mode only)
 }
 
 // ------------------------------------------------------------------------------------------------
