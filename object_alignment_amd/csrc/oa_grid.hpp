@@ -48,6 +48,12 @@ __device__ __forceinline__ double grid_axis_gap(double v, double lo, double h, i
     return g > 0.0 ? g : 0.0;
 }
 
+// float square root that never underestimates (hardware sqrt is within 1 ulp; the factor covers it and the cast)
+__device__ __forceinline__ float grid_sqrt_up(float x)
+{
+    return __builtin_sqrtf(x) * 1.000001f + 1e-18f;                 // + 1e-18: x below the float normal range (sqrt < 1.1e-19)
+}
+
 __global__ void k_grid_count(const float *__restrict__ xyz, int nt, GridParams gp, int *__restrict__ cell_of,
                              int *__restrict__ counts)
 {
@@ -80,6 +86,13 @@ __global__ void k_grid_scatter(const float *__restrict__ xyz, int nt, const int 
     const int c = cell_of[i];
     const int pos = cell_start[c] + atomicAdd(&cursor[c], 1);    // order inside a cell is irrelevant: (d2, index) min
     sorted[pos] = make_float4(xyz[3ll * i], xyz[3ll * i + 1], xyz[3ll * i + 2], __int_as_float(i));
+}
+
+__device__ __forceinline__ void grid_candidate(float px, float py, float pz, const float4 q, float &best, uint32_t &bidx)
+{
+    const float d = d2_metric(px, py, pz, q.x, q.y, q.z);
+    const uint32_t qi = (uint32_t)__float_as_int(q.w);
+    if (d < best || (d == best && qi < bidx && d < INFINITY)) { best = d; bidx = qi; }
 }
 
 __global__ __launch_bounds__(256) void k_nn_search_grid(const DevState *__restrict__ st,
@@ -128,44 +141,65 @@ __global__ __launch_bounds__(256) void k_nn_search_grid(const DevState *__restri
     if (finite) {
         for (int r = 0; r <= gp.r_max && !settled && budget >= 0; ++r) {
             const int x0 = max(c[0] - r, 0), x1 = min(c[0] + r, gp.n[0] - 1);
-            const int y0 = max(c[1] - r, 0), y1 = min(c[1] + r, gp.n[1] - 1);
-            const int z0 = max(c[2] - r, 0), z1 = min(c[2] + r, gp.n[2] - 1);
-            for (int z = z0; z <= z1 && budget >= 0; ++z) {
-                const double dz = grid_axis_gap(pc[2], gp.lo[2], gp.h, z, gp.slack);
-                for (int y = y0; y <= y1 && budget >= 0; ++y) {
+            // The (2r+1)^2 rows (y, z) of the ring are handled nine at a time: first the cell ranges of all nine rows
+            // are fetched (up to 36 independent loads in flight), then their vertices are scanned four per trip.  A
+            // thread's time is a chain of memory round trips; this keeps the chain at ~2 + (vertices / 4) per batch
+            // instead of 2 per row + 1 per vertex.
+            const int side = 2 * r + 1, n_rows = side * side;
+            const unsigned div_mul = 65536u / (unsigned)side + 1u;  // k / side == (k * div_mul) >> 16 for k < 64, side <= 7
+            for (int b0 = 0; b0 < n_rows && budget >= 0; b0 += 9) {
+                int ja[9], jb[9], jc[9], jd[9];                     // row k: vertices [ja, jb) and [jc, jd) of `sorted`
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    ja[k] = jb[k] = jc[k] = jd[k] = 0;
+                    const int kk = b0 + k;
+                    if (kk >= n_rows) continue;
+                    const int qz = (int)(((unsigned)kk * div_mul) >> 16);
+                    const int dzi = qz - r, dyi = kk - qz * side - r;
+                    const int z = c[2] + dzi, y = c[1] + dyi;
+                    if (z < 0 || z >= gp.n[2] || y < 0 || y >= gp.n[1]) continue;
                     // every vertex of this row of cells is at real distance^2 >= off2 + dy^2 + dz^2 from the query
+                    const double dz = grid_axis_gap(pc[2], gp.lo[2], gp.h, z, gp.slack);
                     const double dy = grid_axis_gap(pc[1], gp.lo[1], gp.h, y, gp.slack);
                     const double row2 = off2 + dz * dz + dy * dy;
                     if (row2 * (1.0 - 1e-5) - 1e-30 > (double)lim) continue;       // cannot beat or tie
                     // cells of the row that can still matter: |x - pc.x| <= sqrt(lim' - row2)
                     int xa = x0, xb = x1;
                     if (lim < INFINITY) {
-                        double w2 = (double)lim * (1.0 + 1e-5) + 1e-30 - row2 * (1.0 - 1e-5);
-                        const double w = sqrt(w2 > 0.0 ? w2 : 0.0) * (1.0 + 1e-6) + gp.slack;
+                        const double w2 = (double)lim * (1.0 + 1e-5) + 1e-30 - row2 * (1.0 - 1e-5);
+                        const double w = (double)grid_sqrt_up((float)(w2 > 0.0 ? w2 * (1.0 + 1e-6) : 0.0)) + gp.slack;
                         xa = max(xa, grid_cell_coord(pc[0] - w, gp.lo[0], gp.inv_h, gp.n[0]));
                         xb = min(xb, grid_cell_coord(pc[0] + w, gp.lo[0], gp.inv_h, gp.n[0]));
                     }
-                    // interior rows were fully covered by ring r-1: only their two end cells are new
-                    const bool shell_row = (r == 0) || z == c[2] - r || z == c[2] + r || y == c[1] - r || y == c[1] + r;
                     const int row = (z * gp.n[1] + y) * gp.n[0];
-                    int segs[2][2];
-                    int n_seg = 0;
-                    if (shell_row) { if (xa <= xb) { segs[0][0] = xa; segs[0][1] = xb; n_seg = 1; } }
-                    else {
+                    // interior rows were fully covered by ring r-1: only their two end cells are new
+                    const bool shell_row = (r == 0) || dzi == -r || dzi == r || dyi == -r || dyi == r;
+                    if (shell_row) {
+                        if (xa <= xb) { ja[k] = cell_start[row + xa]; jb[k] = cell_start[row + xb + 1]; }
+                    } else {
                         const int xl = c[0] - r, xr = c[0] + r;
-                        if (xl >= xa && xl <= xb) { segs[n_seg][0] = xl; segs[n_seg][1] = xl; ++n_seg; }
-                        if (xr >= xa && xr <= xb) { segs[n_seg][0] = xr; segs[n_seg][1] = xr; ++n_seg; }
+                        if (xl >= xa && xl <= xb) { ja[k] = cell_start[row + xl]; jb[k] = cell_start[row + xl + 1]; }
+                        if (xr >= xa && xr <= xb) { jc[k] = cell_start[row + xr]; jd[k] = cell_start[row + xr + 1]; }
                     }
-                    for (int sg = 0; sg < n_seg; ++sg) {
-                        const int j0 = cell_start[row + segs[sg][0]], j1 = cell_start[row + segs[sg][1] + 1];
+                }
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+#pragma unroll
+                    for (int sg = 0; sg < 2; ++sg) {
+                        const int j0 = sg ? jc[k] : ja[k], j1 = sg ? jd[k] : jb[k];
+                        if (j1 <= j0) continue;
                         budget -= j1 - j0;
                         if (budget < 0) break;                       // crowded cells: one wave of the tree search is faster
-                        for (int j = j0; j < j1; ++j) {
-                            const float4 q = sorted[j];
-                            const float d = d2_metric(px, py, pz, q.x, q.y, q.z);
-                            const uint32_t qi = (uint32_t)__float_as_int(q.w);
-                            if (d < best || (d == best && qi < bidx && d < INFINITY)) { best = d; bidx = qi; lim = fminf(best, cutf); }
+                        const int last = j1 - 1;
+                        for (int j = j0; j < j1; j += 4) {           // the clamped repeats of the last vertex change nothing
+                            const float4 q0 = sorted[j], q1 = sorted[min(j + 1, last)], q2 = sorted[min(j + 2, last)],
+                                         q3 = sorted[min(j + 3, last)];
+                            grid_candidate(px, py, pz, q0, best, bidx);
+                            grid_candidate(px, py, pz, q1, best, bidx);
+                            grid_candidate(px, py, pz, q2, best, bidx);
+                            grid_candidate(px, py, pz, q3, best, bidx);
                         }
+                        lim = fminf(best, cutf);
                     }
                 }
             }

@@ -68,6 +68,12 @@ int env_int(const char *name, int dflt)
     return (v && *v) ? atoi(v) : dflt;
 }
 
+double env_double(const char *name, double dflt)
+{
+    const char *v = getenv(name);
+    return (v && *v) ? atof(v) : dflt;
+}
+
 }  // namespace
 
 struct oa_ctx {
@@ -96,6 +102,7 @@ struct oa_ctx {
     float4 *d_tri9 = nullptr;
     oa::GridParams tgp;
     int *d_tcell_start = nullptr, *d_tcell_tris = nullptr;
+    float4 *d_tcell_sph = nullptr;   // bounding sphere of each cell-list entry (same order as d_tcell_tris)
     // bounding-box trees (oa_bvh.hpp): over the vertices, and over the triangles in surface mode
     bool bvh_ok = false, tbvh_ok = false;
     oa::BvhParams bvh, tbvh;
@@ -537,7 +544,7 @@ OA_EXPORT void oa_destroy(oa_ctx *c)
     dev_free(c->d_valid); dev_free(c->d_b); dev_free(c->d_dist); dev_free(c->d_counts); dev_free(c->d_offsets);
     dev_free(c->d_A); dev_free(c->d_B);
     dev_free(c->d_bvh_box); dev_free(c->d_bvh_prims); dev_free(c->d_tbvh_box); dev_free(c->d_tbvh_prims);
-    dev_free(c->d_tri9); dev_free(c->d_tcell_start); dev_free(c->d_tcell_tris);
+    dev_free(c->d_tri9); dev_free(c->d_tcell_start); dev_free(c->d_tcell_tris); dev_free(c->d_tcell_sph);
     dev_free(c->d_sel); dev_free(c->d_src_n); dev_free(c->d_tgt_n); dev_free(c->d_src4o); dev_free(c->d_perm);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->ev_loop0) (void)hipEventDestroy(c->ev_loop0);
@@ -659,7 +666,7 @@ int build_grid(oa_ctx *c)
         // a clamped axis (1024 cells) needs a cell edge that still covers the extent
         for (int a = 0; a < 3; ++a) if (ext[a] > 0.0 && ext[a] / h >= gp.n[a]) h = std::max(h, ext[a] / (gp.n[a] - 0.5));
         gp.h = h; gp.inv_h = 1.0 / h;
-        gp.r_max = env_int("OA_GRID_RMAX", 3);
+        gp.r_max = std::min(env_int("OA_GRID_RMAX", 3), 3);
         gp.budget = env_int("OA_GRID_BUDGET", 128);
         gp.slack = 1e-10 * scale + 1e-300;
         gp.scale = scale;
@@ -707,7 +714,7 @@ OA_EXPORT int oa_set_target(oa_ctx *c, const float *xyz, int64_t n, int on_devic
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
     dev_free(c->d_tgt_xyz); dev_free(c->d_tg); dev_free(c->d_tf); dev_free(c->d_tf3);
-    dev_free(c->d_tri9); dev_free(c->d_tcell_start); dev_free(c->d_tcell_tris);
+    dev_free(c->d_tri9); dev_free(c->d_tcell_start); dev_free(c->d_tcell_tris); dev_free(c->d_tcell_sph);
     dev_free(c->d_bvh_box); dev_free(c->d_bvh_prims); dev_free(c->d_tbvh_box); dev_free(c->d_tbvh_prims);
     c->surface = false; c->tri_grid_ok = false; c->n_tris = 0; c->bvh_ok = false; c->tbvh_ok = false;
     dev_free(c->d_tgt_n);
@@ -880,7 +887,7 @@ int sort_source_slots(oa_ctx *c, const float *d_xyz, long long n_verts)
 int build_tri_grid(oa_ctx *c)
 {
     c->tri_grid_ok = false;
-    dev_free(c->d_tcell_start); dev_free(c->d_tcell_tris);
+    dev_free(c->d_tcell_start); dev_free(c->d_tcell_tris); dev_free(c->d_tcell_sph);
     if (!c->filter_ok || c->grid_mode == 0 || c->n_tris < 64) return OA_OK;
     DevTmp<double> d_sum;
     HIPCHK(d_sum.alloc(1));
@@ -896,7 +903,7 @@ int build_tri_grid(oa_ctx *c)
         max_ext = std::max(max_ext, ext[a]);
         scale = std::max(scale, std::max(fabs(c->bb_lo[a]), fabs(c->bb_hi[a])));
     }
-    double h = 1.5 * diag_sum / (double)c->n_tris;                  // ~1.5 mean triangle bbox diagonals per cell
+    double h = env_double("OA_TRI_CELL", 1.5) * diag_sum / (double)c->n_tris;   // ~1.5 mean triangle bbox diagonals per cell
     if (!(h > 0.0) || !(h < INFINITY)) h = max_ext > 0.0 ? max_ext / 64.0 : 1.0;
     h = std::max(h, max_ext / 512.0);
     const long long max_cells = 1ll << 24;
@@ -918,7 +925,7 @@ int build_tri_grid(oa_ctx *c)
         }
         if (total > max_cells) { h *= 1.3; n_cells = 0; continue; }
         gp.h = h; gp.inv_h = 1.0 / h;
-        gp.r_max = env_int("OA_GRID_RMAX", 3);
+        gp.r_max = std::min(env_int("OA_GRID_RMAX", 3), 3);
         gp.budget = env_int("OA_GRID_BUDGET", 128);
         gp.scale = scale;
         gp.slack = 1e-10 * scale + 1e-300;
@@ -927,7 +934,7 @@ int build_tri_grid(oa_ctx *c)
         HIPCHK(hipMemsetAsync(d_counts, 0, sizeof(int) * ((size_t)n_cells + 1), c->stream));
         HIPCHK(hipMemsetAsync(d_total, 0, sizeof(unsigned long long), c->stream));
         hipLaunchKernelGGL(oa::k_tri_grid_bin<false>, dim3((c->n_tris + 255) / 256), dim3(256), 0, c->stream, c->d_tri9,
-                           c->n_tris, gp, d_counts.p, (const int *)nullptr, (int *)nullptr, d_total.p);
+                           c->n_tris, gp, d_counts.p, (const int *)nullptr, (int *)nullptr, (float4 *)nullptr, d_total.p);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(&entries, d_total, sizeof(entries), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -939,14 +946,18 @@ int build_tri_grid(oa_ctx *c)
     HIPCHK(d_off.alloc((size_t)n_cells + 1));
     HIPCHK(hipMalloc(&c->d_tcell_start, sizeof(int) * (size_t)(n_cells + 1)));
     HIPCHK(hipMalloc(&c->d_tcell_tris, sizeof(int) * (size_t)entries));
+    HIPCHK(hipMalloc(&c->d_tcell_sph, sizeof(float4) * (size_t)entries));
     { int rcs = scan_counts(c, d_counts.p, n_cells, d_off.p); if (rcs) return rcs; }
     hipLaunchKernelGGL(oa::k_grid_starts, dim3((n_cells + 256) / 256), dim3(256), 0, c->stream, d_off.p, n_cells, c->d_tcell_start, d_counts.p);
     hipLaunchKernelGGL(oa::k_tri_grid_bin<true>, dim3((c->n_tris + 255) / 256), dim3(256), 0, c->stream, c->d_tri9, c->n_tris,
-                       gp, d_counts.p, (const int *)c->d_tcell_start, c->d_tcell_tris, (unsigned long long *)nullptr);
+                       gp, d_counts.p, (const int *)c->d_tcell_start, c->d_tcell_tris, c->d_tcell_sph, (unsigned long long *)nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     c->tgp = gp;
     c->tri_grid_ok = true;
+    if (getenv("OA_DEBUG"))
+        fprintf(stderr, "[oa] tri grid: h=%g cells=%dx%dx%d entries=%llu (%.2f per triangle)\n", gp.h, gp.n[0], gp.n[1], gp.n[2],
+                entries, (double)entries / c->n_tris);
     return OA_OK;
 }
 
@@ -961,7 +972,7 @@ int launch_tri_search(oa_ctx *c)
     if (use_grid) {
         if (!c->loop_active) HIPCHK(hipMemsetAsync(c->d_todo_count, 0, sizeof(int), c->stream));
         hipLaunchKernelGGL(oa::k_tri_search_grid, dim3((c->ns + 255) / 256), dim3(256), 0, c->stream, c->d_state, c->d_src4,
-                           c->ns, c->tgp, c->d_tcell_start, c->d_tcell_tris, c->d_tri9, c->d_prev, c->d_keys,
+                           c->ns, c->tgp, c->d_tcell_start, c->d_tcell_tris, c->d_tcell_sph, c->d_tri9, c->d_prev, c->d_keys,
                            c->d_todo_list, c->d_todo_count);
         HIPCHK(hipGetLastError());
         return launch_bvh<true>(c, c->d_todo_list, c->d_todo_count);       // the far queries: tree search

@@ -70,11 +70,30 @@ __device__ __forceinline__ void tri_cell_range(const float4 *__restrict__ tri9, 
     }
 }
 
-// pass 0: counts[cell] += 1 for every cell overlapped; pass 1: write the triangle id at cell_start[cell] + cursor++
+// bounding sphere of a triangle for the cell lists: centre = centre of its bounding box, radius rounded UP, so that
+// every point of the triangle is within r of the centre (the search subtracts r from the distance to the centre)
+__device__ __forceinline__ float4 tri_sphere(const float *a, const float *b, const float *c)
+{
+    float ctr[3];
+    for (int k = 0; k < 3; ++k)
+        ctr[k] = 0.5f * fminf(fminf(a[k], b[k]), c[k]) + 0.5f * fmaxf(fmaxf(a[k], b[k]), c[k]);
+    double r2 = 0.0;
+    const float *v[3] = { a, b, c };
+    for (int i = 0; i < 3; ++i) {
+        double s = 0.0;
+        for (int k = 0; k < 3; ++k) { const double d = (double)v[i][k] - (double)ctr[k]; s += d * d; }
+        r2 = s > r2 ? s : r2;
+    }
+    const double r = sqrt(r2) * (1.0 + 1e-6) + 1e-37;
+    return make_float4(ctr[0], ctr[1], ctr[2], r < 3.0e38 ? (float)r : INFINITY);   // NaN stays NaN: never skipped, never selected
+}
+
+// pass 0: counts[cell] += 1 for every cell overlapped; pass 1: write the triangle id (and its bounding sphere, so the
+// search can discard most candidates from one contiguous 16-byte record) at cell_start[cell] + cursor++
 template <bool FILL>
 __global__ void k_tri_grid_bin(const float4 *__restrict__ tri9, int n_tris, GridParams gp, int *__restrict__ counts,
                                const int *__restrict__ cell_start, int *__restrict__ cell_tris,
-                               unsigned long long *__restrict__ total)
+                               float4 *__restrict__ cell_sph, unsigned long long *__restrict__ total)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_tris) return;
@@ -82,13 +101,22 @@ __global__ void k_tri_grid_bin(const float4 *__restrict__ tri9, int n_tris, Grid
     bool ok;
     tri_cell_range(tri9, t, gp, lo, hi, ok);
     if (!ok) return;
+    float4 sph = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (FILL) {
+        float a[3], b[3], c[3];
+        load_tri(tri9, t, a, b, c);
+        sph = tri_sphere(a, b, c);
+    }
     unsigned long long n = 0;
     for (int z = lo[2]; z <= hi[2]; ++z)
         for (int y = lo[1]; y <= hi[1]; ++y)
             for (int x = lo[0]; x <= hi[0]; ++x) {
                 const int cidx = (z * gp.n[1] + y) * gp.n[0] + x;
-                if (FILL) cell_tris[cell_start[cidx] + atomicAdd(&counts[cidx], 1)] = t;
-                else atomicAdd(&counts[cidx], 1);
+                if (FILL) {
+                    const int pos = cell_start[cidx] + atomicAdd(&counts[cidx], 1);
+                    cell_tris[pos] = t;
+                    cell_sph[pos] = sph;
+                } else atomicAdd(&counts[cidx], 1);
                 ++n;
             }
     if (!FILL && total) atomicAdd(total, n);
@@ -112,6 +140,14 @@ __device__ __forceinline__ float tri_skip_threshold(float best, double delta)
     if (!(best < INFINITY)) return INFINITY;
     const double s = delta + sqrt(((double)best + 1e-30) / (1.0 - 1e-5));
     return (float)(s * s * (1.0 + 3e-6));
+}
+
+// sqrt of the threshold, rounded up: how far from the query a triangle may be and still matter (sphere test)
+__device__ __forceinline__ float tri_reach(float thr)
+{
+    if (!(thr < INFINITY)) return INFINITY;
+    const double r = sqrt((double)thr) * (1.0 + 1e-6) + 1e-37;
+    return r < 3.0e38 ? (float)r : INFINITY;
 }
 
 // tri_eval behind the bounding-box test; `thr` follows `best` (recomputed only when the best improves)
@@ -138,16 +174,67 @@ __device__ __forceinline__ void tri_eval_boxed(const float *p, const float4 *__r
     }
 }
 
+struct TriSearchState {
+    float best; uint32_t bidx;
+    float lim, thr, reach;    // lim = min(best, search radius^2); thr = squared-gap threshold; reach = sqrt(thr), rounded up
+    double reach2;            // (delta + sqrt((lim + 1e-30) / (1 - 1e-5)))^2: rows / rings whose squared gap exceeds it are out
+};
+
+// everything derived from `lim` (called when the best improves: rare)
+__device__ __forceinline__ void tri_state_refresh(TriSearchState &s, double delta)
+{
+    s.thr = tri_skip_threshold(s.lim, delta);
+    s.reach = tri_reach(s.thr);
+    if (s.lim < INFINITY) {
+        const double r = (delta + sqrt(((double)s.lim + 1e-30) / (1.0 - 1e-5))) * (1.0 + 1e-9);
+        s.reach2 = r * r;
+    } else s.reach2 = INFINITY;
+}
+
+// Cell-list candidates go through two phases so that divergence does not multiply the expensive part.  Phase 1
+// (tri_candidate): sphere test on the contiguous 16-byte record; survivors' triangle ids are pushed on a per-thread
+// queue in LDS.  Phase 2 (tri_queue_flush): every lane evaluates ITS k-th survivor in the same trip, so a wave pays
+// max-over-lanes(survivors) closest-point evaluations instead of one per candidate slot in which any lane survived
+// (measured: 18.5k -> VALU instructions per wave before, see profiles/).
+constexpr int TRI_QUEUE = 16;
+
+__device__ __forceinline__ void tri_candidate(const float *p, const float4 sph, const int *__restrict__ cell_tris, int j,
+                                              const TriSearchState &s, int (*queue)[256], int &nq)
+{
+    const float dx = sph.x - p[0], dy = sph.y - p[1], dz = sph.z - p[2];
+    const float D2 = dx * dx + dy * dy + dz * dz;
+    const float rs = sph.w + s.reach;
+    if (D2 > rs * rs * 1.000003f) return;                          // farther than radius + reach: cannot beat or tie
+    queue[nq][threadIdx.x] = cell_tris[j];                         // the caller keeps nq <= TRI_QUEUE - 4 before a trip
+    ++nq;
+}
+
+__device__ __forceinline__ void tri_queue_flush(const float *p, const float4 *__restrict__ tri9, TriSearchState &s,
+                                                int (*queue)[256], int &nq, double delta, float cutf)
+{
+    for (int k = 0; __any(k < nq); ++k) {
+        if (k < nq) {
+            const float before = s.best;
+            tri_eval_boxed(p, tri9, (uint32_t)queue[k][threadIdx.x], s.best, s.bidx, s.lim, s.thr, delta, cutf);
+            if (s.best < before) tri_state_refresh(s, delta);
+        }
+    }
+    nq = 0;
+}
+
 __global__ __launch_bounds__(256) void k_tri_search_grid(const DevState *__restrict__ st,
                                                          const float4 *__restrict__ src4, int ns, GridParams gp,
                                                          const int *__restrict__ cell_start,
                                                          const int *__restrict__ cell_tris,
+                                                         const float4 *__restrict__ cell_sph,
                                                          const float4 *__restrict__ tri9,
                                                          const int *__restrict__ prev,
                                                          unsigned long long *__restrict__ keys,
                                                          int *__restrict__ todo_list, int *__restrict__ todo_count)
 {
     if (st->halt) return;
+    __shared__ int queue[TRI_QUEUE][256];
+    int nq = 0;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ns) return;
     const float4 p4 = src4[i];
@@ -176,49 +263,74 @@ __global__ __launch_bounds__(256) void k_tri_search_grid(const DevState *__restr
     const double delta = 64.0 * 5.9604644775390625e-08 * (gp.scale + pabs) + gp.slack;
     // `lim`: the best so far or the search radius (search_cutoff2), whichever is smaller -- see k_nn_search_grid
     const float cutf = search_cutoff2(st, pf[0], pf[1], pf[2]);
-    float lim = fminf(best, cutf);
-    float thr = tri_skip_threshold(lim, delta);
+    TriSearchState S;
+    S.best = best; S.bidx = bidx;
+    S.lim = fminf(best, cutf);
+    tri_state_refresh(S, delta);
     bool settled = false;
     int budget = gp.budget;                                        // candidates this thread may look at (see GridParams)
     if (finite) {
         for (int r = 0; r <= gp.r_max && !settled && budget >= 0; ++r) {
             const int x0 = max(c[0] - r, 0), x1 = min(c[0] + r, gp.n[0] - 1);
-            const int y0 = max(c[1] - r, 0), y1 = min(c[1] + r, gp.n[1] - 1);
-            const int z0 = max(c[2] - r, 0), z1 = min(c[2] + r, gp.n[2] - 1);
-            for (int z = z0; z <= z1 && budget >= 0; ++z) {
-                const double dz = grid_axis_gap(pc[2], gp.lo[2], gp.h, z, gp.slack);
-                for (int y = y0; y <= y1 && budget >= 0; ++y) {
+            // rows of the ring nine at a time: cell ranges first (independent loads), then the candidates -- as in
+            // k_nn_search_grid
+            const int side = 2 * r + 1, n_rows = side * side;
+            const unsigned div_mul = 65536u / (unsigned)side + 1u;
+            for (int b0 = 0; b0 < n_rows && budget >= 0; b0 += 9) {
+                int ja[9], jb[9], jc[9], jd[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    ja[k] = jb[k] = jc[k] = jd[k] = 0;
+                    const int kk = b0 + k;
+                    if (kk >= n_rows) continue;
+                    const int qz = (int)(((unsigned)kk * div_mul) >> 16);
+                    const int dzi = qz - r, dyi = kk - qz * side - r;
+                    const int z = c[2] + dzi, y = c[1] + dyi;
+                    if (z < 0 || z >= gp.n[2] || y < 0 || y >= gp.n[1]) continue;
+                    const double dz = grid_axis_gap(pc[2], gp.lo[2], gp.h, z, gp.slack);
                     const double dy = grid_axis_gap(pc[1], gp.lo[1], gp.h, y, gp.slack);
                     const double row2 = off2 + dz * dz + dy * dy;
-                    double lb = sqrt(row2) - delta;
-                    lb = lb > 0.0 ? lb : 0.0;
-                    if (lb * lb * (1.0 - 1e-5) - 1e-30 > (double)lim) continue;
-                    // cells of the row whose slab along x can still hold a triangle at distance <= sqrt(lim) + delta
+                    // (sqrt(row2) - delta)^2 (1 - 1e-5) - 1e-30 > lim  <=>  row2 > reach2: nothing in this row can matter
+                    if (row2 * (1.0 - 1e-9) > S.reach2) continue;
+                    // cells of the row whose slab along x can still hold a triangle within reach: |x - pc.x| <= w
                     int xa = x0, xb = x1;
-                    if (lim < INFINITY) {
-                        const double reach = (delta + sqrt(((double)lim + 1e-30) / (1.0 - 1e-5))) * (1.0 + 1e-9);
-                        double w2 = reach * reach - row2 * (1.0 - 1e-9);
-                        const double w = sqrt(w2 > 0.0 ? w2 : 0.0) * (1.0 + 1e-6) + gp.slack;
+                    if (S.reach2 < 1e300) {
+                        const double w2 = S.reach2 - row2 * (1.0 - 1e-9);
+                        const double w = (double)grid_sqrt_up((float)(w2 > 0.0 ? w2 * (1.0 + 1e-6) : 0.0)) + gp.slack;
                         xa = max(xa, grid_cell_coord(pc[0] - w, gp.lo[0], gp.inv_h, gp.n[0]));
                         xb = min(xb, grid_cell_coord(pc[0] + w, gp.lo[0], gp.inv_h, gp.n[0]));
                     }
-                    const bool shell_row = (r == 0) || z == c[2] - r || z == c[2] + r || y == c[1] - r || y == c[1] + r;
                     const int row = (z * gp.n[1] + y) * gp.n[0];
-                    int segs[2][2];
-                    int n_seg = 0;
-                    if (shell_row) { if (xa <= xb) { segs[0][0] = xa; segs[0][1] = xb; n_seg = 1; } }
-                    else {
+                    const bool shell_row = (r == 0) || dzi == -r || dzi == r || dyi == -r || dyi == r;
+                    if (shell_row) {
+                        if (xa <= xb) { ja[k] = cell_start[row + xa]; jb[k] = cell_start[row + xb + 1]; }
+                    } else {
                         const int xl = c[0] - r, xr = c[0] + r;
-                        if (xl >= xa && xl <= xb) { segs[n_seg][0] = xl; segs[n_seg][1] = xl; ++n_seg; }
-                        if (xr >= xa && xr <= xb) { segs[n_seg][0] = xr; segs[n_seg][1] = xr; ++n_seg; }
-                    }
-                    for (int sg = 0; sg < n_seg; ++sg) {
-                        const int j0 = cell_start[row + segs[sg][0]], j1 = cell_start[row + segs[sg][1] + 1];
-                        budget -= j1 - j0;
-                        if (budget < 0) break;                       // crowded cells: one wave of the tree search is faster
-                        for (int j = j0; j < j1; ++j) tri_eval_boxed(pf, tri9, (uint32_t)cell_tris[j], best, bidx, lim, thr, delta, cutf);
+                        if (xl >= xa && xl <= xb) { ja[k] = cell_start[row + xl]; jb[k] = cell_start[row + xl + 1]; }
+                        if (xr >= xa && xr <= xb) { jc[k] = cell_start[row + xr]; jd[k] = cell_start[row + xr + 1]; }
                     }
                 }
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+#pragma unroll
+                    for (int sg = 0; sg < 2; ++sg) {
+                        const int j0 = sg ? jc[k] : ja[k], j1 = sg ? jd[k] : jb[k];
+                        if (j1 <= j0) continue;
+                        budget -= j1 - j0;
+                        if (budget < 0) break;                       // crowded cells: one wave of the tree search is faster
+                        const int last = j1 - 1;
+                        for (int j = j0; j < j1; j += 4) {
+                            if (__any(nq > TRI_QUEUE - 4)) tri_queue_flush(pf, tri9, S, queue, nq, delta, cutf);
+                            const float4 s0 = cell_sph[j], s1 = cell_sph[min(j + 1, last)], s2 = cell_sph[min(j + 2, last)],
+                                         s3 = cell_sph[min(j + 3, last)];
+                            tri_candidate(pf, s0, cell_tris, j, S, queue, nq);
+                            if (j + 1 < j1) tri_candidate(pf, s1, cell_tris, j + 1, S, queue, nq);
+                            if (j + 2 < j1) tri_candidate(pf, s2, cell_tris, j + 2, S, queue, nq);
+                            if (j + 3 < j1) tri_candidate(pf, s3, cell_tris, j + 3, S, queue, nq);
+                        }
+                    }
+                }
+                tri_queue_flush(pf, tri9, S, queue, nq, delta, cutf);   // a better best prunes the next batch of rows
             }
             if (budget < 0) break;
             double m = INFINITY;
@@ -230,13 +342,11 @@ __global__ __launch_bounds__(256) void k_tri_search_grid(const DevState *__restr
             else {
                 m -= gp.slack;
                 m = m > 0.0 ? m : 0.0;
-                double lb = sqrt(off2 + m * m) - delta;
-                lb = lb > 0.0 ? lb : 0.0;
-                if (lb * lb * (1.0 - 1e-5) - 1e-30 > (double)lim) settled = true;
+                if ((off2 + m * m) * (1.0 - 1e-9) > S.reach2) settled = true;   // same test as for a row
             }
         }
     }
-    keys[i] = ((unsigned long long)__float_as_uint(best) << 32) | bidx;
+    keys[i] = ((unsigned long long)__float_as_uint(S.best) << 32) | S.bidx;
     if (!settled) todo_list[atomicAdd(todo_count, 1)] = i;
 }
 
