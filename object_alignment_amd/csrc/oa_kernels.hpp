@@ -156,10 +156,13 @@ __host__ __device__ inline void rotation_from_covariance(const double H[9], doub
                 const double npp = g[0][p] * g[0][p] + g[1][p] * g[1][p] + g[2][p] * g[2][p];
                 const double nqq = g[0][q] * g[0][q] + g[1][q] * g[1][q] + g[2][q] * g[2][q];
                 const double dpq = g[0][p] * g[0][q] + g[1][p] * g[1][q] + g[2][p] * g[2][q];
-                if (dpq == 0.0 || fabs(dpq) <= 1e-15 * sqrt(npp * nqq)) continue;   // ~4.5 eps: R good to 1e-15
+                if (dpq == 0.0 || dpq * dpq <= 1e-30 * (npp * nqq)) continue;       // |dpq| <= 1e-15 |g_p||g_q| (~4.5 eps)
                 any = true;
-                const double zeta = (nqq - npp) / (2.0 * dpq);
-                const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                // t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)), zeta = (nqq - npp) / (2 dpq), written with one
+                // division: t = 2 dpq sign(w) / (|w| + sqrt(w^2 + 4 dpq^2)), w = nqq - npp (the chain is a single
+                // fp64 lane on the device: every sqrt / divide is ~30 dependent instructions)
+                const double w = nqq - npp, d2 = 2.0 * dpq;
+                const double t = (w >= 0.0 ? d2 : -d2) / (fabs(w) + sqrt(w * w + d2 * d2));
                 const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
                 for (int r = 0; r < 3; ++r) {
                     const double gp = g[r][p], gq = g[r][q], vp = v[r][p], vq = v[r][q];
