@@ -1009,3 +1009,42 @@ def test_overflowing_distances_select_nothing(orc, mode):
         e.set_target_mesh(tgt, tris)
         idx, d2, _ = e.nn_search()
         assert np.array_equal(idx, fidx) and np.array_equal(d2, fd2)
+
+
+@pytest.mark.gpu
+def test_landmark_prealignment_golden(golden_dir):
+    """OBJECT_OT_align_pick_points.align_obj (operators/align_pick_points.py:415-465) against what the reference's own
+    method produced: unequal pick counts, rigid and rot+loc+scale, take_m_with."""
+    import types
+    from object_alignment_amd.operators import LandmarkAlign, OBJECT_OT_align_pick_points, IcpSettings
+    from object_alignment_amd.operators import icp_align as icp_mod, align_pick_points as pick_mod
+    g = np.load(os.path.join(golden_dir, "landmarks.npz"))
+    for i in range(int(g["n_cases"])):
+        p = "c%02d_" % i
+        settings = IcpSettings(take_m_with=bool(g[p + "take_m"]), align_meth=str(g[p + "meth"]))
+        align = types.SimpleNamespace(name="align", type="MESH", matrix_world=g[p + "mx_align"].copy())
+        base = types.SimpleNamespace(name="base", type="MESH", matrix_world=g[p + "mx_base"].copy())
+        marker = types.SimpleNamespace(name="m_marker", matrix_world=g[p + "m_start"].copy())
+        ctx = types.SimpleNamespace(object=align, selected_objects=[base, align],
+                                    scene=types.SimpleNamespace(objects=[align, base, marker]))
+        old = pick_mod.get_addon_preferences
+        pick_mod.get_addon_preferences = lambda: settings
+        try:
+            assert OBJECT_OT_align_pick_points.poll(ctx)
+            op = OBJECT_OT_align_pick_points().begin(ctx)
+            for h in g[p + "hits_align"]:
+                op.pick_align(h)
+            for h in g[p + "hits_base"]:
+                op.pick_base(h)
+            M = op.align_obj(ctx)
+        finally:
+            pick_mod.get_addon_preferences = old
+        name = str(g[p + "name"])
+        assert np.abs(np.asarray(align.matrix_world) - g[p + "final_world"]).max() <= 4 * F32_ULP, name
+        assert np.abs(np.asarray(marker.matrix_world) - g[p + "m_final"]).max() <= 8 * F32_ULP, name
+        if not bool(g[p + "take_m"]):
+            assert np.array_equal(np.asarray(marker.matrix_world), g[p + "m_start"])
+        M2, new_mat = LandmarkAlign(settings).solve(list(g[p + "hits_align"]), list(g[p + "stored_base"]))
+        assert np.array_equal(M, M2) and new_mat.dtype == np.float32
+    with pytest.raises(ValueError, match="input arrays are of wrong shape or type"):
+        LandmarkAlign(IcpSettings()).solve([np.zeros(3)] * 2, [np.zeros(3)] * 2)

@@ -128,6 +128,28 @@ def test_hostmath_matches_oracle(orc):
         assert np.array_equal(_hostmath.mat4_mul(a, b), orc.mat4_mul(a, b))
 
 
+def test_landmark_pick_bookkeeping_golden(golden_dir, orc):
+    """operators/align_pick_points.py:184 -- a base pick stored in the align object's local space, with mathutils'
+    float32 rounding: bit-exact against what the reference's own expression produced (tests/golden/landmarks.npz),
+    and the numpy inverse / mat-vec helpers against the oracle's C restatement."""
+    from object_alignment_amd import _hostmath
+    from object_alignment_amd.operators import base_pick_to_align_local
+    g = np.load(os.path.join(golden_dir, "landmarks.npz"))
+    for i in range(int(g["n_cases"])):
+        p = "c%02d_" % i
+        got = np.array([base_pick_to_align_local(g[p + "mx_align"], g[p + "mx_base"], h) for h in g[p + "hits_base"]])
+        assert np.array_equal(got, g[p + "stored_base"]), str(g[p + "name"])
+    rng = np.random.default_rng(5)
+    for _ in range(50):
+        m = np.identity(4, dtype=np.float32)
+        m[:3, :] = rng.normal(size=(3, 4)).astype(np.float32) * np.float32(10.0 ** rng.integers(-3, 4))
+        assert np.array_equal(_hostmath.mat4_inverted(m), orc.mat4_inverted(m))
+        v = rng.normal(size=3).astype(np.float32)
+        assert np.array_equal(_hostmath.mat4_mul_vec3(m, v), orc.mat4_mul_vec3(m, v))
+    with pytest.raises(ValueError):
+        _hostmath.mat4_inverted(np.zeros((4, 4), np.float32))
+
+
 def test_synthetic_configs_are_deterministic():
     from object_alignment_amd import synth
     assert synth.icosphere(4).shape == (2562, 3)
