@@ -111,8 +111,12 @@ int oa_set_target_mesh(oa_ctx *ctx, const float *xyz, int64_t n_verts, int on_de
                        const int32_t *tris, int64_t n_tris);
 /* source (align object) vertices, align-LOCAL, n_verts x 3 float32.
  * vlist (host, may be NULL = all vertices) is the operator's vertex list; stride > 1 applies
- * vlist[0::stride] (functions/general.py:274-275).  The selected list is then cut into
- * shard_count contiguous shards and this context keeps shard shard_index. */
+ * vlist[0::stride] (functions/general.py:274-275).  The selected list is then cut into shard_count shards of
+ * ceil(n_selected / shard_count) points and this context keeps shard shard_index.  With shard_count > 1 the
+ * shards are equal ranges of the selection in MORTON order (every rank passes the same arrays and derives the
+ * same partition), so that a shard is a compact region of space; for non-finite coordinates they are contiguous
+ * ranges in the caller's order.  Per-point outputs of a shard (oa_make_pairs, oa_nn_search) list its points in the
+ * caller's order.  The sums the loop all-reduces do not depend on the partition. */
 int oa_set_source(oa_ctx *ctx, const float *xyz, int64_t n_verts, int on_device,
                   const int64_t *vlist, int64_t n_vlist, int32_t stride,
                   int32_t shard_index, int32_t shard_count);

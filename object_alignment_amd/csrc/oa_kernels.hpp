@@ -315,12 +315,13 @@ __device__ __forceinline__ void load_tri(const float4 *__restrict__ tri9, long l
 // ------------------------------------------------------------------------------------------------
 // source: gather xyz[vlist[(begin + i) * stride]] -> float4; the tail up to ns_pad repeats the last point
 __global__ void k_pack_source(const float *__restrict__ xyz, const long long *__restrict__ vlist, long long stride,
-                              long long begin, int ns, int ns_pad, float4 *__restrict__ src4,
-                              int *__restrict__ sel_vertex)
+                              long long begin, const int *__restrict__ members, int ns, int ns_pad,
+                              float4 *__restrict__ src4, int *__restrict__ sel_vertex)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ns_pad) return;
-    const long long s = begin + (long long)(i < ns ? i : (ns > 0 ? ns - 1 : 0));
+    const int k = i < ns ? i : (ns > 0 ? ns - 1 : 0);
+    const long long s = members ? (long long)members[k] : begin + (long long)k;   // position in the selection
     const long long v = vlist ? vlist[s * stride] : s * stride;
     float4 p;
     p.x = xyz[3 * v]; p.y = xyz[3 * v + 1]; p.z = xyz[3 * v + 2]; p.w = 0.f;

@@ -1048,3 +1048,49 @@ def test_landmark_prealignment_golden(golden_dir):
         assert np.array_equal(M, M2) and new_mat.dtype == np.float32
     with pytest.raises(ValueError, match="input arrays are of wrong shape or type"):
         LandmarkAlign(IcpSettings()).solve([np.zeros(3)] * 2, [np.zeros(3)] * 2)
+
+
+@pytest.mark.gpu
+def test_spatial_shards_partition_the_selection(orc, monkeypatch):
+    """shard_count > 1: shards are equal ranges of the Morton-ordered selection.  Together they hold every selected
+    point exactly once (pairs of all shards == pairs of the unsharded run, as sets), each lists its points in the
+    caller's order, each is spatially compact, and OA_SHARD_SPATIAL=0 (contiguous ranges) gives the same pairs."""
+    from object_alignment_amd.engine import IcpEngine, shard_bounds
+    rng = np.random.default_rng(12)
+    tgt = rng.uniform(-1, 1, size=(30000, 3)).astype(np.float32)
+    src = (tgt[rng.permutation(30000)[:20001]] + rng.normal(0, 5e-3, size=(20001, 3))).astype(np.float32)
+    vlist = np.sort(rng.choice(len(src), size=15000, replace=False)).astype(np.int64)
+    eye = np.identity(4, dtype=np.float32)
+    mxa = np.identity(4, dtype=np.float32); mxa[:3, 3] = [0.01, -0.02, 0.005]
+    rA, rB, _ = orc.make_pairs(src, tgt, mxa, eye, 0.05, vlist=vlist, sample=2, calc_stats=True)
+    world = 4                                     # a power of two: each Morton range is a union of octants
+
+    def run(spatial):
+        monkeypatch.setenv("OA_SHARD_SPATIAL", "1" if spatial else "0")
+        parts, boxes = [], []
+        for r in range(world):
+            with IcpEngine(0) as e:
+                e.set_target(tgt)
+                e.set_source(src, vlist=vlist, stride=2, shard_index=r, shard_count=world)
+                b, en = shard_bounds(7500, r, world)
+                assert e.n_selected == en - b
+                e.set_matrices(mxa, eye)
+                A, B, _ = e.make_pairs(0.05, calc_stats=False)
+            parts.append((A, B))
+            boxes.append(np.prod(A.max(axis=1) - A.min(axis=1)) if A.shape[1] else 0.0)
+        return parts, boxes
+
+    for spatial in (True, False):
+        parts, boxes = run(spatial)
+        A = np.concatenate([p[0] for p in parts], axis=1)
+        B = np.concatenate([p[1] for p in parts], axis=1)
+        assert A.shape == rA.shape
+        order, rorder = np.lexsort(A), np.lexsort(rA)
+        assert np.array_equal(A[:, order], rA[:, rorder]) and np.array_equal(B[:, order], rB[:, rorder])
+        for pA, _ in parts:                       # caller order inside a shard: a subsequence of the unsharded columns
+            idx = [np.flatnonzero((rA == pA[:, [k]]).all(axis=0))[0] for k in range(0, pA.shape[1], 97)]
+            assert idx == sorted(idx)
+        if spatial:
+            assert max(boxes) < 0.7 * np.prod(rA.max(axis=1) - rA.min(axis=1))
+        else:
+            assert np.array_equal(A, rA)          # contiguous ranges: the concatenation IS the unsharded order
