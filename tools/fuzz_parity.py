@@ -4,7 +4,9 @@
 Every trial draws a cloud family, sizes, scales, offsets and two (possibly non-uniformly scaled) matrix_world
 matrices, then checks, for search modes brute, grid and bvh:
   * oa_nn_search == oracle brute force (index and float32 d2, bit exact) -- vertex mode and surface mode;
-  * oa_make_pairs == oracle make_pairs (A, B bit exact; d_stats to 1e-9).
+  * oa_make_pairs == oracle make_pairs (A, B bit exact; d_stats to 1e-9);
+  * for well-conditioned clouds, three iterations of the device loop == the oracle's loop (K per iteration equal,
+    per-iteration transforms to 1e-7) -- seeds, search radius and the grid -> tree hand-over across iterations.
 Usage: python tools/fuzz_parity.py [trials] [seed]
 """
 import os
@@ -49,6 +51,17 @@ def rand_matrix(rng, scaled):
     return M.astype(np.float32)
 
 
+def well_posed(A, B):
+    """The rotation is only defined when the covariance has rank >= 2: skip the loop comparison when
+    the pairs are degenerate (e.g. a tiny source cloud whose points all find the same target vertex)."""
+    Ac, Bc = A - A.mean(axis=1, keepdims=True), B - B.mean(axis=1, keepdims=True)
+    sv = np.linalg.svd(Bc @ Ac.T, compute_uv=False)
+    # ... and when the cloud is resolved by float32 at all (a 1e-6-sized object 1 unit from the origin is ~10 quanta
+    # across: its covariance is rounding noise and the iteration is chaotic)
+    resolved = min(np.abs(Ac).max(), np.abs(Bc).max()) > 1e-3 * max(np.abs(A).max(), np.abs(B).max())
+    return bool(sv[0] > 0 and sv[1] > 1e-2 * sv[0] and resolved)
+
+
 def main():
     from object_alignment_amd.engine import IcpEngine
     from oracle import oracle as orc
@@ -60,6 +73,7 @@ def main():
     for m, e in engines.items():
         e.set_search_mode(m)
     bad = 0
+    loops = 0
     t0 = time.time()
     for t in range(trials):
         kt, ks = rng.choice(kinds), rng.choice(kinds)
@@ -101,17 +115,49 @@ def main():
                 # population std: accumulated around the first pass's mean on the GPU, two-pass in the oracle
                 ok_p = abs(ds[0] - rds[0]) <= 1e-9 * abs(rds[0]) and abs(ds[1] - rds[1]) <= 1e-8 * abs(rds[1]) + 1e-13 * abs(rds[0])
                 detail = "d_stats %r vs %r" % (ds, rds) if not ok_p else ""
-            if not (ok and ok_p):
+            ok_l, detail_l = True, ""
+            if ok and ok_p and kt in ("uniform", "gauss", "sphere") and ks in ("uniform", "gauss", "sphere") and rA.shape[1] >= 50 and nt >= 17 and well_posed(rA, rB):
+                loops += 1
+                if mode == "brute":
+                    ref_loop = orc.icp_run(src, tgt, mxa, mxb, iters=3, sample=stride, thresh=thresh, target_d=1e-300,
+                                           vlist=vlist, tris=tris)
+                e.set_matrices(mxa, mxb)
+                try:
+                    res = e.run(iters=3, thresh=thresh, target_d=1e-300)
+                    sK, sM = res.step_K, res.step_M
+                except ValueError:
+                    sK, sM = np.array([-1]), np.zeros((1, 4, 4))
+                n_it = len(ref_loop["step_K"])
+                ok_l = len(sK) == n_it and np.array_equal(sK, ref_loop["step_K"])
+                dM = float("nan")
+                if ok_l and n_it:
+                    # rotation part to 1e-7; translation relative to the coordinates' magnitude
+                    dR = float(np.abs(sM[:, :3, :3] - ref_loop["step_M"][:, :3, :3]).max())
+                    dT = float(np.abs(sM[:, :3, 3] - ref_loop["step_M"][:, :3, 3]).max())
+                    mag = float(np.abs(src).max()) + 1e-300
+                    dM = max(dR, dT / mag)
+                    ok_l = dM <= 1e-7
+                if mode == "brute":
+                    brute_M = sM
+                elif ok_l:
+                    ok_l = np.array_equal(sM, brute_M)           # the search modes must agree bit for bit
+                detail_l = "" if ok_l else "loop K %s vs %s, dM %.3g" % ([int(k) for k in sK], [int(k) for k in ref_loop["step_K"]], dM)
+                if not ok_l and os.environ.get("FUZZ_DEBUG"):
+                    np.set_printoptions(precision=9, linewidth=200)
+                    print("stride", stride, "vlist", None if vlist is None else len(vlist), "thresh", thresh, "\nmxa\n", mxa, "\nmxb\n", mxb)
+                    for k in range(min(len(sM), n_it)):
+                        print("iter", k, "max |dM|", np.abs(sM[k] - ref_loop["step_M"][k]).max(), "\n", sM[k], "\n", ref_loop["step_M"][k])
+            if not (ok and ok_p and ok_l):
                 bad += 1
                 nd = int(np.count_nonzero(idx != ridx))
                 print("MISMATCH trial %d mode %s surface %s kinds %s/%s ns %d nt %d scale %g: nn ok %s (%d idx differ) "
-                      "pairs ok %s (K %d vs %d) %s" % (t, mode, surface, ks, kt, ns, nt, scale, ok, nd, ok_p, A.shape[1],
-                                                        rA.shape[1], detail), flush=True)
+                      "pairs ok %s (K %d vs %d) %s loop ok %s %s" % (t, mode, surface, ks, kt, ns, nt, scale, ok, nd, ok_p, A.shape[1],
+                                                        rA.shape[1], detail, ok_l, detail_l), flush=True)
         if (t + 1) % 10 == 0:
             print("trial %d/%d  mismatches %d  (%.0f s)" % (t + 1, trials, bad, time.time() - t0), flush=True)
     for e in engines.values():
         e.close()
-    print("FUZZ DONE: %d trials, %d mismatches" % (trials, bad))
+    print("FUZZ DONE: %d trials, %d mismatches (%d three-iteration loop comparisons)" % (trials, bad, loops))
     sys.exit(1 if bad else 0)
 
 
