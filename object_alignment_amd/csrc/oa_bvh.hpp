@@ -35,8 +35,6 @@ struct BvhParams {
 
 #if defined(__HIPCC__)
 
-constexpr unsigned long long KEY_NONE = 0x7F800000FFFFFFFFull;     // (d2 = +inf, no index)
-
 // ---- wave-wide unsigned minimum, result uniform (DPP inside rows of 16, readlane across the 4 rows)
 __device__ __forceinline__ uint32_t dpp_min_step(uint32_t v, const int ctrl_sel)
 {

@@ -11,9 +11,10 @@
 // Query (one thread per source point): project the query onto the grid's box (pc), search the cube of cells within
 // Chebyshev radius r = 0, 1, 2, ... around pc's cell.  Every vertex not yet seen lies outside that cube, hence at
 // real distance >= sqrt(|p - pc|^2 + m^2), m = distance from pc to the nearest cube face that is interior to the
-// grid.  The metric satisfies d2 >= D (1 - 5.01 u); the loop stops when (|p-pc|^2 + m^2)(1 - 1e-5) > best, i.e. no
-// unseen vertex can beat OR tie the current best.  Queries not settled within `r_max` rings are appended to a list and
-// finished by the brute-force kernel (k_nn_search_filtered in list mode), so the result is exact for any input.
+// grid.  The metric satisfies d2 >= D (1 - 5.01 u); the loop stops when (|p-pc|^2 + m^2)(1 - 1e-5) > lim, i.e. no
+// unseen vertex can beat OR tie the current best (or lie within the search radius, DevState::cut_a).  Queries not
+// settled within `r_max` rings, or whose cells hold more than `budget` candidates, are appended to a list that the
+// tree search (oa_bvh.hpp: k_bvh_search) finishes, so the result is exact for any input.
 #pragma once
 #include "oa_kernels.hpp"
 

@@ -128,7 +128,7 @@ struct oa_ctx {
     int n_splits = 1, groups_per_split = 0, acc_blocks = 1;
     int tile_groups = oa::FTILE_GROUPS;   // LDS tile of k_nn_search_filtered: 256 groups, 64 for small targets
     int R_env = 0;                      // OA_NN_R override (0 = choose from the shard size)
-    bool use_filter = true, use_pk = false;
+    bool use_filter = true;
     double d_pivot0 = 0.0;           // initial distance pivot for the next loop / one-shot (see DevState::d_pivot)
     // device state
     oa::DevState h_state;
@@ -275,8 +275,8 @@ int launch_nn(oa_ctx *c)
         const bool small = (c->tile_groups == 64);
 #define OA_LAUNCH_F(RR)                                                                                              \
         do {                                                                                                         \
-            if (small) hipLaunchKernelGGL((oa::k_nn_search_filtered<RR, false, 64>), grid, block, 0, c->stream, OA_NNF_ARGS); \
-            else hipLaunchKernelGGL((oa::k_nn_search_filtered<RR, false, oa::FTILE_GROUPS>), grid, block, 0, c->stream, OA_NNF_ARGS); \
+            if (small) hipLaunchKernelGGL((oa::k_nn_search_filtered<RR, 64>), grid, block, 0, c->stream, OA_NNF_ARGS); \
+            else hipLaunchKernelGGL((oa::k_nn_search_filtered<RR, oa::FTILE_GROUPS>), grid, block, 0, c->stream, OA_NNF_ARGS); \
         } while (0)
         switch (c->R) {
         case 1: OA_LAUNCH_F(1); break;
@@ -528,7 +528,6 @@ OA_EXPORT int oa_create(oa_ctx **out, int device)
     if (c->R_env != 1 && c->R_env != 2 && c->R_env != 4 && c->R_env != 8) c->R_env = 0;
     c->R = c->R_env ? c->R_env : 4;
     c->use_filter = env_int("OA_NN_FILTER", 1) != 0;
-    c->use_pk = env_int("OA_NN_PK", 0) != 0;
     c->grid_mode = env_int("OA_NN_GRID", -1);
     *out = c;
     return OA_OK;
@@ -1026,8 +1025,7 @@ int launch_tri_search(oa_ctx *c)
         return launch_bvh<true>(c, c->d_todo_list, c->d_todo_count);       // the far queries: tree search
     } else {
         hipLaunchKernelGGL(oa::k_tri_search_all, dim3(std::min((c->ns + 255) / 256, 65535)), dim3(256), 0, c->stream,
-                           c->d_state, c->d_src4, c->ns, c->d_tri9, c->n_tris, c->d_prev, c->d_keys,
-                           (const int *)nullptr, (const int *)nullptr);
+                           c->d_state, c->d_src4, c->ns, c->d_tri9, c->n_tris, c->d_prev, c->d_keys);
     }
     HIPCHK(hipGetLastError());
     return OA_OK;

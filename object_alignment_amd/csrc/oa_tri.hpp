@@ -10,8 +10,11 @@
 // cells around its (box-projected) position exactly like k_nn_search_grid.  A triangle that has not been seen after
 // ring r has a bounding box disjoint from the searched cube, so all of it is at real distance >= sqrt(|p-pc|^2 + m^2);
 // the float32 evaluation can undershoot the real distance by at most delta = 64 u (|coords|), hence the stop rule
-// (sqrt(|p-pc|^2 + m^2) - delta)^2 (1 - 1e-5) > best.  Unsettled queries are finished by brute force over all
-// triangles (k_tri_search_all in list mode), which is also the whole search for small meshes.
+// (sqrt(|p-pc|^2 + m^2) - delta)^2 (1 - 1e-5) > lim  (lim = best so far, or the search radius of DevState::cut_a).
+// Each cell-list entry carries the triangle's bounding sphere; candidates are filtered on those contiguous records
+// and the survivors evaluated in a second phase (tri_queue_flush).  Queries the grid cannot settle -- far from the
+// surface, or in crowded cells -- are finished by the triangle tree (oa_bvh.hpp); k_tri_search_all (every triangle
+// for every query) is what OA_SEARCH_BRUTE runs.
 #pragma once
 #include "oa_grid.hpp"
 
@@ -350,32 +353,22 @@ __global__ __launch_bounds__(256) void k_tri_search_grid(const DevState *__restr
     if (!settled) todo_list[atomicAdd(todo_count, 1)] = i;
 }
 
-// brute force over all triangles: every source point (list == nullptr) or the points the grid could not settle
+// brute force over all triangles for every source point (OA_SEARCH_BRUTE; the oracle's oo_nn_tri_brute on the device)
 __global__ __launch_bounds__(256) void k_tri_search_all(const DevState *__restrict__ st,
                                                         const float4 *__restrict__ src4, int ns,
                                                         const float4 *__restrict__ tri9, int n_tris,
                                                         const int *__restrict__ prev,
-                                                        unsigned long long *__restrict__ keys,
-                                                        const int *__restrict__ list, const int *__restrict__ list_count)
+                                                        unsigned long long *__restrict__ keys)
 {
     if (st->halt) return;
-    const int n_items = list ? *list_count : ns;
-    for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n_items; slot += gridDim.x * blockDim.x) {
-        const int i = list ? list[slot] : slot;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) {
         const float4 p4 = src4[i];
         float wx, wy, wz, pf[3];
         m4_mul_v3(st->mx1, p4.x, p4.y, p4.z, wx, wy, wz);
         m4_mul_v3(st->imx2, wx, wy, wz, pf[0], pf[1], pf[2]);
         float best = INFINITY;
         uint32_t bidx = IDX_NONE;
-        if (list) {
-            const unsigned long long k0 = keys[i];
-            best = __uint_as_float((uint32_t)(k0 >> 32));
-            bidx = (uint32_t)k0;
-            if (!(best < INFINITY)) { best = INFINITY; bidx = IDX_NONE; }
-        } else if (prev && prev[i] >= 0) {
-            tri_eval(pf, tri9, (uint32_t)prev[i], best, bidx);
-        }
+        if (prev && prev[i] >= 0) tri_eval(pf, tri9, (uint32_t)prev[i], best, bidx);
         for (int t = 0; t < n_tris; ++t) tri_eval(pf, tri9, (uint32_t)t, best, bidx);
         keys[i] = ((unsigned long long)__float_as_uint(best) << 32) | bidx;
     }
