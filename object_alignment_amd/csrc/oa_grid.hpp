@@ -96,7 +96,7 @@ __device__ __forceinline__ void grid_candidate(float px, float py, float pz, con
     if (d < best || (d == best && qi < bidx && d < INFINITY)) { best = d; bidx = qi; }
 }
 
-__global__ __launch_bounds__(256) void k_nn_search_grid(const DevState *__restrict__ st,
+__global__ __launch_bounds__(256, 6) void k_nn_search_grid(const DevState *__restrict__ st,
                                                         const float4 *__restrict__ src4, int ns, GridParams gp,
                                                         const int *__restrict__ cell_start,
                                                         const float4 *__restrict__ sorted,
