@@ -657,6 +657,9 @@ __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_filt
     if (st->halt) return;
     // TG = groups of 4 targets per LDS tile: 256 for large targets, 64 for small ones (more, shorter workgroups)
     constexpr int TILE_F4 = TG * 3, LOADS = (TILE_F4 + NN_THREADS - 1) / NN_THREADS;
+    // whole tiles per thread (TG = 256): the staging registers must not be predicated, or the compiler parks them in
+    // scratch and the tile loop writes and re-reads 48 B per lane per tile through HBM (PMC: 4.9 GB per launch)
+    constexpr bool FULL = (TILE_F4 % NN_THREADS) == 0;
     __shared__ float4 tile[2][TILE_F4];
     const int tid = threadIdx.x;
     const double qmax = st->qmax;
@@ -694,10 +697,18 @@ __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_filt
     const int n_tiles = (g_end - g_begin) / TG;
     const float4 *tsrc = tf2 + 3ll * g_begin;
 
-    float4 stg[LOADS];
-#pragma unroll
-    for (int k = 0; k < LOADS; ++k)
-        if (k * NN_THREADS + tid < TILE_F4) { stg[k] = tsrc[k * NN_THREADS + tid]; tile[0][k * NN_THREADS + tid] = stg[k]; }
+    // staging registers for the next tile: named scalars (an indexed array ends up in scratch, see FULL above)
+    static_assert(LOADS <= 3, "k_nn_search_filtered: tile of at most 3 float4 per thread");
+    float4 stg0 = make_float4(0.f, 0.f, 0.f, 0.f), stg1 = stg0, stg2 = stg0;
+#define OA_STG_EACH(OP)                                                                     \
+    do {                                                                                    \
+        if (LOADS > 0 && (FULL || 0 * NN_THREADS + tid < TILE_F4)) { OP(0, stg0); }         \
+        if (LOADS > 1 && (FULL || 1 * NN_THREADS + tid < TILE_F4)) { OP(1, stg1); }         \
+        if (LOADS > 2 && (FULL || 2 * NN_THREADS + tid < TILE_F4)) { OP(2, stg2); }         \
+    } while (0)
+#define OA_STG_FIRST(k, reg) reg = tsrc[(k) * NN_THREADS + tid]; tile[0][(k) * NN_THREADS + tid] = reg
+    OA_STG_EACH(OA_STG_FIRST);
+#undef OA_STG_FIRST
     __syncthreads();
 
     for (int t = 0; t < n_tiles; ++t) {
@@ -705,9 +716,9 @@ __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_filt
         const bool more = (t + 1 < n_tiles);
         if (more) {                                               // next tile: global -> registers, hidden under compute
             const float4 *nsrc = tsrc + 3ll * TG * (t + 1);
-#pragma unroll
-            for (int k = 0; k < LOADS; ++k)
-                if (k * NN_THREADS + tid < TILE_F4) stg[k] = nsrc[k * NN_THREADS + tid];
+#define OA_STG_LOAD(k, reg) reg = nsrc[(k) * NN_THREADS + tid]
+            OA_STG_EACH(OA_STG_LOAD);
+#undef OA_STG_LOAD
         }
         const int gbase = g_begin + t * TG;
         // GW groups (4*GW targets) per skip test.  Level 1 (hot): 2 fma + min per pair in the kept plane; level 2 (rare):
@@ -773,12 +784,13 @@ __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_filt
             }
         }
         if (more) {
-#pragma unroll
-            for (int k = 0; k < LOADS; ++k)
-                if (k * NN_THREADS + tid < TILE_F4) tile[cur ^ 1][k * NN_THREADS + tid] = stg[k];
+#define OA_STG_STORE(k, reg) tile[cur ^ 1][(k) * NN_THREADS + tid] = reg
+            OA_STG_EACH(OA_STG_STORE);
+#undef OA_STG_STORE
         }
         __syncthreads();
     }
+#undef OA_STG_EACH
 
 #pragma unroll
     for (int r = 0; r < R; ++r) {
