@@ -144,53 +144,76 @@ __host__ __device__ inline bool m4_inverted(const float *Af, float *out)
 // One-sided Jacobi gives H V = U S; the reflection-corrected rotation U diag(1,1,det(UV^T)) V^T equals
 // [u1 u2 u1xu2][v1 v2 v1xv2]^T, so only the two leading singular triplets are needed (rank >= 2).
 // ------------------------------------------------------------------------------------------------
+// One Jacobi rotation of columns (P, Q) of g and v; returns whether the pair needed one.  P, Q are template
+// parameters so that every index is static: on the device the arrays then live in registers instead of scratch
+// memory (the solve is a single fp64 lane; a scratch round trip per element dominated it).
+template <int P, int Q>
+__host__ __device__ inline bool jacobi_rotate(double g[3][3], double v[3][3])
+{
+    const double npp = g[0][P] * g[0][P] + g[1][P] * g[1][P] + g[2][P] * g[2][P];
+    const double nqq = g[0][Q] * g[0][Q] + g[1][Q] * g[1][Q] + g[2][Q] * g[2][Q];
+    const double dpq = g[0][P] * g[0][Q] + g[1][P] * g[1][Q] + g[2][P] * g[2][Q];
+    if (dpq == 0.0 || dpq * dpq <= 1e-30 * (npp * nqq)) return false;     // |dpq| <= 1e-15 |g_p||g_q| (~4.5 eps)
+    // t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)), zeta = (nqq - npp) / (2 dpq), written with one division:
+    // t = 2 dpq sign(w) / (|w| + sqrt(w^2 + 4 dpq^2)), w = nqq - npp
+    const double w = nqq - npp, d2 = 2.0 * dpq;
+    const double t = (w >= 0.0 ? d2 : -d2) / (fabs(w) + sqrt(w * w + d2 * d2));
+    const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int r = 0; r < 3; ++r) {
+        const double gp = g[r][P], gq = g[r][Q], vp = v[r][P], vq = v[r][Q];
+        g[r][P] = c * gp - s * gq; g[r][Q] = s * gp + c * gq;
+        v[r][P] = c * vp - s * vq; v[r][Q] = s * vp + c * vq;
+    }
+    return true;
+}
+
+// column j of a 3x3 held in registers (select chain instead of a dynamic index)
+__host__ __device__ inline double col3(const double m[3][3], int r, int j)
+{
+    return j == 0 ? m[r][0] : (j == 1 ? m[r][1] : m[r][2]);
+}
+
 __host__ __device__ inline void rotation_from_covariance(const double H[9], double R[9])
 {
     double g[3][3], v[3][3];
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) { g[i][j] = H[3 * i + j]; v[i][j] = (i == j) ? 1.0 : 0.0; }
+    g[0][0] = H[0]; g[0][1] = H[1]; g[0][2] = H[2];
+    g[1][0] = H[3]; g[1][1] = H[4]; g[1][2] = H[5];
+    g[2][0] = H[6]; g[2][1] = H[7]; g[2][2] = H[8];
+    v[0][0] = 1.0; v[0][1] = 0.0; v[0][2] = 0.0;
+    v[1][0] = 0.0; v[1][1] = 1.0; v[1][2] = 0.0;
+    v[2][0] = 0.0; v[2][1] = 0.0; v[2][2] = 1.0;
     for (int sweep = 0; sweep < 64; ++sweep) {
-        bool any = false;
-        for (int p = 0; p < 2; ++p)
-            for (int q = p + 1; q < 3; ++q) {
-                const double npp = g[0][p] * g[0][p] + g[1][p] * g[1][p] + g[2][p] * g[2][p];
-                const double nqq = g[0][q] * g[0][q] + g[1][q] * g[1][q] + g[2][q] * g[2][q];
-                const double dpq = g[0][p] * g[0][q] + g[1][p] * g[1][q] + g[2][p] * g[2][q];
-                if (dpq == 0.0 || dpq * dpq <= 1e-30 * (npp * nqq)) continue;       // |dpq| <= 1e-15 |g_p||g_q| (~4.5 eps)
-                any = true;
-                // t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)), zeta = (nqq - npp) / (2 dpq), written with one
-                // division: t = 2 dpq sign(w) / (|w| + sqrt(w^2 + 4 dpq^2)), w = nqq - npp (the chain is a single
-                // fp64 lane on the device: every sqrt / divide is ~30 dependent instructions)
-                const double w = nqq - npp, d2 = 2.0 * dpq;
-                const double t = (w >= 0.0 ? d2 : -d2) / (fabs(w) + sqrt(w * w + d2 * d2));
-                const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
-                for (int r = 0; r < 3; ++r) {
-                    const double gp = g[r][p], gq = g[r][q], vp = v[r][p], vq = v[r][q];
-                    g[r][p] = c * gp - s * gq; g[r][q] = s * gp + c * gq;
-                    v[r][p] = c * vp - s * vq; v[r][q] = s * vp + c * vq;
-                }
-            }
+        bool any = jacobi_rotate<0, 1>(g, v);
+        any = jacobi_rotate<0, 2>(g, v) || any;
+        any = jacobi_rotate<1, 2>(g, v) || any;
         if (!any) break;
     }
-    double sg[3];
-    for (int j = 0; j < 3; ++j) sg[j] = sqrt(g[0][j] * g[0][j] + g[1][j] * g[1][j] + g[2][j] * g[2][j]);
+    const double sg0 = sqrt(g[0][0] * g[0][0] + g[1][0] * g[1][0] + g[2][0] * g[2][0]);
+    const double sg1 = sqrt(g[0][1] * g[0][1] + g[1][1] * g[1][1] + g[2][1] * g[2][1]);
+    const double sg2 = sqrt(g[0][2] * g[0][2] + g[1][2] * g[1][2] + g[2][2] * g[2][2]);
     int j1 = 0;
-    if (sg[1] > sg[j1]) j1 = 1;
-    if (sg[2] > sg[j1]) j1 = 2;
+    if (sg1 > sg0) j1 = 1;
+    if (sg2 > (j1 == 0 ? sg0 : sg1)) j1 = 2;
     int j2 = (j1 == 0) ? 1 : 0;
-    for (int j = 0; j < 3; ++j) if (j != j1 && sg[j] > sg[j2]) j2 = j;
+    for (int j = 0; j < 3; ++j) {
+        const double sj = j == 0 ? sg0 : (j == 1 ? sg1 : sg2), s2 = j2 == 0 ? sg0 : (j2 == 1 ? sg1 : sg2);
+        if (j != j1 && sj > s2) j2 = j;
+    }
+    const double s_j1 = j1 == 0 ? sg0 : (j1 == 1 ? sg1 : sg2), s_j2 = j2 == 0 ? sg0 : (j2 == 1 ? sg1 : sg2);
     double u1[3], u2[3], v1[3], v2[3];
     for (int r = 0; r < 3; ++r) {
-        v1[r] = v[r][j1]; v2[r] = v[r][j2];
-        u1[r] = (sg[j1] > 0.0) ? g[r][j1] / sg[j1] : (r == 0 ? 1.0 : 0.0);
-        u2[r] = (sg[j2] > 0.0) ? g[r][j2] / sg[j2] : 0.0;
+        v1[r] = col3(v, r, j1); v2[r] = col3(v, r, j2);
+        u1[r] = (s_j1 > 0.0) ? col3(g, r, j1) / s_j1 : (r == 0 ? 1.0 : 0.0);
+        u2[r] = (s_j2 > 0.0) ? col3(g, r, j2) / s_j2 : 0.0;
     }
-    if (!(sg[j2] > 0.0)) {   // rank <= 1: the rotation is not unique; complete u2 deterministically
+    if (!(s_j2 > 0.0)) {   // rank <= 1: the rotation is not unique; complete u2 deterministically
         int m = 0;
         if (fabs(u1[1]) < fabs(u1[m])) m = 1;
-        if (fabs(u1[2]) < fabs(u1[m])) m = 2;
-        double e[3] = { 0.0, 0.0, 0.0 };
-        e[m] = 1.0;
+        if (fabs(u1[2]) < fabs(m == 0 ? u1[0] : u1[1])) m = 2;
+        const double e[3] = { m == 0 ? 1.0 : 0.0, m == 1 ? 1.0 : 0.0, m == 2 ? 1.0 : 0.0 };
         const double d = e[0] * u1[0] + e[1] * u1[1] + e[2] * u1[2];
         double nn = 0.0;
         for (int r = 0; r < 3; ++r) { u2[r] = e[r] - d * u1[r]; nn += u2[r] * u2[r]; }
