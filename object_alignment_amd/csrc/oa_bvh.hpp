@@ -18,7 +18,7 @@
 // box (vertex mode: float32 gaps, relative error < 6u, metric >= D (1 - 5.01u); triangle mode: double, minus
 // delta = 64u(|coords|) for the float32 closest-point evaluation, as in oa_tri.hpp).
 #pragma once
-#include "oa_grid.hpp"
+#include "oa_tri.hpp"
 
 namespace oa {
 
@@ -243,6 +243,7 @@ __global__ __launch_bounds__(256) void k_bvh_search(const DevState *__restrict__
         float lim = fminf(best, cutf);
         const bool finite = fabsf(p[0]) < INFINITY && fabsf(p[1]) < INFINITY && fabsf(p[2]) < INFINITY;
         const double delta = TRI ? 64.0 * 5.9604644775390625e-08 * (bp.scale + fabs((double)p[0]) + fabs((double)p[1]) + fabs((double)p[2])) + bp.slack : 0.0;
+        float thr = TRI ? tri_skip_threshold(lim, delta) : 0.f;     // squared bounding-box gap beyond which a triangle is out
 
         if (finite) {                                               // a non-finite query has no finite distance: stays (inf, none)
             int level = top;
@@ -294,6 +295,16 @@ __global__ __launch_bounds__(256) void k_bvh_search(const DevState *__restrict__
                     float a[3], b[3], c[3], r[3];
                     load_tri(prims, j, a, b, c);
                     qi = __float_as_uint(prims[3 * j + 2].y);
+                    // the leaf's box passed, but it bounds 64 triangles: when no single triangle's own box can matter
+                    // the ~300-instruction closest-point evaluation of the whole wave is skipped
+                    float lb = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const float lo = fminf(fminf(a[k], b[k]), c[k]), hi = fmaxf(fmaxf(a[k], b[k]), c[k]);
+                        const float g = fmaxf(fmaxf(lo - p[k], p[k] - hi), 0.f);
+                        lb += g * g;
+                    }
+                    if (!__any(!(lb > thr))) continue;
                     closest_on_tri(p, a, b, c, r);
                     d = tri_dist2(p, r);
                 } else {
@@ -305,7 +316,10 @@ __global__ __launch_bounds__(256) void k_bvh_search(const DevState *__restrict__
                 const uint32_t md = wave_min_u32(dbits);
                 if (md <= __float_as_uint(best) && md != 0xFFFFFFFFu) {
                     const uint32_t mi = wave_min_u32(dbits == md ? qi : IDX_NONE);
-                    if (md < __float_as_uint(best) || mi < bidx) { best = __uint_as_float(md); bidx = mi; lim = fminf(best, cutf); }
+                    if (md < __float_as_uint(best) || mi < bidx) {
+                        best = __uint_as_float(md); bidx = mi; lim = fminf(best, cutf);
+                        if (TRI) thr = tri_skip_threshold(lim, delta);
+                    }
                 }
             }
         }
