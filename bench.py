@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--n-target", type=int, default=1_000_000)
     ap.add_argument("--cpu-iters", type=int, default=3, help="iterations of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-surface", action="store_true", help="skip the surface-mode leg (1M points vs a 2M-triangle mesh)")
     return ap.parse_args()
 
 
@@ -181,6 +182,34 @@ def main():
     except Exception as exc:                                  # never lose the headline line
         grid = ("error: %r" % (exc,),)
 
+    # SURVEY 8f rank 1 ("next" row, reported beside the headline): surface mode -- closest point on the base mesh's
+    # triangles, what the reference's BVHTree.find_nearest returns -- on a 1M-point cloud against a ~1M-vertex /
+    # ~2M-triangle mesh of the synthetic bunny surface, library-default search (grid + tree).  N = 1 only.
+    surf = None
+    if world == 1 and not args.no_surface:
+        try:
+            sv, st = synth.lattice_surface_mesh(700, 1400)
+            ssrc = synth.bunny_surface(args.n_source, offset=0.37)
+            s_mxa = synth.rigid4(synth.rotation_from_rotvec([0.02, -0.015, 0.025]), [0.01, -0.008, 0.012])
+            eye4 = np.identity(4, dtype=np.float32)
+            with IcpEngine(local_rank) as se:
+                se.set_target_mesh(sv, st)
+                se.set_source(ssrc, stride=1)
+                se.set_matrices(s_mxa, eye4)
+                se.run(iters=3, thresh=0.05, early_exit=False)             # warm-up (module load, first launches)
+                se.set_matrices(s_mxa, eye4)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                sres = se.run(iters=30, thresh=0.05, early_exit=False)
+                s_dt = time.perf_counter() - t0
+            surf = {"what": "SURVEY 8f rank 1 (next row): surface mode, closest point on triangles (k_tri_search_grid + "
+                            "k_bvh_search), bit-identical to the oracle's brute force over all triangles (tests)",
+                    "n_source": int(len(ssrc)), "n_target_vertices": int(len(sv)), "n_target_triangles": int(len(st)),
+                    "steps": 30, "value": 30 / s_dt, "unit": "iterations/s", "ms_per_step": 1e3 * s_dt / 30,
+                    "ms_per_nn_search": sres.nn_ms_total / 30, "last_K": sres.last_K, "mean_dist": sres.mean_dist}
+        except Exception as exc:                                  # never lose the headline line
+            surf = {"error": repr(exc)}
+
     if rank == 0:
         assert res.iters_done == args.steps, (res.iters_done, args.steps)
         ns_local = eng.n_selected
@@ -237,6 +266,8 @@ def main():
             }
         elif grid is not None:
             out["grid_path"] = {"error": grid[0]}
+        if surf is not None:
+            out["surface_path"] = surf
         prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(prof):
             try:

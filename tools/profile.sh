@@ -8,7 +8,7 @@ OUT="$REPO/gpurun_out"
 STEPS="${STEPS:-5}"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --steps $STEPS --warmup 1 --no-cpu-baseline"
+BENCH="python $REPO/bench.py --steps $STEPS --warmup 1 --no-cpu-baseline --no-surface"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_stats" -- $BENCH > "$OUT/prof_stats.log" 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d "$OUT/prof_pmc_$c" -- $BENCH > "$OUT/prof_pmc_$c.log" 2>&1

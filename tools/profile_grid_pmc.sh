@@ -4,7 +4,7 @@ REPO="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 OUT="$REPO/gpurun_out"
 mkdir -p "$OUT"; rm -rf "$OUT/prof_grid_pmc"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU --output-format csv -d "$OUT/prof_grid_pmc" -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/prof_grid_pmc.log" 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU --output-format csv -d "$OUT/prof_grid_pmc" -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-surface > "$OUT/prof_grid_pmc.log" 2>&1
 python - <<PY
 import csv,glob,collections
 f=glob.glob("$OUT/prof_grid_pmc/*/*_counter_collection.csv")[0]

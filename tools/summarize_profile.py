@@ -44,7 +44,7 @@ def main():
             if k.startswith("k_nn_search"):
                 agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
     lines = ["# %s: %s" % (tag, header),
-             "# rocprofv3 PMC passes of `python bench.py --steps 5 --warmup 1 --no-cpu-baseline` (tools/profile.sh); per-dispatch means", ""]
+             "# rocprofv3 PMC passes of `python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-surface` (tools/profile.sh); per-dispatch means", ""]
     mean = {}
     order = {"FETCH_SIZE": 0, "WRITE_SIZE": 1}
     for (k, c), v in sorted(agg.items(), key=lambda kv: (order.get(kv[0][1], 2), kv[0][1] if kv[0][1] not in order else "", kv[0][0])):
