@@ -198,7 +198,7 @@ __device__ __forceinline__ void tri_state_refresh(TriSearchState &s, double delt
 // (tri_candidate): sphere test on the contiguous 16-byte record; survivors' triangle ids are pushed on a per-thread
 // queue in LDS.  Phase 2 (tri_queue_flush): every lane evaluates ITS k-th survivor in the same trip, so a wave pays
 // max-over-lanes(survivors) closest-point evaluations instead of one per candidate slot in which any lane survived
-// (measured: 18.5k -> VALU instructions per wave before, see profiles/).
+// (measured with SQ_INSTS_VALU: 18.5k -> 9.5k instructions per wave, profiles/r01g_surface_1M_pmc_summary.txt).
 constexpr int TRI_QUEUE = 16;
 
 __device__ __forceinline__ void tri_candidate(const float *p, const float4 sph, const int *__restrict__ cell_tris, int j,
