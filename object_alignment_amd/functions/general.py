@@ -96,10 +96,12 @@ class AlignObject:
 
 
 class GpuBVH:
-    """What `base_bvh` is in this build: the target vertices resident on the GPU.
+    """What `base_bvh` is in this build: the base object's geometry resident on the GPU, with its search structures
+    (uniform grid + box tree, csrc/oa_grid.hpp, oa_tri.hpp, oa_bvh.hpp).
 
-    Mirrors `BVHTree.FromObject(base_obj, depsgraph)` (operators/icp_align.py:53).  The search it
-    serves is nearest target VERTEX, not closest point on the triangle surface.
+    Mirrors `BVHTree.FromObject(base_obj, depsgraph)` (operators/icp_align.py:53): an object with faces is searched
+    for the closest point on its triangle SURFACE (what `find_nearest` returns); an object without faces -- a point
+    cloud -- for its nearest vertex.
     """
 
     def __init__(self, target_xyz, engine: IcpEngine | None = None, tris=None):
@@ -115,8 +117,15 @@ class GpuBVH:
     @classmethod
     def FromObject(cls, base_obj, depsgraph=None, engine: IcpEngine | None = None, surface=True):
         """Like BVHTree.FromObject: when the object has faces the tree answers with the closest SURFACE point;
-        an object without faces (or surface=False) is searched as a vertex cloud."""
-        return cls(_coords_of(base_obj), engine, _tris_of(base_obj) if surface else None)
+        an object without faces (or surface=False) is searched as a vertex cloud.  With a depsgraph the EVALUATED
+        object (modifiers applied) is used, as Blender's BVHTree.FromObject(obj, depsgraph) does."""
+        obj = base_obj
+        if depsgraph is not None and hasattr(base_obj, "evaluated_get"):
+            try:
+                obj = base_obj.evaluated_get(depsgraph)
+            except Exception:
+                obj = base_obj
+        return cls(_coords_of(obj), engine, _tris_of(obj) if surface else None)
 
     def _bind_source(self, xyz, vlist, sample):
         key = (id(xyz), xyz.shape, None if vlist is None else (len(vlist), hash(bytes(memoryview(vlist)))), sample)
