@@ -83,6 +83,24 @@ def _tris_of(obj):
     return None
 
 
+def evaluated_base(base_obj, context_or_depsgraph=None):
+    """The object whose geometry the base search uses: the EVALUATED base object (modifiers applied) when a depsgraph
+    is available, as `BVHTree.FromObject(base_obj, context.evaluated_depsgraph_get())` does (operators/icp_align.py:
+    52-53); the object itself otherwise (duck-typed objects, arrays)."""
+    dg = context_or_depsgraph
+    if dg is not None and hasattr(dg, "evaluated_depsgraph_get"):
+        try:
+            dg = dg.evaluated_depsgraph_get()
+        except Exception:
+            dg = None
+    if dg is not None and hasattr(base_obj, "evaluated_get"):
+        try:
+            return base_obj.evaluated_get(dg)
+        except Exception:
+            pass
+    return base_obj
+
+
 class AlignObject:
     """Blender-free stand-in for an object: local coordinates + matrix_world (float32 4x4) (+ optional triangles)."""
 
@@ -119,12 +137,7 @@ class GpuBVH:
         """Like BVHTree.FromObject: when the object has faces the tree answers with the closest SURFACE point;
         an object without faces (or surface=False) is searched as a vertex cloud.  With a depsgraph the EVALUATED
         object (modifiers applied) is used, as Blender's BVHTree.FromObject(obj, depsgraph) does."""
-        obj = base_obj
-        if depsgraph is not None and hasattr(base_obj, "evaluated_get"):
-            try:
-                obj = base_obj.evaluated_get(depsgraph)
-            except Exception:
-                obj = base_obj
+        obj = evaluated_base(base_obj, depsgraph)
         return cls(_coords_of(obj), engine, _tris_of(obj) if surface else None)
 
     def _bind_source(self, xyz, vlist, sample):

@@ -12,7 +12,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from ..engine import IcpEngine, RunResult
-from ..functions.general import _coords_of, _matrix_to_np, _tris_of, default_engine
+from ..functions.general import _coords_of, _matrix_to_np, _tris_of, default_engine, evaluated_base
 
 try:                                              # inside Blender the operator registers as usual
     import bpy as _bpy                            # noqa: F401
@@ -142,9 +142,10 @@ class OBJECT_OT_icp_align(_OperatorBase):
         except Exception:
             pass
         vlist = build_vlist(align_obj)
-        res = IcpAlign(settings).run(_coords_of(align_obj), _coords_of(base_obj),
+        base_geo = evaluated_base(base_obj, context)            # BVHTree.FromObject(base_obj, depsgraph)  (:52-53)
+        res = IcpAlign(settings).run(_coords_of(align_obj), _coords_of(base_geo),
                                      _matrix_to_np(align_obj.matrix_world), _matrix_to_np(base_obj.matrix_world),
-                                     vlist=vlist, target_tris=_tris_of(base_obj))
+                                     vlist=vlist, target_tris=_tris_of(base_geo))
         _assign_matrix(align_obj, res.matrix_world)
         if settings.take_m_with:                                # :123-127, replayed in iteration order
             from .. import _hostmath

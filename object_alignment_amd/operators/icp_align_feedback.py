@@ -19,7 +19,7 @@ from dataclasses import dataclass, field
 import numpy as np
 
 from .. import _hostmath
-from ..functions.general import _coords_of, _matrix_to_np, _tris_of, default_engine
+from ..functions.general import _coords_of, _matrix_to_np, _tris_of, default_engine, evaluated_base
 from .icp_align import _OperatorBase, _assign_matrix, _bpy, build_vlist, get_addon_preferences
 
 RING = 5
@@ -74,7 +74,7 @@ class OBJECT_OT_icp_align_feedback(_OperatorBase):
         run.ring_t = [run.target_d * 2.0] * RING
         run.ring_r = [None] * RING
         self._run = run
-        self._upload(run, stride=round(1 / prefs.sample_fraction))
+        self._upload(run, stride=round(1 / prefs.sample_fraction), context=context)
         try:
             align.rotation_mode = 'QUATERNION'
         except Exception:
@@ -128,13 +128,14 @@ class OBJECT_OT_icp_align_feedback(_OperatorBase):
             run.converged = max(run.ring_t) < run.target_d
 
     # ------------------------------------------------------------------ helpers
-    def _upload(self, run, stride):
+    def _upload(self, run, stride, context=None):
         eng = self.engine = default_engine()
-        tris = _tris_of(run.base_obj)
+        base_geo = evaluated_base(run.base_obj, context)         # the evaluated mesh, as the reference's BVH (:57)
+        tris = _tris_of(base_geo)
         if tris is None:
-            eng.set_target(_coords_of(run.base_obj))
+            eng.set_target(_coords_of(base_geo))
         else:
-            eng.set_target_mesh(_coords_of(run.base_obj), tris)
+            eng.set_target_mesh(_coords_of(base_geo), tris)
         eng.set_source(_coords_of(run.align_obj), vlist=build_vlist(run.align_obj), stride=stride)
         eng.set_matrices(_matrix_to_np(run.align_obj.matrix_world), _matrix_to_np(run.base_obj.matrix_world))
 
