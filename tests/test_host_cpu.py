@@ -150,6 +150,24 @@ def test_landmark_pick_bookkeeping_golden(golden_dir, orc):
         _hostmath.mat4_inverted(np.zeros((4, 4), np.float32))
 
 
+def test_evaluated_base_object_is_used():
+    """BVHTree.FromObject(base_obj, context.evaluated_depsgraph_get()) searches the EVALUATED mesh
+    (operators/icp_align.py:52-53): the host does the same when the context offers a depsgraph."""
+    import types
+    from object_alignment_amd.functions.general import evaluated_base, AlignObject
+    raw = AlignObject(np.zeros((3, 3), np.float32))
+    cooked = AlignObject(np.ones((5, 3), np.float32))
+    dg = object()
+    raw.evaluated_get = lambda d: cooked if d is dg else None
+    ctx = types.SimpleNamespace(evaluated_depsgraph_get=lambda: dg)
+    assert evaluated_base(raw, ctx) is cooked            # context
+    assert evaluated_base(raw, dg) is cooked             # depsgraph itself
+    assert evaluated_base(raw, None) is raw
+    assert evaluated_base(AlignObject(np.zeros((1, 3))), ctx).xyz.shape == (1, 3)   # no evaluated_get: the object itself
+    broken = types.SimpleNamespace(evaluated_depsgraph_get=lambda: (_ for _ in ()).throw(RuntimeError("no depsgraph")))
+    assert evaluated_base(raw, broken) is raw
+
+
 def test_synthetic_configs_are_deterministic():
     from object_alignment_amd import synth
     assert synth.icosphere(4).shape == (2562, 3)
