@@ -1022,6 +1022,12 @@ int launch_tri_search(oa_ctx *c)
                            c->ns, c->tgp, c->d_tcell_start, c->d_tcell_tris, c->d_tcell_sph, c->d_tri9, c->d_prev, c->d_keys,
                            c->d_todo_list, c->d_todo_count);
         HIPCHK(hipGetLastError());
+        if (getenv("OA_DEBUG")) {                                  // how many queries the grid handed over (debug only: syncs)
+            int n_todo = 0;
+            HIPCHK(hipMemcpyAsync(&n_todo, c->d_todo_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            fprintf(stderr, "[oa] tri grid handed %d of %d queries to the tree\n", n_todo, c->ns);
+        }
         return launch_bvh<true>(c, c->d_todo_list, c->d_todo_count);       // the far queries: tree search
     } else {
         hipLaunchKernelGGL(oa::k_tri_search_all, dim3(std::min((c->ns + 255) / 256, 65535)), dim3(256), 0, c->stream,
