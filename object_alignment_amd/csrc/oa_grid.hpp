@@ -138,7 +138,14 @@ __global__ __launch_bounds__(256, 6) void k_nn_search_grid(const DevState *__res
     const float cutf = search_cutoff2(st, px, py, pz);
     float lim = fminf(best, cutf);
     bool settled = false;
+    // candidates this thread may look at before the tree takes the query over; doubled while the pose still moves by a
+    // good part of a cell per iteration (stale seeds: most queries need the second ring) -- see k_tri_search_grid
     int budget = gp.budget;
+    {
+        const int last = (st->n + 4) % 5;
+        const double moved = st->use_target && st->n > 0 ? (st->ring_t[last] + st->ring_r[last] * gp.scale) * st->local_per_world : 0.0;
+        if (st->n == 0 || moved > 0.25 * gp.h) budget *= 2;
+    }
     if (finite) {
         for (int r = 0; r <= gp.r_max && !settled && budget >= 0; ++r) {
             const int x0 = max(c[0] - r, 0), x1 = min(c[0] + r, gp.n[0] - 1);

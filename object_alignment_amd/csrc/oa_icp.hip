@@ -358,8 +358,10 @@ void init_loop_state(oa_ctx *c, const oa_settings *st, int iters, bool cutoff = 
     oa::DevState &s = c->h_state;
     // search radius (DevState::cut_a / cut_b): only the grid / tree searches use it
     s.cut_a = INFINITY; s.cut_b = 0.0;
+    s.local_per_world = 0.0;
     if (cutoff && c->filter_ok && c->grid_mode != 0 && env_int("OA_NN_CUTOFF", 1)) {
         const double smin = min_singular_3x3(s.mx2) * (1.0 - 1e-9);
+        if (smin > 0.0) s.local_per_world = 1.0 / smin;
         double m2norm = 0.0, tmax = 0.0, tscale = 0.0;
         for (int i = 0; i < 3; ++i) {
             m2norm = std::max(m2norm, fabs((double)s.mx2[4 * i]) + fabs((double)s.mx2[4 * i + 1]) + fabs((double)s.mx2[4 * i + 2]));

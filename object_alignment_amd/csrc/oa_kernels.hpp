@@ -55,6 +55,7 @@ struct DevState {
     // cut_a + cut_b (|x| + |y| + |z|) in base-local space is certain to fail `dist < thresh` (general.py:300), so
     // the search may stop there.  cut_a = +inf switches it off (oa_nn_search, brute-force mode).  See search_cutoff().
     double cut_a, cut_b;
+    double local_per_world;   // 1 / sigma_min(mx2): upper bound of |local| / |world| distances (0 = unknown)
 };
 
 // Squared local search radius for the query p (rounded up to float).  Derivation: the pair test measures

@@ -271,7 +271,16 @@ __global__ __launch_bounds__(256) void k_tri_search_grid(const DevState *__restr
     S.lim = fminf(best, cutf);
     tri_state_refresh(S, delta);
     bool settled = false;
-    int budget = gp.budget;                                        // candidates this thread may look at (see GridParams)
+    // candidates this thread may look at (see GridParams).  While the pose still moves by a good part of a cell per
+    // iteration (first iteration, or last iteration's translation + rotation x object size above h / 4) the seeds are
+    // stale and most queries need the second ring: handing them all to the tree costs more than letting the grid
+    // look at twice as many candidates.
+    int budget = gp.budget;
+    {
+        const int last = (st->n + 4) % 5;
+        const double moved = st->use_target && st->n > 0 ? (st->ring_t[last] + st->ring_r[last] * gp.scale) * st->local_per_world : 0.0;
+        if (st->n == 0 || moved > 0.25 * gp.h) budget *= 2;
+    }
     if (finite) {
         for (int r = 0; r <= gp.r_max && !settled && budget >= 0; ++r) {
             const int x0 = max(c[0] - r, 0), x1 = min(c[0] + r, gp.n[0] - 1);
