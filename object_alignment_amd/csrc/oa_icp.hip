@@ -241,7 +241,7 @@ template <bool TRI>
 int launch_bvh(oa_ctx *c, const int *list, const int *list_count)
 {
     const int items = list ? std::min(c->ns, 1 << 17) : c->ns;
-    const unsigned blocks = (unsigned)std::max(1, std::min((items + 3) / 4, c->n_cu * 64));
+    const unsigned blocks = (unsigned)std::max(1, std::min((items + 3) / 4, c->n_cu * 16));   // 16 waves per SIMD: enough to fill the chip, cheap to dispatch when the list is empty
     hipLaunchKernelGGL(oa::k_bvh_search<TRI>, dim3(blocks), dim3(256), 0, c->stream, c->d_state, c->d_src4, c->ns,
                        TRI ? c->tbvh : c->bvh, TRI ? c->d_tbvh_box : c->d_bvh_box, TRI ? c->d_tbvh_prims : c->d_bvh_prims,
                        c->d_tgt_xyz, c->d_tri9, c->d_prev, c->d_keys, list, list_count);
