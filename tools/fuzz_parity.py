@@ -44,7 +44,7 @@ def cloud(rng, kind, n):
 def rand_matrix(rng, scaled):
     from object_alignment_amd import synth
     R = synth.rotation_from_rotvec(rng.normal(size=3) * rng.choice([0.01, 0.3, 2.0]))
-    S = np.diag(rng.uniform(0.5, 2.0, size=3)) if scaled else np.identity(3)
+    S = np.diag(rng.uniform(0.5, 2.0, size=3) * rng.choice([1.0, 1.0, 1.0, -1.0], size=3)) if scaled else np.identity(3)   # now and then a mirrored axis
     M = np.identity(4)
     M[:3, :3] = R @ S
     M[:3, 3] = rng.normal(size=3) * rng.choice([0.0, 0.05, 1.0])
