@@ -178,6 +178,28 @@ template <typename F> double time_kernel(F launch, int reps = 5)
     return best;
 }
 
+// integer probes: is a packed 8-bit dot product (4 MACs) issued at the v_fma_f32 rate?  (candidate for a cheaper
+// first filter level: one v_dot4 + one v_min per pair instead of 2 v_fma + 1 v_min)
+#define INT_PROBE(NAME, ASM)                                                                         \
+__global__ __launch_bounds__(256) void NAME(float *out, float a, float b)                            \
+{                                                                                                    \
+    int acc[UNROLL];                                                                                 \
+    const int va = __float_as_int(a) ^ threadIdx.x, vb = __float_as_int(b) + threadIdx.x;            \
+    _Pragma("unroll") for (int i = 0; i < UNROLL; ++i) acc[i] = threadIdx.x + i;                     \
+    for (int it = 0; it < ITERS; ++it) {                                                             \
+        _Pragma("unroll") for (int i = 0; i < UNROLL; ++i) asm volatile(ASM : "+v"(acc[i]) : "v"(va), "v"(vb)); \
+    }                                                                                                \
+    int s = 0;                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < UNROLL; ++i) s += acc[i];                                  \
+    out[blockIdx.x * 256 + threadIdx.x] = (float)s;                                                  \
+}
+INT_PROBE(k_dot4_iu8, "v_dot4_i32_i8 %0, %1, %2, %0")
+INT_PROBE(k_dot2_i16, "v_dot2_i32_i16 %0, %1, %2, %0")
+INT_PROBE(k_min_i32, "v_min_i32 %0, %0, %1")
+INT_PROBE(k_min3_i32, "v_min3_i32 %0, %0, %1, %2")
+INT_PROBE(k_min_f32, "v_min_f32 %0, %0, %1")
+INT_PROBE(k_mad_i32_i24, "v_mad_i32_i24 %0, %1, %2, %0")
+
 int main()
 {
     hipDeviceProp_t prop;
@@ -196,6 +218,9 @@ int main()
         { "v_pk_mul_f32", k_pk_mul, 2, n_inst }, { "v_min3_f32", k_min3, 1, n_inst },
         { "v_cmp+v_cndmask", k_cmp_cnd, 1, 2 * n_inst },
         { "ds_read_b128 bcast+4 add", k_lds_bcast, 1, (double)(ITERS / 4) * 64 * 5 },
+        { "v_dot4_i32_i8 (4 MAC)", k_dot4_iu8, 1, n_inst }, { "v_dot2_i32_i16 (2 MAC)", k_dot2_i16, 1, n_inst },
+        { "v_min_i32", k_min_i32, 1, n_inst }, { "v_min3_i32", k_min3_i32, 1, n_inst }, { "v_min_f32", k_min_f32, 1, n_inst },
+        { "v_mad_i32_i24", k_mad_i32_i24, 1, n_inst },
     };
     for (auto &p : probes) {
         const double ms = time_kernel([&] { hipLaunchKernelGGL(p.k, dim3(blocks), dim3(256), 0, 0, out, 1.0001f, 0.5f); });
