@@ -1141,3 +1141,36 @@ def test_surface_full_size_property(orc):
     pick = rng.choice(n, size=150, replace=False)
     face, _, rd2 = orc.nn_tri_brute(off[pick], verts, tris)
     assert np.array_equal(idx_off[pick], face) and np.array_equal(d2_off[pick], rd2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["auto", "grid"])
+def test_step_mode_equals_fused_loop_surface_and_shards(mode):
+    """oa_iterate (one iteration per call, the modal operator's step) and oa_run (the whole loop enqueued ahead, with
+    the halt flag polled) walk through bitwise the same iterations -- surface mode, masked source, and the same again
+    with the search strategies forced."""
+    from object_alignment_amd import synth
+    from object_alignment_amd.engine import IcpEngine
+    verts, tris = synth.lattice_surface_mesh(120, 240)
+    src = synth.bunny_surface(30000, 0.5)
+    vlist = np.arange(0, len(src), 3, dtype=np.int64)
+    mxa = synth.rigid4(synth.rotation_from_rotvec([0.05, -0.04, 0.06]), [0.03, -0.02, 0.02])
+    mxb = synth.rigid4(synth.rotation_from_rotvec([0.2, 0.1, -0.3]), [0.1, 0.0, -0.1])
+    kw = dict(thresh=0.2, target_d=1e-4, use_target=True)
+    with IcpEngine(0) as e:
+        e.set_search_mode(mode)
+        e.set_target_mesh(verts, tris)
+        e.set_source(src, vlist=vlist, stride=1)
+        e.set_matrices(mxb @ mxa, mxb)
+        ref = e.run(iters=40, early_exit=True, **kw)
+        assert 5 < ref.iters_done <= 40
+        e.set_matrices(mxb @ mxa, mxb)
+        Ms, Ks = [], []
+        for _ in range(ref.iters_done):
+            M, st = e.iterate(**kw)
+            Ms.append(M)
+            Ks.append(st["K"])
+        assert st["converged"] == ref.converged
+        assert np.array_equal(np.array(Ms), ref.step_M)
+        assert np.array_equal(np.array(Ks), ref.step_K)
+        assert np.array_equal(e.matrix_world(), ref.matrix_world)
