@@ -231,8 +231,8 @@ int check_ready(oa_ctx *c)
 bool grid_active(const oa_ctx *c);
 // every query through the tree: on request, and in auto mode for shards of up to `auto_max` points -- one wave per
 // query has far lower latency than the one-thread-per-query grid kernels until the waves no longer fit the chip
-// (measured crossover: 3e4 .. 1e5 points for vertices, 6e4 .. 1.5e5 for triangles, later for big targets whose grid
-// no longer sits in cache; profiles/r01g_search_mode_crossover.txt)
+// (measured crossover: 2.5e4 .. 6.5e4 points for vertices, 5e4 .. 1.7e5 for triangles, later for big targets whose
+// grid no longer sits in cache; profiles/r01g_search_mode_crossover.txt)
 inline bool bvh_whole(const oa_ctx *c, bool ok, int auto_max)
 {
     if (!ok) return false;
@@ -265,7 +265,7 @@ int launch_nn(oa_ctx *c)
         return fail(OA_E_BAD_ARG, "shard of %d points exceeds the launch grid (use more shards or OA_NN_R=8)", c->ns);
     dim3 grid(c->n_splits, c->ns_pad / (oa::NN_THREADS * c->R));
     dim3 block(oa::NN_THREADS);
-    if (bvh_whole(c, c->bvh_ok, c->nt >= 500000 ? 98304 : 32768)) return launch_bvh<false>(c, nullptr, nullptr);
+    if (bvh_whole(c, c->bvh_ok, c->nt >= 500000 ? 65536 : 24576)) return launch_bvh<false>(c, nullptr, nullptr);
     if (grid_active(c)) {
         // the grid search settles the queries near the target; the rest (far away, or in crowded cells) are appended
         // to a list that the tree search finishes.  Inside the loop k_solve_update leaves the list counter at zero;
@@ -1021,7 +1021,7 @@ int build_tri_grid(oa_ctx *c)
 
 int launch_tri_search(oa_ctx *c)
 {
-    if (bvh_whole(c, c->tbvh_ok, c->n_tris >= 500000 ? 131072 : 65536)) return launch_bvh<true>(c, nullptr, nullptr);
+    if (bvh_whole(c, c->tbvh_ok, c->n_tris >= 500000 ? 131072 : 49152)) return launch_bvh<true>(c, nullptr, nullptr);
     const bool use_grid = c->tri_grid_ok && c->tbvh_ok && c->grid_mode != 0;
     if (getenv("OA_DEBUG"))
         fprintf(stderr, "[oa] tri search: grid=%d ns=%d n_tris=%d state=%p src4=%p tri9=%p prev=%p keys=%p todo=%p/%p cells=%p/%p\n",
