@@ -1472,7 +1472,7 @@ OA_EXPORT int oa_run(oa_ctx *c, const oa_settings *st, oa_report *rep)
     // launches are issued after the loop has halted.
     if ((rc = ensure_events(c, 1))) return rc;
     const bool poll = st->early_exit && st->use_target && c->h_poll && env_int("OA_RUN_POLL", 1);
-    const int chunk = 4;
+    const int chunk = 2;
     for (int it = 0; it < st->iters; ++it) {
         if (poll && it % chunk == 0 && it >= 2 * chunk) {
             const int slot = (it / chunk) % 2;
