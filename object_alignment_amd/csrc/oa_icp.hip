@@ -149,8 +149,7 @@ struct oa_ctx {
     std::vector<hipEvent_t> ev;
     int ev_used = 0;
     hipEvent_t ev_loop0 = nullptr, ev_loop1 = nullptr;
-    int32_t *h_poll = nullptr;          // pinned: halt flag read back by oa_run (two slots)
-    hipEvent_t ev_poll[2] = { nullptr, nullptr };
+    int32_t *h_poll = nullptr;          // pinned, device-mapped: the solve kernel mirrors DevState.halt here for oa_run
     oa_settings settings;
 };
 
@@ -190,6 +189,10 @@ int ensure_common(oa_ctx *c)
     if (!c->d_partials) HIPCHK(hipMalloc(&c->d_partials, sizeof(double) * oa::NSUMS * oa::ACC_MAX_BLOCKS));
     if (!c->d_sums) HIPCHK(hipMalloc(&c->d_sums, sizeof(double) * oa::NSUMS));
     if (!c->d_solve) HIPCHK(hipMalloc(&c->d_solve, sizeof(double) * 32));
+    if (!c->h_poll) {
+        HIPCHK(hipHostMalloc((void **)&c->h_poll, sizeof(int32_t), hipHostMallocMapped));
+        *c->h_poll = 0;
+    }
     return OA_OK;
 }
 
@@ -211,11 +214,6 @@ int ensure_events(oa_ctx *c, int n_pairs)
         c->ev.push_back(e);
     }
     if (!c->ev_loop0) { HIPCHK(hipEventCreate(&c->ev_loop0)); HIPCHK(hipEventCreate(&c->ev_loop1)); }
-    if (!c->h_poll) {
-        HIPCHK(hipHostMalloc((void **)&c->h_poll, 2 * sizeof(int32_t), hipHostMallocDefault));
-        HIPCHK(hipEventCreateWithFlags(&c->ev_poll[0], hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&c->ev_poll[1], hipEventDisableTiming));
-    }
     return OA_OK;
 }
 
@@ -367,6 +365,11 @@ void init_loop_state(oa_ctx *c, const oa_settings *st, int iters, bool cutoff = 
     // search radius (DevState::cut_a / cut_b): only the grid / tree searches use it
     s.cut_a = INFINITY; s.cut_b = 0.0;
     s.local_per_world = 0.0;
+    s.host_halt = nullptr;
+    if (c->h_poll) {
+        void *dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, c->h_poll, 0) == hipSuccess) s.host_halt = (int32_t *)dp;
+    }
     if (cutoff && c->filter_ok && c->grid_mode != 0 && env_int("OA_NN_CUTOFF", 1)) {
         const double smin = min_singular_3x3(s.mx2) * (1.0 - 1e-9);
         if (smin > 0.0) s.local_per_world = 1.0 / smin;
@@ -409,6 +412,8 @@ int begin_loop(oa_ctx *c, const oa_settings *st, int iters)
     if ((rc = ensure_common(c))) return rc;
     if ((rc = ensure_history(c, iters))) return rc;
     c->settings = *st;
+    HIPCHK(hipStreamSynchronize(c->stream));                    // nothing of an earlier loop may still write the host flag
+    if (c->h_poll) *c->h_poll = 0;
     init_loop_state(c, st, iters);
     HIPCHK(hipMemcpyAsync(c->d_state, &c->h_state, sizeof(oa::DevState), hipMemcpyHostToDevice, c->stream));
     if (c->d_todo_count) HIPCHK(hipMemsetAsync(c->d_todo_count, 0, sizeof(int), c->stream));   // kept at zero by k_solve_update
@@ -557,7 +562,7 @@ OA_EXPORT void oa_destroy(oa_ctx *c)
     dev_free(c->d_sel); dev_free(c->d_src_n); dev_free(c->d_tgt_n); dev_free(c->d_src4o); dev_free(c->d_perm);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->ev_loop0) (void)hipEventDestroy(c->ev_loop0);
-    if (c->h_poll) { (void)hipHostFree(c->h_poll); (void)hipEventDestroy(c->ev_poll[0]); (void)hipEventDestroy(c->ev_poll[1]); }
+    if (c->h_poll) (void)hipHostFree(c->h_poll);
     if (c->ev_loop1) (void)hipEventDestroy(c->ev_loop1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -1467,24 +1472,20 @@ OA_EXPORT int oa_run(oa_ctx *c, const oa_settings *st, oa_report *rep)
     if (rc) return rc;
     // The whole loop is enqueued ahead of the GPU.  With early exit on, iterations after convergence would still cost
     // three empty launches each (the kernels see DevState.halt and return) -- for a small mesh that converges in 7 of 50
-    // iterations, more than the real work.  So the halt flag is read back every `chunk` iterations through pinned
-    // memory, two chunks behind the enqueue front: the GPU never waits for the host, and at most two chunks of empty
-    // launches are issued after the loop has halted.
-    if ((rc = ensure_events(c, 1))) return rc;
-    const bool poll = st->early_exit && st->use_target && c->h_poll && env_int("OA_RUN_POLL", 1);
-    const int chunk = 2;
+    // iterations, more than the real work.  k_solve_update therefore mirrors the halt flag into a pinned host word,
+    // and the host looks at it before it enqueues the next iteration: no copies, nothing added to the stream -- a
+    // stale 0 only means a few more empty launches.
+    // The host also stays at most `lag` iterations ahead of the GPU (it waits for the timing event that follows the
+    // search of iteration it - lag): enqueuing is much faster than executing, and a host that is 40 iterations ahead
+    // learns about the halt too late to save anything.  Two iterations are always queued, so the GPU never idles.
+    const bool poll = c->h_poll && st->early_exit && env_int("OA_RUN_POLL", 1);
+    const int lag = 2;
     for (int it = 0; it < st->iters; ++it) {
-        if (poll && it % chunk == 0 && it >= 2 * chunk) {
-            const int slot = (it / chunk) % 2;
-            HIPCHK(hipEventSynchronize(c->ev_poll[slot]));
-            if (c->h_poll[slot]) break;
+        if (poll) {
+            if (it >= lag) HIPCHK(hipEventSynchronize(c->ev[2 * (it - lag) + 1]));
+            if (*(volatile int32_t *)c->h_poll) break;
         }
         if ((rc = iter_fused(c, true))) return rc;
-        if (poll && (it + 1) % chunk == 0) {
-            const int slot = ((it + 1) / chunk - 1) % 2;
-            HIPCHK(hipMemcpyAsync(&c->h_poll[slot], &c->d_state->halt, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipEventRecord(c->ev_poll[slot], c->stream));
-        }
     }
     return oa_run_end(c, rep);
 }

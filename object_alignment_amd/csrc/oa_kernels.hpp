@@ -56,6 +56,7 @@ struct DevState {
     // the search may stop there.  cut_a = +inf switches it off (oa_nn_search, brute-force mode).  See search_cutoff().
     double cut_a, cut_b;
     double local_per_world;   // 1 / sigma_min(mx2): upper bound of |local| / |world| distances (0 = unknown)
+    int32_t *host_halt;       // pinned host word that mirrors `halt` (oa_run reads it to stop enqueuing), or nullptr
 };
 
 // Squared local search radius for the query p (rounded up to float).  Derivation: the pair test measures
@@ -1119,6 +1120,7 @@ __device__ __forceinline__ void solve_update_body(DevState *__restrict__ st, con
     st->d_pivot = mean_d;                                           // next iteration sums d relative to this mean
     st->n = n + 1;                                                  // n += 1                        (:151)
     if ((st->converged && st->early_exit) || st->n >= st->iters) st->halt = 1;
+    if (st->halt && st->host_halt) { *st->host_halt = 1; __threadfence_system(); }   // tell the host to stop enqueuing
 }
 
 // split-phase form (one process per GPU): the sums come back from the all-reduce
