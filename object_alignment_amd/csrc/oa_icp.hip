@@ -1026,7 +1026,7 @@ int build_tri_grid(oa_ctx *c)
 
 int launch_tri_search(oa_ctx *c)
 {
-    if (bvh_whole(c, c->tbvh_ok, c->n_tris >= 500000 ? 131072 : 49152)) return launch_bvh<true>(c, nullptr, nullptr);
+    if (bvh_whole(c, c->tbvh_ok, c->n_tris >= 1000000 ? 131072 : (c->n_tris >= 250000 ? 86016 : 49152))) return launch_bvh<true>(c, nullptr, nullptr);
     const bool use_grid = c->tri_grid_ok && c->tbvh_ok && c->grid_mode != 0;
     if (getenv("OA_DEBUG"))
         fprintf(stderr, "[oa] tri search: grid=%d ns=%d n_tris=%d state=%p src4=%p tri9=%p prev=%p keys=%p todo=%p/%p cells=%p/%p\n",
