@@ -13,6 +13,8 @@
 #include "../../include/oa_icp.h"
 
 #include <algorithm>
+#include <chrono>
+#include <thread>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -149,7 +151,9 @@ struct oa_ctx {
     std::vector<hipEvent_t> ev;
     int ev_used = 0;
     hipEvent_t ev_loop0 = nullptr, ev_loop1 = nullptr;
-    int32_t *h_poll = nullptr;          // pinned, device-mapped: the solve kernel mirrors DevState.halt here for oa_run
+    int32_t *h_poll = nullptr;          // pinned, device-mapped {halt, n}: the solve kernel mirrors them here for oa_run
+    bool time_events = true;            // hipEvent pair around every search (brute force); else GPU-side stamps (see iter_fused)
+    double wall_clock_khz = 100000.0;   // rate of wall_clock64()
     oa_settings settings;
 };
 
@@ -190,8 +194,8 @@ int ensure_common(oa_ctx *c)
     if (!c->d_sums) HIPCHK(hipMalloc(&c->d_sums, sizeof(double) * oa::NSUMS));
     if (!c->d_solve) HIPCHK(hipMalloc(&c->d_solve, sizeof(double) * 32));
     if (!c->h_poll) {
-        HIPCHK(hipHostMalloc((void **)&c->h_poll, sizeof(int32_t), hipHostMallocMapped));
-        *c->h_poll = 0;
+        HIPCHK(hipHostMalloc((void **)&c->h_poll, 2 * sizeof(int32_t), hipHostMallocMapped));
+        c->h_poll[0] = 0; c->h_poll[1] = 0;
     }
     return OA_OK;
 }
@@ -231,6 +235,8 @@ bool grid_active(const oa_ctx *c);
 // query has far lower latency than the one-thread-per-query grid kernels until the waves no longer fit the chip
 // (measured crossover: 2.5e4 .. 6.5e4 points for vertices, 5e4 .. 1.7e5 for triangles, later for big targets whose
 // grid no longer sits in cache; profiles/r01g_search_mode_crossover.txt)
+inline int vertex_tree_max(const oa_ctx *c) { return c->nt >= 500000 ? 65536 : 24576; }
+inline int tri_tree_max(const oa_ctx *c) { return c->n_tris >= 1000000 ? 131072 : (c->n_tris >= 250000 ? 86016 : 49152); }
 inline bool bvh_whole(const oa_ctx *c, bool ok, int auto_max)
 {
     if (!ok) return false;
@@ -263,7 +269,7 @@ int launch_nn(oa_ctx *c)
         return fail(OA_E_BAD_ARG, "shard of %d points exceeds the launch grid (use more shards or OA_NN_R=8)", c->ns);
     dim3 grid(c->n_splits, c->ns_pad / (oa::NN_THREADS * c->R));
     dim3 block(oa::NN_THREADS);
-    if (bvh_whole(c, c->bvh_ok, c->nt >= 500000 ? 65536 : 24576)) return launch_bvh<false>(c, nullptr, nullptr);
+    if (bvh_whole(c, c->bvh_ok, vertex_tree_max(c))) return launch_bvh<false>(c, nullptr, nullptr);
     if (grid_active(c)) {
         // the grid search settles the queries near the target; the rest (far away, or in crowded cells) are appended
         // to a list that the tree search finishes.  Inside the loop k_solve_update leaves the list counter at zero;
@@ -314,11 +320,13 @@ int launch_accumulate(oa_ctx *c, bool emit, int *nn_idx, float *nn_d2)
         po.valid = c->d_valid; po.b = c->d_b; po.dist = c->d_dist; po.nn_idx = nn_idx; po.nn_d2 = nn_d2; po.perm = c->d_perm;
         hipLaunchKernelGGL(oa::k_pair_accumulate<true>, dim3(c->acc_blocks), dim3(oa::ACC_THREADS), 0, c->stream,
                            c->d_state, c->d_src4, c->ns, c->d_tgt_xyz, c->d_keys, c->d_prev,
-                           c->surface ? (const float4 *)c->d_tri9 : (const float4 *)nullptr, nrm, c->d_partials, po);
+                           c->surface ? (const float4 *)c->d_tri9 : (const float4 *)nullptr, nrm, c->d_partials, po,
+                           (unsigned long long *)nullptr);
     } else {
         hipLaunchKernelGGL(oa::k_pair_accumulate<false>, dim3(c->acc_blocks), dim3(oa::ACC_THREADS), 0, c->stream,
                            c->d_state, c->d_src4, c->ns, c->d_tgt_xyz, c->d_keys, c->d_prev,
-                           c->surface ? (const float4 *)c->d_tri9 : (const float4 *)nullptr, nrm, c->d_partials, po);
+                           c->surface ? (const float4 *)c->d_tri9 : (const float4 *)nullptr, nrm, c->d_partials, po,
+                           c->loop_active ? &c->d_state->t_acc_start : (unsigned long long *)nullptr);
     }
     HIPCHK(hipGetLastError());
     return OA_OK;
@@ -366,6 +374,7 @@ void init_loop_state(oa_ctx *c, const oa_settings *st, int iters, bool cutoff = 
     s.cut_a = INFINITY; s.cut_b = 0.0;
     s.local_per_world = 0.0;
     s.host_halt = nullptr;
+    s.t_prev_end = 0; s.t_acc_start = 0;
     if (c->h_poll) {
         void *dp = nullptr;
         if (hipHostGetDevicePointer(&dp, c->h_poll, 0) == hipSuccess) s.host_halt = (int32_t *)dp;
@@ -413,11 +422,18 @@ int begin_loop(oa_ctx *c, const oa_settings *st, int iters)
     if ((rc = ensure_history(c, iters))) return rc;
     c->settings = *st;
     HIPCHK(hipStreamSynchronize(c->stream));                    // nothing of an earlier loop may still write the host flag
-    if (c->h_poll) *c->h_poll = 0;
+    if (c->h_poll) { c->h_poll[0] = 0; c->h_poll[1] = 0; }
     init_loop_state(c, st, iters);
     HIPCHK(hipMemcpyAsync(c->d_state, &c->h_state, sizeof(oa::DevState), hipMemcpyHostToDevice, c->stream));
     if (c->d_todo_count) HIPCHK(hipMemsetAsync(c->d_todo_count, 0, sizeof(int), c->stream));   // kept at zero by k_solve_update
+    hipLaunchKernelGGL(oa::k_stamp_start, dim3(1), dim3(64), 0, c->stream, c->d_state);
+    HIPCHK(hipGetLastError());
     c->ev_used = 0;
+    {
+        const bool brute = !c->surface ? !(bvh_whole(c, c->bvh_ok, vertex_tree_max(c)) || grid_active(c))
+                                       : (c->grid_mode == 0 || !c->tbvh_ok);
+        c->time_events = env_int("OA_TIME_EVENTS", brute ? 1 : 0) != 0;
+    }
     c->loop_active = true;
     return OA_OK;
 }
@@ -425,6 +441,10 @@ int begin_loop(oa_ctx *c, const oa_settings *st, int iters)
 int iter_partial(oa_ctx *c, double *d_sums, bool timed)
 {
     int rc;
+    // hipEvent pairs around the search cost ~7 us of stream time per iteration (two barrier packets): fine for the
+    // brute-force kernel (50 ms per launch), not for the grid / tree searches, whose launches are that short
+    // themselves -- those are timed on the GPU instead (DevState::t_prev_end / t_acc_start, StepRecord::search_ticks)
+    timed = timed && c->time_events;
     if (timed) {
         if ((rc = ensure_events(c, c->ev_used + 1))) return rc;
         HIPCHK(hipEventRecord(c->ev[2 * c->ev_used], c->stream));
@@ -449,6 +469,10 @@ int iter_finish(oa_ctx *c, const double *d_sums)
 int iter_fused(oa_ctx *c, bool timed)
 {
     int rc;
+    // hipEvent pairs around the search cost ~7 us of stream time per iteration (two barrier packets): fine for the
+    // brute-force kernel (50 ms per launch), not for the grid / tree searches, whose launches are that short
+    // themselves -- those are timed on the GPU instead (DevState::t_prev_end / t_acc_start, StepRecord::search_ticks)
+    timed = timed && c->time_events;
     if (timed) {
         if ((rc = ensure_events(c, c->ev_used + 1))) return rc;
         HIPCHK(hipEventRecord(c->ev[2 * c->ev_used], c->stream));
@@ -493,10 +517,21 @@ int fill_report(oa_ctx *c, oa_report *rep)
         if (s.use_target) { for (int k = 0; k < m; ++k) a += s.ring_r[k]; rep->mean_rot_angle = a / m; }
         else rep->mean_rot_angle = r.angle;
     }
+    // search time: hipEvent pairs around every launch (brute force), else the GPU-side stamps the loop left in the
+    // step records (end of the previous iteration -> start of k_pair_accumulate)
     double nn_ms = 0.0;
-    for (int k = 0; k < c->ev_used; ++k) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, c->ev[2 * k], c->ev[2 * k + 1]) == hipSuccess) nn_ms += ms;
+    if (c->time_events) {
+        for (int k = 0; k < c->ev_used; ++k) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, c->ev[2 * k], c->ev[2 * k + 1]) == hipSuccess) nn_ms += ms;
+        }
+    } else if (s.n > 0 && c->d_hist) {
+        const int m = std::min(s.n, c->max_records);
+        std::vector<oa::StepRecord> h((size_t)m);
+        HIPCHK(hipMemcpy(h.data(), c->d_hist, sizeof(oa::StepRecord) * (size_t)m, hipMemcpyDeviceToHost));
+        double ticks = 0.0;
+        for (int k = 0; k < m; ++k) ticks += h[k].search_ticks;
+        nn_ms = ticks / c->wall_clock_khz * ((double)s.n / (double)m);
     }
     rep->nn_ms_total = nn_ms;
     return OA_OK;
@@ -536,6 +571,10 @@ OA_EXPORT int oa_create(oa_ctx **out, int device)
     hipDeviceProp_t prop;
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
     if (e == hipSuccess) { c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; }
+    if (e == hipSuccess) {
+        int khz = 0;
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) c->wall_clock_khz = (double)khz;
+    }
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fail(OA_E_HIP, "oa_create: %s", hipGetErrorString(e)); }
     c->stream = c->own_stream;
@@ -1026,7 +1065,7 @@ int build_tri_grid(oa_ctx *c)
 
 int launch_tri_search(oa_ctx *c)
 {
-    if (bvh_whole(c, c->tbvh_ok, c->n_tris >= 1000000 ? 131072 : (c->n_tris >= 250000 ? 86016 : 49152))) return launch_bvh<true>(c, nullptr, nullptr);
+    if (bvh_whole(c, c->tbvh_ok, tri_tree_max(c))) return launch_bvh<true>(c, nullptr, nullptr);
     const bool use_grid = c->tri_grid_ok && c->tbvh_ok && c->grid_mode != 0;
     if (getenv("OA_DEBUG"))
         fprintf(stderr, "[oa] tri search: grid=%d ns=%d n_tris=%d state=%p src4=%p tri9=%p prev=%p keys=%p todo=%p/%p cells=%p/%p\n",
@@ -1475,15 +1514,20 @@ OA_EXPORT int oa_run(oa_ctx *c, const oa_settings *st, oa_report *rep)
     // iterations, more than the real work.  k_solve_update therefore mirrors the halt flag into a pinned host word,
     // and the host looks at it before it enqueues the next iteration: no copies, nothing added to the stream -- a
     // stale 0 only means a few more empty launches.
-    // The host also stays at most `lag` iterations ahead of the GPU (it waits for the timing event that follows the
-    // search of iteration it - lag): enqueuing is much faster than executing, and a host that is 40 iterations ahead
-    // learns about the halt too late to save anything.  Two iterations are always queued, so the GPU never idles.
+    // The host also stays at most `lag` iterations ahead of the GPU (the solve kernel mirrors its iteration counter
+    // next to the halt flag): enqueuing is much faster than executing, and a host that is 40 iterations ahead learns
+    // about the halt too late to save anything.  Two iterations are always queued, so the GPU never idles.
     const bool poll = c->h_poll && st->early_exit && env_int("OA_RUN_POLL", 1);
     const int lag = 2;
+    volatile int32_t *progress = c->h_poll;
     for (int it = 0; it < st->iters; ++it) {
         if (poll) {
-            if (it >= lag) HIPCHK(hipEventSynchronize(c->ev[2 * (it - lag) + 1]));
-            if (*(volatile int32_t *)c->h_poll) break;
+            const auto t_wait = std::chrono::steady_clock::now();
+            while (!progress[0] && progress[1] < it - lag) {
+                if (std::chrono::steady_clock::now() - t_wait > std::chrono::seconds(5)) break;   // never hang on a sick GPU
+                std::this_thread::yield();
+            }
+            if (progress[0]) break;
         }
         if ((rc = iter_fused(c, true))) return rc;
     }

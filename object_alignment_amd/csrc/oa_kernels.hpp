@@ -34,7 +34,8 @@ constexpr int ACC_MAX_BLOCKS = 512;
 struct StepRecord {
     double M[16];
     float  new_mat[16];
-    double K, mean_d, std_d, trans, angle, pad;
+    double K, mean_d, std_d, trans, angle;
+    double search_ticks;      // wall_clock64 ticks from the end of the previous iteration to the start of k_pair_accumulate
 };
 
 struct DevState {
@@ -56,7 +57,10 @@ struct DevState {
     // the search may stop there.  cut_a = +inf switches it off (oa_nn_search, brute-force mode).  See search_cutoff().
     double cut_a, cut_b;
     double local_per_world;   // 1 / sigma_min(mx2): upper bound of |local| / |world| distances (0 = unknown)
-    int32_t *host_halt;       // pinned host word that mirrors `halt` (oa_run reads it to stop enqueuing), or nullptr
+    int32_t *host_halt;       // pinned host words {halt, n} mirrored for oa_run (stop enqueuing / stay near the GPU), or nullptr
+    // GPU-side timing of the search (no hipEvents in the stream: they cost ~3 us each): k_stamp_start / the solve
+    // kernel leave the end of the previous iteration in t_prev_end, k_pair_accumulate its own start in t_acc_start
+    unsigned long long t_prev_end, t_acc_start;
 };
 
 // Squared local search radius for the query p (rounded up to float).  Derivation: the pair test measures
@@ -906,9 +910,11 @@ __global__ __launch_bounds__(ACC_THREADS) void k_pair_accumulate(const DevState 
                                                                  unsigned long long *__restrict__ keys,
                                                                  int *__restrict__ prev,
                                                                  const float4 *__restrict__ tri9, NormalTest nrm,
-                                                                 double *__restrict__ partials, PairOut out)
+                                                                 double *__restrict__ partials, PairOut out,
+                                                                 unsigned long long *__restrict__ t_acc_start)
 {
     __shared__ double red[ACC_THREADS / 64][NSUMS];
+    if (t_acc_start && blockIdx.x == 0 && threadIdx.x == 0) *t_acc_start = wall_clock64();   // ~ the end of the search
     double acc[NSUMS];
 #pragma unroll
     for (int k = 0; k < NSUMS; ++k) acc[k] = 0.0;
@@ -1108,7 +1114,8 @@ __device__ __forceinline__ void solve_update_body(DevState *__restrict__ st, con
     if (hist && st->max_records > 0) {
         StepRecord &r = hist[n % st->max_records];
         for (int k = 0; k < 16; ++k) { r.M[k] = M[k]; r.new_mat[k] = new_mat[k]; }
-        r.K = K; r.mean_d = mean_d; r.std_d = sqrt(var); r.trans = trans; r.angle = angle; r.pad = 0.0;
+        r.K = K; r.mean_d = mean_d; r.std_d = sqrt(var); r.trans = trans; r.angle = angle;
+        r.search_ticks = (st->t_acc_start > st->t_prev_end) ? (double)(st->t_acc_start - st->t_prev_end) : 0.0;
     }
     if (st->use_target) {                                           // if d_stats:                  (:136)
         st->ring_t[n % 5] = trans;                                  // conv_t_list[i] = trans.length (:137-138)
@@ -1120,7 +1127,18 @@ __device__ __forceinline__ void solve_update_body(DevState *__restrict__ st, con
     st->d_pivot = mean_d;                                           // next iteration sums d relative to this mean
     st->n = n + 1;                                                  // n += 1                        (:151)
     if ((st->converged && st->early_exit) || st->n >= st->iters) st->halt = 1;
-    if (st->halt && st->host_halt) { *st->host_halt = 1; __threadfence_system(); }   // tell the host to stop enqueuing
+    st->t_prev_end = wall_clock64();                                // the next search starts (about) now
+    if (st->host_halt) {                                            // progress and halt flag for the enqueuing host
+        st->host_halt[1] = st->n;
+        if (st->halt) st->host_halt[0] = 1;
+        __threadfence_system();
+    }
+}
+
+// loop start: the first search begins (about) now
+__global__ void k_stamp_start(DevState *__restrict__ st)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) st->t_prev_end = wall_clock64();
 }
 
 // split-phase form (one process per GPU): the sums come back from the all-reduce
