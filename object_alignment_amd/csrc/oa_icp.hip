@@ -137,6 +137,8 @@ struct oa_ctx {
     oa::DevState *d_state = nullptr;
     bool have_mats = false, loop_active = false;
     oa::StepRecord *d_hist = nullptr;
+    std::vector<oa::StepRecord> h_hist;   // host copy of the executed iterations' records, filled by fill_report
+    bool h_hist_valid = false;
     int max_records = 0;
     double *d_partials = nullptr, *d_sums = nullptr, *d_solve = nullptr;
     // make_pairs scratch (sized to ns)
@@ -429,6 +431,7 @@ int begin_loop(oa_ctx *c, const oa_settings *st, int iters)
     hipLaunchKernelGGL(oa::k_stamp_start, dim3(1), dim3(64), 0, c->stream, c->d_state);
     HIPCHK(hipGetLastError());
     c->ev_used = 0;
+    c->h_hist_valid = false;
     {
         const bool brute = !c->surface ? !(bvh_whole(c, c->bvh_ok, vertex_tree_max(c)) || grid_active(c))
                                        : (c->grid_mode == 0 || !c->tbvh_ok);
@@ -506,15 +509,19 @@ int fill_report(oa_ctx *c, oa_report *rep)
     rep->converged = s.converged;
     rep->status = s.status;
     rep->mean_dist = rep->std_dist = NAN;
-    if (s.n > 0 && c->d_hist) {
-        oa::StepRecord r;
-        HIPCHK(hipMemcpy(&r, c->d_hist + ((s.n - 1) % c->max_records), sizeof r, hipMemcpyDeviceToHost));
+    c->h_hist_valid = false;
+    const int m = (s.n > 0 && c->d_hist) ? std::min(s.n, c->max_records) : 0;
+    if (m > 0) {                                                  // one copy serves the report, the timing and oa_get_history
+        c->h_hist.resize((size_t)m);
+        HIPCHK(hipMemcpy(c->h_hist.data(), c->d_hist, sizeof(oa::StepRecord) * (size_t)m, hipMemcpyDeviceToHost));
+        c->h_hist_valid = true;
+        const oa::StepRecord &r = c->h_hist[(size_t)((s.n - 1) % c->max_records)];
         rep->last_K = (int64_t)r.K;
         rep->last_translation = r.trans;
         if (s.use_target) { rep->mean_dist = r.mean_d; rep->std_dist = r.std_d; }
         double a = 0.0;
-        const int m = std::min(s.n, 5);
-        if (s.use_target) { for (int k = 0; k < m; ++k) a += s.ring_r[k]; rep->mean_rot_angle = a / m; }
+        const int mm = std::min(s.n, 5);
+        if (s.use_target) { for (int k = 0; k < mm; ++k) a += s.ring_r[k]; rep->mean_rot_angle = a / mm; }
         else rep->mean_rot_angle = r.angle;
     }
     // search time: hipEvent pairs around every launch (brute force), else the GPU-side stamps the loop left in the
@@ -525,12 +532,9 @@ int fill_report(oa_ctx *c, oa_report *rep)
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, c->ev[2 * k], c->ev[2 * k + 1]) == hipSuccess) nn_ms += ms;
         }
-    } else if (s.n > 0 && c->d_hist) {
-        const int m = std::min(s.n, c->max_records);
-        std::vector<oa::StepRecord> h((size_t)m);
-        HIPCHK(hipMemcpy(h.data(), c->d_hist, sizeof(oa::StepRecord) * (size_t)m, hipMemcpyDeviceToHost));
+    } else if (m > 0) {
         double ticks = 0.0;
-        for (int k = 0; k < m; ++k) ticks += h[k].search_ticks;
+        for (int k = 0; k < m; ++k) ticks += c->h_hist[(size_t)k].search_ticks;
         nn_ms = ticks / c->wall_clock_khz * ((double)s.n / (double)m);
     }
     rep->nn_ms_total = nn_ms;
@@ -1566,9 +1570,13 @@ OA_EXPORT int oa_get_history(oa_ctx *c, int32_t max_n, double *step_M, float *st
     if (use_device(c)) return OA_E_HIP;
     const int n = std::min(std::min(c->h_state.n, c->max_records), (int)max_n);
     if (n <= 0) return 0;
-    std::vector<oa::StepRecord> h((size_t)n);
-    if (hipMemcpy(h.data(), c->d_hist, sizeof(oa::StepRecord) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess)
-        return fail(OA_E_HIP, "oa_get_history: copy failed");
+    std::vector<oa::StepRecord> h_local;
+    if (!(c->h_hist_valid && (int)c->h_hist.size() >= n)) {
+        h_local.resize((size_t)n);
+        if (hipMemcpy(h_local.data(), c->d_hist, sizeof(oa::StepRecord) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess)
+            return fail(OA_E_HIP, "oa_get_history: copy failed");
+    }
+    const std::vector<oa::StepRecord> &h = h_local.empty() ? c->h_hist : h_local;
     for (int i = 0; i < n; ++i) {
         if (step_M) memcpy(step_M + 16 * i, h[i].M, sizeof h[i].M);
         if (step_new) memcpy(step_new + 16 * i, h[i].new_mat, sizeof h[i].new_mat);
