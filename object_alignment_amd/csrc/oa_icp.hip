@@ -14,6 +14,8 @@
 
 #include <algorithm>
 #include <chrono>
+#include <mutex>
+#include <unordered_map>
 #include <thread>
 #include <cstdarg>
 #include <cstdio>
@@ -47,9 +49,87 @@ int fail(int code, const char *fmt, ...)
             return fail(OA_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
+// Device allocations go through a small process-wide cache keyed by (device, size): hipFree costs ~135 us a call on
+// this stack (it synchronises the device), and an upload frees and reallocates ~25 buffers of unchanged size -- more
+// than half of oa_set_target + oa_set_source at 1M points.  A released block is kept for the next request of the same
+// size; blocks that sit unused for CACHE_MAX_AGE releases, or push the cache past CACHE_MAX_BYTES, are really freed.
+// Like hipFree, releasing waits for the device first (callers may still have kernels in flight that read the block).
+struct DevCache {
+    struct Block { void *p; size_t bytes; int device; unsigned long long stamp; };
+    std::mutex mu;
+    std::vector<Block> free_blocks;
+    std::unordered_map<void *, std::pair<size_t, int>> live;    // pointer -> (bytes, device)
+    size_t cached_bytes = 0;
+    unsigned long long clock = 0;
+    static constexpr size_t CACHE_MAX_BYTES = 8ull << 30;
+    static constexpr unsigned long long CACHE_MAX_AGE = 512;
+
+    hipError_t alloc(void **out, size_t bytes)
+    {
+        if (bytes == 0) bytes = 1;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (size_t i = 0; i < free_blocks.size(); ++i)
+                if (free_blocks[i].bytes == bytes && free_blocks[i].device == dev) {
+                    *out = free_blocks[i].p;
+                    cached_bytes -= bytes;
+                    free_blocks[i] = free_blocks.back();
+                    free_blocks.pop_back();
+                    live[*out] = { bytes, dev };
+                    return hipSuccess;
+                }
+        }
+        hipError_t e = hipMalloc(out, bytes);
+        if (e != hipSuccess) {                                     // out of memory: drop the cache and retry once
+            trim(0, 0);
+            e = hipMalloc(out, bytes);
+        }
+        if (e == hipSuccess) { std::lock_guard<std::mutex> lk(mu); live[*out] = { bytes, dev }; }
+        return e;
+    }
+
+    void release(void *p)
+    {
+        if (!p) return;
+        (void)hipDeviceSynchronize();                              // what hipFree would have done
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = live.find(p);
+        if (it == live.end()) { (void)hipFree(p); return; }
+        free_blocks.push_back(Block{ p, it->second.first, it->second.second, ++clock });
+        cached_bytes += it->second.first;
+        live.erase(it);
+        trim_locked(CACHE_MAX_BYTES, CACHE_MAX_AGE);
+    }
+
+    void trim(size_t max_bytes, unsigned long long max_age) { std::lock_guard<std::mutex> lk(mu); trim_locked(max_bytes, max_age); }
+
+    void trim_locked(size_t max_bytes, unsigned long long max_age)
+    {
+        for (size_t i = 0; i < free_blocks.size();) {
+            const bool old = clock - free_blocks[i].stamp > max_age;
+            if (old || cached_bytes > max_bytes) {
+                (void)hipFree(free_blocks[i].p);
+                cached_bytes -= free_blocks[i].bytes;
+                free_blocks[i] = free_blocks.back();
+                free_blocks.pop_back();
+            } else ++i;
+        }
+    }
+};
+
+DevCache &dev_cache()
+{
+    static DevCache *cache = new DevCache();                      // never destroyed: the HIP runtime may already be gone at exit
+    return *cache;
+}
+
+template <typename T> hipError_t dev_malloc(T **p, size_t bytes) { return dev_cache().alloc((void **)p, bytes); }
+
 template <typename T> void dev_free(T *&p)
 {
-    if (p) { (void)hipFree(p); p = nullptr; }
+    if (p) { dev_cache().release((void *)p); p = nullptr; }
 }
 
 // temporary device buffer, released on every exit path
@@ -59,8 +139,8 @@ template <typename T> struct DevTmp {
     DevTmp(const DevTmp &) = delete;
     DevTmp &operator=(const DevTmp &) = delete;
     ~DevTmp() { reset(); }
-    hipError_t alloc(size_t n) { reset(); return hipMalloc(&p, sizeof(T) * (n ? n : 1)); }
-    void reset() { if (p) { (void)hipFree(p); p = nullptr; } }
+    hipError_t alloc(size_t n) { reset(); return dev_malloc(&p, sizeof(T) * (n ? n : 1)); }
+    void reset() { dev_free(p); }
     operator T *() const { return p; }
 };
 
@@ -191,10 +271,10 @@ void plan_geometry(oa_ctx *c)
 
 int ensure_common(oa_ctx *c)
 {
-    if (!c->d_state) HIPCHK(hipMalloc(&c->d_state, sizeof(oa::DevState)));
-    if (!c->d_partials) HIPCHK(hipMalloc(&c->d_partials, sizeof(double) * oa::NSUMS * oa::ACC_MAX_BLOCKS));
-    if (!c->d_sums) HIPCHK(hipMalloc(&c->d_sums, sizeof(double) * oa::NSUMS));
-    if (!c->d_solve) HIPCHK(hipMalloc(&c->d_solve, sizeof(double) * 32));
+    if (!c->d_state) HIPCHK(dev_malloc(&c->d_state, sizeof(oa::DevState)));
+    if (!c->d_partials) HIPCHK(dev_malloc(&c->d_partials, sizeof(double) * oa::NSUMS * oa::ACC_MAX_BLOCKS));
+    if (!c->d_sums) HIPCHK(dev_malloc(&c->d_sums, sizeof(double) * oa::NSUMS));
+    if (!c->d_solve) HIPCHK(dev_malloc(&c->d_solve, sizeof(double) * 32));
     if (!c->h_poll) {
         HIPCHK(hipHostMalloc((void **)&c->h_poll, 2 * sizeof(int32_t), hipHostMallocMapped));
         c->h_poll[0] = 0; c->h_poll[1] = 0;
@@ -207,7 +287,7 @@ int ensure_history(oa_ctx *c, int n)
     n = std::max(16, std::min(n, 1 << 16));
     if (n <= c->max_records) return OA_OK;
     dev_free(c->d_hist);
-    HIPCHK(hipMalloc(&c->d_hist, sizeof(oa::StepRecord) * (size_t)n));
+    HIPCHK(dev_malloc(&c->d_hist, sizeof(oa::StepRecord) * (size_t)n));
     c->max_records = n;
     return OA_OK;
 }
@@ -672,8 +752,8 @@ int build_filter(oa_ctx *c)
     if (c->fax[0] > c->fax[1]) std::swap(c->fax[0], c->fax[1]);
     const int blocks = (c->n_groups_pad + 255) / 256;
     DevTmp<double> d_mx;
-    HIPCHK(hipMalloc(&c->d_tf, sizeof(float4) * 3 * (size_t)c->n_groups_pad));
-    HIPCHK(hipMalloc(&c->d_tf3, sizeof(float4) * 2 * (size_t)c->n_groups_pad));
+    HIPCHK(dev_malloc(&c->d_tf, sizeof(float4) * 3 * (size_t)c->n_groups_pad));
+    HIPCHK(dev_malloc(&c->d_tf3, sizeof(float4) * 2 * (size_t)c->n_groups_pad));
     HIPCHK(d_mx.alloc((size_t)blocks));
     hipLaunchKernelGGL(oa::k_pack_filter, dim3(blocks), dim3(256), 0, c->stream, c->d_tgt_xyz, c->nt, c->n_groups_pad,
                        c->tc[0], c->tc[1], c->tc[2], c->fax[0], c->fax[1], c->fax[2], c->d_tf, c->d_tf3, d_mx.p);
@@ -745,8 +825,8 @@ int build_grid(oa_ctx *c)
         break;
     }
     if (n_cells <= 0) return OA_OK;
-    HIPCHK(hipMalloc(&c->d_cell_start, sizeof(int) * (size_t)(n_cells + 1)));
-    HIPCHK(hipMalloc(&c->d_sorted, sizeof(float4) * (size_t)c->nt));
+    HIPCHK(dev_malloc(&c->d_cell_start, sizeof(int) * (size_t)(n_cells + 1)));
+    HIPCHK(dev_malloc(&c->d_sorted, sizeof(float4) * (size_t)c->nt));
     { int rcs = scan_counts(c, d_counts.p, n_cells, d_off.p); if (rcs) return rcs; }
     hipLaunchKernelGGL(oa::k_grid_starts, dim3((n_cells + 256) / 256), dim3(256), 0, c->stream, d_off.p, n_cells, c->d_cell_start, d_counts.p);
     hipLaunchKernelGGL(oa::k_grid_scatter, dim3((c->nt + 255) / 256), dim3(256), 0, c->stream, c->d_tgt_xyz, c->nt, d_cell_of.p, c->d_cell_start, d_counts.p, c->d_sorted);
@@ -785,13 +865,13 @@ OA_EXPORT int oa_set_target(oa_ctx *c, const float *xyz, int64_t n, int on_devic
         HIPCHK(hipStreamSynchronize(c->stream));
     }
     if (n == 0) return OA_OK;
-    HIPCHK(hipMalloc(&c->d_tgt_xyz, sizeof(float) * 3 * (size_t)n));
+    HIPCHK(dev_malloc(&c->d_tgt_xyz, sizeof(float) * 3 * (size_t)n));
     HIPCHK(hipMemcpyAsync(c->d_tgt_xyz, xyz, sizeof(float) * 3 * (size_t)n,
                           on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
     const long long groups = (n + 3) / 4;
     const long long tiles = (groups + oa::TILE_GROUPS - 1) / oa::TILE_GROUPS;
     c->n_groups_pad = (int)(tiles * oa::TILE_GROUPS);
-    HIPCHK(hipMalloc(&c->d_tg, sizeof(float4) * 3 * (size_t)c->n_groups_pad));
+    HIPCHK(dev_malloc(&c->d_tg, sizeof(float4) * 3 * (size_t)c->n_groups_pad));
     hipLaunchKernelGGL(oa::k_pack_target, dim3((c->n_groups_pad + 255) / 256), dim3(256), 0, c->stream, c->d_tgt_xyz,
                        c->nt, c->n_groups_pad, c->d_tg);
     HIPCHK(hipGetLastError());
@@ -869,8 +949,8 @@ int build_bvh(oa_ctx *c, bool tri)
     DevTmp<char> tmp;
     HIPCHK(tmp.alloc(bytes));
     HIPCHK(rocprim::radix_sort_pairs((void *)tmp.p, bytes, k_in.p, k_out.p, v_in.p, v_out.p, (size_t)n, 0, 30, c->stream));
-    HIPCHK(hipMalloc(&d_prims, sizeof(float4) * (tri ? 3 : 1) * (size_t)n_pad));
-    HIPCHK(hipMalloc(&d_box, sizeof(float4) * 2 * (size_t)total));
+    HIPCHK(dev_malloc(&d_prims, sizeof(float4) * (tri ? 3 : 1) * (size_t)n_pad));
+    HIPCHK(dev_malloc(&d_box, sizeof(float4) * 2 * (size_t)total));
     const dim3 grd_pad((unsigned)((n_pad + 255) / 256));
     if (tri) hipLaunchKernelGGL(oa::k_bvh_gather<true>, grd_pad, blk, 0, c->stream, (const float *)c->d_tgt_xyz, (const float4 *)c->d_tri9,
                                 (const int *)v_out.p, n, n_pad, d_prims);
@@ -967,7 +1047,7 @@ int sort_source_slots(oa_ctx *c, const float *d_xyz, long long n_verts)
     DevTmp<unsigned> k_in, k_out;
     DevTmp<int> v_in;
     HIPCHK(k_in.alloc((size_t)c->ns)); HIPCHK(k_out.alloc((size_t)c->ns)); HIPCHK(v_in.alloc((size_t)c->ns));
-    HIPCHK(hipMalloc(&c->d_perm, sizeof(int) * (size_t)c->ns));
+    HIPCHK(dev_malloc(&c->d_perm, sizeof(int) * (size_t)c->ns));
     hipLaunchKernelGGL(oa::k_morton_keys, dim3((c->ns + 255) / 256), dim3(256), 0, c->stream, (const float4 *)c->d_src4, c->ns,
                        lo[0], lo[1], lo[2], sc[0], sc[1], sc[2], k_in.p, v_in.p);
     HIPCHK(hipGetLastError());
@@ -979,7 +1059,7 @@ int sort_source_slots(oa_ctx *c, const float *d_xyz, long long n_verts)
     // d_src4 / d_sel become the sorted images; the packed originals move to d_src4o / a temporary
     DevTmp<int> selo;
     HIPCHK(selo.alloc((size_t)c->ns_pad));
-    HIPCHK(hipMalloc(&c->d_src4o, sizeof(float4) * (size_t)c->ns_pad));
+    HIPCHK(dev_malloc(&c->d_src4o, sizeof(float4) * (size_t)c->ns_pad));
     HIPCHK(hipMemcpyAsync(c->d_src4o, c->d_src4, sizeof(float4) * (size_t)c->ns_pad, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(selo, c->d_sel, sizeof(int) * (size_t)c->ns_pad, hipMemcpyDeviceToDevice, c->stream));
     hipLaunchKernelGGL(oa::k_apply_perm, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, (const float4 *)c->d_src4o,
@@ -1050,9 +1130,9 @@ int build_tri_grid(oa_ctx *c)
     }
     if (n_cells <= 0 || entries == 0) return OA_OK;
     HIPCHK(d_off.alloc((size_t)n_cells + 1));
-    HIPCHK(hipMalloc(&c->d_tcell_start, sizeof(int) * (size_t)(n_cells + 1)));
-    HIPCHK(hipMalloc(&c->d_tcell_tris, sizeof(int) * (size_t)entries));
-    HIPCHK(hipMalloc(&c->d_tcell_sph, sizeof(float4) * (size_t)entries));
+    HIPCHK(dev_malloc(&c->d_tcell_start, sizeof(int) * (size_t)(n_cells + 1)));
+    HIPCHK(dev_malloc(&c->d_tcell_tris, sizeof(int) * (size_t)entries));
+    HIPCHK(dev_malloc(&c->d_tcell_sph, sizeof(float4) * (size_t)entries));
     { int rcs = scan_counts(c, d_counts.p, n_cells, d_off.p); if (rcs) return rcs; }
     hipLaunchKernelGGL(oa::k_grid_starts, dim3((n_cells + 256) / 256), dim3(256), 0, c->stream, d_off.p, n_cells, c->d_tcell_start, d_counts.p);
     hipLaunchKernelGGL(oa::k_tri_grid_bin<true>, dim3((c->n_tris + 255) / 256), dim3(256), 0, c->stream, c->d_tri9, c->n_tris,
@@ -1111,7 +1191,7 @@ OA_EXPORT int oa_set_target_mesh(oa_ctx *c, const float *xyz, int64_t n_verts, i
     HIPCHK(d_bad.alloc(1));
     HIPCHK(hipMemcpyAsync(d_tris, tris, sizeof(int) * 3 * (size_t)n_tris, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(int), c->stream));
-    HIPCHK(hipMalloc(&c->d_tri9, sizeof(float4) * 3 * (size_t)n_tris));
+    HIPCHK(dev_malloc(&c->d_tri9, sizeof(float4) * 3 * (size_t)n_tris));
     hipLaunchKernelGGL(oa::k_pack_tris, dim3((unsigned)((n_tris + 255) / 256)), dim3(256), 0, c->stream, c->d_tgt_xyz,
                        (int)n_verts, (const int *)d_tris.p, (int)n_tris, c->d_tri9, d_bad.p);
     HIPCHK(hipGetLastError());
@@ -1160,14 +1240,14 @@ OA_EXPORT int oa_set_source(oa_ctx *c, const float *xyz, int64_t n_verts, int on
     const int chunk = oa::NN_THREADS * c->R;
     c->ns_pad = (int)(((count + chunk - 1) / chunk) * chunk);
     if (c->ns_pad == 0) c->ns_pad = chunk;
-    HIPCHK(hipMalloc(&c->d_src4, sizeof(float4) * (size_t)c->ns_pad));
-    HIPCHK(hipMalloc(&c->d_keys, sizeof(unsigned long long) * (size_t)c->ns_pad));
-    HIPCHK(hipMalloc(&c->d_prev, sizeof(int) * (size_t)c->ns_pad));
-    HIPCHK(hipMalloc(&c->d_sel, sizeof(int) * (size_t)c->ns_pad));
+    HIPCHK(dev_malloc(&c->d_src4, sizeof(float4) * (size_t)c->ns_pad));
+    HIPCHK(dev_malloc(&c->d_keys, sizeof(unsigned long long) * (size_t)c->ns_pad));
+    HIPCHK(dev_malloc(&c->d_prev, sizeof(int) * (size_t)c->ns_pad));
+    HIPCHK(dev_malloc(&c->d_sel, sizeof(int) * (size_t)c->ns_pad));
     HIPCHK(hipMemsetAsync(c->d_sel, 0, sizeof(int) * (size_t)c->ns_pad, c->stream));
     dev_free(c->d_todo_list); dev_free(c->d_todo_count);
-    HIPCHK(hipMalloc(&c->d_todo_list, sizeof(int) * (size_t)c->ns_pad));
-    HIPCHK(hipMalloc(&c->d_todo_count, sizeof(int)));
+    HIPCHK(dev_malloc(&c->d_todo_list, sizeof(int) * (size_t)c->ns_pad));
+    HIPCHK(dev_malloc(&c->d_todo_count, sizeof(int)));
     HIPCHK(hipMemsetAsync(c->d_todo_count, 0, sizeof(int), c->stream));
     hipLaunchKernelGGL(oa::k_fill_int, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, c->d_prev, c->ns_pad, -1);
     c->pivot[0] = c->pivot[1] = c->pivot[2] = 0.0;
@@ -1235,13 +1315,13 @@ OA_EXPORT int oa_set_normals(oa_ctx *c, const float *src_normals, int64_t n_vert
     HIPCHK(tmp.alloc(3 * (size_t)n_verts));
     HIPCHK(hipMemcpyAsync(tmp, src_normals, sizeof(float) * 3 * (size_t)n_verts, hipMemcpyHostToDevice, c->stream));
     dev_free(c->d_src_n); dev_free(c->d_tgt_n);
-    HIPCHK(hipMalloc(&c->d_src_n, sizeof(float) * 3 * (size_t)std::max(1, c->ns)));
+    HIPCHK(dev_malloc(&c->d_src_n, sizeof(float) * 3 * (size_t)std::max(1, c->ns)));
     if (c->ns > 0)
         hipLaunchKernelGGL(oa::k_gather_rows3, dim3((c->ns + 255) / 256), dim3(256), 0, c->stream, (const float *)tmp.p,
                            (const int *)c->d_sel, c->ns, c->d_src_n);
     HIPCHK(hipGetLastError());
     if (!c->surface) {
-        HIPCHK(hipMalloc(&c->d_tgt_n, sizeof(float) * 3 * (size_t)nt));
+        HIPCHK(dev_malloc(&c->d_tgt_n, sizeof(float) * 3 * (size_t)nt));
         HIPCHK(hipMemcpyAsync(c->d_tgt_n, tgt_normals, sizeof(float) * 3 * (size_t)nt, hipMemcpyHostToDevice, c->stream));
     }
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1348,13 +1428,13 @@ OA_EXPORT int oa_make_pairs(oa_ctx *c, double thresh, int calc_stats, double *A,
     if (c->emit_cap < c->ns) {
         dev_free(c->d_valid); dev_free(c->d_b); dev_free(c->d_dist); dev_free(c->d_counts); dev_free(c->d_offsets);
         dev_free(c->d_A); dev_free(c->d_B);
-        HIPCHK(hipMalloc(&c->d_valid, (size_t)c->ns));
-        HIPCHK(hipMalloc(&c->d_b, sizeof(float) * 3 * (size_t)c->ns));
-        HIPCHK(hipMalloc(&c->d_dist, sizeof(double) * (size_t)c->ns));
-        HIPCHK(hipMalloc(&c->d_counts, sizeof(int) * (size_t)n_blocks));
-        HIPCHK(hipMalloc(&c->d_offsets, sizeof(long long) * (size_t)(n_blocks + 1)));
-        HIPCHK(hipMalloc(&c->d_A, sizeof(double) * 3 * (size_t)c->ns));
-        HIPCHK(hipMalloc(&c->d_B, sizeof(double) * 3 * (size_t)c->ns));
+        HIPCHK(dev_malloc(&c->d_valid, (size_t)c->ns));
+        HIPCHK(dev_malloc(&c->d_b, sizeof(float) * 3 * (size_t)c->ns));
+        HIPCHK(dev_malloc(&c->d_dist, sizeof(double) * (size_t)c->ns));
+        HIPCHK(dev_malloc(&c->d_counts, sizeof(int) * (size_t)n_blocks));
+        HIPCHK(dev_malloc(&c->d_offsets, sizeof(long long) * (size_t)(n_blocks + 1)));
+        HIPCHK(dev_malloc(&c->d_A, sizeof(double) * 3 * (size_t)c->ns));
+        HIPCHK(dev_malloc(&c->d_B, sizeof(double) * 3 * (size_t)c->ns));
         c->emit_cap = c->ns;
     }
     c->d_pivot0 = 0.0;
