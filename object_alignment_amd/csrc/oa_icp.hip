@@ -64,9 +64,12 @@ struct DevCache {
     static constexpr size_t CACHE_MAX_BYTES = 8ull << 30;
     static constexpr unsigned long long CACHE_MAX_AGE = 512;
 
+    const bool enabled = !(getenv("OA_DEV_CACHE") && atoi(getenv("OA_DEV_CACHE")) == 0);   // OA_DEV_CACHE=0: plain hipMalloc / hipFree
+
     hipError_t alloc(void **out, size_t bytes)
     {
         if (bytes == 0) bytes = 1;
+        if (!enabled) return hipMalloc(out, bytes);
         int dev = 0;
         (void)hipGetDevice(&dev);
         {
@@ -93,6 +96,7 @@ struct DevCache {
     void release(void *p)
     {
         if (!p) return;
+        if (!enabled) { (void)hipFree(p); return; }
         (void)hipDeviceSynchronize();                              // what hipFree would have done
         std::lock_guard<std::mutex> lk(mu);
         auto it = live.find(p);
