@@ -141,11 +141,36 @@ class GpuBVH:
         return cls(_coords_of(obj), engine, _tris_of(obj) if surface else None)
 
     def _bind_source(self, xyz, vlist, sample):
-        key = (id(xyz), xyz.shape, None if vlist is None else (len(vlist), hash(bytes(memoryview(vlist)))), sample)
+        # re-upload only when something changed; the vertex list is fingerprinted in O(n) numpy time (1 ms at 1M),
+        # not hashed byte by byte
+        vkey = None if vlist is None else (len(vlist), int(vlist.sum()), int(vlist[::max(1, len(vlist) // 61)].sum()))
+        key = (id(xyz), xyz.shape, vkey, sample)
         if key != self._src_key:
             self.engine.set_source(xyz, vlist=vlist, stride=sample)
             self._src_key = key
             self._keep = xyz
+
+
+_VLIST_CACHE = {}
+
+
+def _vlist_array(vlist):
+    """int64 array of a vertex list.  The operators hand over a Python list (as the reference builds it) and reuse it
+    every iteration: converting a million-element list costs ~60 ms, so the converted array is remembered per list
+    object (identity + length + a sample of its elements)."""
+    if isinstance(vlist, np.ndarray):
+        return np.ascontiguousarray(vlist, dtype=np.int64)
+    n = len(vlist)
+    step = max(1, n // 31)
+    probe = (n, tuple(vlist[i] for i in range(0, n, step)), vlist[-1] if n else None)
+    hit = _VLIST_CACHE.get(id(vlist))
+    if hit is not None and hit[0] == probe:
+        return hit[1]
+    arr = np.ascontiguousarray(vlist, dtype=np.int64)
+    if len(_VLIST_CACHE) > 8:
+        _VLIST_CACHE.clear()
+    _VLIST_CACHE[id(vlist)] = (probe, arr)
+    return arr
 
 
 def make_pairs(align_obj, base_obj, base_bvh, vlist, thresh, sample=0, calc_stats=False):
@@ -161,7 +186,7 @@ def make_pairs(align_obj, base_obj, base_bvh, vlist, thresh, sample=0, calc_stat
     if not isinstance(base_bvh, GpuBVH):
         raise TypeError("base_bvh must be an object_alignment_amd GpuBVH (GpuBVH.FromObject(base_obj))")
     xyz = _coords_of(align_obj)
-    vl = np.ascontiguousarray(vlist, dtype=np.int64)
+    vl = _vlist_array(vlist)
     base_bvh._bind_source(xyz, vl, int(sample))
     eng = base_bvh.engine
     eng.set_matrices(_matrix_to_np(align_obj.matrix_world), _matrix_to_np(base_obj.matrix_world))
