@@ -196,8 +196,8 @@ def make_pairs(align_obj, base_obj, base_bvh, vlist, thresh, sample=0, calc_stat
 def affine_matrix_from_points(v0, v1, shear=True, scale=True, usesvd=True):
     """Same contract as the reference's affine_matrix_from_points (functions/general.py:105-217)
     for the branch the ICP operators use: 3-D, shear=False (rigid, or similarity when scale=True)."""
-    v0 = np.array(v0, dtype=np.float64, copy=True)
-    v1 = np.array(v1, dtype=np.float64, copy=True)
+    v0 = np.asarray(v0, dtype=np.float64)        # the reference copies (:146-147) because it centres in place; nothing
+    v1 = np.asarray(v1, dtype=np.float64)        # is modified here
     if v0.ndim != 2 or v1.ndim != 2:
         raise ValueError(REF_VALUEERROR)
     ndims = v0.shape[0]
