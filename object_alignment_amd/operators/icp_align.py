@@ -73,6 +73,15 @@ def build_vlist(align_obj):
     return [v.index for v in mesh.vertices]
 
 
+def vlist_for_engine(align_obj):
+    """build_vlist() for the engine: None when the object has neither an `icp_include` nor an `icp_exclude` group --
+    the engine then takes every vertex itself, and a million-element Python list is neither built nor converted."""
+    names = {g.name for g in (getattr(align_obj, "vertex_groups", None) or ())}
+    if "icp_include" in names or "icp_exclude" in names:
+        return build_vlist(align_obj)
+    return None
+
+
 def vlist_from_weights(n_verts, include=None, exclude=None):
     """Array form of the same mask: include / exclude are None or iterables of (vertex_index, weight)."""
     if include is not None:
@@ -141,7 +150,7 @@ class OBJECT_OT_icp_align(_OperatorBase):
             align_obj.rotation_mode = 'QUATERNION'
         except Exception:
             pass
-        vlist = build_vlist(align_obj)
+        vlist = vlist_for_engine(align_obj)
         base_geo = evaluated_base(base_obj, context)            # BVHTree.FromObject(base_obj, depsgraph)  (:52-53)
         res = IcpAlign(settings).run(_coords_of(align_obj), _coords_of(base_geo),
                                      _matrix_to_np(align_obj.matrix_world), _matrix_to_np(base_obj.matrix_world),

@@ -20,7 +20,7 @@ import numpy as np
 
 from .. import _hostmath
 from ..functions.general import _coords_of, _matrix_to_np, _tris_of, default_engine, evaluated_base
-from .icp_align import _OperatorBase, _assign_matrix, _bpy, build_vlist, get_addon_preferences
+from .icp_align import _OperatorBase, _assign_matrix, _bpy, get_addon_preferences, vlist_for_engine
 
 RING = 5
 
@@ -136,7 +136,7 @@ class OBJECT_OT_icp_align_feedback(_OperatorBase):
             eng.set_target(_coords_of(base_geo))
         else:
             eng.set_target_mesh(_coords_of(base_geo), tris)
-        eng.set_source(_coords_of(run.align_obj), vlist=build_vlist(run.align_obj), stride=stride)
+        eng.set_source(_coords_of(run.align_obj), vlist=vlist_for_engine(run.align_obj), stride=stride)
         eng.set_matrices(_matrix_to_np(run.align_obj.matrix_world), _matrix_to_np(run.base_obj.matrix_world))
 
     @staticmethod
