@@ -220,7 +220,9 @@ struct oa_ctx {
     oa::DevState h_state;
     oa::DevState *d_state = nullptr;
     bool have_mats = false, loop_active = false;
-    oa::StepRecord *d_hist = nullptr;
+    oa::StepRecord *d_hist = nullptr;       // device view of h_hist_map: the solve kernel writes the records straight into host memory
+    oa::StepRecord *h_hist_map = nullptr;   // pinned, device-mapped history (read after a stream sync, no copy)
+    oa::DevState *h_state_pin = nullptr;    // pinned staging of DevState (pageable copies cost ~30 us each way)
     std::vector<oa::StepRecord> h_hist;   // host copy of the executed iterations' records, filled by fill_report
     bool h_hist_valid = false;
     int max_records = 0;
@@ -283,6 +285,7 @@ int ensure_common(oa_ctx *c)
         HIPCHK(hipHostMalloc((void **)&c->h_poll, 2 * sizeof(int32_t), hipHostMallocMapped));
         c->h_poll[0] = 0; c->h_poll[1] = 0;
     }
+    if (!c->h_state_pin) HIPCHK(hipHostMalloc((void **)&c->h_state_pin, sizeof(oa::DevState), hipHostMallocDefault));
     return OA_OK;
 }
 
@@ -290,8 +293,12 @@ int ensure_history(oa_ctx *c, int n)
 {
     n = std::max(16, std::min(n, 1 << 16));
     if (n <= c->max_records) return OA_OK;
-    dev_free(c->d_hist);
-    HIPCHK(dev_malloc(&c->d_hist, sizeof(oa::StepRecord) * (size_t)n));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->h_hist_map) { (void)hipHostFree(c->h_hist_map); c->h_hist_map = nullptr; c->d_hist = nullptr; }
+    HIPCHK(hipHostMalloc((void **)&c->h_hist_map, sizeof(oa::StepRecord) * (size_t)n, hipHostMallocMapped));
+    void *dp = nullptr;
+    HIPCHK(hipHostGetDevicePointer(&dp, c->h_hist_map, 0));
+    c->d_hist = (oa::StepRecord *)dp;
     c->max_records = n;
     return OA_OK;
 }
@@ -510,7 +517,8 @@ int begin_loop(oa_ctx *c, const oa_settings *st, int iters)
     HIPCHK(hipStreamSynchronize(c->stream));                    // nothing of an earlier loop may still write the host flag
     if (c->h_poll) { c->h_poll[0] = 0; c->h_poll[1] = 0; }
     init_loop_state(c, st, iters);
-    HIPCHK(hipMemcpyAsync(c->d_state, &c->h_state, sizeof(oa::DevState), hipMemcpyHostToDevice, c->stream));
+    *c->h_state_pin = c->h_state;                               // pinned staging copy (the stream is idle, see above)
+    HIPCHK(hipMemcpyAsync(c->d_state, c->h_state_pin, sizeof(oa::DevState), hipMemcpyHostToDevice, c->stream));
     if (c->d_todo_count) HIPCHK(hipMemsetAsync(c->d_todo_count, 0, sizeof(int), c->stream));   // kept at zero by k_solve_update
     hipLaunchKernelGGL(oa::k_stamp_start, dim3(1), dim3(64), 0, c->stream, c->d_state);
     HIPCHK(hipGetLastError());
@@ -578,8 +586,17 @@ int iter_fused(oa_ctx *c, bool timed)
 
 int fetch_state(oa_ctx *c)
 {
-    HIPCHK(hipMemcpyAsync(&c->h_state, c->d_state, sizeof(oa::DevState), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_state_pin, c->d_state, sizeof(oa::DevState), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    c->h_state = *c->h_state_pin;
+    return OA_OK;
+}
+
+// host mirror -> device through the pinned staging copy (the stream must be idle: the staging copy is reused)
+int push_state(oa_ctx *c)
+{
+    *c->h_state_pin = c->h_state;
+    HIPCHK(hipMemcpyAsync(c->d_state, c->h_state_pin, sizeof(oa::DevState), hipMemcpyHostToDevice, c->stream));
     return OA_OK;
 }
 
@@ -597,7 +614,7 @@ int fill_report(oa_ctx *c, oa_report *rep)
     const int m = (s.n > 0 && c->d_hist) ? std::min(s.n, c->max_records) : 0;
     if (m > 0) {                                                  // one copy serves the report, the timing and oa_get_history
         c->h_hist.resize((size_t)m);
-        HIPCHK(hipMemcpy(c->h_hist.data(), c->d_hist, sizeof(oa::StepRecord) * (size_t)m, hipMemcpyDeviceToHost));
+        memcpy(c->h_hist.data(), c->h_hist_map, sizeof(oa::StepRecord) * (size_t)m);   // the stream is idle: fetch_state synchronised
         c->h_hist_valid = true;
         const oa::StepRecord &r = c->h_hist[(size_t)((s.n - 1) % c->max_records)];
         rep->last_K = (int64_t)r.K;
@@ -681,7 +698,9 @@ OA_EXPORT void oa_destroy(oa_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     dev_free(c->d_tgt_xyz); dev_free(c->d_tg); dev_free(c->d_tf); dev_free(c->d_tf3); dev_free(c->d_prev); dev_free(c->d_cell_start); dev_free(c->d_sorted); dev_free(c->d_todo_list); dev_free(c->d_todo_count); dev_free(c->d_src4); dev_free(c->d_keys); dev_free(c->d_state);
-    dev_free(c->d_hist); dev_free(c->d_partials); dev_free(c->d_sums); dev_free(c->d_solve);
+    if (c->h_hist_map) (void)hipHostFree(c->h_hist_map);
+    if (c->h_state_pin) (void)hipHostFree(c->h_state_pin);
+    dev_free(c->d_partials); dev_free(c->d_sums); dev_free(c->d_solve);
     dev_free(c->d_valid); dev_free(c->d_b); dev_free(c->d_dist); dev_free(c->d_counts); dev_free(c->d_offsets);
     dev_free(c->d_A); dev_free(c->d_B);
     dev_free(c->d_bvh_box); dev_free(c->d_bvh_prims); dev_free(c->d_tbvh_box); dev_free(c->d_tbvh_prims);
@@ -1376,7 +1395,9 @@ int push_state_for_oneshot(oa_ctx *c, double thresh, bool cutoff)
     oa_settings st{};
     st.iters = 1; st.use_target = 1; st.with_scale = 0; st.early_exit = 0; st.thresh = thresh; st.target_d = 0.0;
     init_loop_state(c, &st, 1, cutoff);
-    HIPCHK(hipMemcpyAsync(c->d_state, &c->h_state, sizeof(oa::DevState), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));                    // the staging copy may still be in flight
+    int rc = push_state(c);
+    if (rc) return rc;
     c->loop_active = false;
     return OA_OK;
 }
@@ -1638,7 +1659,7 @@ OA_EXPORT int oa_iterate(oa_ctx *c, const oa_settings *st, double M_step[16], do
     if (s.status == OA_E_SINGULAR) { c->loop_active = false; return fail(OA_E_SINGULAR, "align matrix_world became singular"); }
     if (s.n <= 0) return fail(OA_E_STATE, "oa_iterate: loop already halted");
     oa::StepRecord r;
-    HIPCHK(hipMemcpy(&r, c->d_hist + ((s.n - 1) % c->max_records), sizeof r, hipMemcpyDeviceToHost));
+    memcpy(&r, c->h_hist_map + ((s.n - 1) % c->max_records), sizeof r);             // fetch_state synchronised the stream
     if (M_step) memcpy(M_step, r.M, sizeof r.M);
     if (stats) {
         stats[0] = r.K; stats[1] = s.use_target ? r.mean_d : NAN; stats[2] = s.use_target ? r.std_d : NAN;
@@ -1657,8 +1678,8 @@ OA_EXPORT int oa_get_history(oa_ctx *c, int32_t max_n, double *step_M, float *st
     std::vector<oa::StepRecord> h_local;
     if (!(c->h_hist_valid && (int)c->h_hist.size() >= n)) {
         h_local.resize((size_t)n);
-        if (hipMemcpy(h_local.data(), c->d_hist, sizeof(oa::StepRecord) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess)
-            return fail(OA_E_HIP, "oa_get_history: copy failed");
+        if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(OA_E_HIP, "oa_get_history: stream error");
+        memcpy(h_local.data(), c->h_hist_map, sizeof(oa::StepRecord) * (size_t)n);
     }
     const std::vector<oa::StepRecord> &h = h_local.empty() ? c->h_hist : h_local;
     for (int i = 0; i < n; ++i) {
