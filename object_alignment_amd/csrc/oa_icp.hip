@@ -223,6 +223,7 @@ struct oa_ctx {
     oa::StepRecord *d_hist = nullptr;       // device view of h_hist_map: the solve kernel writes the records straight into host memory
     oa::StepRecord *h_hist_map = nullptr;   // pinned, device-mapped history (read after a stream sync, no copy)
     oa::DevState *h_state_pin = nullptr;    // pinned staging of DevState (pageable copies cost ~30 us each way)
+    char *h_scratch = nullptr;              // pinned scratch for small read-backs (read_small)
     std::vector<oa::StepRecord> h_hist;   // host copy of the executed iterations' records, filled by fill_report
     bool h_hist_valid = false;
     int max_records = 0;
@@ -286,6 +287,23 @@ int ensure_common(oa_ctx *c)
         c->h_poll[0] = 0; c->h_poll[1] = 0;
     }
     if (!c->h_state_pin) HIPCHK(hipHostMalloc((void **)&c->h_state_pin, sizeof(oa::DevState), hipHostMallocDefault));
+    return OA_OK;
+}
+
+// small device -> host read-back through a pinned scratch buffer, then a stream sync (a pageable destination costs
+// ~30 us per copy; uploads do half a dozen of these)
+int read_small(oa_ctx *c, void *dst, const void *d_src, size_t bytes)
+{
+    constexpr size_t SCRATCH = 1 << 16;
+    if (!c->h_scratch) HIPCHK(hipHostMalloc((void **)&c->h_scratch, SCRATCH, hipHostMallocDefault));
+    if (bytes <= SCRATCH) {
+        HIPCHK(hipMemcpyAsync(c->h_scratch, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        memcpy(dst, c->h_scratch, bytes);
+    } else {
+        HIPCHK(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
     return OA_OK;
 }
 
@@ -700,6 +718,7 @@ OA_EXPORT void oa_destroy(oa_ctx *c)
     dev_free(c->d_tgt_xyz); dev_free(c->d_tg); dev_free(c->d_tf); dev_free(c->d_tf3); dev_free(c->d_prev); dev_free(c->d_cell_start); dev_free(c->d_sorted); dev_free(c->d_todo_list); dev_free(c->d_todo_count); dev_free(c->d_src4); dev_free(c->d_keys); dev_free(c->d_state);
     if (c->h_hist_map) (void)hipHostFree(c->h_hist_map);
     if (c->h_state_pin) (void)hipHostFree(c->h_state_pin);
+    if (c->h_scratch) (void)hipHostFree(c->h_scratch);
     dev_free(c->d_partials); dev_free(c->d_sums); dev_free(c->d_solve);
     dev_free(c->d_valid); dev_free(c->d_b); dev_free(c->d_dist); dev_free(c->d_counts); dev_free(c->d_offsets);
     dev_free(c->d_A); dev_free(c->d_B);
@@ -754,8 +773,7 @@ int build_filter(oa_ctx *c)
     hipLaunchKernelGGL(oa::k_bbox_partial, dim3(nb), dim3(256), 0, c->stream, c->d_tgt_xyz, c->nt, d_bb.p);
     HIPCHK(hipGetLastError());
     std::vector<float> bb(6 * nb);
-    HIPCHK(hipMemcpyAsync(bb.data(), d_bb, sizeof(float) * 6 * nb, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    { int rcr = read_small(c, bb.data(), d_bb, sizeof(float) * 6 * nb); if (rcr) return rcr; }
     double lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
     bool finite = true;
     for (int b = 0; b < nb; ++b)
@@ -782,8 +800,7 @@ int build_filter(oa_ctx *c)
                        c->tc[0], c->tc[1], c->tc[2], c->fax[0], c->fax[1], c->fax[2], c->d_tf, c->d_tf3, d_mx.p);
     HIPCHK(hipGetLastError());
     std::vector<double> mx((size_t)blocks);
-    HIPCHK(hipMemcpyAsync(mx.data(), d_mx, sizeof(double) * (size_t)blocks, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    { int rcr = read_small(c, mx.data(), d_mx, sizeof(double) * (size_t)blocks); if (rcr) return rcr; }
     double m = 0.0;
     for (double v : mx) if (v > m) m = v;
     c->qmax = sqrt(m) * (1.0 + 1e-6);
@@ -840,8 +857,7 @@ int build_grid(oa_ctx *c)
         hipLaunchKernelGGL(oa::k_count_nonzero, dim3((n_cells + 255) / 256), dim3(256), 0, c->stream, d_counts.p, n_cells, d_nz.p);
         HIPCHK(hipGetLastError());
         int occupied = 0;
-        HIPCHK(hipMemcpyAsync(&occupied, d_nz, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        { int rcr = read_small(c, &occupied, d_nz, sizeof(int)); if (rcr) return rcr; }
         const double avg = occupied > 0 ? (double)c->nt / occupied : 0.0;
         // surfaces fill few cells: refine until occupied cells hold a handful of vertices each
         if (avg > 6.0 && total * 8 <= max_cells && attempt < 5) { h *= 0.5; continue; }
@@ -1007,8 +1023,7 @@ int morton_frame(oa_ctx *c, const float *d_xyz, long long n_verts, float lo[3], 
     hipLaunchKernelGGL(oa::k_bbox_partial, dim3(nb), dim3(256), 0, c->stream, d_xyz, (int)n_verts, d_bb.p);
     HIPCHK(hipGetLastError());
     std::vector<float> bb(6 * nb);
-    HIPCHK(hipMemcpyAsync(bb.data(), d_bb, sizeof(float) * 6 * nb, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    { int rcr = read_small(c, bb.data(), d_bb, sizeof(float) * 6 * nb); if (rcr) return rcr; }
     float hi[3] = { -INFINITY, -INFINITY, -INFINITY };
     lo[0] = lo[1] = lo[2] = INFINITY;
     for (int b = 0; b < nb; ++b)
@@ -1104,8 +1119,7 @@ int build_tri_grid(oa_ctx *c)
     hipLaunchKernelGGL(oa::k_tri_diag_sum, dim3((c->n_tris + 255) / 256), dim3(256), 0, c->stream, c->d_tri9, c->n_tris, d_sum.p);
     HIPCHK(hipGetLastError());
     double diag_sum = 0.0;
-    HIPCHK(hipMemcpyAsync(&diag_sum, d_sum, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    { int rcr = read_small(c, &diag_sum, d_sum, sizeof(double)); if (rcr) return rcr; }
     double ext[3], scale = 0.0, max_ext = 0.0;
     for (int a = 0; a < 3; ++a) {
         ext[a] = c->bb_hi[a] - c->bb_lo[a];
@@ -1145,8 +1159,7 @@ int build_tri_grid(oa_ctx *c)
         hipLaunchKernelGGL(oa::k_tri_grid_bin<false>, dim3((c->n_tris + 255) / 256), dim3(256), 0, c->stream, c->d_tri9,
                            c->n_tris, gp, d_counts.p, (const int *)nullptr, (int *)nullptr, (float4 *)nullptr, d_total.p);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(&entries, d_total, sizeof(entries), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        { int rcr = read_small(c, &entries, d_total, sizeof(entries)); if (rcr) return rcr; }
         // triangles much larger than a cell explode the lists: coarsen
         if (entries > 32ull * (unsigned long long)c->n_tris + (1ull << 20) || entries > 0x7FFFFFF0ull) { h *= 2.0; n_cells = 0; continue; }
         break;
@@ -1186,8 +1199,7 @@ int launch_tri_search(oa_ctx *c)
         HIPCHK(hipGetLastError());
         if (getenv("OA_DEBUG")) {                                  // how many queries the grid handed over (debug only: syncs)
             int n_todo = 0;
-            HIPCHK(hipMemcpyAsync(&n_todo, c->d_todo_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipStreamSynchronize(c->stream));
+            { int rcr = read_small(c, &n_todo, c->d_todo_count, sizeof(int)); if (rcr) return rcr; }
             fprintf(stderr, "[oa] tri grid handed %d of %d queries to the tree\n", n_todo, c->ns);
         }
         return launch_bvh<true>(c, c->d_todo_list, c->d_todo_count);       // the far queries: tree search
@@ -1219,8 +1231,7 @@ OA_EXPORT int oa_set_target_mesh(oa_ctx *c, const float *xyz, int64_t n_verts, i
                        (int)n_verts, (const int *)d_tris.p, (int)n_tris, c->d_tri9, d_bad.p);
     HIPCHK(hipGetLastError());
     int bad = 0;
-    HIPCHK(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    { int rcr = read_small(c, &bad, d_bad, sizeof(int)); if (rcr) return rcr; }
     if (bad) { dev_free(c->d_tri9); return fail(OA_E_BAD_ARG, "oa_set_target_mesh: %d triangle corners index outside 0..%lld", bad, (long long)n_verts - 1); }
     c->n_tris = (int)n_tris;
     c->surface = true;
@@ -1471,8 +1482,7 @@ OA_EXPORT int oa_make_pairs(oa_ctx *c, double thresh, int calc_stats, double *A,
         // np.std is two-pass; redo the (cheap) accumulation around the mean of the first pass so that the
         // population std is accurate even when it is tiny compared with the mean
         double s1[oa::NSUMS];
-        HIPCHK(hipMemcpyAsync(s1, c->d_sums, sizeof s1, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        { int rcr = read_small(c, s1, c->d_sums, sizeof s1); if (rcr) return rcr; }
         if (s1[oa::S_K] > 0.0) {
             c->d_pivot0 = s1[oa::S_D] / s1[oa::S_K];
             if ((rc = push_state_for_oneshot(c, thresh, true))) { c->d_pivot0 = 0.0; return rc; }
@@ -1491,8 +1501,7 @@ OA_EXPORT int oa_make_pairs(oa_ctx *c, double thresh, int calc_stats, double *A,
     double sums[oa::NSUMS];
     long long total = 0;
     HIPCHK(hipMemcpyAsync(sums, c->d_sums, sizeof sums, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(&total, c->d_offsets + n_blocks, sizeof total, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    { int rcr = read_small(c, &total, c->d_offsets + n_blocks, sizeof total); if (rcr) return rcr; }
     if (total > cap) return fail(OA_E_CAPACITY, "oa_make_pairs: %lld pairs but capacity %lld", total, (long long)cap);
     for (int a = 0; a < 3 && total > 0; ++a) {
         HIPCHK(hipMemcpyAsync(A + (size_t)a * cap, c->d_A + (size_t)a * c->ns, sizeof(double) * (size_t)total, hipMemcpyDeviceToHost, c->stream));
@@ -1521,8 +1530,7 @@ int solve_on_device(oa_ctx *c, const double *d_sums, const double pv[3], int wit
     hipLaunchKernelGGL(oa::k_solve_only, dim3(1), dim3(64), 0, c->stream, d_sums, pv[0], pv[1], pv[2], with_scale, c->d_solve);
     HIPCHK(hipGetLastError());
     double out[17];
-    HIPCHK(hipMemcpyAsync(out, c->d_solve, sizeof out, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    { int rcr = read_small(c, out, c->d_solve, sizeof out); if (rcr) return rcr; }
     if (out[16] != 1.0) return fail(OA_E_TOO_FEW_PAIRS, "input arrays are of wrong shape or type");
     memcpy(M, out, sizeof(double) * 16);
     return OA_OK;
