@@ -168,6 +168,24 @@ def test_evaluated_base_object_is_used():
     assert evaluated_base(raw, broken) is raw
 
 
+def test_vlist_conversion_cache():
+    """make_pairs remembers the int64 form of a vertex LIST per list object (a million-element conversion costs
+    ~60 ms per call otherwise); a list that changed -- other length, or other sampled elements -- is converted again."""
+    from object_alignment_amd.functions.general import _vlist_array
+    v = list(range(0, 5000, 2))
+    a = _vlist_array(v)
+    assert a.dtype == np.int64 and np.array_equal(a, np.arange(0, 5000, 2))
+    assert _vlist_array(v) is a                          # same object, unchanged: no second conversion
+    v.append(77)
+    b = _vlist_array(v)
+    assert b is not a and b[-1] == 77 and len(b) == len(a) + 1
+    v[0] = 3                                             # element 0 is always sampled
+    assert _vlist_array(v)[0] == 3
+    arr = np.arange(10, dtype=np.int32)
+    out = _vlist_array(arr)
+    assert out.dtype == np.int64 and np.array_equal(out, arr)
+
+
 def test_synthetic_configs_are_deterministic():
     from object_alignment_amd import synth
     assert synth.icosphere(4).shape == (2562, 3)
