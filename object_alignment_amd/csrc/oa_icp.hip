@@ -273,7 +273,8 @@ void plan_geometry(oa_ctx *c)
     const int tiles_per_split = (tiles_total + splits - 1) / splits;
     c->groups_per_split = tiles_per_split * c->tile_groups;
     c->n_splits = (tiles_total + tiles_per_split - 1) / tiles_per_split;
-    c->acc_blocks = std::max(1, std::min(oa::ACC_MAX_BLOCKS, (c->ns + oa::ACC_THREADS - 1) / oa::ACC_THREADS));
+    const int acc_cap = std::max(1, std::min(oa::ACC_MAX_BLOCKS, env_int("OA_ACC_BLOCKS", 512)));
+    c->acc_blocks = std::max(1, std::min(acc_cap, (c->ns + oa::ACC_THREADS - 1) / oa::ACC_THREADS));
 }
 
 int ensure_common(oa_ctx *c)

@@ -29,7 +29,7 @@ constexpr uint32_t IDX_NONE = 0xFFFFFFFFu;
 constexpr int NN_THREADS = 256;
 constexpr int TILE_GROUPS = 256;          // groups of 4 targets per LDS tile (1024 targets, 12 KiB)
 constexpr int ACC_THREADS = 256;
-constexpr int ACC_MAX_BLOCKS = 512;
+constexpr int ACC_MAX_BLOCKS = 4096;
 
 struct StepRecord {
     double M[16];
@@ -1013,8 +1013,19 @@ __device__ __forceinline__ void reduce_partials_block(const double *__restrict__
     __shared__ double red[32][32];
     const int j = threadIdx.x & 31, s = threadIdx.x >> 5;
     double v = 0.0;
-    if (j < NSUMS)
-        for (int b = s; b < n_blocks; b += 32) v += partials[(long long)b * NSUMS + j];
+    if (j < NSUMS) {
+        // loads eight rows ahead of the (ordered) adds: a plain loop serialises on the memory latency of every row
+        const double *__restrict__ col = partials + j;
+        int b = s;
+        for (; b + 7 * 32 < n_blocks; b += 8 * 32) {
+            double p[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) p[u] = col[(long long)(b + 32 * u) * NSUMS];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += p[u];
+        }
+        for (; b < n_blocks; b += 32) v += col[(long long)b * NSUMS];
+    }
     red[s][j] = v;
     __syncthreads();
     if (threadIdx.x < NSUMS) {
