@@ -191,14 +191,16 @@ __device__ __forceinline__ bool bvh_prune(float lb, float best)
     return lb * 0.99999f - 1e-30f > best;                          // cannot beat or tie
 }
 
-// One wave per query.  list == nullptr: every source point, seeded with last iteration's primitive (`prev`, original
-// index, evaluated through tgt_xyz / tri9); else the points the grid search could not settle, seeded with keys[i].
+// One wave per query.  list == nullptr: every source point, seeded with last iteration's primitive (vertex mode: the
+// winner record win[i]; triangles: `prev`, original index, evaluated through tri9); else the points the grid search
+// could not settle, seeded with keys[i].
 template <bool TRI>
 __global__ __launch_bounds__(256) void k_bvh_search(const DevState *__restrict__ st, const float4 *__restrict__ src4,
                                                     int ns, BvhParams bp, const float4 *__restrict__ boxes,
                                                     const float4 *__restrict__ prims,
-                                                    const float *__restrict__ tgt_xyz, const float4 *__restrict__ tri9,
-                                                    const int *__restrict__ prev, unsigned long long *__restrict__ keys,
+                                                    const float4 *__restrict__ tri9,
+                                                    const int *__restrict__ prev, float4 *__restrict__ win,
+                                                    unsigned long long *__restrict__ keys,
                                                     const int *__restrict__ list, const int *__restrict__ list_count)
 {
     if (st->halt) return;
@@ -219,23 +221,30 @@ __global__ __launch_bounds__(256) void k_bvh_search(const DevState *__restrict__
 
         float best = INFINITY;
         uint32_t bidx = IDX_NONE;
+        // vertex mode: (bx, by, bz) follow the winner's coordinates; win[i] is the slot's winner record (coordinates +
+        // index) -- the seed of a whole search, the grid search's partial answer in list mode
+        float bx = 0.f, by = 0.f, bz = 0.f;
         if (list) {
             const unsigned long long k0 = keys[i];
             const float b0 = __uint_as_float((uint32_t)(k0 >> 32));
-            if (b0 < INFINITY) { best = b0; bidx = (uint32_t)k0; }
-        } else {
+            if (b0 < INFINITY) {
+                best = b0; bidx = (uint32_t)k0;
+                if (!TRI) { const float4 sw = win[i]; bx = sw.x; by = sw.y; bz = sw.z; }
+            }
+        } else if (TRI) {
             const int s = prev ? prev[i] : -1;
             if (s >= 0) {
-                float d;
-                if (TRI) {
-                    float a[3], b[3], c[3], r[3];
-                    load_tri(tri9, s, a, b, c);
-                    closest_on_tri(p, a, b, c, r);
-                    d = tri_dist2(p, r);
-                } else {
-                    d = d2_metric(p[0], p[1], p[2], tgt_xyz[3ll * s], tgt_xyz[3ll * s + 1], tgt_xyz[3ll * s + 2]);
-                }
+                float a[3], b[3], c[3], r[3];
+                load_tri(tri9, s, a, b, c);
+                closest_on_tri(p, a, b, c, r);
+                const float d = tri_dist2(p, r);
                 if (d < INFINITY) { best = d; bidx = (uint32_t)s; }
+            }
+        } else {
+            const float4 sw = win[i];
+            if (__float_as_int(sw.w) >= 0) {
+                const float d = d2_metric(p[0], p[1], p[2], sw.x, sw.y, sw.z);
+                if (d < INFINITY) { best = d; bidx = (uint32_t)__float_as_int(sw.w); bx = sw.x; by = sw.y; bz = sw.z; }
             }
         }
         // `lim`: the best so far or the search radius (search_cutoff2), whichever is smaller -- see k_nn_search_grid
@@ -291,6 +300,7 @@ __global__ __launch_bounds__(256) void k_bvh_search(const DevState *__restrict__
                 const long long j = child * BVH_W + lane;
                 float d;
                 uint32_t qi;
+                float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (TRI) {
                     float a[3], b[3], c[3], r[3];
                     load_tri(prims, j, a, b, c);
@@ -308,7 +318,7 @@ __global__ __launch_bounds__(256) void k_bvh_search(const DevState *__restrict__
                     closest_on_tri(p, a, b, c, r);
                     d = tri_dist2(p, r);
                 } else {
-                    const float4 q = prims[j];
+                    q = prims[j];
                     qi = __float_as_uint(q.w);
                     d = d2_metric(p[0], p[1], p[2], q.x, q.y, q.z);
                 }
@@ -319,11 +329,18 @@ __global__ __launch_bounds__(256) void k_bvh_search(const DevState *__restrict__
                     if (md < __float_as_uint(best) || mi < bidx) {
                         best = __uint_as_float(md); bidx = mi; lim = fminf(best, cutf);
                         if (TRI) thr = tri_skip_threshold(lim, delta);
+                        else {
+                            const int wl = __ffsll((long long)__ballot(dbits == md && qi == mi)) - 1;   // the winner's lane
+                            bx = __shfl(q.x, wl, 64); by = __shfl(q.y, wl, 64); bz = __shfl(q.z, wl, 64);
+                        }
                     }
                 }
             }
         }
-        if (lane == 0) keys[i] = ((unsigned long long)__float_as_uint(best) << 32) | bidx;
+        if (lane == 0) {
+            keys[i] = ((unsigned long long)__float_as_uint(best) << 32) | bidx;
+            if (!TRI) win[i] = make_float4(bx, by, bz, __int_as_float((int)bidx));
+        }
     }
 }
 

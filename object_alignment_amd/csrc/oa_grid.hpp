@@ -89,19 +89,20 @@ __global__ void k_grid_scatter(const float *__restrict__ xyz, int nt, const int 
     sorted[pos] = make_float4(xyz[3ll * i], xyz[3ll * i + 1], xyz[3ll * i + 2], __int_as_float(i));
 }
 
-__device__ __forceinline__ void grid_candidate(float px, float py, float pz, const float4 q, float &best, uint32_t &bidx)
+// `bj` follows the winner's position in `sorted` (-1: still the seed)
+__device__ __forceinline__ void grid_candidate(float px, float py, float pz, const float4 q, int j, float &best,
+                                               uint32_t &bidx, int &bj)
 {
     const float d = d2_metric(px, py, pz, q.x, q.y, q.z);
     const uint32_t qi = (uint32_t)__float_as_int(q.w);
-    if (d < best || (d == best && qi < bidx && d < INFINITY)) { best = d; bidx = qi; }
+    if (d < best || (d == best && qi < bidx && d < INFINITY)) { best = d; bidx = qi; bj = j; }
 }
 
-__global__ __launch_bounds__(256, 6) void k_nn_search_grid(const DevState *__restrict__ st,
+__global__ __launch_bounds__(256, 5) void k_nn_search_grid(const DevState *__restrict__ st,
                                                         const float4 *__restrict__ src4, int ns, GridParams gp,
                                                         const int *__restrict__ cell_start,
                                                         const float4 *__restrict__ sorted,
-                                                        const float *__restrict__ tgt_xyz,
-                                                        const int *__restrict__ prev,
+                                                        float4 *__restrict__ win,
                                                         unsigned long long *__restrict__ keys,
                                                         int *__restrict__ todo_list, int *__restrict__ todo_count)
 {
@@ -113,12 +114,17 @@ __global__ __launch_bounds__(256, 6) void k_nn_search_grid(const DevState *__res
     m4_mul_v3(st->mx1, p4.x, p4.y, p4.z, wx, wy, wz);
     m4_mul_v3(st->imx2, wx, wy, wz, px, py, pz);                // co_find (general.py:287)
 
+    // seed: this slot's winner record (coordinates + index) of the previous search -- one coalesced load where an
+    // index would cost a dependent gather from the caller-ordered target array
     float best = INFINITY;
     uint32_t bidx = IDX_NONE;
-    const int s = prev ? prev[i] : -1;
-    if (s >= 0) {
-        const float d = d2_metric(px, py, pz, tgt_xyz[3ll * s], tgt_xyz[3ll * s + 1], tgt_xyz[3ll * s + 2]);
-        if (d < INFINITY) { best = d; bidx = (uint32_t)s; }
+    int bj = -1;
+    {
+        const float4 sw = win[i];
+        if (__float_as_int(sw.w) >= 0) {
+            const float d = d2_metric(px, py, pz, sw.x, sw.y, sw.z);
+            if (d < INFINITY) { best = d; bidx = (uint32_t)__float_as_int(sw.w); }
+        }
     }
 
     // projection of the query onto the grid's box, and its cell
@@ -202,10 +208,10 @@ __global__ __launch_bounds__(256, 6) void k_nn_search_grid(const DevState *__res
                         for (int j = j0; j < j1; j += 4) {           // the clamped repeats of the last vertex change nothing
                             const float4 q0 = sorted[j], q1 = sorted[min(j + 1, last)], q2 = sorted[min(j + 2, last)],
                                          q3 = sorted[min(j + 3, last)];
-                            grid_candidate(px, py, pz, q0, best, bidx);
-                            grid_candidate(px, py, pz, q1, best, bidx);
-                            grid_candidate(px, py, pz, q2, best, bidx);
-                            grid_candidate(px, py, pz, q3, best, bidx);
+                            grid_candidate(px, py, pz, q0, j, best, bidx, bj);
+                            grid_candidate(px, py, pz, q1, min(j + 1, last), best, bidx, bj);
+                            grid_candidate(px, py, pz, q2, min(j + 2, last), best, bidx, bj);
+                            grid_candidate(px, py, pz, q3, min(j + 3, last), best, bidx, bj);
                         }
                         lim = fminf(best, cutf);
                     }
@@ -228,6 +234,9 @@ __global__ __launch_bounds__(256, 6) void k_nn_search_grid(const DevState *__res
         }
     }
     keys[i] = ((unsigned long long)__float_as_uint(best) << 32) | bidx;
+    // the winner record is read by k_pair_accumulate, the tree search and the next search; a winner that is still the
+    // seed (the usual case once the loop converges) is already there
+    if (bj >= 0) win[i] = sorted[bj];
     if (!settled) todo_list[atomicAdd(todo_count, 1)] = i;      // finished exactly by the tree search (k_bvh_search)
 }
 

@@ -201,6 +201,7 @@ struct oa_ctx {
     float4 *d_src4 = nullptr;
     unsigned long long *d_keys = nullptr;
     int *d_prev = nullptr;           // nearest index of the previous search (seed), -1 = none
+    float4 *d_win = nullptr;         // vertex mode: per slot, the last winner's coordinates + index in .w (-1 = none)
     int *d_sel = nullptr;            // vertex index held by each source slot
     float4 *d_src4o = nullptr;       // the same points in the caller's (vlist) order -- only oa_make_pairs needs it
     int *d_perm = nullptr;           // sorted slot -> caller-order slot (nullptr: not sorted)
@@ -368,7 +369,7 @@ int launch_bvh(oa_ctx *c, const int *list, const int *list_count)
     const unsigned blocks = (unsigned)std::max(1, std::min((items + 3) / 4, c->n_cu * 16));   // 16 waves per SIMD: enough to fill the chip, cheap to dispatch when the list is empty
     hipLaunchKernelGGL(oa::k_bvh_search<TRI>, dim3(blocks), dim3(256), 0, c->stream, c->d_state, c->d_src4, c->ns,
                        TRI ? c->tbvh : c->bvh, TRI ? c->d_tbvh_box : c->d_bvh_box, TRI ? c->d_tbvh_prims : c->d_bvh_prims,
-                       c->d_tgt_xyz, c->d_tri9, c->d_prev, c->d_keys, list, list_count);
+                       c->d_tri9, c->d_prev, TRI ? (float4 *)nullptr : c->d_win, c->d_keys, list, list_count);
     HIPCHK(hipGetLastError());
     return OA_OK;
 }
@@ -388,7 +389,7 @@ int launch_nn(oa_ctx *c)
         // one-shot calls clear it here.
         if (!c->loop_active) HIPCHK(hipMemsetAsync(c->d_todo_count, 0, sizeof(int), c->stream));
         hipLaunchKernelGGL(oa::k_nn_search_grid, dim3((c->ns + 255) / 256), dim3(256), 0, c->stream, c->d_state, c->d_src4,
-                           c->ns, c->gp, c->d_cell_start, c->d_sorted, c->d_tgt_xyz, c->d_prev, c->d_keys,
+                           c->ns, c->gp, c->d_cell_start, c->d_sorted, c->d_win, c->d_keys,
                            c->d_todo_list, c->d_todo_count);
         HIPCHK(hipGetLastError());
         return launch_bvh<false>(c, c->d_todo_list, c->d_todo_count);
@@ -431,12 +432,12 @@ int launch_accumulate(oa_ctx *c, bool emit, int *nn_idx, float *nn_d2)
     if (emit) {
         po.valid = c->d_valid; po.b = c->d_b; po.dist = c->d_dist; po.nn_idx = nn_idx; po.nn_d2 = nn_d2; po.perm = c->d_perm;
         hipLaunchKernelGGL(oa::k_pair_accumulate<true>, dim3(c->acc_blocks), dim3(oa::ACC_THREADS), 0, c->stream,
-                           c->d_state, c->d_src4, c->ns, c->d_tgt_xyz, c->d_keys, c->d_prev,
+                           c->d_state, c->d_src4, c->ns, c->d_tgt_xyz, c->d_keys, c->d_prev, c->surface ? (float4 *)nullptr : c->d_win,
                            c->surface ? (const float4 *)c->d_tri9 : (const float4 *)nullptr, nrm, c->d_partials, po,
                            (unsigned long long *)nullptr);
     } else {
         hipLaunchKernelGGL(oa::k_pair_accumulate<false>, dim3(c->acc_blocks), dim3(oa::ACC_THREADS), 0, c->stream,
-                           c->d_state, c->d_src4, c->ns, c->d_tgt_xyz, c->d_keys, c->d_prev,
+                           c->d_state, c->d_src4, c->ns, c->d_tgt_xyz, c->d_keys, c->d_prev, c->surface ? (float4 *)nullptr : c->d_win,
                            c->surface ? (const float4 *)c->d_tri9 : (const float4 *)nullptr, nrm, c->d_partials, po,
                            c->loop_active ? &c->d_state->t_acc_start : (unsigned long long *)nullptr);
     }
@@ -597,7 +598,7 @@ int iter_fused(oa_ctx *c, bool timed)
         c->ev_used++;
     }
     if ((rc = launch_accumulate(c, false, nullptr, nullptr))) return rc;
-    hipLaunchKernelGGL(oa::k_reduce_solve_update, dim3(1), dim3(1024), 0, c->stream, c->d_state, (const double *)c->d_partials,
+    hipLaunchKernelGGL(oa::k_reduce_solve_update, dim3(1), dim3(512), 0, c->stream, c->d_state, (const double *)c->d_partials,
                        c->acc_blocks, c->d_sums, c->d_hist, c->d_todo_count);
     HIPCHK(hipGetLastError());
     return OA_OK;
@@ -716,7 +717,7 @@ OA_EXPORT void oa_destroy(oa_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    dev_free(c->d_tgt_xyz); dev_free(c->d_tg); dev_free(c->d_tf); dev_free(c->d_tf3); dev_free(c->d_prev); dev_free(c->d_cell_start); dev_free(c->d_sorted); dev_free(c->d_todo_list); dev_free(c->d_todo_count); dev_free(c->d_src4); dev_free(c->d_keys); dev_free(c->d_state);
+    dev_free(c->d_tgt_xyz); dev_free(c->d_tg); dev_free(c->d_tf); dev_free(c->d_tf3); dev_free(c->d_prev); dev_free(c->d_win); dev_free(c->d_cell_start); dev_free(c->d_sorted); dev_free(c->d_todo_list); dev_free(c->d_todo_count); dev_free(c->d_src4); dev_free(c->d_keys); dev_free(c->d_state);
     if (c->h_hist_map) (void)hipHostFree(c->h_hist_map);
     if (c->h_state_pin) (void)hipHostFree(c->h_state_pin);
     if (c->h_scratch) (void)hipHostFree(c->h_scratch);
@@ -902,6 +903,7 @@ OA_EXPORT int oa_set_target(oa_ctx *c, const float *xyz, int64_t n, int on_devic
     c->n_groups_pad = 0;
     if (c->d_prev) {   // seeds index the old target
         hipLaunchKernelGGL(oa::k_fill_int, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, c->d_prev, c->ns_pad, -1);
+        HIPCHK(hipMemsetAsync(c->d_win, 0xFF, sizeof(float4) * (size_t)c->ns_pad, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
     }
     if (n == 0) return OA_OK;
@@ -1262,7 +1264,7 @@ OA_EXPORT int oa_set_source(oa_ctx *c, const float *xyz, int64_t n_verts, int on
     int rc = use_device(c);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
-    dev_free(c->d_src4); dev_free(c->d_keys); dev_free(c->d_prev); dev_free(c->d_sel); dev_free(c->d_src_n);
+    dev_free(c->d_src4); dev_free(c->d_keys); dev_free(c->d_prev); dev_free(c->d_win); dev_free(c->d_sel); dev_free(c->d_src_n);
     dev_free(c->d_src4o); dev_free(c->d_perm);
     c->normals_on = false;
     c->src_n_verts = n_verts;
@@ -1278,6 +1280,8 @@ OA_EXPORT int oa_set_source(oa_ctx *c, const float *xyz, int64_t n_verts, int on
     HIPCHK(dev_malloc(&c->d_src4, sizeof(float4) * (size_t)c->ns_pad));
     HIPCHK(dev_malloc(&c->d_keys, sizeof(unsigned long long) * (size_t)c->ns_pad));
     HIPCHK(dev_malloc(&c->d_prev, sizeof(int) * (size_t)c->ns_pad));
+    HIPCHK(dev_malloc(&c->d_win, sizeof(float4) * (size_t)c->ns_pad));
+    HIPCHK(hipMemsetAsync(c->d_win, 0xFF, sizeof(float4) * (size_t)c->ns_pad, c->stream));
     HIPCHK(dev_malloc(&c->d_sel, sizeof(int) * (size_t)c->ns_pad));
     HIPCHK(hipMemsetAsync(c->d_sel, 0, sizeof(int) * (size_t)c->ns_pad, c->stream));
     dev_free(c->d_todo_list); dev_free(c->d_todo_count);

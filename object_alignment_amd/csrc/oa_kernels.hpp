@@ -908,7 +908,7 @@ __global__ __launch_bounds__(ACC_THREADS) void k_pair_accumulate(const DevState 
                                                                  const float4 *__restrict__ src4, int ns,
                                                                  const float *__restrict__ tgt_xyz,
                                                                  unsigned long long *__restrict__ keys,
-                                                                 int *__restrict__ prev,
+                                                                 int *__restrict__ prev, float4 *__restrict__ win,
                                                                  const float4 *__restrict__ tri9, NormalTest nrm,
                                                                  double *__restrict__ partials, PairOut out,
                                                                  unsigned long long *__restrict__ t_acc_start)
@@ -933,6 +933,11 @@ __global__ __launch_bounds__(ACC_THREADS) void k_pair_accumulate(const DevState 
             float bx = 0.f, by = 0.f, bz = 0.f;
             double dist = 0.0;
             const float4 p = src4[i];
+            // vertex mode: the slot's winner record (coordinates + index).  The grid and tree searches leave this
+            // search's winner there; after a brute-force search it still holds the previous winner, which in a
+            // converging loop is mostly the same vertex.  A matching index saves the gather from the target array.
+            float4 wrec = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+            if (win) wrec = win[i];
             if (idx != IDX_NONE) {
                 float wx, wy, wz, cx, cy, cz;
                 m4_mul_v3(st->mx1, p.x, p.y, p.z, wx, wy, wz);
@@ -953,7 +958,11 @@ __global__ __launch_bounds__(ACC_THREADS) void k_pair_accumulate(const DevState 
                         tn[2] = e1[0] * e2[1] - e1[1] * e2[0];
                     }
                 } else {                                             // vertex mode: target vertex `idx`
-                    qx = tgt_xyz[3ll * idx]; qy = tgt_xyz[3ll * idx + 1]; qz = tgt_xyz[3ll * idx + 2];
+                    if ((uint32_t)__float_as_int(wrec.w) == idx) { qx = wrec.x; qy = wrec.y; qz = wrec.z; }
+                    else {
+                        qx = tgt_xyz[3ll * idx]; qy = tgt_xyz[3ll * idx + 1]; qz = tgt_xyz[3ll * idx + 2];
+                        if (win) win[i] = make_float4(qx, qy, qz, __int_as_float((int)idx));
+                    }
                     if (nrm.src_n) { tn[0] = nrm.tgt_n[3ll * idx]; tn[1] = nrm.tgt_n[3ll * idx + 1]; tn[2] = nrm.tgt_n[3ll * idx + 2]; }
                 }
                 float ax, ay, az, wbx, wby, wbz;
@@ -1007,26 +1016,30 @@ __global__ __launch_bounds__(ACC_THREADS) void k_pair_accumulate(const DevState 
 }
 
 // fixed-order reduction of the per-block partials: 32 interleaved slices, then slices 0..31 in order.
-// Called by all 1024 threads of a block; the totals land in out[0..NSUMS) (shared or global memory).
+// Called by all THREADS (1024 or 512) threads of a block -- with 512 every 32-thread group sums two slices, one after
+// the other: same arithmetic, same bits; the totals land in out[0..NSUMS) (shared or global memory).
+template <int THREADS>
 __device__ __forceinline__ void reduce_partials_block(const double *__restrict__ partials, int n_blocks, double *out)
 {
     __shared__ double red[32][32];
-    const int j = threadIdx.x & 31, s = threadIdx.x >> 5;
-    double v = 0.0;
-    if (j < NSUMS) {
-        // loads eight rows ahead of the (ordered) adds: a plain loop serialises on the memory latency of every row
-        const double *__restrict__ col = partials + j;
-        int b = s;
-        for (; b + 7 * 32 < n_blocks; b += 8 * 32) {
-            double p[8];
+    const int j = threadIdx.x & 31;
+    for (int s = threadIdx.x >> 5; s < 32; s += THREADS / 32) {
+        double v = 0.0;
+        if (j < NSUMS) {
+            // loads eight rows ahead of the (ordered) adds: a plain loop serialises on the memory latency of every row
+            const double *__restrict__ col = partials + j;
+            int b = s;
+            for (; b + 7 * 32 < n_blocks; b += 8 * 32) {
+                double p[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) p[u] = col[(long long)(b + 32 * u) * NSUMS];
+                for (int u = 0; u < 8; ++u) p[u] = col[(long long)(b + 32 * u) * NSUMS];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v += p[u];
+                for (int u = 0; u < 8; ++u) v += p[u];
+            }
+            for (; b < n_blocks; b += 32) v += col[(long long)b * NSUMS];
         }
-        for (; b < n_blocks; b += 32) v += col[(long long)b * NSUMS];
+        red[s][j] = v;
     }
-    red[s][j] = v;
     __syncthreads();
     if (threadIdx.x < NSUMS) {
         double t = red[0][threadIdx.x];
@@ -1038,7 +1051,7 @@ __device__ __forceinline__ void reduce_partials_block(const double *__restrict__
 __global__ __launch_bounds__(1024) void k_reduce_partials(const double *__restrict__ partials, int n_blocks,
                                                           double *__restrict__ sums)
 {
-    reduce_partials_block(partials, n_blocks, sums);
+    reduce_partials_block<1024>(partials, n_blocks, sums);
 }
 
 // sums over explicit pairs (contract 2: oa_kabsch).  A, B: 3 x K row-major with leading dimension ld.
@@ -1153,7 +1166,7 @@ __global__ void k_stamp_start(DevState *__restrict__ st)
 }
 
 // split-phase form (one process per GPU): the sums come back from the all-reduce
-__global__ void k_solve_update(DevState *__restrict__ st, const double *__restrict__ sums, StepRecord *__restrict__ hist,
+__global__ __launch_bounds__(64) void k_solve_update(DevState *__restrict__ st, const double *__restrict__ sums, StepRecord *__restrict__ hist,
                                int *__restrict__ todo_count)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -1161,12 +1174,13 @@ __global__ void k_solve_update(DevState *__restrict__ st, const double *__restri
 }
 
 // single-GPU form: the fixed-order reduction and the solve in one launch (same arithmetic, one boundary less)
-__global__ __launch_bounds__(1024) void k_reduce_solve_update(DevState *__restrict__ st, const double *__restrict__ partials,
+// (512 threads: the one-thread solve needs more than the 128 registers a 1024-thread workgroup leaves a lane)
+__global__ __launch_bounds__(512) void k_reduce_solve_update(DevState *__restrict__ st, const double *__restrict__ partials,
                                                               int n_blocks, double *__restrict__ sums_out,
                                                               StepRecord *__restrict__ hist, int *__restrict__ todo_count)
 {
     __shared__ double sums[NSUMS];
-    reduce_partials_block(partials, n_blocks, sums);
+    reduce_partials_block<512>(partials, n_blocks, sums);
     __syncthreads();
     if (threadIdx.x < NSUMS && sums_out) sums_out[threadIdx.x] = sums[threadIdx.x];
     if (threadIdx.x == 0) solve_update_body(st, sums, hist, todo_count);
