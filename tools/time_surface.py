@@ -22,6 +22,8 @@ mxa = synth.rigid4(synth.rotation_from_rotvec([0.02, -0.015, 0.025]), [0.01, -0.
 mxb = np.identity(4, dtype=np.float32)
 print("target %d vertices, %d triangles; source %d points" % (len(tgt), len(tris), ns), flush=True)
 combos = [("surface", "grid"), ("surface", "bvh"), ("vertex", "grid"), ("vertex", "bvh")]
+if os.environ.get("ONLY"):                               # e.g. ONLY=surface:grid
+    combos = [tuple(os.environ["ONLY"].split(":"))]
 for mode, search in combos:
     with IcpEngine(0) as e:
         e.set_search_mode(search)
