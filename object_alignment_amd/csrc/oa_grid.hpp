@@ -98,6 +98,12 @@ __device__ __forceinline__ void grid_candidate(float px, float py, float pz, con
     if (d < best || (d == best && qi < bidx && d < INFINITY)) { best = d; bidx = qi; bj = j; }
 }
 
+// L = 1, 2 or 4 lanes per query.  A thread's time is a chain of dependent memory round trips, and a search of fewer
+// than ~300k queries leaves most of the chip's wave slots empty: with L lanes the rows of a ring are dealt out to the
+// lanes (row k of a batch goes to lane k mod L), every lane scans its rows with its own running best, and the lanes
+// merge (d2, index) lexicographically after every batch -- the same candidates as one lane would see or more (a lane
+// prunes with its own, looser, `lim`), so the same answer, in a chain 1/L as long.
+template <int L>
 __global__ __launch_bounds__(256, 5) void k_nn_search_grid(const DevState *__restrict__ st,
                                                         const float4 *__restrict__ src4, int ns, GridParams gp,
                                                         const int *__restrict__ cell_start,
@@ -106,8 +112,11 @@ __global__ __launch_bounds__(256, 5) void k_nn_search_grid(const DevState *__res
                                                         unsigned long long *__restrict__ keys,
                                                         int *__restrict__ todo_list, int *__restrict__ todo_count)
 {
+    constexpr int RPL = (9 + L - 1) / L;                            // rows per lane and batch
+    constexpr int BATCH = RPL * L;                                  // 9, 10, 12 rows per batch
     if (st->halt) return;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = gt / L, sub = gt % L;                             // the L lanes of a query are neighbours in a wave
     if (i >= ns) return;
     const float4 p4 = src4[i];
     float wx, wy, wz, px, py, pz;
@@ -143,30 +152,32 @@ __global__ __launch_bounds__(256, 5) void k_nn_search_grid(const DevState *__res
     // (dist < thresh) fails anyway, whichever is smaller
     const float cutf = search_cutoff2(st, px, py, pz);
     float lim = fminf(best, cutf);
-    bool settled = false;
-    // candidates this thread may look at before the tree takes the query over; doubled while the pose still moves by a
-    // good part of a cell per iteration (stale seeds: most queries need the second ring) -- see k_tri_search_grid
+    bool settled = false, over = false;
+    // candidates this query may look at before the tree takes it over (split between its lanes); doubled while the
+    // pose still moves by a good part of a cell per iteration (stale seeds: most queries need the second ring) -- see
+    // k_tri_search_grid
     int budget = gp.budget;
     {
         const int last = (st->n + 4) % 5;
         const double moved = st->use_target && st->n > 0 ? (st->ring_t[last] + st->ring_r[last] * gp.scale) * st->local_per_world : 0.0;
         if (st->n == 0 || moved > 0.25 * gp.h) budget *= 2;
+        if (L > 1) budget = budget / L + 8;
     }
     if (finite) {
-        for (int r = 0; r <= gp.r_max && !settled && budget >= 0; ++r) {
+        for (int r = 0; r <= gp.r_max && !settled && !over; ++r) {
             const int x0 = max(c[0] - r, 0), x1 = min(c[0] + r, gp.n[0] - 1);
-            // The (2r+1)^2 rows (y, z) of the ring are handled nine at a time: first the cell ranges of all nine rows
+            // The (2r+1)^2 rows (y, z) of the ring are handled BATCH at a time: first the cell ranges of a lane's rows
             // are fetched (up to 36 independent loads in flight), then their vertices are scanned four per trip.  A
             // thread's time is a chain of memory round trips; this keeps the chain at ~2 + (vertices / 4) per batch
             // instead of 2 per row + 1 per vertex.
             const int side = 2 * r + 1, n_rows = side * side;
             const unsigned div_mul = 65536u / (unsigned)side + 1u;  // k / side == (k * div_mul) >> 16 for k < 64, side <= 7
-            for (int b0 = 0; b0 < n_rows && budget >= 0; b0 += 9) {
-                int ja[9], jb[9], jc[9], jd[9];                     // row k: vertices [ja, jb) and [jc, jd) of `sorted`
+            for (int b0 = 0; b0 < n_rows && !over; b0 += BATCH) {
+                int ja[RPL], jb[RPL], jc[RPL], jd[RPL];             // row m: vertices [ja, jb) and [jc, jd) of `sorted`
 #pragma unroll
-                for (int k = 0; k < 9; ++k) {
-                    ja[k] = jb[k] = jc[k] = jd[k] = 0;
-                    const int kk = b0 + k;
+                for (int m = 0; m < RPL; ++m) {
+                    ja[m] = jb[m] = jc[m] = jd[m] = 0;
+                    const int kk = b0 + sub + L * m;
                     if (kk >= n_rows) continue;
                     const int qz = (int)(((unsigned)kk * div_mul) >> 16);
                     const int dzi = qz - r, dyi = kk - qz * side - r;
@@ -189,18 +200,18 @@ __global__ __launch_bounds__(256, 5) void k_nn_search_grid(const DevState *__res
                     // interior rows were fully covered by ring r-1: only their two end cells are new
                     const bool shell_row = (r == 0) || dzi == -r || dzi == r || dyi == -r || dyi == r;
                     if (shell_row) {
-                        if (xa <= xb) { ja[k] = cell_start[row + xa]; jb[k] = cell_start[row + xb + 1]; }
+                        if (xa <= xb) { ja[m] = cell_start[row + xa]; jb[m] = cell_start[row + xb + 1]; }
                     } else {
                         const int xl = c[0] - r, xr = c[0] + r;
-                        if (xl >= xa && xl <= xb) { ja[k] = cell_start[row + xl]; jb[k] = cell_start[row + xl + 1]; }
-                        if (xr >= xa && xr <= xb) { jc[k] = cell_start[row + xr]; jd[k] = cell_start[row + xr + 1]; }
+                        if (xl >= xa && xl <= xb) { ja[m] = cell_start[row + xl]; jb[m] = cell_start[row + xl + 1]; }
+                        if (xr >= xa && xr <= xb) { jc[m] = cell_start[row + xr]; jd[m] = cell_start[row + xr + 1]; }
                     }
                 }
 #pragma unroll
-                for (int k = 0; k < 9; ++k) {
+                for (int m = 0; m < RPL; ++m) {
 #pragma unroll
                     for (int sg = 0; sg < 2; ++sg) {
-                        const int j0 = sg ? jc[k] : ja[k], j1 = sg ? jd[k] : jb[k];
+                        const int j0 = sg ? jc[m] : ja[m], j1 = sg ? jd[m] : jb[m];
                         if (j1 <= j0) continue;
                         budget -= j1 - j0;
                         if (budget < 0) break;                       // crowded cells: one wave of the tree search is faster
@@ -216,8 +227,23 @@ __global__ __launch_bounds__(256, 5) void k_nn_search_grid(const DevState *__res
                         lim = fminf(best, cutf);
                     }
                 }
+                if (L > 1) {                                         // the lanes of the query agree on the best so far
+#pragma unroll
+                    for (int o = 1; o < L; o <<= 1) {
+                        const float ob = __shfl_xor(best, o, 64);
+                        const uint32_t oi = (uint32_t)__shfl_xor((int)bidx, o, 64);
+                        const int oj = __shfl_xor(bj, o, 64);
+                        if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; bj = oj; }
+                    }
+                    lim = fminf(best, cutf);
+                }
+                over = budget < 0;
+                if (L > 1) {
+#pragma unroll
+                    for (int o = 1; o < L; o <<= 1) over = (__shfl_xor((int)over, o, 64) != 0) || over;
+                }
             }
-            if (budget < 0) break;
+            if (over) break;
             // lower bound for everything outside the cube of radius r
             double m = INFINITY;
             for (int a = 0; a < 3; ++a) {
@@ -233,6 +259,7 @@ __global__ __launch_bounds__(256, 5) void k_nn_search_grid(const DevState *__res
             }
         }
     }
+    if (sub != 0) return;
     keys[i] = ((unsigned long long)__float_as_uint(best) << 32) | bidx;
     // the winner record is read by k_pair_accumulate, the tree search and the next search; a winner that is still the
     // seed (the usual case once the loop converges) is already there

@@ -200,6 +200,7 @@ struct oa_ctx {
     int ns = 0, ns_pad = 0, R = 4;
     float4 *d_src4 = nullptr;
     unsigned long long *d_keys = nullptr;
+    int grid_lanes = 0;              // OA_GRID_LANES: lanes per query of k_nn_search_grid (0 = by shard size)
     int *d_prev = nullptr;           // nearest index of the previous search (seed), -1 = none
     float4 *d_win = nullptr;         // vertex mode: per slot, the last winner's coordinates + index in .w (-1 = none)
     int *d_sel = nullptr;            // vertex index held by each source slot
@@ -346,9 +347,10 @@ int check_ready(oa_ctx *c)
 bool grid_active(const oa_ctx *c);
 // every query through the tree: on request, and in auto mode for shards of up to `auto_max` points -- one wave per
 // query has far lower latency than the one-thread-per-query grid kernels until the waves no longer fit the chip
-// (measured crossover: 2.5e4 .. 6.5e4 points for vertices, 5e4 .. 1.7e5 for triangles, later for big targets whose
-// grid no longer sits in cache; profiles/r01g_search_mode_crossover.txt)
-inline int vertex_tree_max(const oa_ctx *c) { return c->nt >= 500000 ? 65536 : 24576; }
+// (measured crossover: 1.2e4 .. 2.4e4 points for vertices -- the grid kernel spreads a query over 2 or 4 lanes when the
+// shard is small --, 5e4 .. 1.7e5 for triangles, later for big targets whose grid no longer sits in cache;
+// profiles/r01h_search_mode_crossover.txt)
+inline int vertex_tree_max(const oa_ctx *c) { return c->nt >= 500000 ? 24576 : 12288; }
 inline int tri_tree_max(const oa_ctx *c) { return c->n_tris >= 1000000 ? 131072 : (c->n_tris >= 250000 ? 86016 : 49152); }
 inline bool bvh_whole(const oa_ctx *c, bool ok, int auto_max)
 {
@@ -388,9 +390,16 @@ int launch_nn(oa_ctx *c)
         // to a list that the tree search finishes.  Inside the loop k_solve_update leaves the list counter at zero;
         // one-shot calls clear it here.
         if (!c->loop_active) HIPCHK(hipMemsetAsync(c->d_todo_count, 0, sizeof(int), c->stream));
-        hipLaunchKernelGGL(oa::k_nn_search_grid, dim3((c->ns + 255) / 256), dim3(256), 0, c->stream, c->d_state, c->d_src4,
-                           c->ns, c->gp, c->d_cell_start, c->d_sorted, c->d_win, c->d_keys,
-                           c->d_todo_list, c->d_todo_count);
+        // lanes per query: shards too small to fill the chip's wave slots split every query's rows between 2 or 4
+        // lanes (measured on 256 CUs: 4 lanes win up to ~40k queries, 2 lanes up to ~200k; 1M queries lose 15 % with 2)
+        int lanes = c->grid_lanes;
+        if (lanes != 1 && lanes != 2 && lanes != 4) lanes = (c->ns <= 160 * c->n_cu) ? 4 : ((c->ns <= 800 * c->n_cu) ? 2 : 1);
+#define OA_GRID_ARGS c->d_state, c->d_src4, c->ns, c->gp, c->d_cell_start, c->d_sorted, c->d_win, c->d_keys, c->d_todo_list, c->d_todo_count
+        const dim3 gblocks((unsigned)(((long long)c->ns * lanes + 255) / 256));
+        if (lanes == 4) hipLaunchKernelGGL(oa::k_nn_search_grid<4>, gblocks, dim3(256), 0, c->stream, OA_GRID_ARGS);
+        else if (lanes == 2) hipLaunchKernelGGL(oa::k_nn_search_grid<2>, gblocks, dim3(256), 0, c->stream, OA_GRID_ARGS);
+        else hipLaunchKernelGGL(oa::k_nn_search_grid<1>, gblocks, dim3(256), 0, c->stream, OA_GRID_ARGS);
+#undef OA_GRID_ARGS
         HIPCHK(hipGetLastError());
         return launch_bvh<false>(c, c->d_todo_list, c->d_todo_count);
     }
@@ -706,6 +715,7 @@ OA_EXPORT int oa_create(oa_ctx **out, int device)
     c->R_env = env_int("OA_NN_R", 0);
     if (c->R_env != 1 && c->R_env != 2 && c->R_env != 4 && c->R_env != 8) c->R_env = 0;
     c->R = c->R_env ? c->R_env : 4;
+    c->grid_lanes = env_int("OA_GRID_LANES", 0);
     c->use_filter = env_int("OA_NN_FILTER", 1) != 0;
     c->grid_mode = env_int("OA_NN_GRID", -1);
     *out = c;

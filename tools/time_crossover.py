@@ -11,7 +11,7 @@ pose = synth.rigid4(synth.rotation_from_rotvec([0.02, -0.015, 0.025]), [0.01, -0
 ident = np.identity(4, dtype=np.float32)
 meshes = {"82k tris": synth.bumpy_icosphere_mesh(6), "2M tris": synth.lattice_surface_mesh(700, 1400)}
 for mname, (tgt, tris) in meshes.items():
-    for ns in (4000, 16000, 32000, 64000, 128000, 256000):
+    for ns in (2000, 4000, 8000, 16000, 32000, 64000, 128000, 256000):
         src = synth.bunny_surface(ns, offset=0.37)
         for surf in (True, False):
             out = []
