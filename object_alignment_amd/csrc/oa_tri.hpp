@@ -153,30 +153,6 @@ __device__ __forceinline__ float tri_reach(float thr)
     return r < 3.0e38 ? (float)r : INFINITY;
 }
 
-// tri_eval behind the bounding-box test; `thr` follows `best` (recomputed only when the best improves)
-__device__ __forceinline__ void tri_eval_boxed(const float *p, const float4 *__restrict__ tri9, uint32_t t, float &best,
-                                               uint32_t &bidx, float &lim, float &thr, double delta, float cutf)
-{
-    if (t == bidx) return;                                         // already the best: listed in several cells
-    float a[3], b[3], c[3], r[3];
-    load_tri(tri9, t, a, b, c);
-    float lb = 0.f;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const float lo = fminf(fminf(a[k], b[k]), c[k]), hi = fmaxf(fmaxf(a[k], b[k]), c[k]);
-        const float g = fmaxf(fmaxf(lo - p[k], p[k] - hi), 0.f);
-        lb += g * g;
-    }
-    if (lb > thr) return;
-    closest_on_tri(p, a, b, c, r);
-    const float d = tri_dist2(p, r);
-    if (d < best || (d == best && t < bidx && d < INFINITY)) {
-        best = d; bidx = t;
-        lim = fminf(best, cutf);
-        thr = tri_skip_threshold(lim, delta);
-    }
-}
-
 struct TriSearchState {
     float best; uint32_t bidx;
     float lim, thr, reach;    // lim = min(best, search radius^2); thr = squared-gap threshold; reach = sqrt(thr), rounded up
@@ -201,31 +177,55 @@ __device__ __forceinline__ void tri_state_refresh(TriSearchState &s, double delt
 // (measured with SQ_INSTS_VALU: 18.5k -> 9.5k instructions per wave, profiles/r01g_surface_1M_pmc_summary.txt).
 constexpr int TRI_QUEUE = 16;
 
-__device__ __forceinline__ void tri_candidate(const float *p, const float4 sph, const int *__restrict__ cell_tris, int j,
-                                              const TriSearchState &s, int (*queue)[256], int &nq)
+__device__ __forceinline__ void tri_candidate(const float *p, const float4 sph, int tid, const TriSearchState &s,
+                                              int (*queue)[256], int &nq)
 {
     const float dx = sph.x - p[0], dy = sph.y - p[1], dz = sph.z - p[2];
     const float D2 = dx * dx + dy * dy + dz * dz;
     const float rs = sph.w + s.reach;
     if (D2 > rs * rs * 1.000003f) return;                          // farther than radius + reach: cannot beat or tie
-    queue[nq][threadIdx.x] = cell_tris[j];                         // the caller keeps nq <= TRI_QUEUE - 4 before a trip
+    queue[nq][threadIdx.x] = tid;                                  // the caller keeps nq <= TRI_QUEUE - 4 before a trip
     ++nq;
 }
 
+// Phase 2.  The triangle of survivor k + 1 is fetched before survivor k is evaluated: a thread's time is a chain of
+// memory round trips, and the ~300-instruction evaluation hides the next fetch instead of following it.
 __device__ __forceinline__ void tri_queue_flush(const float *p, const float4 *__restrict__ tri9, TriSearchState &s,
                                                 int (*queue)[256], int &nq, double delta, float cutf)
 {
+    float4 u = make_float4(0.f, 0.f, 0.f, 0.f), v = u, w = u;
+    uint32_t t = IDX_NONE;
+    if (nq > 0) { t = (uint32_t)queue[0][threadIdx.x]; u = tri9[3ll * t]; v = tri9[3ll * t + 1]; w = tri9[3ll * t + 2]; }
     for (int k = 0; __any(k < nq); ++k) {
-        if (k < nq) {
-            const float before = s.best;
-            tri_eval_boxed(p, tri9, (uint32_t)queue[k][threadIdx.x], s.best, s.bidx, s.lim, s.thr, delta, cutf);
-            if (s.best < before) tri_state_refresh(s, delta);
+        float4 nu = u, nv = v, nw = w;
+        uint32_t nt = IDX_NONE;
+        if (k + 1 < nq) { nt = (uint32_t)queue[k + 1][threadIdx.x]; nu = tri9[3ll * nt]; nv = tri9[3ll * nt + 1]; nw = tri9[3ll * nt + 2]; }
+        if (k < nq && t != s.bidx) {                               // (already the best: listed in several cells)
+            const float a[3] = { u.x, u.y, u.z }, b[3] = { u.w, v.x, v.y }, c[3] = { v.z, v.w, w.x };
+            float lb = 0.f;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                const float lo = fminf(fminf(a[m], b[m]), c[m]), hi = fmaxf(fmaxf(a[m], b[m]), c[m]);
+                const float g = fmaxf(fmaxf(lo - p[m], p[m] - hi), 0.f);
+                lb += g * g;
+            }
+            if (!(lb > s.thr)) {
+                float r[3];
+                closest_on_tri(p, a, b, c, r);
+                const float d = tri_dist2(p, r);
+                if (d < s.best || (d == s.best && t < s.bidx && d < INFINITY)) {
+                    const bool closer = d < s.best;
+                    s.best = d; s.bidx = t;
+                    if (closer) { s.lim = fminf(s.best, cutf); tri_state_refresh(s, delta); }
+                }
+            }
         }
+        t = nt; u = nu; v = nv; w = nw;
     }
     nq = 0;
 }
 
-__global__ __launch_bounds__(256) void k_tri_search_grid(const DevState *__restrict__ st,
+__global__ __launch_bounds__(256, 4) void k_tri_search_grid(const DevState *__restrict__ st,
                                                          const float4 *__restrict__ src4, int ns, GridParams gp,
                                                          const int *__restrict__ cell_start,
                                                          const int *__restrict__ cell_tris,
@@ -333,12 +333,14 @@ __global__ __launch_bounds__(256) void k_tri_search_grid(const DevState *__restr
                         const int last = j1 - 1;
                         for (int j = j0; j < j1; j += 4) {
                             if (__any(nq > TRI_QUEUE - 4)) tri_queue_flush(pf, tri9, S, queue, nq, delta, cutf);
-                            const float4 s0 = cell_sph[j], s1 = cell_sph[min(j + 1, last)], s2 = cell_sph[min(j + 2, last)],
-                                         s3 = cell_sph[min(j + 3, last)];
-                            tri_candidate(pf, s0, cell_tris, j, S, queue, nq);
-                            if (j + 1 < j1) tri_candidate(pf, s1, cell_tris, j + 1, S, queue, nq);
-                            if (j + 2 < j1) tri_candidate(pf, s2, cell_tris, j + 2, S, queue, nq);
-                            if (j + 3 < j1) tri_candidate(pf, s3, cell_tris, j + 3, S, queue, nq);
+                            // the records and (whether or not they pass) their triangle ids: eight independent loads
+                            const int e1 = min(j + 1, last), e2 = min(j + 2, last), e3 = min(j + 3, last);
+                            const float4 s0 = cell_sph[j], s1 = cell_sph[e1], s2 = cell_sph[e2], s3 = cell_sph[e3];
+                            const int t0 = cell_tris[j], t1 = cell_tris[e1], t2 = cell_tris[e2], t3 = cell_tris[e3];
+                            tri_candidate(pf, s0, t0, S, queue, nq);
+                            if (j + 1 < j1) tri_candidate(pf, s1, t1, S, queue, nq);
+                            if (j + 2 < j1) tri_candidate(pf, s2, t2, S, queue, nq);
+                            if (j + 3 < j1) tri_candidate(pf, s3, t3, S, queue, nq);
                         }
                     }
                 }
