@@ -348,10 +348,10 @@ bool grid_active(const oa_ctx *c);
 // every query through the tree: on request, and in auto mode for shards of up to `auto_max` points -- one wave per
 // query has far lower latency than the one-thread-per-query grid kernels until the waves no longer fit the chip
 // (measured crossover: 1.2e4 .. 2.4e4 points for vertices -- the grid kernel spreads a query over 2 or 4 lanes when the
-// shard is small --, 5e4 .. 1.7e5 for triangles, later for big targets whose grid no longer sits in cache;
+// shard is small --, 2.8e4 .. 4e4 for triangles, later for big targets whose grid no longer sits in cache;
 // profiles/r01h_search_mode_crossover.txt)
 inline int vertex_tree_max(const oa_ctx *c) { return c->nt >= 500000 ? 24576 : 12288; }
-inline int tri_tree_max(const oa_ctx *c) { return c->n_tris >= 1000000 ? 131072 : (c->n_tris >= 250000 ? 86016 : 49152); }
+inline int tri_tree_max(const oa_ctx *c) { return c->n_tris >= 1000000 ? 40960 : (c->n_tris >= 250000 ? 36864 : 28672); }
 inline bool bvh_whole(const oa_ctx *c, bool ok, int auto_max)
 {
     if (!ok) return false;
@@ -1206,9 +1206,16 @@ int launch_tri_search(oa_ctx *c)
                 (void *)c->d_keys, (void *)c->d_todo_list, (void *)c->d_todo_count, (void *)c->d_tcell_start, (void *)c->d_tcell_tris);
     if (use_grid) {
         if (!c->loop_active) HIPCHK(hipMemsetAsync(c->d_todo_count, 0, sizeof(int), c->stream));
-        hipLaunchKernelGGL(oa::k_tri_search_grid, dim3((c->ns + 255) / 256), dim3(256), 0, c->stream, c->d_state, c->d_src4,
-                           c->ns, c->tgp, c->d_tcell_start, c->d_tcell_tris, c->d_tcell_sph, c->d_tri9, c->d_prev, c->d_keys,
-                           c->d_todo_list, c->d_todo_count);
+        // lanes per query, as for the vertex grid; these chains are longer, so more lanes pay for longer (measured on
+        // 256 CUs: 4 lanes win up to ~128k queries, 2 lanes up to ~600k)
+        int lanes = c->grid_lanes;
+        if (lanes != 1 && lanes != 2 && lanes != 4) lanes = (c->ns <= 512 * c->n_cu) ? 4 : ((c->ns <= 2400 * c->n_cu) ? 2 : 1);
+#define OA_TGRID_ARGS c->d_state, c->d_src4, c->ns, c->tgp, c->d_tcell_start, c->d_tcell_tris, c->d_tcell_sph, c->d_tri9, c->d_prev, c->d_keys, c->d_todo_list, c->d_todo_count
+        const dim3 gblocks((unsigned)(((long long)c->ns * lanes + 255) / 256));
+        if (lanes == 4) hipLaunchKernelGGL(oa::k_tri_search_grid<4>, gblocks, dim3(256), 0, c->stream, OA_TGRID_ARGS);
+        else if (lanes == 2) hipLaunchKernelGGL(oa::k_tri_search_grid<2>, gblocks, dim3(256), 0, c->stream, OA_TGRID_ARGS);
+        else hipLaunchKernelGGL(oa::k_tri_search_grid<1>, gblocks, dim3(256), 0, c->stream, OA_TGRID_ARGS);
+#undef OA_TGRID_ARGS
         HIPCHK(hipGetLastError());
         if (getenv("OA_DEBUG")) {                                  // how many queries the grid handed over (debug only: syncs)
             int n_todo = 0;

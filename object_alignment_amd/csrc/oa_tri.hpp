@@ -225,6 +225,9 @@ __device__ __forceinline__ void tri_queue_flush(const float *p, const float4 *__
     nq = 0;
 }
 
+// L = 1, 2 or 4 lanes per query, as in k_nn_search_grid: the rows of a ring are dealt out to the lanes, every lane runs
+// both phases on its rows with its own state, and the lanes merge (d2, index) after every batch of rows.
+template <int L>
 __global__ __launch_bounds__(256, 4) void k_tri_search_grid(const DevState *__restrict__ st,
                                                          const float4 *__restrict__ src4, int ns, GridParams gp,
                                                          const int *__restrict__ cell_start,
@@ -235,10 +238,13 @@ __global__ __launch_bounds__(256, 4) void k_tri_search_grid(const DevState *__re
                                                          unsigned long long *__restrict__ keys,
                                                          int *__restrict__ todo_list, int *__restrict__ todo_count)
 {
+    constexpr int RPL = (9 + L - 1) / L;                            // rows per lane and batch
+    constexpr int BATCH = RPL * L;
     if (st->halt) return;
     __shared__ int queue[TRI_QUEUE][256];
     int nq = 0;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = gt / L, sub = gt % L;                             // the L lanes of a query are neighbours in a wave
     if (i >= ns) return;
     const float4 p4 = src4[i];
     float wx, wy, wz, pf[3];
@@ -270,8 +276,8 @@ __global__ __launch_bounds__(256, 4) void k_tri_search_grid(const DevState *__re
     S.best = best; S.bidx = bidx;
     S.lim = fminf(best, cutf);
     tri_state_refresh(S, delta);
-    bool settled = false;
-    // candidates this thread may look at (see GridParams).  While the pose still moves by a good part of a cell per
+    bool settled = false, over = false;
+    // candidates this query may look at (see GridParams; split between its lanes).  While the pose still moves by a good part of a cell per
     // iteration (first iteration, or last iteration's translation + rotation x object size above h / 4) the seeds are
     // stale and most queries need the second ring: handing them all to the tree costs more than letting the grid
     // look at twice as many candidates.
@@ -280,20 +286,21 @@ __global__ __launch_bounds__(256, 4) void k_tri_search_grid(const DevState *__re
         const int last = (st->n + 4) % 5;
         const double moved = st->use_target && st->n > 0 ? (st->ring_t[last] + st->ring_r[last] * gp.scale) * st->local_per_world : 0.0;
         if (st->n == 0 || moved > 0.25 * gp.h) budget *= 2;
+        if (L > 1) budget = budget / L + 8;
     }
     if (finite) {
-        for (int r = 0; r <= gp.r_max && !settled && budget >= 0; ++r) {
+        for (int r = 0; r <= gp.r_max && !settled && !over; ++r) {
             const int x0 = max(c[0] - r, 0), x1 = min(c[0] + r, gp.n[0] - 1);
             // rows of the ring nine at a time: cell ranges first (independent loads), then the candidates -- as in
             // k_nn_search_grid
             const int side = 2 * r + 1, n_rows = side * side;
             const unsigned div_mul = 65536u / (unsigned)side + 1u;
-            for (int b0 = 0; b0 < n_rows && budget >= 0; b0 += 9) {
-                int ja[9], jb[9], jc[9], jd[9];
+            for (int b0 = 0; b0 < n_rows && !over; b0 += BATCH) {
+                int ja[RPL], jb[RPL], jc[RPL], jd[RPL];
 #pragma unroll
-                for (int k = 0; k < 9; ++k) {
+                for (int k = 0; k < RPL; ++k) {
                     ja[k] = jb[k] = jc[k] = jd[k] = 0;
-                    const int kk = b0 + k;
+                    const int kk = b0 + sub + L * k;
                     if (kk >= n_rows) continue;
                     const int qz = (int)(((unsigned)kk * div_mul) >> 16);
                     const int dzi = qz - r, dyi = kk - qz * side - r;
@@ -323,7 +330,7 @@ __global__ __launch_bounds__(256, 4) void k_tri_search_grid(const DevState *__re
                     }
                 }
 #pragma unroll
-                for (int k = 0; k < 9; ++k) {
+                for (int k = 0; k < RPL; ++k) {
 #pragma unroll
                     for (int sg = 0; sg < 2; ++sg) {
                         const int j0 = sg ? jc[k] : ja[k], j1 = sg ? jd[k] : jb[k];
@@ -345,8 +352,21 @@ __global__ __launch_bounds__(256, 4) void k_tri_search_grid(const DevState *__re
                     }
                 }
                 tri_queue_flush(pf, tri9, S, queue, nq, delta, cutf);   // a better best prunes the next batch of rows
+                over = budget < 0;
+                if (L > 1) {                                         // the lanes of the query agree on the best so far
+                    bool changed = false;
+#pragma unroll
+                    for (int o = 1; o < L; o <<= 1) {
+                        const float ob = __shfl_xor(S.best, o, 64);
+                        const uint32_t oi = (uint32_t)__shfl_xor((int)S.bidx, o, 64);
+                        if (ob < S.best) { S.best = ob; S.bidx = oi; changed = true; }
+                        else if (ob == S.best && oi < S.bidx) S.bidx = oi;
+                        over = (__shfl_xor((int)over, o, 64) != 0) || over;
+                    }
+                    if (changed) { S.lim = fminf(S.best, cutf); tri_state_refresh(S, delta); }
+                }
             }
-            if (budget < 0) break;
+            if (over) break;
             double m = INFINITY;
             for (int a = 0; a < 3; ++a) {
                 if (c[a] - r > 0) { const double f = pc[a] - (gp.lo[a] + (double)(c[a] - r) * gp.h); m = f < m ? f : m; }
@@ -360,6 +380,7 @@ __global__ __launch_bounds__(256, 4) void k_tri_search_grid(const DevState *__re
             }
         }
     }
+    if (sub != 0) return;
     keys[i] = ((unsigned long long)__float_as_uint(S.best) << 32) | S.bidx;
     if (!settled) todo_list[atomicAdd(todo_count, 1)] = i;
 }
