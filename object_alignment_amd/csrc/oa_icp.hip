@@ -391,9 +391,14 @@ int launch_nn(oa_ctx *c)
         // one-shot calls clear it here.
         if (!c->loop_active) HIPCHK(hipMemsetAsync(c->d_todo_count, 0, sizeof(int), c->stream));
         // lanes per query: shards too small to fill the chip's wave slots split every query's rows between 2 or 4
-        // lanes (measured on 256 CUs: 4 lanes win up to ~40k queries, 2 lanes up to ~200k; 1M queries lose 15 % with 2)
+        // lanes.  Measured on 256 CUs (profiles/r01h_grid_lanes_sweep.txt): against a target that sits in cache 4 lanes
+        // win up to ~65k queries and 2 up to ~200k; against >= 500k vertices every round trip is longer and the lanes
+        // pay for longer: 4 up to ~200k queries, 2 up to ~600k; 1M queries lose 15 % with 2
         int lanes = c->grid_lanes;
-        if (lanes != 1 && lanes != 2 && lanes != 4) lanes = (c->ns <= 160 * c->n_cu) ? 4 : ((c->ns <= 800 * c->n_cu) ? 2 : 1);
+        if (lanes != 1 && lanes != 2 && lanes != 4) {
+            const bool big = c->nt >= 500000;
+            lanes = (c->ns <= (big ? 768 : 256) * c->n_cu) ? 4 : ((c->ns <= (big ? 2400 : 800) * c->n_cu) ? 2 : 1);
+        }
 #define OA_GRID_ARGS c->d_state, c->d_src4, c->ns, c->gp, c->d_cell_start, c->d_sorted, c->d_win, c->d_keys, c->d_todo_list, c->d_todo_count
         const dim3 gblocks((unsigned)(((long long)c->ns * lanes + 255) / 256));
         if (lanes == 4) hipLaunchKernelGGL(oa::k_nn_search_grid<4>, gblocks, dim3(256), 0, c->stream, OA_GRID_ARGS);
