@@ -201,9 +201,10 @@ __global__ __launch_bounds__(256) void k_bvh_search(const DevState *__restrict__
                                                     const float4 *__restrict__ tri9,
                                                     const int *__restrict__ prev, float4 *__restrict__ win,
                                                     unsigned long long *__restrict__ keys,
-                                                    const int *__restrict__ list, const int *__restrict__ list_count)
+                                                    const int *__restrict__ list, const int *__restrict__ list_count, int turn)
 {
     if (st->halt) return;
+    if (turn >= 0 && (st->tree_turn != 0) != (turn != 0)) return;  // not this kernel's turn (DevState::tree_turn)
     __shared__ float s_lb[4][BVH_MAX_LEVELS + 1][BVH_W];
     __shared__ unsigned long long s_mask[4][BVH_MAX_LEVELS + 1];
     __shared__ int s_node[4][BVH_MAX_LEVELS + 1];

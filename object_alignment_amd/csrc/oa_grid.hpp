@@ -110,11 +110,12 @@ __global__ __launch_bounds__(256, 5) void k_nn_search_grid(const DevState *__res
                                                         const float4 *__restrict__ sorted,
                                                         float4 *__restrict__ win,
                                                         unsigned long long *__restrict__ keys,
-                                                        int *__restrict__ todo_list, int *__restrict__ todo_count)
+                                                        int *__restrict__ todo_list, int *__restrict__ todo_count, int turn)
 {
     constexpr int RPL = (9 + L - 1) / L;                            // rows per lane and batch
     constexpr int BATCH = RPL * L;                                  // 9, 10, 12 rows per batch
     if (st->halt) return;
+    if (turn >= 0 && (st->tree_turn != 0) != (turn != 0)) return;  // not this kernel's turn (DevState::tree_turn)
     const int gt = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = gt / L, sub = gt % L;                             // the L lanes of a query are neighbours in a wave
     if (i >= ns) return;

@@ -201,6 +201,9 @@ struct oa_ctx {
     float4 *d_src4 = nullptr;
     unsigned long long *d_keys = nullptr;
     int grid_lanes = 0;              // OA_GRID_LANES: lanes per query of k_nn_search_grid (0 = by shard size)
+    double turn_frac = 0.1;          // OA_TURN_FRAC: the tree keeps its turn while the pose moves by more than this part of a cell
+    int turns_on = 1;                // OA_SEARCH_TURNS: tree while the pose moves, grid afterwards (mid-size shards, AUTO)
+    bool seeded = false;             // a search has run since the last set_source / set_target (seeds exist)
     int *d_prev = nullptr;           // nearest index of the previous search (seed), -1 = none
     float4 *d_win = nullptr;         // vertex mode: per slot, the last winner's coordinates + index in .w (-1 = none)
     int *d_sel = nullptr;            // vertex index held by each source slot
@@ -352,6 +355,12 @@ bool grid_active(const oa_ctx *c);
 // profiles/r01h_search_mode_crossover.txt)
 inline int vertex_tree_max(const oa_ctx *c) { return c->nt >= 500000 ? 24576 : 12288; }
 inline int tri_tree_max(const oa_ctx *c) { return c->n_tris >= 1000000 ? 40960 : (c->n_tris >= 250000 ? 36864 : 28672); }
+// ... and while the pose still moves by a good part of a cell per iteration (stale seeds, long reach: the first
+// iterations of a run, i.e. ALL of a typical early-exit run) the tree wins up to much larger shards (5-iteration runs
+// from a cold start, profiles/r01h_search_mode_crossover_short_runs.txt): shards between the two limits get both
+// searches enqueued and DevState::tree_turn decides on the device
+inline int vertex_tree_early(const oa_ctx *c) { return c->nt >= 500000 ? 49152 : 14336; }
+inline int tri_tree_early(const oa_ctx *c) { return c->n_tris >= 1000000 ? 393216 : (c->n_tris >= 250000 ? 163840 : 57344); }
 inline bool bvh_whole(const oa_ctx *c, bool ok, int auto_max)
 {
     if (!ok) return false;
@@ -365,18 +374,25 @@ int launch_tri_search(oa_ctx *c);
 
 // one wave per query: 4 queries per workgroup, workgroups loop when there are more queries than that
 template <bool TRI>
-int launch_bvh(oa_ctx *c, const int *list, const int *list_count)
+int launch_bvh(oa_ctx *c, const int *list, const int *list_count, int turn = -1)
 {
     const int items = list ? std::min(c->ns, 1 << 17) : c->ns;
     const unsigned blocks = (unsigned)std::max(1, std::min((items + 3) / 4, c->n_cu * 16));   // 16 waves per SIMD: enough to fill the chip, cheap to dispatch when the list is empty
     hipLaunchKernelGGL(oa::k_bvh_search<TRI>, dim3(blocks), dim3(256), 0, c->stream, c->d_state, c->d_src4, c->ns,
                        TRI ? c->tbvh : c->bvh, TRI ? c->d_tbvh_box : c->d_bvh_box, TRI ? c->d_tbvh_prims : c->d_bvh_prims,
-                       c->d_tri9, c->d_prev, TRI ? (float4 *)nullptr : c->d_win, c->d_keys, list, list_count);
+                       c->d_tri9, c->d_prev, TRI ? (float4 *)nullptr : c->d_win, c->d_keys, list, list_count, turn);
     HIPCHK(hipGetLastError());
     return OA_OK;
 }
 
+int launch_nn_impl(oa_ctx *c);
 int launch_nn(oa_ctx *c)
+{
+    const int rc = launch_nn_impl(c);
+    if (rc == OA_OK) c->seeded = true;
+    return rc;
+}
+int launch_nn_impl(oa_ctx *c)
 {
     if (c->ns <= 0) return OA_OK;
     if (c->surface) return launch_tri_search(c);
@@ -390,6 +406,9 @@ int launch_nn(oa_ctx *c)
         // to a list that the tree search finishes.  Inside the loop k_solve_update leaves the list counter at zero;
         // one-shot calls clear it here.
         if (!c->loop_active) HIPCHK(hipMemsetAsync(c->d_todo_count, 0, sizeof(int), c->stream));
+        const bool dual = c->grid_mode == -1 && c->turns_on && c->ns <= vertex_tree_early(c);
+        if (dual) { int rcb = launch_bvh<false>(c, nullptr, nullptr, 1); if (rcb) return rcb; }   // runs when DevState::tree_turn
+        const int turn = dual ? 0 : -1;
         // lanes per query: shards too small to fill the chip's wave slots split every query's rows between 2 or 4
         // lanes.  Measured on 256 CUs (profiles/r01h_grid_lanes_sweep.txt): against a target that sits in cache 4 lanes
         // win up to ~65k queries and 2 up to ~200k; against >= 500k vertices every round trip is longer and the lanes
@@ -399,7 +418,7 @@ int launch_nn(oa_ctx *c)
             const bool big = c->nt >= 500000;
             lanes = (c->ns <= (big ? 768 : 256) * c->n_cu) ? 4 : ((c->ns <= (big ? 2400 : 800) * c->n_cu) ? 2 : 1);
         }
-#define OA_GRID_ARGS c->d_state, c->d_src4, c->ns, c->gp, c->d_cell_start, c->d_sorted, c->d_win, c->d_keys, c->d_todo_list, c->d_todo_count
+#define OA_GRID_ARGS c->d_state, c->d_src4, c->ns, c->gp, c->d_cell_start, c->d_sorted, c->d_win, c->d_keys, c->d_todo_list, c->d_todo_count, turn
         const dim3 gblocks((unsigned)(((long long)c->ns * lanes + 255) / 256));
         if (lanes == 4) hipLaunchKernelGGL(oa::k_nn_search_grid<4>, gblocks, dim3(256), 0, c->stream, OA_GRID_ARGS);
         else if (lanes == 2) hipLaunchKernelGGL(oa::k_nn_search_grid<2>, gblocks, dim3(256), 0, c->stream, OA_GRID_ARGS);
@@ -502,6 +521,14 @@ void init_loop_state(oa_ctx *c, const oa_settings *st, int iters, bool cutoff = 
     s.local_per_world = 0.0;
     s.host_halt = nullptr;
     s.t_prev_end = 0; s.t_acc_start = 0;
+    {   // first search of a loop: the tree (cold or stale seeds); a one-shot call on warm seeds: the grid
+        const bool grid_up = c->surface ? c->tri_grid_ok : c->grid_ok;
+        const oa::GridParams &g = c->surface ? c->tgp : c->gp;
+        s.turn_limit = grid_up ? c->turn_frac * g.h : 0.0;
+        s.turn_scale = grid_up ? g.scale : 0.0;
+        s.tree_turn = (iters > 1 || !c->seeded) ? 1 : 0;
+        s.pad3 = 0;
+    }
     if (c->h_poll) {
         void *dp = nullptr;
         if (hipHostGetDevicePointer(&dp, c->h_poll, 0) == hipSuccess) s.host_halt = (int32_t *)dp;
@@ -721,6 +748,8 @@ OA_EXPORT int oa_create(oa_ctx **out, int device)
     if (c->R_env != 1 && c->R_env != 2 && c->R_env != 4 && c->R_env != 8) c->R_env = 0;
     c->R = c->R_env ? c->R_env : 4;
     c->grid_lanes = env_int("OA_GRID_LANES", 0);
+    c->turns_on = env_int("OA_SEARCH_TURNS", 1);
+    c->turn_frac = env_double("OA_TURN_FRAC", 0.1);
     c->use_filter = env_int("OA_NN_FILTER", 1) != 0;
     c->grid_mode = env_int("OA_NN_GRID", -1);
     *out = c;
@@ -916,6 +945,7 @@ OA_EXPORT int oa_set_target(oa_ctx *c, const float *xyz, int64_t n, int on_devic
     c->filter_ok = false;
     c->nt = (int)n;
     c->n_groups_pad = 0;
+    c->seeded = false;
     if (c->d_prev) {   // seeds index the old target
         hipLaunchKernelGGL(oa::k_fill_int, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, c->d_prev, c->ns_pad, -1);
         HIPCHK(hipMemsetAsync(c->d_win, 0xFF, sizeof(float4) * (size_t)c->ns_pad, c->stream));
@@ -1211,11 +1241,14 @@ int launch_tri_search(oa_ctx *c)
                 (void *)c->d_keys, (void *)c->d_todo_list, (void *)c->d_todo_count, (void *)c->d_tcell_start, (void *)c->d_tcell_tris);
     if (use_grid) {
         if (!c->loop_active) HIPCHK(hipMemsetAsync(c->d_todo_count, 0, sizeof(int), c->stream));
+        const bool dual = c->grid_mode == -1 && c->turns_on && c->ns <= tri_tree_early(c);
+        if (dual) { int rcb = launch_bvh<true>(c, nullptr, nullptr, 1); if (rcb) return rcb; }    // runs when DevState::tree_turn
+        const int turn = dual ? 0 : -1;
         // lanes per query, as for the vertex grid; these chains are longer, so more lanes pay for longer (measured on
         // 256 CUs: 4 lanes win up to ~128k queries, 2 lanes up to ~600k)
         int lanes = c->grid_lanes;
         if (lanes != 1 && lanes != 2 && lanes != 4) lanes = (c->ns <= 512 * c->n_cu) ? 4 : ((c->ns <= 2400 * c->n_cu) ? 2 : 1);
-#define OA_TGRID_ARGS c->d_state, c->d_src4, c->ns, c->tgp, c->d_tcell_start, c->d_tcell_tris, c->d_tcell_sph, c->d_tri9, c->d_prev, c->d_keys, c->d_todo_list, c->d_todo_count
+#define OA_TGRID_ARGS c->d_state, c->d_src4, c->ns, c->tgp, c->d_tcell_start, c->d_tcell_tris, c->d_tcell_sph, c->d_tri9, c->d_prev, c->d_keys, c->d_todo_list, c->d_todo_count, turn
         const dim3 gblocks((unsigned)(((long long)c->ns * lanes + 255) / 256));
         if (lanes == 4) hipLaunchKernelGGL(oa::k_tri_search_grid<4>, gblocks, dim3(256), 0, c->stream, OA_TGRID_ARGS);
         else if (lanes == 2) hipLaunchKernelGGL(oa::k_tri_search_grid<2>, gblocks, dim3(256), 0, c->stream, OA_TGRID_ARGS);
@@ -1304,6 +1337,7 @@ OA_EXPORT int oa_set_source(oa_ctx *c, const float *xyz, int64_t n_verts, int on
     HIPCHK(dev_malloc(&c->d_prev, sizeof(int) * (size_t)c->ns_pad));
     HIPCHK(dev_malloc(&c->d_win, sizeof(float4) * (size_t)c->ns_pad));
     HIPCHK(hipMemsetAsync(c->d_win, 0xFF, sizeof(float4) * (size_t)c->ns_pad, c->stream));
+    c->seeded = false;
     HIPCHK(dev_malloc(&c->d_sel, sizeof(int) * (size_t)c->ns_pad));
     HIPCHK(hipMemsetAsync(c->d_sel, 0, sizeof(int) * (size_t)c->ns_pad, c->stream));
     dev_free(c->d_todo_list); dev_free(c->d_todo_count);

@@ -61,6 +61,12 @@ struct DevState {
     // GPU-side timing of the search (no hipEvents in the stream: they cost ~3 us each): k_stamp_start / the solve
     // kernel leave the end of the previous iteration in t_prev_end, k_pair_accumulate its own start in t_acc_start
     unsigned long long t_prev_end, t_acc_start;
+    // Shards in the zone where the tree search wins while the pose still moves (stale seeds, long reach) and the grid
+    // search once it has settled: both are enqueued every iteration and `tree_turn` says whose turn it is.  Set by the
+    // host for the first search (no seeds: tree) and by the solve kernel afterwards, from the same quantity the grid
+    // kernels double their budget on: last step's translation + rotation x object size against a fraction of a cell.
+    double turn_limit, turn_scale;   // OA_TURN_FRAC (0.1) x cell edge and largest |coordinate| of the grid in use
+    int32_t tree_turn, pad3;
 };
 
 // Squared local search radius for the query p (rounded up to float).  Derivation: the pair test measures
@@ -1151,6 +1157,11 @@ __device__ __forceinline__ void solve_update_body(DevState *__restrict__ st, con
     st->d_pivot = mean_d;                                           // next iteration sums d relative to this mean
     st->n = n + 1;                                                  // n += 1                        (:151)
     if ((st->converged && st->early_exit) || st->n >= st->iters) st->halt = 1;
+    {   // whose turn is the next search (DevState::tree_turn)
+        const int last = n % 5;
+        const double moved = st->use_target ? (st->ring_t[last] + st->ring_r[last] * st->turn_scale) * st->local_per_world : 0.0;
+        st->tree_turn = (moved > st->turn_limit) ? 1 : 0;
+    }
     st->t_prev_end = wall_clock64();                                // the next search starts (about) now
     if (st->host_halt) {                                            // progress and halt flag for the enqueuing host
         st->host_halt[1] = st->n;

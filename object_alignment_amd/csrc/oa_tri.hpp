@@ -236,11 +236,12 @@ __global__ __launch_bounds__(256, 4) void k_tri_search_grid(const DevState *__re
                                                          const float4 *__restrict__ tri9,
                                                          const int *__restrict__ prev,
                                                          unsigned long long *__restrict__ keys,
-                                                         int *__restrict__ todo_list, int *__restrict__ todo_count)
+                                                         int *__restrict__ todo_list, int *__restrict__ todo_count, int turn)
 {
     constexpr int RPL = (9 + L - 1) / L;                            // rows per lane and batch
     constexpr int BATCH = RPL * L;
     if (st->halt) return;
+    if (turn >= 0 && (st->tree_turn != 0) != (turn != 0)) return;  // not this kernel's turn (DevState::tree_turn)
     __shared__ int queue[TRI_QUEUE][256];
     int nq = 0;
     const int gt = blockIdx.x * blockDim.x + threadIdx.x;

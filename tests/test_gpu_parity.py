@@ -1212,3 +1212,52 @@ def test_search_mode_changes_between_steps():
             assert a[1] == b[1], (modes, k)
             assert np.array_equal(a[0], b[0]) and a[2] == b[2], (modes, k)
         assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2)
+
+
+@pytest.mark.parametrize("surface", [False, True])
+def test_tree_then_grid_turns(surface):
+    """Shards between the late and the early tree / grid limits get both searches enqueued every iteration and
+    DevState::tree_turn (solve kernel: did the pose still move by more than a tenth of a cell?) picks one on the
+    device.  Whatever the sequence of turns, every step equals the brute-force run bit for bit -- also with the turns
+    switched off (OA_SEARCH_TURNS=0) and with the tree keeping its turn for ever (OA_TURN_FRAC=0)."""
+    import os
+    from object_alignment_amd import synth
+    from object_alignment_amd.engine import IcpEngine
+    tv, tt = synth.bumpy_icosphere_mesh(5)                              # 10k vertices, 20k triangles
+    ns = 40_000 if surface else 13_500                                  # inside (late, early] for either mode
+    src = synth.bunny_surface(ns, offset=0.41).astype(np.float32)
+    src *= np.float32(np.linalg.norm(tv, axis=1).mean() / np.linalg.norm(src, axis=1).mean())
+    pose = synth.rigid4(synth.rotation_from_rotvec([0.05, -0.04, 0.06]), [0.03, -0.02, 0.025])
+    eye = np.identity(4, dtype=np.float32)
+    kw = dict(thresh=0.3, target_d=1e-12, use_target=True)
+
+    def steps(mode, env=None):
+        old = {k: os.environ.get(k) for k in (env or {})}
+        os.environ.update(env or {})
+        try:
+            out = []
+            with IcpEngine(0) as e:
+                e.set_search_mode(mode)
+                if surface:
+                    e.set_target_mesh(tv, tt)
+                else:
+                    e.set_target(tv)
+                e.set_source(src)
+                e.set_matrices(pose, eye)
+                for _ in range(12):
+                    M, st = e.iterate(**kw)
+                    out.append((M.copy(), st["K"], st["mean_dist"]))
+            return out
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+
+    ref = steps("brute")
+    assert ref[0][1] > 0.9 * ns and ref[-1][2] < ref[0][2]              # a real, converging run
+    for env in (None, {"OA_SEARCH_TURNS": "0"}, {"OA_TURN_FRAC": "0"}, {"OA_TURN_FRAC": "1e9"}):
+        got = steps("auto", env)
+        for k, (a, b) in enumerate(zip(ref, got)):
+            assert a[1] == b[1] and a[2] == b[2] and np.array_equal(a[0], b[0]), (env, k)

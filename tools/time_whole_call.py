@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""GPU box: wall time of one whole alignment call from host arrays -- set_target (+ index build) + set_source +
+set_matrices + a 50-iteration run with early exit -- on a context that is kept between calls (steady state: device
+blocks come from the library's cache)."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from object_alignment_amd import synth
+from object_alignment_amd.engine import IcpEngine
+
+cases = {}
+s, t, a, b = synth.c1_icospheres(); cases["C1 2562 <-> 2562 (vertex)"] = (s, t, None, a, b, 0.5)
+s, t, a, b = synth.c2_bunny_pair(100_000); cases["C2 100k <-> 100k (vertex)"] = (s, t, None, a, b, 0.5)
+s, t, a, b = synth.c3_random_pair(1_000_000); cases["C3 1M <-> 1M (vertex)"] = (s, t, None, a, b, 0.5)
+tv, tt = synth.bumpy_icosphere_mesh(6)
+pose = synth.rigid4(synth.rotation_from_rotvec([0.02, -0.015, 0.025]), [0.01, -0.008, 0.012])
+eye = np.identity(4, dtype=np.float32)
+cases["41k points on an 82k-triangle mesh (surface)"] = (synth.bunny_surface(41_000, offset=0.37), tv, tt, pose, eye, 0.05)
+cases["200k points on an 82k-triangle mesh (surface)"] = (synth.bunny_surface(200_000, offset=0.37), tv, tt, pose, eye, 0.05)
+
+with IcpEngine(0) as e:
+    for name, (src, tgt, tris, mxa, mxb, thresh) in cases.items():
+        best, parts, res = 1e9, None, None
+        for rep in range(8):
+            t0 = time.perf_counter()
+            if tris is None:
+                e.set_target(tgt)
+            else:
+                e.set_target_mesh(tgt, tris)
+            t1 = time.perf_counter()
+            e.set_source(src, stride=1)
+            e.set_matrices(mxa, mxb)
+            t2 = time.perf_counter()
+            r = e.run(iters=50, thresh=thresh, target_d=0.01, use_target=True, early_exit=True)
+            t3 = time.perf_counter()
+            if t3 - t0 < best:
+                best, parts, res = t3 - t0, (t1 - t0, t2 - t1, t3 - t2), r
+        print("%-48s %7.2f ms  (target %.2f, source %.2f, run %.2f: %d iterations, converged %s, K %d)" % (
+            name, 1e3 * best, 1e3 * parts[0], 1e3 * parts[1], 1e3 * parts[2], res.iters_done, res.converged, res.last_K), flush=True)
