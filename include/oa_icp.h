@@ -89,8 +89,10 @@ int         oa_set_stream(oa_ctx *ctx, void *stream);
  *   OA_SEARCH_GRID   k_nn_search_grid: exact search through a uniform grid; points it cannot settle within a few
  *                    rings (far from the target: partial overlaps, holes) are finished by the tree search
  *   OA_SEARCH_BVH    k_bvh_search: every query through the 64-ary bounding-box tree, one wavefront per query
- *   OA_SEARCH_AUTO   the tree for small shards (up to ~2.5e4 .. 1.3e5 points, by target size and kind), the grid with
- *                    the tree behind it for larger ones; brute force only for targets with non-finite coordinates
+ *   OA_SEARCH_AUTO   the tree for small shards (up to ~1.2e4 .. 4e4 points, by target size and kind), the grid with
+ *                    the tree behind it for larger ones; shards of up to ~1.4e4 .. 3.9e5 points take the tree while the
+ *                    pose still moves and the grid once it has settled (decided on the device, per iteration);
+ *                    brute force only for targets with non-finite coordinates
  * The same modes apply to surface targets (oa_set_target_mesh) with triangles in place of vertices.
  * Default: OA_SEARCH_AUTO (env OA_NN_GRID = 0 / 1 / 2 overrides at oa_create). */
 #define OA_SEARCH_AUTO  (-1)
