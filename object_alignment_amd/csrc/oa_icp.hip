@@ -927,8 +927,9 @@ bool grid_active(const oa_ctx *c)
     if (c->grid_mode == 2) return false;
     return true;                                                      // auto: shards of <= 32768 points took the tree already
 }
-}  // namespace
-OA_EXPORT int oa_set_target(oa_ctx *c, const float *xyz, int64_t n, int on_device)
+// vertex_index = false: the caller (oa_set_target_mesh) searches triangles; the vertex grid and vertex tree would never
+// be used (their build is ~40 % of a mesh upload)
+int set_target_common(oa_ctx *c, const float *xyz, int64_t n, int on_device, bool vertex_index)
 {
     if (!c) return fail(OA_E_BAD_ARG, "null context");
     if (n < 0 || n > 0x7FFF0000ll) return fail(OA_E_BAD_ARG, "target vertex count %lld out of range", (long long)n);
@@ -965,10 +966,17 @@ OA_EXPORT int oa_set_target(oa_ctx *c, const float *xyz, int64_t n, int on_devic
     HIPCHK(hipStreamSynchronize(c->stream));
     int rcf = build_filter(c);
     if (rcf) return rcf;
-    if ((rcf = build_grid(c))) return rcf;
-    if ((rcf = build_bvh(c, false))) return rcf;
+    if (vertex_index) {
+        if ((rcf = build_grid(c))) return rcf;
+        if ((rcf = build_bvh(c, false))) return rcf;
+    }
     plan_geometry(c);
     return OA_OK;
+}
+}  // namespace
+OA_EXPORT int oa_set_target(oa_ctx *c, const float *xyz, int64_t n, int on_device)
+{
+    return set_target_common(c, xyz, n, on_device, true);
 }
 
 namespace {
@@ -1276,7 +1284,7 @@ OA_EXPORT int oa_set_target_mesh(oa_ctx *c, const float *xyz, int64_t n_verts, i
     if (!c) return fail(OA_E_BAD_ARG, "null context");
     if (n_tris < 1 || !tris) return fail(OA_E_BAD_ARG, "oa_set_target_mesh: no triangles");
     if (n_tris > 0x2AAAAAA0ll) return fail(OA_E_BAD_ARG, "too many triangles");
-    int rc = oa_set_target(c, xyz, n_verts, on_device);             // vertex images + bbox + filter (and vertex grid)
+    int rc = set_target_common(c, xyz, n_verts, on_device, false);  // vertex images + bbox + filter; no vertex grid / tree
     if (rc) return rc;
     if (n_verts < 1) return fail(OA_E_BAD_ARG, "oa_set_target_mesh: no vertices");
     DevTmp<int> d_tris, d_bad;
