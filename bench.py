@@ -253,7 +253,7 @@ def main():
         }
         if grid is not None and len(grid) == 4:
             g_steps, g_elapsed, g_nn_ms, same = grid
-            g_bytes = 28.0 * ns_local + 16.0 * args.n_target        # source float4 + key + seed, sorted target image
+            g_bytes = 40.0 * ns_local + 16.0 * args.n_target        # source float4 + winner record + key, sorted target image
             out["grid_path"] = {
                 "what": "SURVEY 8f rank 2 (next row): k_nn_search_grid, exact uniform-grid search, same correspondences",
                 "value": g_steps / g_elapsed, "unit": "iterations/s", "steps": g_steps,
@@ -278,6 +278,9 @@ def main():
                     out["roofline_hbm"]["traffic"] = tr[key]["bytes_per_launch"]
                     if "valu_instructions_per_pair" in tr[key]:
                         out["roofline"]["valu_instructions_per_pair_pmc"] = tr[key]["valu_instructions_per_pair"]
+                gkey = "grid_" + key
+                if gkey in tr and "roofline" in out.get("grid_path", {}):
+                    out["grid_path"]["roofline"]["traffic"] = tr[gkey]["bytes_per_launch"]
             except Exception:
                 pass
         if world == 1 and not args.no_cpu_baseline and args.cpu_iters > 0:
