@@ -202,6 +202,7 @@ struct oa_ctx {
     unsigned long long *d_keys = nullptr;
     int grid_lanes = 0;              // OA_GRID_LANES: lanes per query of k_nn_search_grid (0 = by shard size)
     double turn_frac = 0.1;          // OA_TURN_FRAC: the tree keeps its turn while the pose moves by more than this part of a cell
+    bool debug = false;              // OA_DEBUG (read at oa_create)
     int turns_on = 1;                // OA_SEARCH_TURNS: tree while the pose moves, grid afterwards (mid-size shards, AUTO)
     bool seeded = false;             // a search has run since the last set_source / set_target (seeds exist)
     int *d_prev = nullptr;           // nearest index of the previous search (seed), -1 = none
@@ -749,6 +750,7 @@ OA_EXPORT int oa_create(oa_ctx **out, int device)
     c->R = c->R_env ? c->R_env : 4;
     c->grid_lanes = env_int("OA_GRID_LANES", 0);
     c->turns_on = env_int("OA_SEARCH_TURNS", 1);
+    c->debug = getenv("OA_DEBUG") != nullptr;
     c->turn_frac = env_double("OA_TURN_FRAC", 0.1);
     c->use_filter = env_int("OA_NN_FILTER", 1) != 0;
     c->grid_mode = env_int("OA_NN_GRID", -1);
@@ -1233,7 +1235,7 @@ int build_tri_grid(oa_ctx *c)
     HIPCHK(hipStreamSynchronize(c->stream));
     c->tgp = gp;
     c->tri_grid_ok = true;
-    if (getenv("OA_DEBUG"))
+    if (c->debug)
         fprintf(stderr, "[oa] tri grid: h=%g cells=%dx%dx%d entries=%llu (%.2f per triangle)\n", gp.h, gp.n[0], gp.n[1], gp.n[2],
                 entries, (double)entries / c->n_tris);
     return OA_OK;
@@ -1243,7 +1245,7 @@ int launch_tri_search(oa_ctx *c)
 {
     if (bvh_whole(c, c->tbvh_ok, tri_tree_max(c))) return launch_bvh<true>(c, nullptr, nullptr);
     const bool use_grid = c->tri_grid_ok && c->tbvh_ok && c->grid_mode != 0;
-    if (getenv("OA_DEBUG"))
+    if (c->debug)
         fprintf(stderr, "[oa] tri search: grid=%d ns=%d n_tris=%d state=%p src4=%p tri9=%p prev=%p keys=%p todo=%p/%p cells=%p/%p\n",
                 (int)use_grid, c->ns, c->n_tris, (void *)c->d_state, (void *)c->d_src4, (void *)c->d_tri9, (void *)c->d_prev,
                 (void *)c->d_keys, (void *)c->d_todo_list, (void *)c->d_todo_count, (void *)c->d_tcell_start, (void *)c->d_tcell_tris);
@@ -1263,7 +1265,7 @@ int launch_tri_search(oa_ctx *c)
         else hipLaunchKernelGGL(oa::k_tri_search_grid<1>, gblocks, dim3(256), 0, c->stream, OA_TGRID_ARGS);
 #undef OA_TGRID_ARGS
         HIPCHK(hipGetLastError());
-        if (getenv("OA_DEBUG")) {                                  // how many queries the grid handed over (debug only: syncs)
+        if (c->debug) {                                            // how many queries the grid handed over (debug only: syncs)
             int n_todo = 0;
             { int rcr = read_small(c, &n_todo, c->d_todo_count, sizeof(int)); if (rcr) return rcr; }
             fprintf(stderr, "[oa] tri grid handed %d of %d queries to the tree\n", n_todo, c->ns);
