@@ -893,6 +893,7 @@ int build_grid(oa_ctx *c)
         for (int a = 0; a < 3; ++a) if (ext[a] > 0.0 && ext[a] / h >= gp.n[a]) h = std::max(h, ext[a] / (gp.n[a] - 0.5));
         gp.h = h; gp.inv_h = 1.0 / h;
         gp.r_max = std::min(env_int("OA_GRID_RMAX", 3), 3);
+        gp.seeded_start = env_int("OA_GRID_SEEDED_START", 1) ? 1 : 0;
         gp.budget = env_int("OA_GRID_BUDGET", 128);
         gp.slack = 1e-10 * scale + 1e-300;
         gp.scale = scale;
@@ -1207,6 +1208,7 @@ int build_tri_grid(oa_ctx *c)
         if (total > max_cells) { h *= 1.3; n_cells = 0; continue; }
         gp.h = h; gp.inv_h = 1.0 / h;
         gp.r_max = std::min(env_int("OA_GRID_RMAX", 3), 3);
+        gp.seeded_start = env_int("OA_TRI_SEEDED_START", 1) ? 1 : 0;
         gp.budget = env_int("OA_GRID_BUDGET", 128);
         gp.scale = scale;
         gp.slack = 1e-10 * scale + 1e-300;

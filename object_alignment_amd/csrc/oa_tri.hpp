@@ -289,8 +289,9 @@ __global__ __launch_bounds__(256, 4) void k_tri_search_grid(const DevState *__re
         if (st->n == 0 || moved > 0.25 * gp.h) budget *= 2;
         if (L > 1) budget = budget / L + 8;
     }
+    const int r_start = (S.bidx != IDX_NONE && gp.seeded_start) ? 1 : 0;   // as in k_nn_search_grid
     if (finite) {
-        for (int r = 0; r <= gp.r_max && !settled && !over; ++r) {
+        for (int r = r_start; r <= gp.r_max && !settled && !over; ++r) {
             const int x0 = max(c[0] - r, 0), x1 = min(c[0] + r, gp.n[0] - 1);
             // rows of the ring nine at a time: cell ranges first (independent loads), then the candidates -- as in
             // k_nn_search_grid
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(256, 4) void k_tri_search_grid(const DevState *__re
                         xb = min(xb, grid_cell_coord(pc[0] + w, gp.lo[0], gp.inv_h, gp.n[0]));
                     }
                     const int row = (z * gp.n[1] + y) * gp.n[0];
-                    const bool shell_row = (r == 0) || dzi == -r || dzi == r || dyi == -r || dyi == r;
+                    const bool shell_row = (r == r_start) || dzi == -r || dzi == r || dyi == -r || dyi == r;
                     if (shell_row) {
                         if (xa <= xb) { ja[k] = cell_start[row + xa]; jb[k] = cell_start[row + xb + 1]; }
                     } else {
