@@ -869,7 +869,7 @@ int build_grid(oa_ctx *c)
         if (ext[a] > 0.0) { vol *= ext[a]; ++nz; }
         scale = std::max(scale, std::max(fabs(c->bb_lo[a]), fabs(c->bb_hi[a])));
     }
-    const double ppc = 2.0;                                          // target vertices per cell
+    const double ppc = env_double("OA_GRID_PPC", 2.0);               // target vertices per cell
     double h = nz ? pow(vol * ppc / (double)c->nt, 1.0 / nz) : 1.0;
     if (!(h > 0.0) || !(h < INFINITY)) return OA_OK;
     const long long max_cells = 1ll << 24;
