@@ -1,28 +1,41 @@
 #!/usr/bin/env python3
-"""bench.py -- ICP iterations/s on BASELINE.json's 1M <-> 1M workload, one process per GPU.
+"""bench.py -- ICP iterations/s on BASELINE.json's 1M <-> 1M workload.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W]                 # N >= 1: ONE process drives all N GPUs
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-         bench.py --gpus N --steps K --warmup W
+         bench.py --gpus N --steps K --warmup W                       # one process per GPU over RCCL
 
 A "step" is one ICP iteration over the whole workload: nearest-vertex search for every source point against the
-whole target cloud, the fused threshold/accumulate pass, (N > 1: one all-reduce of 24 doubles over RCCL) and the
-Kabsch solve + matrix_world update.  Inputs are resident in HBM before the timed region; the early-exit of the
-convergence test is disabled so exactly K full iterations execute.
+whole target cloud, the fused threshold/accumulate pass, the exchange of 24 doubles between the GPUs (N > 1) and the
+Kabsch solve + matrix_world update.  Inputs are resident in HBM before the timed region; the early exit of the
+convergence test is disabled so exactly K full iterations execute; the timed run starts COLD (initial pose, no
+correspondence seeds from the warm-up: `oa_reset_seeds`), as a real K-iteration alignment does.
 
 N = 1: BASELINE config "1M <-> 1M random point clouds with 5% Gaussian noise, 50 iters, 1xMI355X".
-N > 1: BASELINE config "1M <-> 1M, source sharded across N GPUs with RCCL covariance all-reduce" (strong scaling:
-       the whole-job work per iteration is fixed, each rank holds 1/N of the source and the whole target).
+N > 1: BASELINE config "1M <-> 1M, source sharded across N GPUs with ... covariance all-reduce" (strong scaling: the
+       whole-job work per iteration is fixed, each GPU holds 1/N of the source and the whole target).
+       Launched plainly, one process holds a multi-device context (oa_create_multi): the exchange lives inside
+       liboa_icp.so (mailbox all-gather; OA_EXCHANGE=rccl: ncclAllReduce).  Launched under torch.distributed.run, every
+       rank holds one context and the 24 sums go through torch.distributed's all_reduce (backend "nccl" = RCCL).
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (k_nn_search): it is fp32-VALU bound
-(SURVEY.md 8d / DESIGN.md), so the primary roofline is 8 flop per (source, target) pair against the 157.3 TFLOP/s
-fp32 vector peak (numerically also the dense fp32 MFMA peak); the HBM view the north-star asks for is reported
-next to it in `roofline_hbm`.  `cpu_baseline` times the CPU oracle (KD-tree + Kabsch; OpenMP on all host cores) on
-a bounded sample of the same workload, rank 0, N = 1 only.
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel of the headline, the brute-force search
+k_nn_search_filtered.  It is bound by fp32 vector-ALU issue (SURVEY.md 8d / DESIGN.md 4.1), so
+
+    roofline.achieved = executed VALU lane-ops/s = (SQ_INSTS_VALU per launch x 64 lanes) / average launch time
+    roofline.peak     = 78.6e12 lane-ops/s       = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
+    roofline.frac     = achieved / peak          (<= 1 by construction)
+
+with the instruction count from the committed PMC pass (profiles/hbm_traffic.json, stamped with the kernel name and
+the commit it was collected at) and the launch time measured live with hipEvents on the kernel's stream.  The
+SURVEY's algorithmic figure -- 8 flop per (source, target) pair -- is reported as `effective_tflops`: the kernel's
+conservative filter proves most pairs losers in ~3 instructions, so that figure can exceed what the chip executes and
+is NOT a roofline fraction.  `cpu_baseline` times the CPU oracle (KD-tree + Kabsch; OpenMP on all host cores) on a
+bounded sample of the same workload, rank 0, N = 1 only.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -34,9 +47,13 @@ if ROOT not in sys.path:
 
 import numpy as np  # noqa: E402
 
-FP32_VECTOR_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: peak FP32 (vector) == peak FP32 (matrix, f32-in MFMA)
+VALU_PEAK_TLANEOPS = 78.6            # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (MI355X_MICROARCH.md), T lane-ops/s
+FP32_VECTOR_PEAK_TFLOPS = 157.3      # the same peak counting an FMA as 2 flop
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FLOP_PER_PAIR = 8                    # 3 sub, 3 mul, 2 add (difference-form squared distance), SURVEY.md 8d
+VALU_PER_PAIR_ISA = 3.0              # hot loop of k_nn_search_filtered: (64 FMA + 16 min3 [2 slots] + 4 cmp) / 32 pairs
+KERNELS = {"brute": "k_nn_search_filtered", "grid": "k_nn_search_grid", "surface_grid": "k_tri_search_grid",
+           "surface_tree": "k_bvh_search"}
 
 
 def parse():
@@ -49,7 +66,35 @@ def parse():
     ap.add_argument("--cpu-iters", type=int, default=3, help="iterations of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-surface", action="store_true", help="skip the surface-mode leg (1M points vs a 2M-triangle mesh)")
+    ap.add_argument("--no-grid", action="store_true", help="skip the grid-search leg")
     return ap.parse_args()
+
+
+def csrc_sha16():
+    """Fingerprint of the kernel sources: a PMC figure collected from other sources is marked stale."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "object_alignment_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_entry(key, kernel):
+    """profiles/hbm_traffic.json[key] if it was collected for `kernel`; (entry or None, stamp dict)."""
+    prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        e = json.load(open(prof)).get(key)
+    except Exception:
+        e = None
+    if not e:
+        return None, {"source": None, "note": "no PMC figure committed for this configuration"}
+    stamp = {"source": e.get("source"), "kernel": e.get("kernel"), "commit": e.get("commit"),
+             "csrc_sha16": e.get("csrc_sha16"), "stale": e.get("csrc_sha16") != csrc_sha16()}
+    if not str(e.get("kernel", "")).startswith(kernel):
+        stamp["note"] = "the committed figure is for another kernel (%s): not reported" % e.get("kernel")
+        return None, stamp
+    return e, stamp
 
 
 def cpu_baseline(src, tgt, mxa, mxb, iters, gpu_step_M):
@@ -100,26 +145,80 @@ def cpu_tiers(src, tgt, mxa, mxb):
     return out
 
 
+def surface_leg(args, local_rank):
+    """SURVEY 8f rank 1 ("next" row, reported beside the headline): surface mode -- closest point on the base mesh's
+    triangles, what the reference's BVHTree.find_nearest returns -- on a 1M-point cloud against a ~1M-vertex /
+    ~2M-triangle mesh of the synthetic bunny surface, library-default search (AUTO: grid + tree).  Two timings from
+    the same cold start: the first 5 iterations (what an early-exit operator call lives in) and 30 iterations."""
+    import torch
+    from object_alignment_amd import synth
+    from object_alignment_amd.engine import IcpEngine
+    sv, st = synth.lattice_surface_mesh(700, 1400)
+    ssrc = synth.bunny_surface(args.n_source, offset=0.37)
+    s_mxa = synth.rigid4(synth.rotation_from_rotvec([0.02, -0.015, 0.025]), [0.01, -0.008, 0.012])
+    eye4 = np.identity(4, dtype=np.float32)
+    legs = {}
+    with IcpEngine(local_rank) as se:
+        se.set_target_mesh(sv, st)
+        se.set_source(ssrc, stride=1)
+        se.set_matrices(s_mxa, eye4)
+        se.run(iters=3, thresh=0.05, early_exit=False)             # warm-up (module load, first launches)
+        entries, cells = se.stat("tri_grid_entries"), se.stat("tri_grid_cells")
+        for iters in (5, 30):
+            se.set_matrices(s_mxa, eye4)
+            se.reset_seeds()                                           # cold start: no correspondences from the last run
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            sres = se.run(iters=iters, thresh=0.05, early_exit=False)
+            dt = time.perf_counter() - t0
+            legs[iters] = (dt, sres)
+    dt30, r30 = legs[30]
+    dt5, r5 = legs[5]
+    ns, ntri = float(len(ssrc)), float(len(st))
+    # one search reads every query (16 B) and its seed (4 B), writes its key (8 B), and touches every triangle image
+    # (36 B of coordinates), cell-list entry (20 B: sphere record + triangle id) and cell offset (4 B) at least once
+    algo = 28.0 * ns + 36.0 * ntri + 20.0 * entries + 4.0 * cells
+    nn30 = r30.nn_ms_total / 30
+    e, stamp = pmc_entry("surface_%dx%d_n1" % (len(ssrc), len(st)), KERNELS["surface_grid"])
+    return {"what": "SURVEY 8f rank 1 (next row): surface mode, closest point on triangles (k_tri_search_grid + "
+                    "k_bvh_search, OA_SEARCH_AUTO), bit-identical to the oracle's brute force over all triangles (tests)",
+            "n_source": int(ns), "n_target_vertices": int(len(sv)), "n_target_triangles": int(ntri),
+            "steps": 30, "value": 30 / dt30, "unit": "iterations/s", "ms_per_step": 1e3 * dt30 / 30,
+            "ms_per_nn_search": nn30, "last_K": r30.last_K, "mean_dist": r30.mean_dist,
+            "cold_5_iterations": {"ms_per_step": 1e3 * dt5 / 5, "ms_per_nn_search": r5.nn_ms_total / 5,
+                                  "note": "same cold start, first 5 iterations only: stale seeds, long reach -- the "
+                                          "regime a typical early-exit operator call (5-10 iterations) runs in"},
+            "roofline": {"bound": "hbm", "achieved": algo / (nn30 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": algo / (nn30 * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_search": algo,
+                         "traffic": e["bytes_per_launch"] if e else None, "traffic_profile": stamp,
+                         "formula": "(28 N_s + 36 N_tris + 20 cell-list entries + 4 cells) bytes / search time "
+                                    "(GPU-side stamps: end of the previous iteration -> start of k_pair_accumulate), "
+                                    "30-iteration average; latency-bound dependent lookups, not a streaming kernel",
+                         "cell_list_entries": entries, "cells": cells}}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:                          # before the HIP runtime comes up: RCCL needs dmabuf IPC on this host driver
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # RCCL needs dmabuf IPC on this host driver
+    if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
 
-    if args.gpus != world and world > 1:
+    if world > 1 and args.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the oa_icp engine has no CPU fallback")
-    # test hooks (not used by the driver): run N ranks on ONE GPU over gloo to exercise the sharded path end to end
-    backend = os.environ.get("OA_BENCH_BACKEND", "nccl")
-    if os.environ.get("OA_BENCH_SAME_DEVICE") == "1":
+    in_process = world == 1 and args.gpus > 1                     # launched plainly: ONE process drives all the GPUs
+    n_gpus = args.gpus if in_process else world
+    same_device = os.environ.get("OA_BENCH_SAME_DEVICE") == "1"  # test hook: all ranks / shards on GPU 0
+    if in_process and not same_device and torch.cuda.device_count() < args.gpus:
+        raise SystemExit("--gpus %d but only %d visible" % (args.gpus, torch.cuda.device_count()))
+    backend = os.environ.get("OA_BENCH_BACKEND", "nccl")          # test hook: gloo
+    if same_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -134,31 +233,50 @@ def main():
     from object_alignment_amd.engine import IcpEngine
 
     src, tgt, mxa, mxb = synth.c3_random_pair(args.n_source, seed=1234, n_target=args.n_target)
-    eng = IcpEngine(local_rank)
-    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    if in_process:
+        devices = [0] * n_gpus if same_device else list(range(n_gpus))
+        eng = IcpEngine(devices=devices)
+        exchange = os.environ.get("OA_EXCHANGE", "mailbox")
+    else:
+        devices = [local_rank]
+        eng = IcpEngine(local_rank)
+        eng.set_stream(torch.cuda.current_stream().cuda_stream)
+        exchange = ("torch.distributed all_reduce (%s)" % backend) if world > 1 else None
     eng.set_search_mode("brute")          # the north-star kernel: LDS-tiled brute force (grid path measured below)
     t0 = time.perf_counter()
     eng.set_target(tgt)
-    eng.set_source(src, stride=1, shard_index=rank, shard_count=world)
-    torch.cuda.synchronize()
+    if in_process:
+        eng.set_source(src, stride=1)
+    else:
+        eng.set_source(src, stride=1, shard_index=rank, shard_count=world)
+    for d in set(devices):
+        torch.cuda.synchronize(d)
     upload_s = time.perf_counter() - t0
-    sums = new_sums_tensor(dev)
+    sums = None if in_process else new_sums_tensor(dev)
     kw = dict(thresh=0.5, target_d=0.01, use_target=True, with_scale=False, early_exit=False)
 
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        for d in set(devices):
+            torch.cuda.synchronize(d)
+
+    def loop(iters):
+        if in_process:
+            return eng.run(iters=iters, **kw)                    # the whole loop inside the library, all GPUs
+        return run_sharded(EngineShard(eng, iters=iters, **kw), iters, sums, world_size=world)
 
     def timed(steps, warmup):
-        """W untimed + exactly `steps` timed iterations from the initial pose; max over ranks."""
+        """W untimed + exactly `steps` timed iterations, both from the initial pose; the timed run starts cold (no
+        correspondence seeds left over from the warm-up); max over ranks."""
         if warmup > 0:
             eng.set_matrices(mxa, mxb)
-            run_sharded(EngineShard(eng, iters=warmup, **kw), warmup, sums, world_size=world)
+            loop(warmup)
         eng.set_matrices(mxa, mxb)
+        eng.reset_seeds()
         barrier()
         t0 = time.perf_counter()
-        r = run_sharded(EngineShard(eng, iters=steps, **kw), steps, sums, world_size=world)
+        r = loop(steps)
         barrier()
         dt = time.perf_counter() - t0
         ms = r.nn_ms_total / max(1, steps)
@@ -173,54 +291,50 @@ def main():
     # SURVEY 8f rank 2 ("next" row, reported beside the headline, never instead of it): the same run with the
     # uniform-grid exact search.  Correspondences are identical, so the final matrix must be bitwise the same.
     grid = None
-    try:
-        eng.set_search_mode("grid")
-        g_steps = max(args.steps, 200)
-        gres, g_elapsed, g_nn_ms = timed(g_steps, max(args.warmup, 5))
-        gcheck, _, _ = timed(args.steps, 0)
-        grid = (g_steps, g_elapsed, g_nn_ms, bool(np.array_equal(gcheck.matrix_world, res.matrix_world)))
-    except Exception as exc:                                  # never lose the headline line
-        grid = ("error: %r" % (exc,),)
-
-    # SURVEY 8f rank 1 ("next" row, reported beside the headline): surface mode -- closest point on the base mesh's
-    # triangles, what the reference's BVHTree.find_nearest returns -- on a 1M-point cloud against a ~1M-vertex /
-    # ~2M-triangle mesh of the synthetic bunny surface, library-default search (grid + tree).  N = 1 only.
-    surf = None
-    if world == 1 and not args.no_surface:
+    if not args.no_grid:
         try:
-            sv, st = synth.lattice_surface_mesh(700, 1400)
-            ssrc = synth.bunny_surface(args.n_source, offset=0.37)
-            s_mxa = synth.rigid4(synth.rotation_from_rotvec([0.02, -0.015, 0.025]), [0.01, -0.008, 0.012])
-            eye4 = np.identity(4, dtype=np.float32)
-            with IcpEngine(local_rank) as se:
-                se.set_target_mesh(sv, st)
-                se.set_source(ssrc, stride=1)
-                se.set_matrices(s_mxa, eye4)
-                se.run(iters=3, thresh=0.05, early_exit=False)             # warm-up (module load, first launches)
-                se.set_matrices(s_mxa, eye4)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                sres = se.run(iters=30, thresh=0.05, early_exit=False)
-                s_dt = time.perf_counter() - t0
-            surf = {"what": "SURVEY 8f rank 1 (next row): surface mode, closest point on triangles (k_tri_search_grid + "
-                            "k_bvh_search), bit-identical to the oracle's brute force over all triangles (tests)",
-                    "n_source": int(len(ssrc)), "n_target_vertices": int(len(sv)), "n_target_triangles": int(len(st)),
-                    "steps": 30, "value": 30 / s_dt, "unit": "iterations/s", "ms_per_step": 1e3 * s_dt / 30,
-                    "ms_per_nn_search": sres.nn_ms_total / 30, "last_K": sres.last_K, "mean_dist": sres.mean_dist}
+            eng.set_search_mode("grid")
+            g_steps = max(args.steps, 200)
+            gres, g_elapsed, g_nn_ms = timed(g_steps, max(args.warmup, 5))
+            gcheck, _, _ = timed(args.steps, 0)
+            grid = (g_steps, g_elapsed, g_nn_ms, bool(np.array_equal(gcheck.matrix_world, res.matrix_world)))
+        except Exception as exc:                                  # never lose the headline line
+            grid = ("error: %r" % (exc,),)
+
+    surf = None
+    if n_gpus == 1 and not args.no_surface:
+        try:
+            surf = surface_leg(args, local_rank)
         except Exception as exc:                                  # never lose the headline line
             surf = {"error": repr(exc)}
 
     if rank == 0:
         assert res.iters_done == args.steps, (res.iters_done, args.steps)
-        ns_local = eng.n_selected
-        pairs = float(ns_local) * float(args.n_target)                      # per launch of k_nn_search on one GPU
-        achieved_tflops = FLOP_PER_PAIR * pairs / (nn_ms * 1e-3) / 1e12
+        ns_local = -(-args.n_source // n_gpus)                              # points per GPU (the largest shard)
+        pairs = float(ns_local) * float(args.n_target)                      # per launch of k_nn_search_filtered on one GPU
+        key = "%dx%d_n%d" % (args.n_source, args.n_target, n_gpus)
+        e, stamp = pmc_entry(key, KERNELS["brute"])
+        per_pair = e.get("valu_instructions_per_pair") if e else None
+        per_pair_src = "pmc" if per_pair else "isa-count"
+        if not per_pair:
+            per_pair = VALU_PER_PAIR_ISA
+        laneops = per_pair * pairs / (nn_ms * 1e-3) / 1e12                  # T lane-ops/s actually executed
+        eff_tflops = FLOP_PER_PAIR * pairs / (nn_ms * 1e-3) / 1e12
         algo_bytes = 16.0 * ns_local + 12.0 * args.n_target + 8.0 * ns_local  # source float4 + target SoA + keys
+        traffic = e["bytes_per_launch"] if e else None
+        if n_gpus == 1:
+            par = "single GPU"
+        elif in_process:
+            par = ("one process, %d GPUs (oa_create_multi): source sharded x%d, target replicated, in-library exchange of "
+                   "24 f64 per iteration (%s)" % (n_gpus, n_gpus, exchange))
+        else:
+            par = ("one process per GPU: source sharded x%d, target replicated, all-reduce of 24 f64 per iteration (%s)"
+                   % (world, exchange))
         out = {
             "metric": "ICP iterations/sec + ms/NN-search, 1M<->1M verts",
             "value": args.steps / elapsed,
             "unit": "iterations/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "ms_per_nn_search": nn_ms,
             "higher_is_better": True,
@@ -229,23 +343,25 @@ def main():
             "dtype": "f32", "accumulate_dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "1M<->1M uniform [-1,1]^3 clouds, sigma = 5%% of mean spacing, seed 1234, "
-                                   "thresh 0.5, stride 1, %d iterations, early-exit off" % args.steps,
-                       "n_source": args.n_source, "n_target": args.n_target,
-                       "parallelism": "source sharded x%d, target replicated, all-reduce of 24 f64 per iteration" % world
-                       if world > 1 else "single GPU"},
-            "roofline": {"bound": "valu", "achieved": achieved_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved_tflops / FP32_VECTOR_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "k_nn_search", "flop_per_pair": FLOP_PER_PAIR, "pairs_per_launch": pairs,
-                         "avg_launch_ms": nn_ms,
-                         "note": "fp32 vector-ALU bound brute-force search; 157.3 TFLOP/s is both the fp32 VALU peak "
-                                 "and the dense f32-input MFMA peak.  `achieved` credits the ALGORITHMIC 8 flop per "
-                                 "(source, target) pair (SURVEY 8d); the kernel's conservative two-level filter proves "
-                                 "most pairs losers with 2 fma + 1 min, so it issues ~3 VALU instructions per pair "
-                                 "(PMC: profiles/) and runs at the chip's measured v_fma issue rate -- a fraction near "
-                                 "1.0 means the issue limit is reached, not that 8 flops per pair were executed"},
+                                   "thresh 0.5, stride 1, %d iterations from a cold start (no seeds), early-exit off" % args.steps,
+                       "n_source": args.n_source, "n_target": args.n_target, "search": "brute force (north-star kernel)",
+                       "parallelism": par},
+            "roofline": {"bound": "valu", "achieved": laneops, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s",
+                         "frac": laneops / VALU_PEAK_TLANEOPS, "traffic": traffic,
+                         "kernel": KERNELS["brute"], "valu_instructions_per_pair": per_pair,
+                         "valu_instructions_per_pair_source": per_pair_src, "pairs_per_launch": pairs,
+                         "avg_launch_ms": nn_ms, "traffic_profile": stamp,
+                         "formula": "frac = valu_instructions_per_pair x pairs_per_launch / avg_launch_ms / 78.6e12 lane-ops/s "
+                                    "(256 CU x 4 SIMD x 32 lanes x 2.4 GHz); valu_instructions_per_pair = SQ_INSTS_VALU x 64 / "
+                                    "pairs from the committed PMC pass (profiles/), avg_launch_ms = hipEvent pairs around "
+                                    "every launch of this run",
+                         "effective_tflops": eff_tflops, "effective_frac_of_157.3": eff_tflops / FP32_VECTOR_PEAK_TFLOPS,
+                         "effective_note": "SURVEY 8d's ALGORITHMIC 8 flop per (source, target) pair / launch time: NOT executed "
+                                           "arithmetic -- the conservative two-level filter proves most pairs losers with 2 fma + "
+                                           "1 min, so this can exceed the chip's peak; it compares kernels, it is not a roofline"},
             "roofline_hbm": {"bound": "hbm", "achieved": algo_bytes / (nn_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": algo_bytes / (nn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             "algorithmic_bytes_per_launch": algo_bytes, "traffic": None},
+                             "algorithmic_bytes_per_launch": algo_bytes, "traffic": traffic},
             "result": {"final_translation": res.last_translation, "last_K": res.last_K,
                        "mean_dist": res.mean_dist, "std_dist": res.std_dist},
             "upload_ms": 1e3 * upload_s,
@@ -254,6 +370,7 @@ def main():
         if grid is not None and len(grid) == 4:
             g_steps, g_elapsed, g_nn_ms, same = grid
             g_bytes = 40.0 * ns_local + 16.0 * args.n_target        # source float4 + winner record + key, sorted target image
+            ge, gstamp = pmc_entry("grid_" + key, KERNELS["grid"])
             out["grid_path"] = {
                 "what": "SURVEY 8f rank 2 (next row): k_nn_search_grid, exact uniform-grid search, same correspondences",
                 "value": g_steps / g_elapsed, "unit": "iterations/s", "steps": g_steps,
@@ -261,29 +378,16 @@ def main():
                 "final_matrix_bitwise_equal_to_brute_force": same,
                 "roofline": {"bound": "hbm", "achieved": g_bytes / (g_nn_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": g_bytes / (g_nn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             "algorithmic_bytes_per_launch": g_bytes, "traffic": None,
+                             "algorithmic_bytes_per_launch": g_bytes, "traffic": ge["bytes_per_launch"] if ge else None,
+                             "traffic_profile": gstamp,
+                             "formula": "(40 N_s,local + 16 N_t) bytes / search time (GPU-side stamps)",
                              "note": "latency-bound dependent lookups (cell range -> vertices); not a streaming kernel"},
             }
         elif grid is not None:
             out["grid_path"] = {"error": grid[0]}
         if surf is not None:
             out["surface_path"] = surf
-        prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(prof):
-            try:
-                tr = json.load(open(prof))
-                key = "%dx%d_n%d" % (args.n_source, args.n_target, world)
-                if key in tr:
-                    out["roofline"]["traffic"] = tr[key]["bytes_per_launch"]
-                    out["roofline_hbm"]["traffic"] = tr[key]["bytes_per_launch"]
-                    if "valu_instructions_per_pair" in tr[key]:
-                        out["roofline"]["valu_instructions_per_pair_pmc"] = tr[key]["valu_instructions_per_pair"]
-                gkey = "grid_" + key
-                if gkey in tr and "roofline" in out.get("grid_path", {}):
-                    out["grid_path"]["roofline"]["traffic"] = tr[gkey]["bytes_per_launch"]
-            except Exception:
-                pass
-        if world == 1 and not args.no_cpu_baseline and args.cpu_iters > 0:
+        if n_gpus == 1 and not args.no_cpu_baseline and args.cpu_iters > 0:
             out["cpu_baseline"] = cpu_baseline(src, tgt, mxa, mxb, min(args.cpu_iters, args.steps), res.step_M)
             try:
                 out["cpu_baseline_tiers"] = cpu_tiers(src, tgt, mxa, mxb)

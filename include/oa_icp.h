@@ -17,9 +17,12 @@
  *   - every function returns OA_OK (0) or a negative error code; the text of the
  *     last error on the calling thread is oa_last_error().  No C++ exception
  *     crosses this boundary.
- *   - one context = one GPU = one host thread at a time (not internally locked).
- *     Multi-GPU = one process (and one context) per GPU; the per-iteration
- *     exchange is 24 doubles (oa_iter_partial -> all-reduce(sum) -> oa_iter_finish).
+ *   - one context = one host thread at a time (not internally locked).
+ *     Multi-GPU, one process: oa_create_multi(devices, n) -- the context shards the
+ *     source over the listed GPUs, replicates the target, and oa_run / oa_iterate join
+ *     the devices' 24 sums inside the library every iteration.
+ *     Multi-GPU, one process per GPU (torchrun, MPI): one oa_create context per rank
+ *     and the split-phase loop oa_iter_partial -> all-reduce(sum) -> oa_iter_finish.
  *   - there is NO CPU fallback: every compute entry point fails with
  *     OA_E_NO_DEVICE / OA_E_HIP when no gfx950 device is usable.
  *
@@ -44,6 +47,8 @@ extern "C" {
 #define OA_E_STATE           -6   /* source / target / matrices not set */
 #define OA_E_BAD_THRESH      -7   /* thresh <= 0: the reference returns None (functions/general.py:277) */
 #define OA_E_CAPACITY        -8
+#define OA_E_RCCL            -9   /* multi-device exchange failed: librccl missing / ncclCommInitAll / ncclAllReduce error,
+                                     or a device's sums did not arrive within OA_EXCHANGE_TIMEOUT_S (default 30 s) */
 
 #define OA_NSUMS 24               /* doubles exchanged per iteration (see oa_iter_partial) */
 
@@ -75,7 +80,30 @@ typedef struct oa_report {
 /* ---- lifetime ------------------------------------------------------------------ */
 int         oa_device_count(void);
 int         oa_create(oa_ctx **out, int device);
+/* One context over n_dev GPUs of this process (1 <= n_dev <= 64; SURVEY.md 8b's oa_create(&ctx, devices, n_dev)).
+ * Every upload goes to all of them (target replicated; source: device i keeps shard i of n_dev, see oa_set_source),
+ * oa_run / oa_iterate drive all devices from the calling thread -- one stream per device, no host round trip per
+ * iteration -- and every iteration the devices exchange their OA_NSUMS partial sums and perform the identical solve
+ * (operators/icp_align.py:96-151 is still ONE call).  A device may be listed more than once (its shards then share
+ * one stream); that is how the path is tested on a single GPU.  Not available on such a context: oa_make_pairs,
+ * oa_nn_search (per-point outputs), oa_set_stream, and the split-phase calls. */
+int         oa_create_multi(oa_ctx **out, const int *devices, int n_dev);
+int         oa_num_devices(oa_ctx *ctx);
+/* How the devices of an oa_create_multi context join their sums (default: OA_EXCHANGE_MAILBOX; env OA_EXCHANGE=rccl):
+ *   OA_EXCHANGE_MAILBOX  all-gather through a pinned host mailbox every device maps; the solve kernel of each device
+ *                        waits for the world's posts and adds them in rank order (bitwise identical everywhere);
+ *                        nothing is added to the streams: ~2 PCIe round trips per iteration
+ *   OA_EXCHANGE_RCCL     ncclAllReduce(OA_NSUMS doubles, sum) over xGMI on every device's stream, single-process
+ *                        communicator (ncclCommInitAll); librccl.so.1 is loaded on first use; needs distinct devices
+ * Returns OA_E_RCCL when RCCL cannot be brought up. */
+#define OA_EXCHANGE_MAILBOX 0
+#define OA_EXCHANGE_RCCL    1
+int         oa_set_exchange(oa_ctx *ctx, int mode);
 void        oa_destroy(oa_ctx *ctx);
+/* Released device blocks are kept in a process-wide cache for the next upload of the same size (hipFree costs
+ * ~135 us a call): at most 256 MiB (env OA_DEV_CACHE_MB; OA_DEV_CACHE=0 switches it off), and nothing at all once
+ * the last context has been destroyed.  This gives the cached blocks back immediately. */
+void        oa_release_cached_memory(void);
 const char *oa_last_error(void);
 const char *oa_version(void);
 /* stream: the hipStream_t every later call enqueues on, used exactly as given -- NULL is HIP's legacy default
@@ -119,7 +147,12 @@ int oa_set_target_mesh(oa_ctx *ctx, const float *xyz, int64_t n_verts, int on_de
  * shards are equal ranges of the selection in MORTON order (every rank passes the same arrays and derives the
  * same partition), so that a shard is a compact region of space; for non-finite coordinates they are contiguous
  * ranges in the caller's order.  Per-point outputs of a shard (oa_make_pairs, oa_nn_search) list its points in the
- * caller's order.  The sums the loop all-reduces do not depend on the partition. */
+ * caller's order.  The sums the loop all-reduces do not depend on the partition.
+ * On an oa_create_multi context pass shard 0 of 1: the context deals the shards to its devices itself.
+ * Limits: a shard holds at most 65 535 x 256 x R selected points for the brute-force search (R = 4 points per
+ * thread for shards >= 65 536 points: ~6.7e7; OA_NN_R=8 doubles it) -- beyond that oa_run fails with OA_E_BAD_ARG and
+ * the job needs more shards; the grid / tree searches take any shard that fits an int32 (< 2^31 - 2^20 points).
+ * Targets: < 2^31 - 2^16 vertices, < 7.1e8 triangles. */
 int oa_set_source(oa_ctx *ctx, const float *xyz, int64_t n_verts, int on_device,
                   const int64_t *vlist, int64_t n_vlist, int32_t stride,
                   int32_t shard_index, int32_t shard_count);
@@ -133,6 +166,19 @@ int oa_set_normals(oa_ctx *ctx, const float *src_normals, int64_t n_verts, const
 /* matrix_world of the align and base objects (functions/general.py:262-263) */
 int oa_set_matrices(oa_ctx *ctx, const float mx_align[16], const float mx_base[16]);
 int oa_get_matrix_world(oa_ctx *ctx, float mx_align[16]);
+/* Forget the correspondences of earlier searches (every search seeds itself with the previous answer of its slot: any
+ * seed gives the same result, a good one gives it sooner).  A new upload does this by itself; oa_set_matrices does
+ * not -- a host-driven make_pairs loop sets the matrices before every call and keeps its seeds.  Timing runs call it to
+ * start cold. */
+int oa_reset_seeds(oa_ctx *ctx);
+/* Introspection (sizes of the search structures, for roofline arithmetic and tests). */
+#define OA_STAT_GRID_CELLS        1   /* cells of the vertex grid (0 = none built) */
+#define OA_STAT_TRI_GRID_CELLS    2   /* cells of the triangle grid */
+#define OA_STAT_TRI_GRID_ENTRIES  3   /* (triangle, cell) entries of the triangle grid's cell lists */
+#define OA_STAT_N_TRIS            4
+#define OA_STAT_SURFACE           5   /* 1 = surface mode (oa_set_target_mesh) */
+#define OA_STAT_CACHE_BYTES       6   /* device bytes currently held by the process-wide allocation cache */
+int oa_get_stat(oa_ctx *ctx, int what, double *value);
 int64_t oa_num_selected(oa_ctx *ctx);     /* selected source points held by this context (its shard) */
 
 /* ---- contract 1: make_pairs (functions/general.py:257-329) ------------------------------------ */
@@ -158,11 +204,16 @@ int oa_get_pivot(oa_ctx *ctx, double pivot[3]);
 
 /* ---- fused fast path: the operator loop (operators/icp_align.py:91-151) ----------------------- */
 /* one iteration, synchronous (the modal operator's per-tick step, icp_align_feedback.py:250-288):
- * M_step = this iteration's 4x4 (float64); stats = [K, mean_dist, std_dist, |translation|, rot_angle, converged] */
+ * M_step = this iteration's 4x4 (float64); stats = [K, mean_dist, std_dist, |translation|, rot_angle, converged].
+ * A sequence of calls with the same thresh / target_d / use_target / with_scale is one loop (n counts up, the 5-slot
+ * convergence ring fills).  Different settings, or any call in between that re-stages the device state
+ * (oa_set_matrices, oa_make_pairs, oa_nn_search, oa_run, a new upload), start a new sequence -- n = 0, fresh ring --
+ * from the current matrix_world.  History: the last 64 iterations of the sequence. */
 int oa_iterate(oa_ctx *ctx, const oa_settings *st, double M_step[16], double stats[6]);
 /* the whole loop, device resident (no host round trip per iteration) */
 int oa_run(oa_ctx *ctx, const oa_settings *st, oa_report *rep);
-/* per-iteration history of the last oa_run / oa_iterate sequence (each may be NULL):
+/* per-iteration history of the last oa_run (its first max_n iterations) / oa_iterate sequence (its last max_n,
+ * oldest first) -- each array may be NULL:
  * step_M n x 16 doubles, step_new n x 16 floats (new_mat, operators/icp_align.py:116-119),
  * step_K n, step_stats n x 2, step_trans n.  Returns the number of iterations recorded. */
 int oa_get_history(oa_ctx *ctx, int32_t max_n, double *step_M, float *step_new,

@@ -21,13 +21,18 @@ OA_E_NO_DEVICE = -5
 OA_E_STATE = -6
 OA_E_BAD_THRESH = -7
 OA_E_CAPACITY = -8
+OA_E_RCCL = -9
+OA_EXCHANGE_MAILBOX = 0
+OA_EXCHANGE_RCCL = 1
 OA_NSUMS = 24
 
 # every symbol include/oa_icp.h declares (tests check that the library exports all of them)
 SYMBOLS = [
-    "oa_device_count", "oa_create", "oa_destroy", "oa_last_error", "oa_version", "oa_set_stream",
+    "oa_device_count", "oa_create", "oa_create_multi", "oa_num_devices", "oa_set_exchange", "oa_release_cached_memory",
+    "oa_destroy", "oa_last_error", "oa_version", "oa_set_stream",
     "oa_set_search_mode",
     "oa_set_target", "oa_set_target_mesh", "oa_set_source", "oa_set_normals", "oa_set_matrices", "oa_get_matrix_world", "oa_num_selected",
+    "oa_reset_seeds", "oa_get_stat",
     "oa_make_pairs", "oa_nn_search", "oa_kabsch", "oa_kabsch_from_sums", "oa_get_pivot",
     "oa_iterate", "oa_run", "oa_get_history", "oa_run_begin", "oa_iter_partial", "oa_iter_finish", "oa_run_end",
 ]
@@ -75,6 +80,10 @@ def load():
     vp, fp, dp, ip = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int64)
     L.oa_device_count.restype = C.c_int
     L.oa_create.argtypes = [C.POINTER(vp), C.c_int]
+    L.oa_create_multi.argtypes = [C.POINTER(vp), C.POINTER(C.c_int), C.c_int]
+    L.oa_num_devices.argtypes = [vp]
+    L.oa_set_exchange.argtypes = [vp, C.c_int]
+    L.oa_release_cached_memory.restype = None
     L.oa_destroy.argtypes = [vp]
     L.oa_destroy.restype = None
     L.oa_last_error.restype = C.c_char_p
@@ -88,6 +97,8 @@ def load():
     L.oa_set_matrices.argtypes = [vp, fp, fp]
     L.oa_get_matrix_world.argtypes = [vp, fp]
     L.oa_num_selected.argtypes = [vp]
+    L.oa_reset_seeds.argtypes = [vp]
+    L.oa_get_stat.argtypes = [vp, C.c_int, dp]
     L.oa_num_selected.restype = C.c_int64
     L.oa_make_pairs.argtypes = [vp, C.c_double, C.c_int, dp, dp, C.c_int64, ip, dp]
     L.oa_nn_search.argtypes = [vp, ip, fp, dp]

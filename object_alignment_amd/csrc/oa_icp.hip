@@ -5,6 +5,8 @@
 // compute entry point needs a usable HIP device and fails loudly otherwise.
 #include <cstring>
 #include <rocprim/rocprim.hpp>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
 
 #include "oa_kernels.hpp"
 #include "oa_grid.hpp"
@@ -26,6 +28,17 @@
 #include <vector>
 
 #define OA_EXPORT extern "C" __attribute__((visibility("default")))
+// a multi-device parent (oa_create_multi) routes the call to every child / to its first child
+#define OA_ROUTE_ALL(c, call)                                                                  \
+    if ((c) && !(c)->subs.empty()) {                                                           \
+        for (oa_ctx *sub : (c)->subs) { const int rc_ = (call); if (rc_) return rc_; }         \
+        return OA_OK;                                                                          \
+    }
+#define OA_ROUTE_FIRST(c, call)                                                                \
+    if ((c) && !(c)->subs.empty()) { oa_ctx *sub = (c)->subs[0]; return (call); }
+#define OA_NOT_MULTI(c, what)                                                                  \
+    if ((c) && !(c)->subs.empty())                                                             \
+        return fail(OA_E_STATE, what ": not available on a multi-device context (use a single-device one)");
 
 namespace {
 
@@ -52,19 +65,28 @@ int fail(int code, const char *fmt, ...)
 // Device allocations go through a small process-wide cache keyed by (device, size): hipFree costs ~135 us a call on
 // this stack (it synchronises the device), and an upload frees and reallocates ~25 buffers of unchanged size -- more
 // than half of oa_set_target + oa_set_source at 1M points.  A released block is kept for the next request of the same
-// size; blocks that sit unused for CACHE_MAX_AGE releases, or push the cache past CACHE_MAX_BYTES, are really freed.
-// Like hipFree, releasing waits for the device first (callers may still have kernels in flight that read the block).
+// size; blocks that sit unused for CACHE_MAX_AGE releases, or push the cache past its cap, are really freed.
+// The library is a guest in somebody else's process (Blender): the cap is 256 MiB by default (OA_DEV_CACHE_MB raises
+// or lowers it, OA_DEV_CACHE=0 switches the cache off), and when the last context is destroyed everything is freed.
+// Releases are STREAM ORDERED, not device-synchronising: a block goes back with an event recorded on the stream of the
+// context that used it (tl_stream, set by use_device); the next owner on the same stream needs no wait at all (stream
+// order), another stream waits for the event on the device.  Only a real hipFree synchronises (the runtime's own rule).
+thread_local hipStream_t tl_stream = nullptr;
+thread_local bool tl_stream_known = false;
+
 struct DevCache {
-    struct Block { void *p; size_t bytes; int device; unsigned long long stamp; };
+    struct Block { void *p; size_t bytes; int device; unsigned long long stamp; hipEvent_t ev; hipStream_t stream; };
     std::mutex mu;
     std::vector<Block> free_blocks;
     std::unordered_map<void *, std::pair<size_t, int>> live;    // pointer -> (bytes, device)
+    std::vector<hipEvent_t> spare_events;
     size_t cached_bytes = 0;
     unsigned long long clock = 0;
-    static constexpr size_t CACHE_MAX_BYTES = 8ull << 30;
+    int contexts = 0;                                           // live oa_ctx objects (single-device ones)
     static constexpr unsigned long long CACHE_MAX_AGE = 512;
 
     const bool enabled = !(getenv("OA_DEV_CACHE") && atoi(getenv("OA_DEV_CACHE")) == 0);   // OA_DEV_CACHE=0: plain hipMalloc / hipFree
+    const size_t max_bytes = (size_t)((getenv("OA_DEV_CACHE_MB") && *getenv("OA_DEV_CACHE_MB")) ? std::max(0.0, atof(getenv("OA_DEV_CACHE_MB"))) : 256.0) << 20;
 
     hipError_t alloc(void **out, size_t bytes)
     {
@@ -73,19 +95,30 @@ struct DevCache {
         int dev = 0;
         (void)hipGetDevice(&dev);
         {
-            std::lock_guard<std::mutex> lk(mu);
+            std::unique_lock<std::mutex> lk(mu);
             for (size_t i = 0; i < free_blocks.size(); ++i)
                 if (free_blocks[i].bytes == bytes && free_blocks[i].device == dev) {
-                    *out = free_blocks[i].p;
+                    const Block b = free_blocks[i];
+                    *out = b.p;
                     cached_bytes -= bytes;
                     free_blocks[i] = free_blocks.back();
                     free_blocks.pop_back();
                     live[*out] = { bytes, dev };
+                    if (b.ev) {
+                        // same stream: stream order is enough; another stream waits for the releasing stream's event
+                        // on the device; unknown stream (no context in use on this thread): wait on the host
+                        hipError_t e = hipSuccess;
+                        if (!(tl_stream_known && b.stream == tl_stream))
+                            e = tl_stream_known ? hipStreamWaitEvent(tl_stream, b.ev, 0) : hipEventSynchronize(b.ev);
+                        spare_events.push_back(b.ev);
+                        if (e != hipSuccess) return e;
+                    }
                     return hipSuccess;
                 }
         }
         hipError_t e = hipMalloc(out, bytes);
         if (e != hipSuccess) {                                     // out of memory: drop the cache and retry once
+            (void)hipGetLastError();
             trim(0, 0);
             e = hipMalloc(out, bytes);
         }
@@ -93,33 +126,62 @@ struct DevCache {
         return e;
     }
 
-    void release(void *p)
+    // synced: the caller has already synchronised the device (oa_destroy) -- no event needed
+    void release(void *p, bool synced = false)
     {
         if (!p) return;
         if (!enabled) { (void)hipFree(p); return; }
-        (void)hipDeviceSynchronize();                              // what hipFree would have done
         std::lock_guard<std::mutex> lk(mu);
         auto it = live.find(p);
         if (it == live.end()) { (void)hipFree(p); return; }
-        free_blocks.push_back(Block{ p, it->second.first, it->second.second, ++clock });
-        cached_bytes += it->second.first;
+        Block b{ p, it->second.first, it->second.second, ++clock, nullptr, nullptr };
         live.erase(it);
-        trim_locked(CACHE_MAX_BYTES, CACHE_MAX_AGE);
+        if (b.bytes > max_bytes) { (void)hipFree(p); return; }     // would not fit under the cap anyway (hipFree synchronises)
+        if (!synced) {
+            if (tl_stream_known) {
+                if (!spare_events.empty()) { b.ev = spare_events.back(); spare_events.pop_back(); }
+                else if (hipEventCreateWithFlags(&b.ev, hipEventDisableTiming) != hipSuccess) b.ev = nullptr;
+                if (b.ev && hipEventRecord(b.ev, tl_stream) != hipSuccess) { spare_events.push_back(b.ev); b.ev = nullptr; }
+                b.stream = tl_stream;
+            }
+            if (!b.ev) (void)hipDeviceSynchronize();               // no stream to order against: what hipFree would have done
+        }
+        free_blocks.push_back(b);
+        cached_bytes += b.bytes;
+        trim_locked(max_bytes, CACHE_MAX_AGE);
     }
 
-    void trim(size_t max_bytes, unsigned long long max_age) { std::lock_guard<std::mutex> lk(mu); trim_locked(max_bytes, max_age); }
+    void trim(size_t cap, unsigned long long max_age) { std::lock_guard<std::mutex> lk(mu); trim_locked(cap, max_age); }
 
-    void trim_locked(size_t max_bytes, unsigned long long max_age)
+    void trim_locked(size_t cap, unsigned long long max_age)
     {
-        for (size_t i = 0; i < free_blocks.size();) {
+        // oldest first, so that what stays is what was released last
+        std::sort(free_blocks.begin(), free_blocks.end(), [](const Block &a, const Block &b) { return a.stamp < b.stamp; });
+        size_t i = 0;
+        while (i < free_blocks.size()) {
             const bool old = clock - free_blocks[i].stamp > max_age;
-            if (old || cached_bytes > max_bytes) {
-                (void)hipFree(free_blocks[i].p);
+            if (old || cached_bytes > cap) {
+                int cur = 0;
+                (void)hipGetDevice(&cur);
+                if (cur != free_blocks[i].device) (void)hipSetDevice(free_blocks[i].device);
+                (void)hipFree(free_blocks[i].p);                   // synchronises the device: pending events are done
+                if (cur != free_blocks[i].device) (void)hipSetDevice(cur);
+                if (free_blocks[i].ev) spare_events.push_back(free_blocks[i].ev);
                 cached_bytes -= free_blocks[i].bytes;
-                free_blocks[i] = free_blocks.back();
-                free_blocks.pop_back();
+                free_blocks.erase(free_blocks.begin() + (long)i);
             } else ++i;
         }
+    }
+
+    void context_created() { std::lock_guard<std::mutex> lk(mu); ++contexts; }
+    void context_destroyed()
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (--contexts > 0) return;
+        contexts = 0;
+        trim_locked(0, 0);                                         // last context gone: give everything back
+        for (hipEvent_t e : spare_events) (void)hipEventDestroy(e);
+        spare_events.clear();
     }
 };
 
@@ -131,9 +193,9 @@ DevCache &dev_cache()
 
 template <typename T> hipError_t dev_malloc(T **p, size_t bytes) { return dev_cache().alloc((void **)p, bytes); }
 
-template <typename T> void dev_free(T *&p)
+template <typename T> void dev_free(T *&p, bool synced = false)
 {
-    if (p) { dev_cache().release((void *)p); p = nullptr; }
+    if (p) { dev_cache().release((void *)p, synced); p = nullptr; }
 }
 
 // temporary device buffer, released on every exit path
@@ -189,6 +251,7 @@ struct oa_ctx {
     oa::GridParams tgp;
     int *d_tcell_start = nullptr, *d_tcell_tris = nullptr;
     float4 *d_tcell_sph = nullptr;   // bounding sphere of each cell-list entry (same order as d_tcell_tris)
+    long long n_tri_entries = 0;     // entries of the triangle grid's cell lists
     // bounding-box trees (oa_bvh.hpp): over the vertices, and over the triangles in surface mode
     bool bvh_ok = false, tbvh_ok = false;
     oa::BvhParams bvh, tbvh;
@@ -250,6 +313,13 @@ struct oa_ctx {
     bool time_events = true;            // hipEvent pair around every search (brute force); else GPU-side stamps (see iter_fused)
     double wall_clock_khz = 100000.0;   // rate of wall_clock64()
     oa_settings settings;
+    bool iterate_mode = false;          // the active loop was opened by oa_iterate (small history ring)
+    // multi-device (oa_create_multi).  The parent only routes: uploads go to every child (target replicated, source
+    // sharded child i of n), the loop drives all children and the exchange below joins their sums every iteration.
+    std::vector<oa_ctx *> subs;         // parent: one child per entry of the device list
+    struct oa_exchange *xch = nullptr;  // parent: owns it; child: the parent's
+    oa_ctx *parent = nullptr;
+    int rank = 0, world = 1;            // child: its place in the device list
 };
 
 namespace {
@@ -257,6 +327,7 @@ namespace {
 int use_device(oa_ctx *c)
 {
     HIPCHK(hipSetDevice(c->device));
+    tl_stream = c->stream; tl_stream_known = true;              // releases of device blocks are ordered on this stream
     return OA_OK;
 }
 
@@ -397,8 +468,6 @@ int launch_nn_impl(oa_ctx *c)
 {
     if (c->ns <= 0) return OA_OK;
     if (c->surface) return launch_tri_search(c);
-    if (c->ns_pad / (oa::NN_THREADS * c->R) > 65535)
-        return fail(OA_E_BAD_ARG, "shard of %d points exceeds the launch grid (use more shards or OA_NN_R=8)", c->ns);
     dim3 grid(c->n_splits, c->ns_pad / (oa::NN_THREADS * c->R));
     dim3 block(oa::NN_THREADS);
     if (bvh_whole(c, c->bvh_ok, vertex_tree_max(c))) return launch_bvh<false>(c, nullptr, nullptr);
@@ -428,6 +497,8 @@ int launch_nn_impl(oa_ctx *c)
         HIPCHK(hipGetLastError());
         return launch_bvh<false>(c, c->d_todo_list, c->d_todo_count);
     }
+    if (c->ns_pad / (oa::NN_THREADS * c->R) > 65535)               // only the brute-force launch has this limit (grid.y)
+        return fail(OA_E_BAD_ARG, "shard of %d points exceeds the brute-force launch grid (use more shards or OA_NN_R=8)", c->ns);
 #define OA_NN_ARGS c->d_state, c->d_src4, c->d_tg, c->groups_per_split, c->n_groups_pad, c->d_keys
 #define OA_NNF_ARGS c->d_state, c->d_src4, c->d_tg, c->d_tf, c->d_tf3, c->d_tgt_xyz, c->d_prev, c->groups_per_split, c->n_groups_pad, c->d_keys
     if (c->filter_ok && c->use_filter) {
@@ -566,6 +637,9 @@ void init_loop_state(oa_ctx *c, const oa_settings *st, int iters, bool cutoff = 
     s.d_pivot = c->d_pivot0;
 }
 
+// oa_iterate opens a loop without an end; its history is a ring of the last ITERATE_RING iterations
+constexpr int ITERATE_OPEN = 0x7FFFFFFF, ITERATE_RING = 64;
+
 int begin_loop(oa_ctx *c, const oa_settings *st, int iters)
 {
     int rc = check_ready(c);
@@ -574,8 +648,9 @@ int begin_loop(oa_ctx *c, const oa_settings *st, int iters)
     if (!(st->thresh > 0.0)) return fail(OA_E_BAD_THRESH, "thresh must be > 0 (the reference's make_pairs returns None)");
     if ((rc = use_device(c))) return rc;
     if ((rc = ensure_common(c))) return rc;
-    if ((rc = ensure_history(c, iters))) return rc;
+    if ((rc = ensure_history(c, iters == ITERATE_OPEN ? ITERATE_RING : iters))) return rc;   // oa_iterate: a small ring
     c->settings = *st;
+    c->iterate_mode = false;
     HIPCHK(hipStreamSynchronize(c->stream));                    // nothing of an earlier loop may still write the host flag
     if (c->h_poll) { c->h_poll[0] = 0; c->h_poll[1] = 0; }
     init_loop_state(c, st, iters);
@@ -704,6 +779,217 @@ int fill_report(oa_ctx *c, oa_report *rep)
     return OA_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// multi-device exchange: how the children of an oa_create_multi context join their sums
+// ------------------------------------------------------------------------------------------------
+//   OA_EXCHANGE_MAILBOX  one-shot all-gather through a mailbox in pinned, portable host memory every device maps:
+//                        k_reduce_post writes a rank's 24 sums + a sequence word, k_gather_solve_update waits for the
+//                        world's posts and adds them in rank order (bitwise identical on every device).  No host
+//                        involvement, no extra launches: an iteration stays search -> accumulate -> post -> solve.
+//   OA_EXCHANGE_RCCL     ncclAllReduce(24 doubles, sum) on every device's stream through a single-process
+//                        ncclCommInitAll communicator (librccl is loaded on first use: liboa_icp.so does not link it).
+}  // namespace
+struct oa_exchange {
+    int world = 0;
+    int mode = OA_EXCHANGE_MAILBOX;
+    oa::MailSlot *h_box = nullptr;                 // [2][world]
+    std::vector<oa::MailSlot *> d_box;             // the same memory as each child's device sees it
+    unsigned long long timeout_ticks = 0;
+    // RCCL
+    void *lib = nullptr;
+    std::vector<ncclComm_t> comms;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+namespace {
+using Exchange = oa_exchange;
+
+#define RCCLCHK(x, expr)                                                                                         \
+    do {                                                                                                         \
+        ncclResult_t r_ = (expr);                                                                                \
+        if (r_ != ncclSuccess)                                                                                   \
+            return fail(OA_E_RCCL, "%s failed: %s", #expr, (x)->GetErrorString ? (x)->GetErrorString(r_) : "?"); \
+    } while (0)
+
+int exchange_init_rccl(oa_ctx *p)
+{
+    Exchange *x = p->xch;
+    if (!x->comms.empty()) return OA_OK;
+    for (size_t i = 0; i < p->subs.size(); ++i)
+        for (size_t j = 0; j < i; ++j)
+            if (p->subs[i]->device == p->subs[j]->device)
+                return fail(OA_E_RCCL, "OA_EXCHANGE_RCCL needs distinct devices (device %d is listed twice); use OA_EXCHANGE_MAILBOX", p->subs[i]->device);
+    if (!x->lib) {
+        const char *names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+        for (const char *nm : names) if ((x->lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL))) break;
+        if (!x->lib) return fail(OA_E_RCCL, "librccl not found (%s)", dlerror());
+        x->CommInitAll = (decltype(x->CommInitAll))dlsym(x->lib, "ncclCommInitAll");
+        x->CommDestroy = (decltype(x->CommDestroy))dlsym(x->lib, "ncclCommDestroy");
+        x->AllReduce = (decltype(x->AllReduce))dlsym(x->lib, "ncclAllReduce");
+        x->GroupStart = (decltype(x->GroupStart))dlsym(x->lib, "ncclGroupStart");
+        x->GroupEnd = (decltype(x->GroupEnd))dlsym(x->lib, "ncclGroupEnd");
+        x->GetErrorString = (decltype(x->GetErrorString))dlsym(x->lib, "ncclGetErrorString");
+        if (!x->CommInitAll || !x->CommDestroy || !x->AllReduce || !x->GroupStart || !x->GroupEnd)
+            return fail(OA_E_RCCL, "librccl lacks the expected entry points");
+    }
+    std::vector<int> devs;
+    for (oa_ctx *c : p->subs) devs.push_back(c->device);
+    x->comms.assign(devs.size(), nullptr);
+    ncclResult_t r = x->CommInitAll(x->comms.data(), (int)devs.size(), devs.data());
+    if (r != ncclSuccess) {
+        x->comms.clear();
+        return fail(OA_E_RCCL, "ncclCommInitAll failed: %s", x->GetErrorString ? x->GetErrorString(r) : "?");
+    }
+    return OA_OK;
+}
+
+void exchange_destroy(Exchange *x)
+{
+    if (!x) return;
+    for (ncclComm_t cm : x->comms) if (cm && x->CommDestroy) (void)x->CommDestroy(cm);
+    if (x->h_box) (void)hipHostFree(x->h_box);
+    // the library handle stays open: unloading RCCL under a live HIP runtime is not worth the risk
+    delete x;
+}
+
+// all children, all-reduce of their d_sums in place (RCCL mode); one group = one launch per device
+int exchange_allreduce_rccl(oa_ctx *p)
+{
+    Exchange *x = p->xch;
+    RCCLCHK(x, x->GroupStart());
+    for (size_t i = 0; i < p->subs.size(); ++i) {
+        oa_ctx *c = p->subs[i];
+        ncclResult_t r = x->AllReduce(c->d_sums, c->d_sums, oa::NSUMS, ncclDouble, ncclSum, x->comms[i], c->stream);
+        if (r != ncclSuccess) { (void)x->GroupEnd(); return fail(OA_E_RCCL, "ncclAllReduce failed: %s", x->GetErrorString ? x->GetErrorString(r) : "?"); }
+    }
+    RCCLCHK(x, x->GroupEnd());
+    return OA_OK;
+}
+
+// one iteration on every child: search + accumulate + post / reduce, [all-reduce], gather + solve
+int multi_iteration(oa_ctx *p, bool timed)
+{
+    Exchange *x = p->xch;
+    int rc;
+    for (oa_ctx *c : p->subs) {
+        if ((rc = use_device(c))) return rc;
+        const bool t = timed && c->time_events;
+        if (t) {
+            if ((rc = ensure_events(c, c->ev_used + 1))) return rc;
+            HIPCHK(hipEventRecord(c->ev[2 * c->ev_used], c->stream));
+        }
+        if ((rc = launch_nn(c))) return rc;
+        if (t) { HIPCHK(hipEventRecord(c->ev[2 * c->ev_used + 1], c->stream)); c->ev_used++; }
+        if ((rc = launch_accumulate(c, false, nullptr, nullptr))) return rc;
+        if (x->mode == OA_EXCHANGE_RCCL) rc = launch_reduce(c, c->d_sums);
+        else {
+            hipLaunchKernelGGL(oa::k_reduce_post, dim3(1), dim3(1024), 0, c->stream, (const oa::DevState *)c->d_state,
+                               (const double *)c->d_partials, c->acc_blocks, x->d_box[(size_t)c->rank], c->rank, x->world);
+            HIPCHK(hipGetLastError());
+        }
+        if (rc) return rc;
+    }
+    if (x->mode == OA_EXCHANGE_RCCL && (rc = exchange_allreduce_rccl(p))) return rc;
+    for (oa_ctx *c : p->subs) {
+        if ((rc = use_device(c))) return rc;
+        if (x->mode == OA_EXCHANGE_RCCL) rc = iter_finish(c, c->d_sums);
+        else {
+            hipLaunchKernelGGL(oa::k_gather_solve_update, dim3(1), dim3(64), 0, c->stream, c->d_state, x->d_box[(size_t)c->rank],
+                               x->world, c->d_sums, c->d_hist, c->d_todo_count, x->timeout_ticks);
+            HIPCHK(hipGetLastError());
+        }
+        if (rc) return rc;
+    }
+    return OA_OK;
+}
+
+void multi_abort(oa_ctx *p)
+{
+    for (oa_ctx *c : p->subs) { if (hipSetDevice(c->device) == hipSuccess) (void)hipStreamSynchronize(c->stream); c->loop_active = false; }
+    p->loop_active = false;
+}
+
+int multi_begin(oa_ctx *p, const oa_settings *st, int iters)
+{
+    Exchange *x = p->xch;
+    int rc;
+    if (x->mode == OA_EXCHANGE_RCCL && (rc = exchange_init_rccl(p))) return rc;
+    for (oa_ctx *c : p->subs) {
+        if ((rc = begin_loop(c, st, iters))) { multi_abort(p); return rc; }     // synchronises the child's stream first
+        if ((rc = ensure_events(c, (c->time_events && iters != ITERATE_OPEN) ? std::max(1, std::min(iters, 1 << 16)) : 1))) { multi_abort(p); return rc; }
+    }
+    // every stream was idle when its begin_loop started and nothing enqueued since touches the mailbox
+    memset(x->h_box, 0, sizeof(oa::MailSlot) * 2 * (size_t)x->world);
+    for (oa_ctx *c : p->subs) {
+        if ((rc = use_device(c))) { multi_abort(p); return rc; }
+        HIPCHK(hipEventRecord(c->ev_loop0, c->stream));
+    }
+    p->settings = *st;
+    p->loop_active = true;
+    return OA_OK;
+}
+
+int status_error(int status)
+{
+    if (status == OA_E_TOO_FEW_PAIRS) return fail(OA_E_TOO_FEW_PAIRS, "input arrays are of wrong shape or type");
+    if (status == OA_E_SINGULAR) return fail(OA_E_SINGULAR, "align matrix_world became singular");
+    if (status == OA_E_RCCL) return fail(OA_E_RCCL, "multi-device exchange: a device's sums did not arrive in time");
+    return OA_OK;
+}
+
+int multi_end(oa_ctx *p, oa_report *rep)
+{
+    int rc = OA_OK;
+    oa_report agg{};
+    for (size_t i = 0; i < p->subs.size(); ++i) {
+        oa_ctx *c = p->subs[i];
+        oa_report r{};
+        int rci = use_device(c);
+        if (!rci && hipEventRecord(c->ev_loop1, c->stream) != hipSuccess) rci = fail(OA_E_HIP, "hipEventRecord failed");
+        if (!rci) rci = fill_report(c, &r);
+        float ms = 0.f;
+        if (!rci && hipEventElapsedTime(&ms, c->ev_loop0, c->ev_loop1) == hipSuccess) r.loop_ms = ms;
+        c->loop_active = false;
+        if (rci) { if (!rc) rc = rci; continue; }
+        if (i == 0) agg = r;
+        else {
+            agg.nn_ms_total = std::max(agg.nn_ms_total, r.nn_ms_total);      // the slowest device sets the pace
+            agg.loop_ms = std::max(agg.loop_ms, r.loop_ms);
+            if (agg.status == 0 && r.status != 0) agg.status = r.status;
+        }
+    }
+    p->loop_active = false;
+    if (rc) return rc;
+    *rep = agg;
+    return status_error(agg.status);
+}
+
+int multi_run(oa_ctx *p, const oa_settings *st, oa_report *rep)
+{
+    int rc = multi_begin(p, st, st->iters);
+    if (rc) return rc;
+    oa_ctx *c0 = p->subs[0];
+    const bool poll = c0->h_poll && st->early_exit && env_int("OA_RUN_POLL", 1);
+    const int lag = 2;
+    volatile int32_t *progress = c0->h_poll;
+    for (int it = 0; it < st->iters; ++it) {
+        if (poll) {                                                     // see oa_run
+            const auto t_wait = std::chrono::steady_clock::now();
+            while (!progress[0] && progress[1] < it - lag) {
+                if (std::chrono::steady_clock::now() - t_wait > std::chrono::seconds(5)) break;
+                std::this_thread::yield();
+            }
+            if (progress[0]) break;
+        }
+        if ((rc = multi_iteration(p, true))) { multi_abort(p); return rc; }
+    }
+    return multi_end(p, rep);
+}
 }  // namespace
 
 // ================================================================================================
@@ -754,37 +1040,116 @@ OA_EXPORT int oa_create(oa_ctx **out, int device)
     c->turn_frac = env_double("OA_TURN_FRAC", 0.1);
     c->use_filter = env_int("OA_NN_FILTER", 1) != 0;
     c->grid_mode = env_int("OA_NN_GRID", -1);
+    dev_cache().context_created();
     *out = c;
     return OA_OK;
 }
 
+// oa_create(&ctx, devices, n_dev).  One process, one child context (and stream) per listed device; the
+// same device may be listed more than once (its children then share one stream, so that the exchange's waits can
+// never starve each other on one hardware queue) -- that is how the multi-device path is tested on a single GPU.
+OA_EXPORT int oa_create_multi(oa_ctx **out, const int *devices, int n_dev)
+{
+    if (!out) return fail(OA_E_BAD_ARG, "oa_create_multi: null out pointer");
+    *out = nullptr;
+    if (!devices || n_dev < 1 || n_dev > 64) return fail(OA_E_BAD_ARG, "oa_create_multi: 1..64 devices, got %d", n_dev);
+    oa_ctx *p = new (std::nothrow) oa_ctx();
+    if (!p) return fail(OA_E_HIP, "out of host memory");
+    memset(&p->h_state, 0, sizeof p->h_state);
+    memset(&p->settings, 0, sizeof p->settings);
+    p->device = devices[0];
+    p->world = n_dev;
+    Exchange *x = new (std::nothrow) Exchange();
+    if (!x) { delete p; return fail(OA_E_HIP, "out of host memory"); }
+    p->xch = x;
+    x->world = n_dev;
+    int rc = OA_OK;
+    for (int i = 0; i < n_dev && !rc; ++i) {
+        oa_ctx *c = nullptr;
+        rc = oa_create(&c, devices[i]);
+        if (rc) break;
+        c->parent = p; c->rank = i; c->world = n_dev; c->xch = x;
+        for (oa_ctx *e : p->subs) if (e->device == c->device) { c->stream = e->stream; break; }   // one stream per device
+        p->subs.push_back(c);
+    }
+    if (!rc) {
+        hipError_t e = hipHostMalloc((void **)&x->h_box, sizeof(oa::MailSlot) * 2 * (size_t)n_dev, hipHostMallocPortable | hipHostMallocMapped);
+        if (e != hipSuccess) rc = fail(OA_E_HIP, "oa_create_multi: mailbox allocation failed: %s", hipGetErrorString(e));
+        else memset(x->h_box, 0, sizeof(oa::MailSlot) * 2 * (size_t)n_dev);
+    }
+    for (int i = 0; i < n_dev && !rc; ++i) {
+        void *dp = nullptr;
+        hipError_t e = hipSetDevice(devices[i]);
+        if (e == hipSuccess) e = hipHostGetDevicePointer(&dp, x->h_box, 0);
+        if (e != hipSuccess) rc = fail(OA_E_HIP, "oa_create_multi: device %d cannot map the mailbox: %s", devices[i], hipGetErrorString(e));
+        x->d_box.push_back((oa::MailSlot *)dp);
+    }
+    if (!rc) {
+        const double secs = std::max(0.05, env_double("OA_EXCHANGE_TIMEOUT_S", 30.0));
+        x->timeout_ticks = (unsigned long long)(secs * p->subs[0]->wall_clock_khz * 1e3);
+        const char *m = getenv("OA_EXCHANGE");
+        if (m && (!strcmp(m, "rccl") || !strcmp(m, "RCCL") || !strcmp(m, "1"))) x->mode = OA_EXCHANGE_RCCL;
+    }
+    if (rc) { const std::string keep = g_err; oa_destroy(p); g_err = keep; return rc; }
+    *out = p;
+    return OA_OK;
+}
+
+OA_EXPORT int oa_set_exchange(oa_ctx *c, int mode)
+{
+    if (!c) return fail(OA_E_BAD_ARG, "null context");
+    if (c->subs.empty()) return fail(OA_E_STATE, "oa_set_exchange: not a multi-device context (oa_create_multi)");
+    if (mode != OA_EXCHANGE_MAILBOX && mode != OA_EXCHANGE_RCCL) return fail(OA_E_BAD_ARG, "exchange mode %d", mode);
+    if (c->loop_active) return fail(OA_E_STATE, "oa_set_exchange inside a loop");
+    c->xch->mode = mode;
+    if (mode == OA_EXCHANGE_RCCL) return exchange_init_rccl(c);       // fails now rather than in the first iteration
+    return OA_OK;
+}
+
+OA_EXPORT int oa_num_devices(oa_ctx *c) { return !c ? 0 : (c->subs.empty() ? 1 : (int)c->subs.size()); }
+
+OA_EXPORT void oa_release_cached_memory(void) { dev_cache().trim(0, 0); }
+
 OA_EXPORT void oa_destroy(oa_ctx *c)
 {
     if (!c) return;
+    if (!c->subs.empty() || c->xch) {
+        if (!c->parent) {                                           // a multi-device parent: children first, then the exchange
+            for (oa_ctx *sub : c->subs) { sub->xch = nullptr; sub->parent = nullptr; oa_destroy(sub); }
+            exchange_destroy(c->xch);
+            delete c;
+            return;
+        }
+    }
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    dev_free(c->d_tgt_xyz); dev_free(c->d_tg); dev_free(c->d_tf); dev_free(c->d_tf3); dev_free(c->d_prev); dev_free(c->d_win); dev_free(c->d_cell_start); dev_free(c->d_sorted); dev_free(c->d_todo_list); dev_free(c->d_todo_count); dev_free(c->d_src4); dev_free(c->d_keys); dev_free(c->d_state);
+    tl_stream_known = false;                                        // the stream below is about to go away
+#define OA_FREE(x) dev_free(c->x, true)
+    OA_FREE(d_tgt_xyz); OA_FREE(d_tg); OA_FREE(d_tf); OA_FREE(d_tf3); OA_FREE(d_prev); OA_FREE(d_win); OA_FREE(d_cell_start);
+    OA_FREE(d_sorted); OA_FREE(d_todo_list); OA_FREE(d_todo_count); OA_FREE(d_src4); OA_FREE(d_keys); OA_FREE(d_state);
+    OA_FREE(d_partials); OA_FREE(d_sums); OA_FREE(d_solve);
+    OA_FREE(d_valid); OA_FREE(d_b); OA_FREE(d_dist); OA_FREE(d_counts); OA_FREE(d_offsets); OA_FREE(d_A); OA_FREE(d_B);
+    OA_FREE(d_bvh_box); OA_FREE(d_bvh_prims); OA_FREE(d_tbvh_box); OA_FREE(d_tbvh_prims);
+    OA_FREE(d_tri9); OA_FREE(d_tcell_start); OA_FREE(d_tcell_tris); OA_FREE(d_tcell_sph);
+    OA_FREE(d_sel); OA_FREE(d_src_n); OA_FREE(d_tgt_n); OA_FREE(d_src4o); OA_FREE(d_perm);
+#undef OA_FREE
     if (c->h_hist_map) (void)hipHostFree(c->h_hist_map);
     if (c->h_state_pin) (void)hipHostFree(c->h_state_pin);
     if (c->h_scratch) (void)hipHostFree(c->h_scratch);
-    dev_free(c->d_partials); dev_free(c->d_sums); dev_free(c->d_solve);
-    dev_free(c->d_valid); dev_free(c->d_b); dev_free(c->d_dist); dev_free(c->d_counts); dev_free(c->d_offsets);
-    dev_free(c->d_A); dev_free(c->d_B);
-    dev_free(c->d_bvh_box); dev_free(c->d_bvh_prims); dev_free(c->d_tbvh_box); dev_free(c->d_tbvh_prims);
-    dev_free(c->d_tri9); dev_free(c->d_tcell_start); dev_free(c->d_tcell_tris); dev_free(c->d_tcell_sph);
-    dev_free(c->d_sel); dev_free(c->d_src_n); dev_free(c->d_tgt_n); dev_free(c->d_src4o); dev_free(c->d_perm);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->ev_loop0) (void)hipEventDestroy(c->ev_loop0);
     if (c->h_poll) (void)hipHostFree(c->h_poll);
     if (c->ev_loop1) (void)hipEventDestroy(c->ev_loop1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
+    dev_cache().context_destroyed();                                // the last context gives the cached blocks back
 }
 
 OA_EXPORT int oa_set_search_mode(oa_ctx *c, int mode)
 {
     if (!c) return fail(OA_E_BAD_ARG, "null context");
     if (mode < -1 || mode > 2) return fail(OA_E_BAD_ARG, "search mode %d (use OA_SEARCH_AUTO/BRUTE/GRID/BVH)", mode);
+    OA_ROUTE_ALL(c, oa_set_search_mode(sub, mode));
     const bool rebuild = (c->grid_mode == 0 && mode != 0 && c->nt > 0);
     c->grid_mode = mode;
     if (rebuild) {                                   // the grids were skipped when the target was uploaded
@@ -801,6 +1166,9 @@ OA_EXPORT int oa_set_search_mode(oa_ctx *c, int mode)
 OA_EXPORT int oa_set_stream(oa_ctx *c, void *stream)
 {
     if (!c) return fail(OA_E_BAD_ARG, "null context");
+    if (!c->subs.empty())
+        return stream == OA_STREAM_OWN ? OA_OK : fail(OA_E_STATE, "oa_set_stream: a multi-device context runs on its own streams (one per device)");
+    if (c->parent && stream != OA_STREAM_OWN) return fail(OA_E_STATE, "oa_set_stream: child of a multi-device context");
     // the handle is used as given: NULL is HIP's legacy default stream (what torch.cuda.current_stream() is
     // unless the caller switched streams); OA_STREAM_OWN selects the context's private non-blocking stream
     c->stream = (stream == OA_STREAM_OWN) ? c->own_stream : (hipStream_t)stream;
@@ -979,6 +1347,7 @@ int set_target_common(oa_ctx *c, const float *xyz, int64_t n, int on_device, boo
 }  // namespace
 OA_EXPORT int oa_set_target(oa_ctx *c, const float *xyz, int64_t n, int on_device)
 {
+    OA_ROUTE_ALL(c, oa_set_target(sub, xyz, n, on_device));                 // replicated on every device
     return set_target_common(c, xyz, n, on_device, true);
 }
 
@@ -1236,6 +1605,7 @@ int build_tri_grid(oa_ctx *c)
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     c->tgp = gp;
+    c->n_tri_entries = (long long)entries;
     c->tri_grid_ok = true;
     if (c->debug)
         fprintf(stderr, "[oa] tri grid: h=%g cells=%dx%dx%d entries=%llu (%.2f per triangle)\n", gp.h, gp.n[0], gp.n[1], gp.n[2],
@@ -1286,6 +1656,7 @@ OA_EXPORT int oa_set_target_mesh(oa_ctx *c, const float *xyz, int64_t n_verts, i
                                  int64_t n_tris)
 {
     if (!c) return fail(OA_E_BAD_ARG, "null context");
+    OA_ROUTE_ALL(c, oa_set_target_mesh(sub, xyz, n_verts, on_device, tris, n_tris));
     if (n_tris < 1 || !tris) return fail(OA_E_BAD_ARG, "oa_set_target_mesh: no triangles");
     if (n_tris > 0x2AAAAAA0ll) return fail(OA_E_BAD_ARG, "too many triangles");
     int rc = set_target_common(c, xyz, n_verts, on_device, false);  // vertex images + bbox + filter; no vertex grid / tree
@@ -1317,6 +1688,11 @@ OA_EXPORT int oa_set_source(oa_ctx *c, const float *xyz, int64_t n_verts, int on
     if (vlist && n_vlist < 0) return fail(OA_E_BAD_ARG, "negative vlist length");
     if (shard_count < 1 || shard_index < 0 || shard_index >= shard_count)
         return fail(OA_E_BAD_ARG, "bad shard %d of %d", shard_index, shard_count);
+    if (!c->subs.empty()) {                                         // multi-device: child i keeps shard i of n_dev
+        if (shard_count != 1) return fail(OA_E_BAD_ARG, "oa_set_source: a multi-device context shards the source itself (pass shard 0 of 1)");
+        const int n_dev = (int)c->subs.size();
+        OA_ROUTE_ALL(c, oa_set_source(sub, xyz, n_verts, on_device, vlist, n_vlist, stride, sub->rank, n_dev));
+    }
     const long long step = stride > 1 ? stride : 1;                 // sample > 1 -> vlist[0::sample] (general.py:274)
     const long long n_all = vlist ? n_vlist : n_verts;
     const long long n_sel = (n_all + step - 1) / step;
@@ -1410,6 +1786,7 @@ OA_EXPORT int oa_set_normals(oa_ctx *c, const float *src_normals, int64_t n_vert
                              double max_angle_deg)
 {
     if (!c) return fail(OA_E_BAD_ARG, "null context");
+    OA_ROUTE_ALL(c, oa_set_normals(sub, src_normals, n_verts, tgt_normals, nt, max_angle_deg));
     c->normals_on = false;
     if (!src_normals || !(max_angle_deg > 0.0) || !(max_angle_deg < 180.0)) return OA_OK;       // switched off
     if (!c->d_src4 || !c->d_sel) return fail(OA_E_STATE, "oa_set_normals: call oa_set_source first");
@@ -1440,6 +1817,8 @@ OA_EXPORT int oa_set_normals(oa_ctx *c, const float *src_normals, int64_t n_vert
 OA_EXPORT int oa_set_matrices(oa_ctx *c, const float mx_align[16], const float mx_base[16])
 {
     if (!c || !mx_align || !mx_base) return fail(OA_E_BAD_ARG, "oa_set_matrices: null argument");
+    if (!c->subs.empty()) c->loop_active = false;
+    OA_ROUTE_ALL(c, oa_set_matrices(sub, mx_align, mx_base));
     float i1[16], i2[16];
     if (!oa::m4_inverted(mx_align, i1)) return fail(OA_E_SINGULAR, "align matrix_world has no inverse");
     if (!oa::m4_inverted(mx_base, i2)) return fail(OA_E_SINGULAR, "base matrix_world has no inverse");
@@ -1452,19 +1831,58 @@ OA_EXPORT int oa_set_matrices(oa_ctx *c, const float mx_align[16], const float m
     return OA_OK;
 }
 
+OA_EXPORT int oa_reset_seeds(oa_ctx *c)
+{
+    if (!c) return fail(OA_E_BAD_ARG, "null context");
+    OA_ROUTE_ALL(c, oa_reset_seeds(sub));
+    c->seeded = false;
+    c->loop_active = false;
+    if (!c->d_prev) return OA_OK;
+    int rc = use_device(c);
+    if (rc) return rc;
+    hipLaunchKernelGGL(oa::k_fill_int, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, c->d_prev, c->ns_pad, -1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemsetAsync(c->d_win, 0xFF, sizeof(float4) * (size_t)c->ns_pad, c->stream));
+    return OA_OK;
+}
+
+OA_EXPORT int oa_get_stat(oa_ctx *c, int what, double *value)
+{
+    if (!c || !value) return fail(OA_E_BAD_ARG, "oa_get_stat: null argument");
+    if (what == OA_STAT_CACHE_BYTES) { *value = (double)dev_cache().cached_bytes; return OA_OK; }
+    OA_ROUTE_FIRST(c, oa_get_stat(sub, what, value));
+    switch (what) {
+    case OA_STAT_GRID_CELLS: *value = c->grid_ok ? (double)c->n_cells : 0.0; return OA_OK;
+    case OA_STAT_TRI_GRID_CELLS: *value = c->tri_grid_ok ? (double)c->tgp.n[0] * c->tgp.n[1] * c->tgp.n[2] : 0.0; return OA_OK;
+    case OA_STAT_TRI_GRID_ENTRIES: *value = c->tri_grid_ok ? (double)c->n_tri_entries : 0.0; return OA_OK;
+    case OA_STAT_N_TRIS: *value = (double)c->n_tris; return OA_OK;
+    case OA_STAT_SURFACE: *value = c->surface ? 1.0 : 0.0; return OA_OK;
+    default: return fail(OA_E_BAD_ARG, "oa_get_stat: unknown key %d", what);
+    }
+}
+
 OA_EXPORT int oa_get_matrix_world(oa_ctx *c, float mx_align[16])
 {
     if (!c || !mx_align) return fail(OA_E_BAD_ARG, "null argument");
+    OA_ROUTE_FIRST(c, oa_get_matrix_world(sub, mx_align));           // identical on every device
     if (!c->have_mats) return fail(OA_E_STATE, "matrices not set");
     memcpy(mx_align, c->h_state.mx1, sizeof(float) * 16);
     return OA_OK;
 }
 
-OA_EXPORT int64_t oa_num_selected(oa_ctx *c) { return c ? c->ns : 0; }
+OA_EXPORT int64_t oa_num_selected(oa_ctx *c)
+{
+    if (!c) return 0;
+    if (c->subs.empty()) return c->ns;
+    int64_t n = 0;
+    for (oa_ctx *sub : c->subs) n += sub->ns;                       // all shards
+    return n;
+}
 
 OA_EXPORT int oa_get_pivot(oa_ctx *c, double pivot[3])
 {
     if (!c || !pivot) return fail(OA_E_BAD_ARG, "null argument");
+    OA_ROUTE_FIRST(c, oa_get_pivot(sub, pivot));
     for (int k = 0; k < 3; ++k) pivot[k] = c->pivot[k];
     return OA_OK;
 }
@@ -1489,6 +1907,7 @@ int push_state_for_oneshot(oa_ctx *c, double thresh, bool cutoff)
 
 OA_EXPORT int oa_nn_search(oa_ctx *c, int64_t *idx, float *d2, double *kernel_ms)
 {
+    OA_NOT_MULTI(c, "oa_nn_search");
     int rc = check_ready(c);
     if (rc) return rc;
     if ((rc = use_device(c))) return rc;
@@ -1524,6 +1943,7 @@ OA_EXPORT int oa_nn_search(oa_ctx *c, int64_t *idx, float *d2, double *kernel_ms
 OA_EXPORT int oa_make_pairs(oa_ctx *c, double thresh, int calc_stats, double *A, double *B, int64_t cap, int64_t *K,
                             double dstats[2])
 {
+    OA_NOT_MULTI(c, "oa_make_pairs");
     int rc = check_ready(c);
     if (rc) return rc;
     if (!K || cap < 0 || (cap > 0 && (!A || !B))) return fail(OA_E_BAD_ARG, "oa_make_pairs: bad output arguments");
@@ -1613,6 +2033,7 @@ int solve_on_device(oa_ctx *c, const double *d_sums, const double pv[3], int wit
 OA_EXPORT int oa_kabsch(oa_ctx *c, const double *A, const double *B, int64_t K, int64_t ld, int with_scale, double M[16])
 {
     if (!c || !M) return fail(OA_E_BAD_ARG, "oa_kabsch: null argument");
+    OA_ROUTE_FIRST(c, oa_kabsch(sub, A, B, K, ld, with_scale, M));
     if (K < 3) return fail(OA_E_TOO_FEW_PAIRS, "input arrays are of wrong shape or type");   // general.py:150-157
     if (!A || !B || ld < K) return fail(OA_E_BAD_ARG, "oa_kabsch: bad arrays");
     int rc = use_device(c);
@@ -1640,6 +2061,7 @@ OA_EXPORT int oa_kabsch_from_sums(oa_ctx *c, const double sums[OA_NSUMS], const 
                                   double M[16])
 {
     if (!c || !sums || !M) return fail(OA_E_BAD_ARG, "oa_kabsch_from_sums: null argument");
+    OA_ROUTE_FIRST(c, oa_kabsch_from_sums(sub, sums, pivot, with_scale, M));
     int rc = use_device(c);
     if (rc) return rc;
     if ((rc = ensure_common(c))) return rc;
@@ -1654,6 +2076,7 @@ OA_EXPORT int oa_kabsch_from_sums(oa_ctx *c, const double sums[OA_NSUMS], const 
 OA_EXPORT int oa_run_begin(oa_ctx *c, const oa_settings *st)
 {
     if (!c || !st) return fail(OA_E_BAD_ARG, "oa_run_begin: null argument");
+    OA_NOT_MULTI(c, "oa_run_begin (the split-phase loop is for one process per GPU)");
     int rc = begin_loop(c, st, st->iters);
     if (rc) return rc;
     if ((rc = ensure_events(c, std::max(1, st->iters)))) return rc;
@@ -1664,6 +2087,7 @@ OA_EXPORT int oa_run_begin(oa_ctx *c, const oa_settings *st)
 OA_EXPORT int oa_iter_partial(oa_ctx *c, double *d_sums)
 {
     if (!c || !d_sums) return fail(OA_E_BAD_ARG, "oa_iter_partial: null argument");
+    OA_NOT_MULTI(c, "oa_iter_partial");
     if (!c->loop_active) return fail(OA_E_STATE, "oa_iter_partial outside oa_run_begin/oa_run_end");
     int rc = use_device(c);
     if (rc) return rc;
@@ -1673,6 +2097,7 @@ OA_EXPORT int oa_iter_partial(oa_ctx *c, double *d_sums)
 OA_EXPORT int oa_iter_finish(oa_ctx *c, const double *d_sums)
 {
     if (!c || !d_sums) return fail(OA_E_BAD_ARG, "oa_iter_finish: null argument");
+    OA_NOT_MULTI(c, "oa_iter_finish");
     if (!c->loop_active) return fail(OA_E_STATE, "oa_iter_finish outside oa_run_begin/oa_run_end");
     int rc = use_device(c);
     if (rc) return rc;
@@ -1682,6 +2107,7 @@ OA_EXPORT int oa_iter_finish(oa_ctx *c, const double *d_sums)
 OA_EXPORT int oa_run_end(oa_ctx *c, oa_report *rep)
 {
     if (!c || !rep) return fail(OA_E_BAD_ARG, "oa_run_end: null argument");
+    OA_NOT_MULTI(c, "oa_run_end");
     int rc = use_device(c);
     if (rc) return rc;
     HIPCHK(hipEventRecord(c->ev_loop1, c->stream));
@@ -1689,14 +2115,13 @@ OA_EXPORT int oa_run_end(oa_ctx *c, oa_report *rep)
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, c->ev_loop0, c->ev_loop1) == hipSuccess) rep->loop_ms = ms;
     c->loop_active = false;
-    if (rep->status == OA_E_TOO_FEW_PAIRS) return fail(OA_E_TOO_FEW_PAIRS, "input arrays are of wrong shape or type");
-    if (rep->status == OA_E_SINGULAR) return fail(OA_E_SINGULAR, "align matrix_world became singular");
-    return OA_OK;
+    return status_error(rep->status);
 }
 
 OA_EXPORT int oa_run(oa_ctx *c, const oa_settings *st, oa_report *rep)
 {
     if (!c || !st || !rep) return fail(OA_E_BAD_ARG, "oa_run: null argument");
+    if (!c->subs.empty()) return multi_run(c, st, rep);
     int rc = oa_run_begin(c, st);
     if (rc) return rc;
     // The whole loop is enqueued ahead of the GPU.  With early exit on, iterations after convergence would still cost
@@ -1719,28 +2144,57 @@ OA_EXPORT int oa_run(oa_ctx *c, const oa_settings *st, oa_report *rep)
             }
             if (progress[0]) break;
         }
-        if ((rc = iter_fused(c, true))) return rc;
+        if ((rc = iter_fused(c, true))) { (void)hipStreamSynchronize(c->stream); c->loop_active = false; return rc; }
     }
     return oa_run_end(c, rep);
 }
 
+namespace {
+bool same_loop_settings(const oa_settings &a, const oa_settings &b)
+{
+    return a.use_target == b.use_target && a.with_scale == b.with_scale && a.thresh == b.thresh && a.target_d == b.target_d;
+}
+}  // namespace
+
+// A modal sequence lasts while oa_iterate is called with the same thresh / target_d / use_target / with_scale.  Changed
+// settings, or any call that re-stages the device state in between (oa_set_matrices, oa_make_pairs, oa_nn_search,
+// oa_run, a new upload), end it: the next oa_iterate starts a new sequence (n = 0, fresh convergence ring) from the
+// current matrix_world.
 OA_EXPORT int oa_iterate(oa_ctx *c, const oa_settings *st, double M_step[16], double stats[6])
 {
     if (!c || !st) return fail(OA_E_BAD_ARG, "oa_iterate: null argument");
+    const bool multi = !c->subs.empty();
     int rc;
-    if (!c->loop_active) {
-        if ((rc = begin_loop(c, st, 0x7FFFFFFF))) return rc;
+    if (c->loop_active && !(c->iterate_mode && same_loop_settings(*st, c->settings))) {
+        if (multi) multi_abort(c);
+        else { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); c->loop_active = false; }
+        if (!multi && (rc = fetch_state(c))) return rc;              // the pose reached so far is where the new sequence starts
+        if (multi) for (oa_ctx *sub : c->subs) { if ((rc = use_device(sub))) return rc; if ((rc = fetch_state(sub))) return rc; }
     }
-    if ((rc = use_device(c))) return rc;
-    c->ev_used = 0;
-    if ((rc = iter_fused(c, false))) return rc;
-    if ((rc = fetch_state(c))) return rc;
-    const oa::DevState &s = c->h_state;
-    if (s.status == OA_E_TOO_FEW_PAIRS) { c->loop_active = false; return fail(OA_E_TOO_FEW_PAIRS, "input arrays are of wrong shape or type"); }
-    if (s.status == OA_E_SINGULAR) { c->loop_active = false; return fail(OA_E_SINGULAR, "align matrix_world became singular"); }
+    if (!c->loop_active) {
+        if ((rc = multi ? multi_begin(c, st, ITERATE_OPEN) : begin_loop(c, st, ITERATE_OPEN))) return rc;
+        c->iterate_mode = true;
+    }
+    oa_ctx *c0 = multi ? c->subs[0] : c;
+    if (multi) {
+        for (oa_ctx *sub : c->subs) sub->ev_used = 0;
+        if ((rc = multi_iteration(c, false))) { multi_abort(c); return rc; }
+        for (oa_ctx *sub : c->subs) { if ((rc = use_device(sub))) return rc; if ((rc = fetch_state(sub))) { multi_abort(c); return rc; } }
+    } else {
+        if ((rc = use_device(c))) return rc;
+        c->ev_used = 0;
+        if ((rc = iter_fused(c, false))) { (void)hipStreamSynchronize(c->stream); c->loop_active = false; return rc; }
+        if ((rc = fetch_state(c))) return rc;
+    }
+    const oa::DevState &s = c0->h_state;
+    if (s.status != 0) {
+        if (multi) multi_abort(c); else c->loop_active = false;
+        if ((rc = status_error(s.status))) return rc;
+        return fail(OA_E_HIP, "oa_iterate: device status %d", s.status);
+    }
     if (s.n <= 0) return fail(OA_E_STATE, "oa_iterate: loop already halted");
     oa::StepRecord r;
-    memcpy(&r, c->h_hist_map + ((s.n - 1) % c->max_records), sizeof r);             // fetch_state synchronised the stream
+    memcpy(&r, c0->h_hist_map + ((s.n - 1) % c0->max_records), sizeof r);           // fetch_state synchronised the stream
     if (M_step) memcpy(M_step, r.M, sizeof r.M);
     if (stats) {
         stats[0] = r.K; stats[1] = s.use_target ? r.mean_d : NAN; stats[2] = s.use_target ? r.std_d : NAN;
@@ -1753,22 +2207,28 @@ OA_EXPORT int oa_get_history(oa_ctx *c, int32_t max_n, double *step_M, float *st
                              double *step_stats, double *step_trans)
 {
     if (!c) return fail(OA_E_BAD_ARG, "null context");
+    OA_ROUTE_FIRST(c, oa_get_history(sub, max_n, step_M, step_new, step_K, step_stats, step_trans));
     if (use_device(c)) return OA_E_HIP;
-    const int n = std::min(std::min(c->h_state.n, c->max_records), (int)max_n);
+    const int total = c->h_state.n, cap = c->max_records;
+    const int held = std::min(total, cap);
+    const int n = std::min(held, (int)max_n);
     if (n <= 0) return 0;
     std::vector<oa::StepRecord> h_local;
-    if (!(c->h_hist_valid && (int)c->h_hist.size() >= n)) {
-        h_local.resize((size_t)n);
+    if (!(c->h_hist_valid && (int)c->h_hist.size() >= held)) {
+        h_local.resize((size_t)held);
         if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(OA_E_HIP, "oa_get_history: stream error");
-        memcpy(h_local.data(), c->h_hist_map, sizeof(oa::StepRecord) * (size_t)n);
+        memcpy(h_local.data(), c->h_hist_map, sizeof(oa::StepRecord) * (size_t)held);
     }
     const std::vector<oa::StepRecord> &h = h_local.empty() ? c->h_hist : h_local;
+    // a loop that fits the history: its first n iterations; a ring that wrapped (oa_iterate): the last n, oldest first
+    const int first = total > cap ? total - n : 0;
     for (int i = 0; i < n; ++i) {
-        if (step_M) memcpy(step_M + 16 * i, h[i].M, sizeof h[i].M);
-        if (step_new) memcpy(step_new + 16 * i, h[i].new_mat, sizeof h[i].new_mat);
-        if (step_K) step_K[i] = (int64_t)h[i].K;
-        if (step_stats) { step_stats[2 * i] = h[i].mean_d; step_stats[2 * i + 1] = h[i].std_d; }
-        if (step_trans) step_trans[i] = h[i].trans;
+        const oa::StepRecord &r = h[(size_t)((first + i) % cap)];
+        if (step_M) memcpy(step_M + 16 * i, r.M, sizeof r.M);
+        if (step_new) memcpy(step_new + 16 * i, r.new_mat, sizeof r.new_mat);
+        if (step_K) step_K[i] = (int64_t)r.K;
+        if (step_stats) { step_stats[2 * i] = r.mean_d; step_stats[2 * i + 1] = r.std_d; }
+        if (step_trans) step_trans[i] = r.trans;
     }
     return n;
 }

@@ -1198,6 +1198,81 @@ __global__ __launch_bounds__(512) void k_reduce_solve_update(DevState *__restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// multi-device exchange (oa_create_multi): the per-iteration all-gather of the OA_NSUMS partial sums through a
+// mailbox in pinned, portable, device-mapped host memory.  box[parity][rank] holds rank's sums of iteration
+// `seq - 1` (parity = seq & 1); every device adds the world's posts in RANK ORDER, so all devices solve from
+// bitwise identical sums and end with identical matrices -- no broadcast.  Two parities suffice: rank A can post
+// iteration k + 2 only after its own solve of iteration k + 1, which needed rank B's post of k + 1, which B enqueued
+// after its solve of iteration k had read A's post of k.
+// ------------------------------------------------------------------------------------------------
+struct MailSlot {
+    double sums[NSUMS];
+    unsigned long long seq;          // iteration number + 1 of the sums above (0 = nothing posted since the loop began)
+    unsigned long long pad[7];       // 256 B per slot: a slot never shares a line with another rank's
+};
+constexpr int STATUS_EXCHANGE = -9;  // OA_E_RCCL: a rank's post did not arrive in time
+
+// step 1 on every device: fixed-order reduction of its per-workgroup partials, posted to the mailbox
+__global__ __launch_bounds__(1024) void k_reduce_post(const DevState *__restrict__ st, const double *__restrict__ partials,
+                                                      int n_blocks, MailSlot *box, int rank, int world)
+{
+    if (st->halt) return;
+    __shared__ double sums[NSUMS];
+    reduce_partials_block<1024>(partials, n_blocks, sums);
+    __syncthreads();
+    const unsigned long long seq = (unsigned long long)st->n + 1ull;
+    MailSlot *slot = box + (size_t)(seq & 1ull) * world + rank;
+    if (threadIdx.x < NSUMS)
+        __hip_atomic_store(&slot->sums[threadIdx.x], sums[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&slot->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// step 2 on every device: wait for the world's posts of this iteration, add them in rank order, solve + update.
+// Lane r waits for rank r (world <= 64).  The wait is bounded (timeout_ticks of wall_clock64): a rank that never
+// posts -- its device faulted -- ends the loop with STATUS_EXCHANGE instead of hanging this one.
+__global__ __launch_bounds__(64) void k_gather_solve_update(DevState *__restrict__ st, MailSlot *box, int world,
+                                                            double *__restrict__ sums_out, StepRecord *__restrict__ hist,
+                                                            int *__restrict__ todo_count, unsigned long long timeout_ticks)
+{
+    __shared__ double sums[NSUMS];
+    __shared__ int arrived;
+    const bool live = st->halt == 0;
+    if (live) {
+        const unsigned long long seq = (unsigned long long)st->n + 1ull;
+        MailSlot *row = box + (size_t)(seq & 1ull) * world;
+        if (threadIdx.x == 0) arrived = 1;
+        __syncthreads();
+        if ((int)threadIdx.x < world) {
+            const unsigned long long t0 = wall_clock64();
+            while (__hip_atomic_load(&row[threadIdx.x].seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+                if (wall_clock64() - t0 > timeout_ticks) { arrived = 0; break; }
+                __builtin_amdgcn_s_sleep(4);
+            }
+        }
+        __syncthreads();
+        if (arrived && threadIdx.x < NSUMS) {
+            double t = __hip_atomic_load(&row[0].sums[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            for (int r = 1; r < world; ++r)
+                t += __hip_atomic_load(&row[r].sums[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            sums[threadIdx.x] = t;
+            if (sums_out) sums_out[threadIdx.x] = t;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    if (live && !arrived) {
+        if (todo_count) *todo_count = 0;
+        st->status = STATUS_EXCHANGE;
+        st->halt = 1;
+        if (st->host_halt) { st->host_halt[0] = 1; __threadfence_system(); }
+        return;
+    }
+    solve_update_body(st, sums, hist, todo_count);
+}
+
+// ------------------------------------------------------------------------------------------------
 // ordered compaction for make_pairs' A, B outputs (functions/general.py:313-321)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_block_counts(const unsigned char *__restrict__ valid, int ns, int *__restrict__ counts)

@@ -50,15 +50,19 @@ def new_sums_tensor(device):
     return torch.zeros(capi.OA_NSUMS, dtype=torch.float64, device=device)
 
 
-def run_sharded(backend: ShardBackend, iters: int, sums, group=None, world_size: int | None = None):
-    """Drive `iters` iterations: partial -> all_reduce(SUM) -> finish.  Returns backend.end()."""
+def run_sharded(backend: ShardBackend, iters: int, sums, group=None, world_size: int | None = None,
+                force_collective: bool = False):
+    """Drive `iters` iterations: partial -> all_reduce(SUM) -> finish.  Returns backend.end().
+    force_collective: issue the all-reduce even in a world of one (how the RCCL call itself is exercised on a
+    one-GPU box)."""
     import torch.distributed as dist
     if world_size is None:
         world_size = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    reduce = world_size > 1 or (force_collective and dist.is_available() and dist.is_initialized())
     backend.begin()
     for _ in range(int(iters)):
         backend.partial(sums)
-        if world_size > 1:
+        if reduce:
             dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
         backend.finish(sums)
     return backend.end()

@@ -39,23 +39,62 @@ def _device_ptr(x):
         if x.is_cuda:
             import torch
             t = x.detach().to(dtype=torch.float32).contiguous().reshape(-1, 3)
+            # the library reads the tensor on its own stream: whatever produced it on torch's stream (including the
+            # conversion above) has to be finished first
+            torch.cuda.current_stream(t.device).synchronize()
             return C.c_void_p(t.data_ptr()), 1, t, t.shape[0]
         x = x.detach().cpu().numpy()
     a = capi.as_f32(np.asarray(x)).reshape(-1, 3)
     return C.c_void_p(a.ctypes.data), 0, a, a.shape[0]
 
 
-class IcpEngine:
-    """One GPU context.  `device` is the HIP device ordinal (LOCAL_RANK in multi-process runs)."""
+def resolve_devices(spec):
+    """A device list from an int, a sequence, "all", or a string like "0,1,2,3" (what OA_DEVICES may hold)."""
+    if spec is None:
+        return None
+    if isinstance(spec, str):
+        spec = spec.strip()
+        if spec.lower() == "all":
+            return list(range(device_count()))
+        return [int(t) for t in spec.replace(";", ",").split(",") if t.strip() != ""]
+    if isinstance(spec, (int, np.integer)):
+        return [int(spec)]
+    return [int(d) for d in spec]
 
-    def __init__(self, device: int = 0):
+
+class IcpEngine:
+    """One context: one GPU (`device`, the HIP ordinal -- LOCAL_RANK in one-process-per-GPU runs), or several GPUs of
+    this process (`devices=[0, 1, ...]`, oa_create_multi): the source is sharded over them, the target replicated,
+    and run() / iterate() join the devices' sums inside the library every iteration.  `exchange`: "mailbox"
+    (default) or "rccl"."""
+
+    def __init__(self, device: int = 0, devices=None, exchange=None):
         self._L = capi.load()
         h = C.c_void_p()
-        capi.check(self._L.oa_create(C.byref(h), int(device)))
+        devs = resolve_devices(devices)
+        if devs is None:
+            capi.check(self._L.oa_create(C.byref(h), int(device)))
+            self.devices = [int(device)]
+            self.multi = False
+        else:
+            arr = (C.c_int * len(devs))(*devs)
+            capi.check(self._L.oa_create_multi(C.byref(h), arr, len(devs)))
+            self.devices = devs
+            self.multi = True
         self._h = h
-        self.device = int(device)
+        self.device = self.devices[0]
         self.n_target = 0
         self.n_selected = 0
+        # who uploaded the geometry last (GpuBVH objects sharing one engine check these before they trust its state)
+        self.target_owner = None
+        self.source_owner = None
+        if exchange is not None:
+            self.set_exchange(exchange)
+
+    def set_exchange(self, mode):
+        """'mailbox' (all-gather through a pinned host mailbox, rank-ordered sum) or 'rccl' (ncclAllReduce over xGMI)."""
+        code = {"mailbox": capi.OA_EXCHANGE_MAILBOX, "rccl": capi.OA_EXCHANGE_RCCL}[mode] if isinstance(mode, str) else int(mode)
+        capi.check(self._L.oa_set_exchange(self._h, code))
 
     # ---- lifetime
     def close(self):
@@ -93,6 +132,7 @@ class IcpEngine:
         p, on_dev, keep, n = _device_ptr(xyz)
         capi.check(self._L.oa_set_target(self._h, p, n, on_dev))
         self.n_target = n
+        self.target_owner = None
         del keep
 
     def set_target_mesh(self, xyz, tris):
@@ -102,6 +142,7 @@ class IcpEngine:
         t = np.ascontiguousarray(tris, dtype=np.int32).reshape(-1, 3)
         capi.check(self._L.oa_set_target_mesh(self._h, p, n, on_dev, t.ctypes.data_as(C.POINTER(C.c_int32)), len(t)))
         self.n_target = n
+        self.target_owner = None
         del keep
 
     def set_source(self, xyz, vlist=None, stride=0, shard_index=0, shard_count=1):
@@ -113,6 +154,7 @@ class IcpEngine:
             vl, vp, nv = None, None, 0
         capi.check(self._L.oa_set_source(self._h, p, n, on_dev, vp, nv, int(stride), int(shard_index), int(shard_count)))
         self.n_selected = int(self._L.oa_num_selected(self._h))
+        self.source_owner = None
         del keep, vl
 
     def set_normals(self, src_normals, tgt_normals=None, max_angle_deg=45.0):
@@ -129,6 +171,17 @@ class IcpEngine:
     def set_matrices(self, mx_align, mx_base):
         a, b = capi.as_f32(mx_align, (4, 4)), capi.as_f32(mx_base, (4, 4))
         capi.check(self._L.oa_set_matrices(self._h, capi.fptr(a), capi.fptr(b)))
+
+    def reset_seeds(self):
+        """Forget the previous searches' answers (the next search starts cold; results are unaffected)."""
+        capi.check(self._L.oa_reset_seeds(self._h))
+
+    STATS = {"grid_cells": 1, "tri_grid_cells": 2, "tri_grid_entries": 3, "n_tris": 4, "surface": 5, "cache_bytes": 6}
+
+    def stat(self, name) -> float:
+        v = C.c_double(0.0)
+        capi.check(self._L.oa_get_stat(self._h, self.STATS[name], C.byref(v)))
+        return float(v.value)
 
     def matrix_world(self) -> np.ndarray:
         out = np.empty((4, 4), np.float32)
@@ -215,7 +268,14 @@ class IcpEngine:
         rep = capi.Report()
         rc = self._L.oa_run(self._h, C.byref(st), C.byref(rep))
         if rc == capi.OA_E_TOO_FEW_PAIRS:
-            raise ValueError(REF_VALUEERROR)
+            # the reference raises out of affine_matrix_from_points in iteration n, after iterations 0..n-1 have been
+            # applied to the objects (operators/icp_align.py:121-127): the partial result travels with the exception
+            err = ValueError(REF_VALUEERROR)
+            try:
+                err.partial = self._result(rep)
+            except Exception:
+                err.partial = None
+            raise err
         capi.check(rc)
         return self._result(rep)
 

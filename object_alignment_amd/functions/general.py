@@ -12,17 +12,25 @@ import numpy as np
 
 from ..engine import IcpEngine, REF_VALUEERROR
 
-__all__ = ["make_pairs", "affine_matrix_from_points", "calc_target_matrix", "GpuBVH", "AlignObject", "default_engine"]
+__all__ = ["make_pairs", "affine_matrix_from_points", "calc_target_matrix", "GpuBVH", "AlignObject", "default_engine",
+           "invalidate_cached_geometry"]
 
-_default_engine = None
+_default_engines = {}
 
 
-def default_engine(device: int = 0) -> IcpEngine:
-    """Process-wide engine used by the free functions (created on first use)."""
-    global _default_engine
-    if _default_engine is None:
-        _default_engine = IcpEngine(device)
-    return _default_engine
+def default_engine(device: int = 0, devices=None) -> IcpEngine:
+    """Process-wide engine used by the free functions and operators (created on first use).  `devices` (a list,
+    "all", "0,1,2,3"; default: the OA_DEVICES environment variable) selects a multi-GPU engine that shards the source
+    over those GPUs inside the library (oa_create_multi); without it, one context on `device`."""
+    import os
+    from ..engine import resolve_devices
+    devs = resolve_devices(devices if devices is not None else (os.environ.get("OA_DEVICES") or None))
+    key = ("multi",) + tuple(devs) if devs is not None and len(devs) > 1 else ("single", devs[0] if devs else int(device))
+    eng = _default_engines.get(key)
+    if eng is None or getattr(eng, "_h", None) is None:
+        eng = IcpEngine(devices=devs) if key[0] == "multi" else IcpEngine(key[1])
+        _default_engines[key] = eng
+    return eng
 
 
 # ------------------------------------------------------------------ object adapters
@@ -37,21 +45,37 @@ def _coords_of(obj) -> np.ndarray:
     """n x 3 float32 local coordinates of a Blender-like object or an AlignObject."""
     if hasattr(obj, "xyz"):
         return obj.xyz
-    cached = getattr(obj, "_oa_xyz_cache", None)
     verts = obj.data.vertices
-    if cached is not None and len(cached) == len(verts):
-        return cached
-    if hasattr(verts, "foreach_get"):                        # real bpy mesh: one C call
+    if hasattr(verts, "foreach_get"):                        # real bpy mesh: one C call, never cached
         flat = np.empty(len(verts) * 3, dtype=np.float32)
         verts.foreach_get("co", flat)
-        xyz = flat.reshape(-1, 3)
-    else:
-        xyz = np.array([[v.co[0], v.co[1], v.co[2]] for v in verts], dtype=np.float32).reshape(-1, 3)
+        return flat.reshape(-1, 3)
+    # duck-typed vertices: the per-vertex interpreter loop costs ~1 us a vertex, so the converted array is remembered
+    # on the object -- and trusted only while a probe of ~64 vertices spread over the mesh still matches it
+    n = len(verts)
+    cached = getattr(obj, "_oa_xyz_cache", None)
+    if cached is not None and len(cached) == n:
+        probe = range(0, n, max(1, n // 64))
+        if all(cached[i, 0] == np.float32(verts[i].co[0]) and cached[i, 1] == np.float32(verts[i].co[1])
+               and cached[i, 2] == np.float32(verts[i].co[2]) for i in probe):
+            return cached
+    xyz = np.array([[v.co[0], v.co[1], v.co[2]] for v in verts], dtype=np.float32).reshape(-1, 3)
     try:
         obj._oa_xyz_cache = xyz
     except Exception:
         pass
     return xyz
+
+
+def invalidate_cached_geometry(obj=None):
+    """Forget what the host side remembers about `obj` (or about everything): converted coordinates, converted
+    vertex lists.  Call after editing geometry or vertex groups in place if the probes above could miss the edit."""
+    if obj is not None and hasattr(obj, "_oa_xyz_cache"):
+        try:
+            del obj._oa_xyz_cache
+        except Exception:
+            pass
+    _VLIST_CACHE.clear()
 
 
 def _tris_of(obj):
@@ -123,13 +147,25 @@ class GpuBVH:
     """
 
     def __init__(self, target_xyz, engine: IcpEngine | None = None, tris=None):
-        self.engine = engine if engine is not None else default_engine()
+        self.engine = engine if engine is not None else default_engine(devices=[0])
+        if self.engine.multi:
+            raise ValueError("make_pairs returns per-point outputs: GpuBVH needs a single-device engine")
         self.target = np.ascontiguousarray(target_xyz, dtype=np.float32).reshape(-1, 3)
         self.tris = tris
-        if tris is not None:        # surface mode: closest point on the triangles, as BVHTree.find_nearest does
-            self.engine.set_target_mesh(self.target, tris)
+        self._src_key = None
+        self._bind_target()
+
+    def _bind_target(self):
+        # The engine may be shared (the process-wide default): another GpuBVH, IcpAlign.run or the modal operator may
+        # have uploaded their own geometry since.  The engine remembers who uploaded last; when it is not this tree,
+        # target AND source go up again -- the reference's base_bvh is self-contained, so must this one be.
+        if self.engine.target_owner is self:
+            return
+        if self.tris is not None:   # surface mode: closest point on the triangles, as BVHTree.find_nearest does
+            self.engine.set_target_mesh(self.target, self.tris)
         else:                       # no faces (point cloud): nearest vertex
             self.engine.set_target(self.target)
+        self.engine.target_owner = self
         self._src_key = None
 
     @classmethod
@@ -143,12 +179,15 @@ class GpuBVH:
     def _bind_source(self, xyz, vlist, sample):
         # re-upload only when something changed; the vertex list is fingerprinted in O(n) numpy time (1 ms at 1M),
         # not hashed byte by byte
+        # (coordinates too: an array modified in place keeps its id)
+        self._bind_target()
         vkey = None if vlist is None else (len(vlist), int(vlist.sum()), int(vlist[::max(1, len(vlist) // 61)].sum()))
-        key = (id(xyz), xyz.shape, vkey, sample)
-        if key != self._src_key:
+        xkey = (xyz.shape, float(xyz.sum()), float(xyz[::max(1, len(xyz) // 61)].sum(dtype=np.float64)))
+        key = (xkey, vkey, sample)
+        if key != self._src_key or self.engine.source_owner is not self:
             self.engine.set_source(xyz, vlist=vlist, stride=sample)
+            self.engine.source_owner = self
             self._src_key = key
-            self._keep = xyz
 
 
 _VLIST_CACHE = {}
@@ -164,12 +203,12 @@ def _vlist_array(vlist):
     step = max(1, n // 31)
     probe = (n, tuple(vlist[i] for i in range(0, n, step)), vlist[-1] if n else None)
     hit = _VLIST_CACHE.get(id(vlist))
-    if hit is not None and hit[0] == probe:
+    if hit is not None and hit[2] is vlist and hit[0] == probe:   # the list itself is kept alive: its id cannot be recycled
         return hit[1]
     arr = np.ascontiguousarray(vlist, dtype=np.int64)
     if len(_VLIST_CACHE) > 8:
         _VLIST_CACHE.clear()
-    _VLIST_CACHE[id(vlist)] = (probe, arr)
+    _VLIST_CACHE[id(vlist)] = (probe, arr, vlist)
     return arr
 
 

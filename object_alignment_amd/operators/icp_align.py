@@ -34,6 +34,9 @@ class IcpSettings:
     use_target: bool = True
     take_m_with: bool = False
     align_meth: str = "0"             # '0' RIGID, '1' ROT_LOC_SCALE
+    # not a preference of the reference: which GPUs the loop may use.  None = one GPU (or what the OA_DEVICES environment
+    # variable lists); "all" / [0, 1, ...] = the source cloud is sharded over those GPUs inside the library
+    devices: object = None
 
 
 _prefs = IcpSettings()
@@ -97,7 +100,7 @@ class IcpAlign:
 
     def __init__(self, settings: IcpSettings | None = None, engine: IcpEngine | None = None):
         self.settings = settings if settings is not None else get_addon_preferences()
-        self.engine = engine if engine is not None else default_engine()
+        self.engine = engine if engine is not None else default_engine(devices=getattr(self.settings, "devices", None))
 
     def run(self, source_xyz, target_xyz, mx_align, mx_base, vlist=None, early_exit=True,
             target_tris=None) -> RunResult:
@@ -152,9 +155,18 @@ class OBJECT_OT_icp_align(_OperatorBase):
             pass
         vlist = vlist_for_engine(align_obj)
         base_geo = evaluated_base(base_obj, context)            # BVHTree.FromObject(base_obj, depsgraph)  (:52-53)
-        res = IcpAlign(settings).run(_coords_of(align_obj), _coords_of(base_geo),
-                                     _matrix_to_np(align_obj.matrix_world), _matrix_to_np(base_obj.matrix_world),
-                                     vlist=vlist, target_tris=_tris_of(base_geo))
+        failure = None
+        try:
+            res = IcpAlign(settings).run(_coords_of(align_obj), _coords_of(base_geo),
+                                         _matrix_to_np(align_obj.matrix_world), _matrix_to_np(base_obj.matrix_world),
+                                         vlist=vlist, target_tris=_tris_of(base_geo))
+        except ValueError as exc:
+            # fewer than 3 pairs in iteration n: the reference has already applied iterations 0..n-1 to align_obj and
+            # the m_* objects when affine_matrix_from_points raises (:109 after :121-127 of the earlier passes)
+            res = getattr(exc, "partial", None)
+            if res is None:
+                raise
+            failure = exc
         _assign_matrix(align_obj, res.matrix_world)
         if settings.take_m_with:                                # :123-127, replayed in iteration order
             from .. import _hostmath
@@ -172,4 +184,6 @@ class OBJECT_OT_icp_align(_OperatorBase):
         if hasattr(context, "view_layer") and hasattr(context.view_layer, "update"):
             context.view_layer.update()
         self.last_result = res
+        if failure is not None:
+            raise failure
         return {'FINISHED'}

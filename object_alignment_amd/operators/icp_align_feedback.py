@@ -129,7 +129,7 @@ class OBJECT_OT_icp_align_feedback(_OperatorBase):
 
     # ------------------------------------------------------------------ helpers
     def _upload(self, run, stride, context=None):
-        eng = self.engine = default_engine()
+        eng = self.engine = default_engine(devices=getattr(get_addon_preferences(), "devices", None))
         base_geo = evaluated_base(run.base_obj, context)         # the evaluated mesh, as the reference's BVH (:57)
         tris = _tris_of(base_geo)
         if tris is None:

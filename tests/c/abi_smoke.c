@@ -49,8 +49,32 @@ int main(void)
     /* expected matrix_world = inverse of the motion applied above: rotation +0.05 about z, then the shift undone */
     const double ex = fabs(mw[0] - cos(0.05)) + fabs(mw[1] + sin(0.05)) + fabs(mw[3] - 0.01) + fabs(mw[7] + 0.02) + fabs(mw[11] - 0.015);
     oa_destroy(ctx);
-    free(tgt); free(src);
     if (!rep.converged || ex > 1e-3) { printf("unexpected result (err %.3g)\n", ex); return 1; }
+
+    /* the same job through a multi-device context (oa_create(&ctx, devices, n_dev)): every visible GPU, or
+     * -- on a one-GPU box -- device 0 listed twice; no torch, no launcher, the exchange lives inside the library */
+    int devs[64];
+    int n_multi = n_dev >= 2 ? (n_dev > 64 ? 64 : n_dev) : 2;
+    for (int i = 0; i < n_multi; ++i) devs[i] = n_dev >= 2 ? i : 0;
+    oa_ctx *mctx = NULL;
+    if (oa_create_multi(&mctx, devs, n_multi) != OA_OK) { printf("oa_create_multi: %s\n", oa_last_error()); return 1; }
+    if (oa_num_devices(mctx) != n_multi) { printf("oa_num_devices\n"); return 1; }
+    if (oa_set_target(mctx, tgt, N, 0) || oa_set_source(mctx, src, N, 0, NULL, 0, 1, 0, 1) || oa_set_matrices(mctx, eye, eye)) {
+        printf("multi setup failed: %s\n", oa_last_error());
+        return 1;
+    }
+    if (oa_num_selected(mctx) != N) { printf("multi: %lld selected\n", (long long)oa_num_selected(mctx)); return 1; }
+    oa_report mrep;
+    if (oa_run(mctx, &st, &mrep) != OA_OK) { printf("multi oa_run: %s\n", oa_last_error()); return 1; }
+    float mw2[16];
+    oa_get_matrix_world(mctx, mw2);
+    double dm = 0.0;
+    for (int i = 0; i < 16; ++i) dm += fabs((double)mw2[i] - (double)mw[i]);
+    printf("multi (%d devices): iters %d converged %d K %lld  |dM|_1 vs single = %.3g\n", n_multi, mrep.iters_done,
+           mrep.converged, (long long)mrep.last_K, dm);
+    oa_destroy(mctx);
+    free(tgt); free(src);
+    if (mrep.iters_done != rep.iters_done || mrep.last_K != rep.last_K || dm > 1e-5) { printf("multi-device result differs\n"); return 1; }
     printf("ABI_SMOKE_OK device\n");
     return 0;
 }

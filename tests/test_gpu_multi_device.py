@@ -1,0 +1,228 @@
+"""The multi-device context (oa_create_multi): one process drives every GPU, the per-iteration
+exchange of the 24 sums lives inside liboa_icp.so.  On the one-GPU test box the device list names device 0 several
+times -- the same exchange code (k_reduce_post / k_gather_solve_update, or RCCL with a world of one)."""
+import os
+import socket
+import subprocess
+import sys
+import json
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+F32_ULP = 2.5e-7
+LOOPS = ["icp_loop_ico_10", "icp_loop_bumpy_converge", "icp_loop_include", "icp_loop_exclude", "icp_loop_bumpy_scale"]
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"), allow_pickle=False)
+
+
+def _run_fixture(g, eng, mode="auto"):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_parity import _settings_from
+    from object_alignment_amd.operators import IcpAlign
+    eng.set_search_mode(mode)
+    return IcpAlign(_settings_from(g), engine=eng).run(g["src"], g["tgt"], g["mx_align"], g["mx_base"], vlist=g["vlist"])
+
+
+@pytest.mark.parametrize("n_dev", [1, 2, 8])
+@pytest.mark.parametrize("name", LOOPS)
+def test_multi_context_reproduces_the_reference_loops(golden_dir, name, n_dev):
+    """The fixtures of the reference's own execute() through n_dev shards and the in-library exchange: iteration
+    count, convergence flag and K per iteration exact, per-iteration M 1e-9, final float32 matrix within 1 ulp --
+    the bar the single-device loop is held to."""
+    from object_alignment_amd.engine import IcpEngine
+    g = _load(golden_dir, name)
+    with IcpEngine(devices=[0] * n_dev) as eng:
+        assert eng.multi and len(eng.devices) == n_dev
+        res = _run_fixture(g, eng)
+    assert res.iters_done == int(g["iters_done"]) and res.converged == bool(g["converged"])
+    assert np.array_equal(res.step_K, g["step_K"])
+    assert np.abs(res.step_M - g["step_M"]).max() < 1e-9
+    assert np.abs(res.matrix_world - g["final_world"]).max() <= F32_ULP
+
+
+def test_multi_context_equals_hand_driven_shards(golden_dir):
+    """Same shards, same fixed-order reduction, sums added in rank order: the library's exchange must give the very
+    bits the split-phase loop gives when the caller adds the two ranks' sums itself."""
+    import torch
+    from object_alignment_amd import _capi
+    from object_alignment_amd.engine import IcpEngine
+    g = _load(golden_dir, "icp_loop_bumpy_converge")
+    kw = dict(iters=int(g["iters_done"]), thresh=0.5, target_d=0.01, use_target=True, early_exit=True)
+    dev = torch.device("cuda:0")
+    engs = [IcpEngine(0) for _ in range(2)]
+    try:
+        sums = [torch.zeros(_capi.OA_NSUMS, dtype=torch.float64, device=dev) for _ in range(2)]
+        for r, e in enumerate(engs):
+            e.set_stream(torch.cuda.current_stream().cuda_stream)
+            e.set_target(g["tgt"])
+            e.set_source(g["src"], stride=1, shard_index=r, shard_count=2)
+            e.set_matrices(g["mx_align"], g["mx_base"])
+            e.run_begin(**kw)
+        for _ in range(kw["iters"]):
+            for r, e in enumerate(engs):
+                e.iter_partial(sums[r].data_ptr())
+            total = sums[0] + sums[1]
+            for e in engs:
+                e.iter_finish(total.data_ptr())
+        hand = [e.run_end() for e in engs][0]
+    finally:
+        for e in engs:
+            e.close()
+    with IcpEngine(devices=[0, 0]) as m:
+        m.set_target(g["tgt"])
+        m.set_source(g["src"], stride=1)
+        assert m.n_selected == len(g["src"])
+        m.set_matrices(g["mx_align"], g["mx_base"])
+        res = m.run(**kw)
+    assert res.iters_done == hand.iters_done and res.converged == hand.converged
+    assert np.array_equal(res.step_K, hand.step_K)
+    assert np.array_equal(res.step_M, hand.step_M)
+    assert np.array_equal(res.matrix_world, hand.matrix_world)
+
+
+@pytest.mark.parametrize("surface", [False, True])
+def test_multi_iterate_equals_run(surface):
+    """The modal step on a multi-device context walks the same iterations as its oa_run."""
+    from object_alignment_amd import synth
+    from object_alignment_amd.engine import IcpEngine
+    v, t = synth.bumpy_icosphere_mesh(4)
+    src = (synth.bumpy_icosphere(4)[::2] * np.float32(1.01)).astype(np.float32)
+    mxa = synth.rigid4(synth.rotation_from_rotvec([0.03, -0.02, 0.04]), [0.02, -0.01, 0.015])
+    eye = np.identity(4, dtype=np.float32)
+    with IcpEngine(devices=[0, 0, 0]) as m:
+        if surface:
+            m.set_target_mesh(v, t)
+        else:
+            m.set_target(v)
+        m.set_source(src)
+        m.set_matrices(mxa, eye)
+        res = m.run(iters=6, thresh=0.5, early_exit=False)
+        m.set_matrices(mxa, eye)
+        steps = [m.iterate(thresh=0.5)[0] for _ in range(6)]
+        mw = m.matrix_world()
+    assert np.array_equal(np.stack(steps), res.step_M)
+    assert np.array_equal(mw, res.matrix_world)
+
+
+def test_rccl_exchange_world_of_one(golden_dir):
+    """OA_EXCHANGE_RCCL on one GPU: librccl is loaded by the library, ncclCommInitAll builds a communicator of one
+    and ncclAllReduce runs on the context's stream every iteration.  Identity for one rank: same bits as the mailbox."""
+    from object_alignment_amd.engine import IcpEngine
+    g = _load(golden_dir, "icp_loop_bumpy_converge")
+    with IcpEngine(devices=[0], exchange="rccl") as e:
+        res = _run_fixture(g, e)
+    with open("/proc/self/maps") as f:
+        assert "librccl" in f.read()
+    with IcpEngine(devices=[0]) as e:
+        ref = _run_fixture(g, e)
+    assert res.iters_done == int(g["iters_done"]) and res.converged
+    assert np.array_equal(res.step_M, ref.step_M) and np.array_equal(res.matrix_world, ref.matrix_world)
+    assert np.abs(res.matrix_world - g["final_world"]).max() <= F32_ULP
+
+
+def test_rccl_exchange_refuses_duplicate_devices():
+    from object_alignment_amd import _capi
+    from object_alignment_amd.engine import IcpEngine
+    with IcpEngine(devices=[0, 0]) as e:
+        with pytest.raises(_capi.OaError) as ei:
+            e.set_exchange("rccl")
+        assert ei.value.code == _capi.OA_E_RCCL
+
+
+def test_torch_distributed_rccl_world_of_one(golden_dir):
+    """The one-process-per-GPU path's collective: torch.distributed backend "nccl" (= RCCL) with a world of one, the
+    all-reduce forced inside run_sharded -- the call the driver's multi-GPU bench issues, executed for real."""
+    code = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from object_alignment_amd.engine import IcpEngine
+from object_alignment_amd.distributed import EngineShard, run_sharded, new_sums_tensor
+g = np.load(%r)
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+with IcpEngine(0) as e:
+    e.set_target(g["tgt"]); e.set_source(g["src"], stride=1); e.set_matrices(g["mx_align"], g["mx_base"])
+    sums = new_sums_tensor(torch.device("cuda:0"))
+    res = run_sharded(EngineShard(e, iters=30, thresh=0.5, target_d=0.01, use_target=True, early_exit=True), 30, sums,
+                      world_size=1, force_collective=True)
+dist.barrier(); dist.destroy_process_group()
+assert "librccl" in open("/proc/self/maps").read()
+assert res.iters_done == int(g["iters_done"]) and res.converged
+assert np.abs(res.matrix_world - g["final_world"]).max() <= 2.5e-7
+print("RCCL_WORLD1_OK")
+''' % (ROOT, os.path.join(golden_dir, "icp_loop_bumpy_converge.npz"))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0 and "RCCL_WORLD1_OK" in p.stdout, p.stdout[-3000:]
+
+
+def test_operator_execute_on_a_multi_device_engine(golden_dir, orc):
+    """OBJECT_OT_icp_align.execute with the `devices` setting: the reference's single call (operators/icp_align.py:
+    47-161), sharded over the device list inside the library; vertex groups and m_ objects as in the fixture."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_parity import _duck_scene, _settings_from
+    from object_alignment_amd.operators import OBJECT_OT_icp_align, icp_align
+    g = _load(golden_dir, "icp_loop_exclude")
+    prefs = icp_align.get_addon_preferences()
+    try:
+        for k, v in _settings_from(g).__dict__.items():
+            setattr(prefs, k, v)
+        prefs.devices = [0, 0, 0, 0]
+        ctx, align, m_obj = _duck_scene(g, orc)
+        op = OBJECT_OT_icp_align()
+        assert op.execute(ctx) == {"FINISHED"}
+        assert op.last_result.iters_done == int(g["iters_done"])
+        assert np.array_equal(op.last_result.step_K, g["step_K"])
+        got = np.array([[align.matrix_world[r][c] for c in range(4)] for r in range(4)], np.float32)
+        assert np.abs(got - g["final_world"]).max() <= F32_ULP
+    finally:
+        for k, v in icp_align.IcpSettings().__dict__.items():
+            setattr(prefs, k, v)
+
+
+def test_device_memory_returns_after_destroy():
+    """Default settings: the allocation cache holds at most 256 MiB while a context lives and nothing once the last
+    context is gone -- device memory is back where it was (the library is a guest in the host application)."""
+    import torch
+    from object_alignment_amd import synth
+    from object_alignment_amd.engine import IcpEngine
+    from object_alignment_amd import _capi
+    torch.cuda.init()
+    _capi.load().oa_release_cached_memory()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info(0)
+    src, tgt, mxa, mxb = synth.c3_random_pair(400_000)
+    for _ in range(2):
+        with IcpEngine(0) as e:
+            e.set_target(tgt)
+            e.set_source(src)
+            e.set_matrices(mxa, mxb)
+            e.run(iters=3, thresh=0.5, early_exit=False)
+            e.set_target(tgt[:300_000])                        # a re-upload leaves released blocks in the cache
+            free_live, _ = torch.cuda.mem_get_info(0)
+            assert free0 - free_live > 20 << 20                # the context really holds device memory
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info(0)
+    assert free0 - free1 <= 8 << 20, (free0, free1)            # back to the baseline (allowing for runtime-internal pools)
+
+
+def test_bench_self_launches_multi_gpu():
+    """`python bench.py --gpus 2` with no launcher: one process, the multi-device context; one JSON line, n_gpus 2."""
+    env = dict(os.environ, OA_BENCH_SAME_DEVICE="1")
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--n-source", "120000",
+           "--n-target", "100000", "--no-cpu-baseline", "--no-surface"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, text=True)
+    assert p.returncode == 0, p.stdout[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["unit"] == "iterations/s" and d["value"] > 0
+    assert "in-library" in d["config"]["parallelism"]
