@@ -13,7 +13,7 @@ import numpy as np
 from ..engine import IcpEngine, REF_VALUEERROR
 
 __all__ = ["make_pairs", "affine_matrix_from_points", "calc_target_matrix", "GpuBVH", "AlignObject", "default_engine",
-           "invalidate_cached_geometry"]
+           "invalidate_cached_geometry", "close_default_engines"]
 
 _default_engines = {}
 
@@ -31,6 +31,17 @@ def default_engine(device: int = 0, devices=None) -> IcpEngine:
         eng = IcpEngine(devices=devs) if key[0] == "multi" else IcpEngine(key[1])
         _default_engines[key] = eng
     return eng
+
+
+def close_default_engines():
+    """Destroy the process-wide engines (their device memory, and -- once no context is left -- the library's
+    allocation cache, go back to the driver).  They are created again on the next use."""
+    for eng in list(_default_engines.values()):
+        try:
+            eng.close()
+        except Exception:
+            pass
+    _default_engines.clear()
 
 
 # ------------------------------------------------------------------ object adapters

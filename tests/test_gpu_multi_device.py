@@ -195,7 +195,11 @@ def test_device_memory_returns_after_destroy():
     from object_alignment_amd import synth
     from object_alignment_amd.engine import IcpEngine
     from object_alignment_amd import _capi
+    from object_alignment_amd.functions.general import close_default_engines
+    import gc
     torch.cuda.init()
+    close_default_engines()                                    # engines other tests left alive keep the cache alive
+    gc.collect()
     _capi.load().oa_release_cached_memory()
     torch.cuda.synchronize()
     free0, _ = torch.cuda.mem_get_info(0)
