@@ -30,7 +30,21 @@ struct GridParams {
     int    seeded_start;     // 1: a seeded query starts with the 3 x 3 x 3 block instead of its own cell (OA_GRID_SEEDED_START)
     int    budget;           // candidates one thread may look at before it hands the query to the tree search
                              // (crowded cells -- clusters, fans of thin triangles -- would otherwise stall its wave)
+    // float images for the per-row arithmetic of the searches (GridQuery): cell edge, its inverse, and a slack that
+    // covers `slack` above plus every float rounding between the double cell frame and a gap (< 2e-6 h), rounded up
+    float  hf, inv_hf, slackf;
+    float  eps_plane;        // triangle grid: how far a triangle's corners may lie from the plane of its record (oa_tri.hpp)
 };
+
+// host: fill the float fields from h / slack
+inline void grid_params_finish(GridParams &gp)
+{
+    gp.hf = (float)gp.h;
+    gp.inv_hf = (float)gp.inv_h;
+    const double s = (gp.slack + 4e-6 * gp.h) * (1.0 + 1e-6);
+    gp.slackf = (float)s;
+    if ((double)gp.slackf < s) gp.slackf = nextafterf(gp.slackf, INFINITY);
+}
 
 #if defined(__HIPCC__)
 
@@ -90,6 +104,85 @@ __global__ void k_grid_scatter(const float *__restrict__ xyz, int nt, const int 
     sorted[pos] = make_float4(xyz[3ll * i], xyz[3ll * i + 1], xyz[3ll * i + 2], __int_as_float(i));
 }
 
+// ---- the query's frame in the grid -----------------------------------------------------------------------------------
+// Located once per query in double (projection onto the grid's box, own cell, position inside that cell); everything
+// per row / per ring afterwards is float arithmetic on three numbers per axis.  All distances derived from it are
+// LOWER bounds: the distance from the projected query pc to the slab of cells c + d along an axis is
+//     d > 0:  d h - f        d < 0:  (-d - 1) h + f        (f = pc - (lo + c h), the position inside the own cell)
+// minus `slackf`, which covers the double-level noise of the build's cell assignment and every float rounding here.
+struct GridQuery {
+    int   c[3];        // own cell (of the projection onto the box)
+    float f[3];        // position of the projection inside the own cell, along each axis
+    float off2;        // squared distance query -> box (0 inside)
+    bool  finite;
+};
+
+__device__ __forceinline__ GridQuery grid_locate(const GridParams &gp, float px, float py, float pz, double *pabs = nullptr)
+{
+    GridQuery q;
+    const double p[3] = { (double)px, (double)py, (double)pz };
+    double off2 = 0.0, pa = 0.0;
+    q.finite = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (!(fabs(p[a]) < INFINITY)) q.finite = false;
+        pa += fabs(p[a]);
+        const double pc = p[a] < gp.lo[a] ? gp.lo[a] : (p[a] > gp.hi[a] ? gp.hi[a] : p[a]);
+        const double d = p[a] - pc;
+        off2 += d * d;
+        q.c[a] = grid_cell_coord(pc, gp.lo[a], gp.inv_h, gp.n[a]);
+        q.f[a] = (float)(pc - (gp.lo[a] + (double)q.c[a] * gp.h));
+    }
+    q.off2 = (float)off2;
+    if (pabs) *pabs = pa;
+    return q;
+}
+
+// lower bound of the distance from the projected query to the slab of cells c + d along one axis
+__device__ __forceinline__ float grid_gap(float f, float h, float slack, int d)
+{
+    const float fd = (float)d;
+    const float g = (d > 0 ? __builtin_fmaf(fd, h, -f) : __builtin_fmaf(-fd - 1.0f, h, f)) - slack;
+    return (d != 0 && g > 0.f) ? g : 0.f;
+}
+
+// A row of cells (fixed y, z) at squared distance >= row2 from the query, searched for everything within squared
+// reach `w2 = reach^2 - row2` along x: how many cells left / right of the own column can still matter (0..r each).
+// Over-inclusion is harmless.  r == 1 needs no square root.
+__device__ __forceinline__ void grid_row_span(float fx, float h, float inv_h, float slack, float w2, int r, int &dl, int &dr)
+{
+    if (!(w2 < 3.0e38f)) { dl = r; dr = r; return; }
+    if (w2 < 0.f) w2 = 0.f;
+    if (r == 1) {
+        const float gl = fmaxf(fx - slack, 0.f), gr = fmaxf((h - fx) - slack, 0.f);
+        dl = (gl * gl <= w2) ? 1 : 0;
+        dr = (gr * gr <= w2) ? 1 : 0;
+        return;
+    }
+    // gap(-d) = (d - 1) h + fx - slack <= sw  <=>  d <= (sw - fx + slack) / h + 1   (and the mirror image to the right)
+    const float sw = grid_sqrt_up(w2) + slack;
+    const float fr = (float)r;
+    const float tl = fminf(fmaxf(__builtin_floorf((sw - fx) * inv_h * 1.000001f) + 1.0f, 0.f), fr);
+    const float tr = fminf(fmaxf(__builtin_floorf((sw - (h - fx)) * inv_h * 1.000001f) + 1.0f, 0.f), fr);
+    dl = (int)tl; dr = (int)tr;
+}
+
+// lower bound of the squared distance from the query to anything outside the cube of Chebyshev radius r around the
+// own cell (only faces interior to the grid count); +inf when the cube covers the grid
+__device__ __forceinline__ float grid_cube_bound2(const GridParams &gp, const GridQuery &q, int r)
+{
+    float m = INFINITY;
+    const float fr = (float)r;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (q.c[a] - r > 0) m = fminf(m, __builtin_fmaf(fr, gp.hf, q.f[a]));                  // f + r h
+        if (q.c[a] + r + 1 < gp.n[a]) m = fminf(m, __builtin_fmaf(fr + 1.0f, gp.hf, -q.f[a]));   // (r + 1) h - f
+    }
+    if (!(m < INFINITY)) return INFINITY;
+    m = fmaxf(m - gp.slackf, 0.f);
+    return __builtin_fmaf(m, m, q.off2);
+}
+
 // `bj` follows the winner's position in `sorted` (-1: still the seed)
 __device__ __forceinline__ void grid_candidate(float px, float py, float pz, const float4 q, int j, float &best,
                                                uint32_t &bidx, int &bj)
@@ -121,6 +214,7 @@ __global__ __launch_bounds__(256, 5) void k_nn_search_grid(const DevState *__res
     const int i = gt / L, sub = gt % L;                             // the L lanes of a query are neighbours in a wave
     if (i >= ns) return;
     const float4 p4 = src4[i];
+    const float4 sw = win[i];                                       // seed: this slot's winner record, see below
     float wx, wy, wz, px, py, pz;
     m4_mul_v3(st->mx1, p4.x, p4.y, p4.z, wx, wy, wz);
     m4_mul_v3(st->imx2, wx, wy, wz, px, py, pz);                // co_find (general.py:287)
@@ -130,26 +224,13 @@ __global__ __launch_bounds__(256, 5) void k_nn_search_grid(const DevState *__res
     float best = INFINITY;
     uint32_t bidx = IDX_NONE;
     int bj = -1;
-    {
-        const float4 sw = win[i];
-        if (__float_as_int(sw.w) >= 0) {
-            const float d = d2_metric(px, py, pz, sw.x, sw.y, sw.z);
-            if (d < INFINITY) { best = d; bidx = (uint32_t)__float_as_int(sw.w); }
-        }
+    if (__float_as_int(sw.w) >= 0) {
+        const float d = d2_metric(px, py, pz, sw.x, sw.y, sw.z);
+        if (d < INFINITY) { best = d; bidx = (uint32_t)__float_as_int(sw.w); }
     }
 
-    // projection of the query onto the grid's box, and its cell
-    const double p[3] = { (double)px, (double)py, (double)pz };
-    double pc[3], off2 = 0.0;
-    int c[3];
-    bool finite = true;
-    for (int a = 0; a < 3; ++a) {
-        if (!(fabs(p[a]) < INFINITY)) finite = false;
-        pc[a] = p[a] < gp.lo[a] ? gp.lo[a] : (p[a] > gp.hi[a] ? gp.hi[a] : p[a]);
-        const double d = p[a] - pc[a];
-        off2 += d * d;
-        c[a] = grid_cell_coord(pc[a], gp.lo[a], gp.inv_h, gp.n[a]);
-    }
+    const GridQuery q = grid_locate(gp, px, py, pz);
+    const float h = gp.hf, inv_h = gp.inv_hf, slack = gp.slackf;
     // `lim` = what an unseen vertex has to beat: the best so far, or the search radius beyond which the pair test
     // (dist < thresh) fails anyway, whichever is smaller
     const float cutf = search_cutoff2(st, px, py, pz);
@@ -170,15 +251,14 @@ __global__ __launch_bounds__(256, 5) void k_nn_search_grid(const DevState *__res
     // loads its own cell only -- and a query near a face (a quarter of them at 1M <-> 1M) saves the separate pass,
     // i.e. two round trips of the wave it shares with 63 others.
     const int r_start = (bidx != IDX_NONE && gp.seeded_start) ? 1 : 0;
-    if (finite) {
+    if (q.finite) {
         for (int r = r_start; r <= gp.r_max && !settled && !over; ++r) {
-            const int x0 = max(c[0] - r, 0), x1 = min(c[0] + r, gp.n[0] - 1);
             // The (2r+1)^2 rows (y, z) of the ring are handled BATCH at a time: first the cell ranges of a lane's rows
             // are fetched (up to 36 independent loads in flight), then their vertices are scanned four per trip.  A
             // thread's time is a chain of memory round trips; this keeps the chain at ~2 + (vertices / 4) per batch
             // instead of 2 per row + 1 per vertex.
             const int side = 2 * r + 1, n_rows = side * side;
-            const unsigned div_mul = 65536u / (unsigned)side + 1u;  // k / side == (k * div_mul) >> 16 for k < 64, side <= 7
+            const unsigned div_mul = 65536u / (unsigned)side + 1u;  // k / side == (k * div_mul) >> 16 for k < 256, side <= 15
             for (int b0 = 0; b0 < n_rows && !over; b0 += BATCH) {
                 int ja[RPL], jb[RPL], jc[RPL], jd[RPL];             // row m: vertices [ja, jb) and [jc, jd) of `sorted`
 #pragma unroll
@@ -188,30 +268,25 @@ __global__ __launch_bounds__(256, 5) void k_nn_search_grid(const DevState *__res
                     if (kk >= n_rows) continue;
                     const int qz = (int)(((unsigned)kk * div_mul) >> 16);
                     const int dzi = qz - r, dyi = kk - qz * side - r;
-                    const int z = c[2] + dzi, y = c[1] + dyi;
+                    const int z = q.c[2] + dzi, y = q.c[1] + dyi;
                     if (z < 0 || z >= gp.n[2] || y < 0 || y >= gp.n[1]) continue;
-                    // every vertex of this row of cells is at real distance^2 >= off2 + dy^2 + dz^2 from the query
-                    const double dz = grid_axis_gap(pc[2], gp.lo[2], gp.h, z, gp.slack);
-                    const double dy = grid_axis_gap(pc[1], gp.lo[1], gp.h, y, gp.slack);
-                    const double row2 = off2 + dz * dz + dy * dy;
-                    if (row2 * (1.0 - 1e-5) - 1e-30 > (double)lim) continue;       // cannot beat or tie
-                    // cells of the row that can still matter: |x - pc.x| <= sqrt(lim' - row2)
-                    int xa = x0, xb = x1;
-                    if (lim < INFINITY) {
-                        const double w2 = (double)lim * (1.0 + 1e-5) + 1e-30 - row2 * (1.0 - 1e-5);
-                        const double w = (double)grid_sqrt_up((float)(w2 > 0.0 ? w2 * (1.0 + 1e-6) : 0.0)) + gp.slack;
-                        xa = max(xa, grid_cell_coord(pc[0] - w, gp.lo[0], gp.inv_h, gp.n[0]));
-                        xb = min(xb, grid_cell_coord(pc[0] + w, gp.lo[0], gp.inv_h, gp.n[0]));
-                    }
+                    // every vertex of this row of cells is at real distance^2 >= off2 + gy^2 + gz^2 from the query
+                    const float gz = grid_gap(q.f[2], h, slack, dzi), gy = grid_gap(q.f[1], h, slack, dyi);
+                    const float row2 = __builtin_fmaf(gy, gy, __builtin_fmaf(gz, gz, q.off2));
+                    if (row2 * 0.99999f - 1e-30f > lim) continue;                   // cannot beat or tie
+                    // cells of the row that can still matter: x-gap^2 <= lim' - row2
+                    int dl, dr;
+                    grid_row_span(q.f[0], h, inv_h, slack, lim * 1.00001f + 1e-30f - row2 * 0.99999f, r, dl, dr);
+                    const int xa = max(q.c[0] - dl, 0), xb = min(q.c[0] + dr, gp.n[0] - 1);
                     const int row = (z * gp.n[1] + y) * gp.n[0];
                     // interior rows were fully covered by ring r-1: only their two end cells are new
                     const bool shell_row = (r == r_start) || dzi == -r || dzi == r || dyi == -r || dyi == r;
                     if (shell_row) {
-                        if (xa <= xb) { ja[m] = cell_start[row + xa]; jb[m] = cell_start[row + xb + 1]; }
+                        ja[m] = cell_start[row + xa]; jb[m] = cell_start[row + xb + 1];
                     } else {
-                        const int xl = c[0] - r, xr = c[0] + r;
-                        if (xl >= xa && xl <= xb) { ja[m] = cell_start[row + xl]; jb[m] = cell_start[row + xl + 1]; }
-                        if (xr >= xa && xr <= xb) { jc[m] = cell_start[row + xr]; jd[m] = cell_start[row + xr + 1]; }
+                        const int xl = q.c[0] - r, xr = q.c[0] + r;
+                        if (dl == r && xl >= 0) { ja[m] = cell_start[row + xl]; jb[m] = cell_start[row + xl + 1]; }
+                        if (dr == r && xr < gp.n[0]) { jc[m] = cell_start[row + xr]; jd[m] = cell_start[row + xr + 1]; }
                     }
                 }
 #pragma unroll
@@ -251,19 +326,9 @@ __global__ __launch_bounds__(256, 5) void k_nn_search_grid(const DevState *__res
                 }
             }
             if (over) break;
-            // lower bound for everything outside the cube of radius r
-            double m = INFINITY;
-            for (int a = 0; a < 3; ++a) {
-                if (c[a] - r > 0) { const double f = pc[a] - (gp.lo[a] + (double)(c[a] - r) * gp.h); m = f < m ? f : m; }
-                if (c[a] + r + 1 < gp.n[a]) { const double f = (gp.lo[a] + (double)(c[a] + r + 1) * gp.h) - pc[a]; m = f < m ? f : m; }
-            }
-            if (!(m < INFINITY)) settled = true;                 // the cube covers the whole grid
-            else {
-                m -= gp.slack;
-                m = m > 0.0 ? m : 0.0;
-                const double bound = (off2 + m * m) * (1.0 - 1e-5) - 1e-30;
-                if (bound > (double)lim) settled = true;         // no unseen vertex can beat or tie `best`, or matter
-            }
+            // lower bound for everything outside the cube of radius r (+inf: the cube covers the whole grid)
+            const float bound = grid_cube_bound2(gp, q, r);
+            if (!(bound < INFINITY) || bound * 0.99999f - 1e-30f > lim) settled = true;   // no unseen vertex can beat or tie, or matter
         }
     }
     if (sub != 0) return;

@@ -249,8 +249,8 @@ struct oa_ctx {
     int n_tris = 0;
     float4 *d_tri9 = nullptr;
     oa::GridParams tgp;
-    int *d_tcell_start = nullptr, *d_tcell_tris = nullptr;
-    float4 *d_tcell_sph = nullptr;   // bounding sphere of each cell-list entry (same order as d_tcell_tris)
+    int *d_tcell_start = nullptr;
+    float4 *d_tcell_rec = nullptr;   // two float4 per cell-list entry: {disc centre, radius} {unit normal, triangle index}
     long long n_tri_entries = 0;     // entries of the triangle grid's cell lists
     // bounding-box trees (oa_bvh.hpp): over the vertices, and over the triangles in surface mode
     bool bvh_ok = false, tbvh_ok = false;
@@ -266,6 +266,7 @@ struct oa_ctx {
     int grid_lanes = 0;              // OA_GRID_LANES: lanes per query of k_nn_search_grid (0 = by shard size)
     double turn_frac = 0.1;          // OA_TURN_FRAC: the tree keeps its turn while the pose moves by more than this part of a cell
     bool debug = false;              // OA_DEBUG (read at oa_create)
+    bool grid_stats = false;         // OA_GRID_STATS: instrumented triangle-grid launches print what the queries did
     int turns_on = 1;                // OA_SEARCH_TURNS: tree while the pose moves, grid afterwards (mid-size shards, AUTO)
     bool seeded = false;             // a search has run since the last set_source / set_target (seeds exist)
     int *d_prev = nullptr;           // nearest index of the previous search (seed), -1 = none
@@ -1037,6 +1038,7 @@ OA_EXPORT int oa_create(oa_ctx **out, int device)
     c->grid_lanes = env_int("OA_GRID_LANES", 0);
     c->turns_on = env_int("OA_SEARCH_TURNS", 1);
     c->debug = getenv("OA_DEBUG") != nullptr;
+    c->grid_stats = env_int("OA_GRID_STATS", 0) != 0;
     c->turn_frac = env_double("OA_TURN_FRAC", 0.1);
     c->use_filter = env_int("OA_NN_FILTER", 1) != 0;
     c->grid_mode = env_int("OA_NN_GRID", -1);
@@ -1130,7 +1132,7 @@ OA_EXPORT void oa_destroy(oa_ctx *c)
     OA_FREE(d_partials); OA_FREE(d_sums); OA_FREE(d_solve);
     OA_FREE(d_valid); OA_FREE(d_b); OA_FREE(d_dist); OA_FREE(d_counts); OA_FREE(d_offsets); OA_FREE(d_A); OA_FREE(d_B);
     OA_FREE(d_bvh_box); OA_FREE(d_bvh_prims); OA_FREE(d_tbvh_box); OA_FREE(d_tbvh_prims);
-    OA_FREE(d_tri9); OA_FREE(d_tcell_start); OA_FREE(d_tcell_tris); OA_FREE(d_tcell_sph);
+    OA_FREE(d_tri9); OA_FREE(d_tcell_start); OA_FREE(d_tcell_rec);
     OA_FREE(d_sel); OA_FREE(d_src_n); OA_FREE(d_tgt_n); OA_FREE(d_src4o); OA_FREE(d_perm);
 #undef OA_FREE
     if (c->h_hist_map) (void)hipHostFree(c->h_hist_map);
@@ -1265,6 +1267,7 @@ int build_grid(oa_ctx *c)
         gp.budget = env_int("OA_GRID_BUDGET", 128);
         gp.slack = 1e-10 * scale + 1e-300;
         gp.scale = scale;
+        oa::grid_params_finish(gp);
         n_cells = (int)total;
         HIPCHK(d_counts.alloc((size_t)n_cells + 1));
         HIPCHK(d_off.alloc((size_t)n_cells + 1));
@@ -1309,7 +1312,7 @@ int set_target_common(oa_ctx *c, const float *xyz, int64_t n, int on_device, boo
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
     dev_free(c->d_tgt_xyz); dev_free(c->d_tg); dev_free(c->d_tf); dev_free(c->d_tf3);
-    dev_free(c->d_tri9); dev_free(c->d_tcell_start); dev_free(c->d_tcell_tris); dev_free(c->d_tcell_sph);
+    dev_free(c->d_tri9); dev_free(c->d_tcell_start); dev_free(c->d_tcell_rec);
     dev_free(c->d_bvh_box); dev_free(c->d_bvh_prims); dev_free(c->d_tbvh_box); dev_free(c->d_tbvh_prims);
     c->surface = false; c->tri_grid_ok = false; c->n_tris = 0; c->bvh_ok = false; c->tbvh_ok = false;
     dev_free(c->d_tgt_n);
@@ -1539,7 +1542,7 @@ int sort_source_slots(oa_ctx *c, const float *d_xyz, long long n_verts)
 int build_tri_grid(oa_ctx *c)
 {
     c->tri_grid_ok = false;
-    dev_free(c->d_tcell_start); dev_free(c->d_tcell_tris); dev_free(c->d_tcell_sph);
+    dev_free(c->d_tcell_start); dev_free(c->d_tcell_rec);
     if (!c->filter_ok || c->grid_mode == 0 || c->n_tris < 64) return OA_OK;
     DevTmp<double> d_sum;
     HIPCHK(d_sum.alloc(1));
@@ -1581,12 +1584,14 @@ int build_tri_grid(oa_ctx *c)
         gp.budget = env_int("OA_GRID_BUDGET", 128);
         gp.scale = scale;
         gp.slack = 1e-10 * scale + 1e-300;
+        oa::grid_params_finish(gp);
+        gp.eps_plane = (float)(8.0 * 5.9604644775390625e-08 * scale + 1e-37);
         n_cells = (int)total;
         HIPCHK(d_counts.alloc((size_t)n_cells + 1));
         HIPCHK(hipMemsetAsync(d_counts, 0, sizeof(int) * ((size_t)n_cells + 1), c->stream));
         HIPCHK(hipMemsetAsync(d_total, 0, sizeof(unsigned long long), c->stream));
         hipLaunchKernelGGL(oa::k_tri_grid_bin<false>, dim3((c->n_tris + 255) / 256), dim3(256), 0, c->stream, c->d_tri9,
-                           c->n_tris, gp, d_counts.p, (const int *)nullptr, (int *)nullptr, (float4 *)nullptr, d_total.p);
+                           c->n_tris, gp, d_counts.p, (const int *)nullptr, (float4 *)nullptr, d_total.p);
         HIPCHK(hipGetLastError());
         { int rcr = read_small(c, &entries, d_total, sizeof(entries)); if (rcr) return rcr; }
         // triangles much larger than a cell explode the lists: coarsen
@@ -1596,12 +1601,11 @@ int build_tri_grid(oa_ctx *c)
     if (n_cells <= 0 || entries == 0) return OA_OK;
     HIPCHK(d_off.alloc((size_t)n_cells + 1));
     HIPCHK(dev_malloc(&c->d_tcell_start, sizeof(int) * (size_t)(n_cells + 1)));
-    HIPCHK(dev_malloc(&c->d_tcell_tris, sizeof(int) * (size_t)entries));
-    HIPCHK(dev_malloc(&c->d_tcell_sph, sizeof(float4) * (size_t)entries));
+    HIPCHK(dev_malloc(&c->d_tcell_rec, sizeof(float4) * 2 * (size_t)entries));
     { int rcs = scan_counts(c, d_counts.p, n_cells, d_off.p); if (rcs) return rcs; }
     hipLaunchKernelGGL(oa::k_grid_starts, dim3((n_cells + 256) / 256), dim3(256), 0, c->stream, d_off.p, n_cells, c->d_tcell_start, d_counts.p);
     hipLaunchKernelGGL(oa::k_tri_grid_bin<true>, dim3((c->n_tris + 255) / 256), dim3(256), 0, c->stream, c->d_tri9, c->n_tris,
-                       gp, d_counts.p, (const int *)c->d_tcell_start, c->d_tcell_tris, c->d_tcell_sph, (unsigned long long *)nullptr);
+                       gp, d_counts.p, (const int *)c->d_tcell_start, c->d_tcell_rec, (unsigned long long *)nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     c->tgp = gp;
@@ -1620,7 +1624,7 @@ int launch_tri_search(oa_ctx *c)
     if (c->debug)
         fprintf(stderr, "[oa] tri search: grid=%d ns=%d n_tris=%d state=%p src4=%p tri9=%p prev=%p keys=%p todo=%p/%p cells=%p/%p\n",
                 (int)use_grid, c->ns, c->n_tris, (void *)c->d_state, (void *)c->d_src4, (void *)c->d_tri9, (void *)c->d_prev,
-                (void *)c->d_keys, (void *)c->d_todo_list, (void *)c->d_todo_count, (void *)c->d_tcell_start, (void *)c->d_tcell_tris);
+                (void *)c->d_keys, (void *)c->d_todo_list, (void *)c->d_todo_count, (void *)c->d_tcell_start, (void *)c->d_tcell_rec);
     if (use_grid) {
         if (!c->loop_active) HIPCHK(hipMemsetAsync(c->d_todo_count, 0, sizeof(int), c->stream));
         const bool dual = c->grid_mode == -1 && c->turns_on && c->ns <= tri_tree_early(c);
@@ -1630,10 +1634,26 @@ int launch_tri_search(oa_ctx *c)
         // 256 CUs: 4 lanes win up to ~128k queries, 2 lanes up to ~600k)
         int lanes = c->grid_lanes;
         if (lanes != 1 && lanes != 2 && lanes != 4) lanes = (c->ns <= 512 * c->n_cu) ? 4 : ((c->ns <= 2400 * c->n_cu) ? 2 : 1);
-#define OA_TGRID_ARGS c->d_state, c->d_src4, c->ns, c->tgp, c->d_tcell_start, c->d_tcell_tris, c->d_tcell_sph, c->d_tri9, c->d_prev, c->d_keys, c->d_todo_list, c->d_todo_count, turn
+#define OA_TGRID_ARGS c->d_state, c->d_src4, c->ns, c->tgp, c->d_tcell_start, c->d_tcell_rec, c->d_tri9, c->d_prev, c->d_keys, c->d_todo_list, c->d_todo_count, turn
         const dim3 gblocks((unsigned)(((long long)c->ns * lanes + 255) / 256));
         if (lanes == 4) hipLaunchKernelGGL(oa::k_tri_search_grid<4>, gblocks, dim3(256), 0, c->stream, OA_TGRID_ARGS);
         else if (lanes == 2) hipLaunchKernelGGL(oa::k_tri_search_grid<2>, gblocks, dim3(256), 0, c->stream, OA_TGRID_ARGS);
+        else if (c->grid_stats) {                                   // OA_GRID_STATS=1: instrumented launch, totals to stderr (synchronises)
+            DevTmp<unsigned long long> d_stats;
+            HIPCHK(d_stats.alloc(oa::TRI_STAT_N));
+            HIPCHK(hipMemsetAsync(d_stats, 0, sizeof(unsigned long long) * oa::TRI_STAT_N, c->stream));
+            hipLaunchKernelGGL((oa::k_tri_search_grid<1, true>), gblocks, dim3(256), 0, c->stream, OA_TGRID_ARGS, d_stats.p);
+            HIPCHK(hipGetLastError());
+            unsigned long long h[oa::TRI_STAT_N];
+            { int rcr = read_small(c, h, d_stats, sizeof h); if (rcr) return rcr; }
+            const double nq = (double)std::max(1ull, h[oa::TRI_STAT_QUERIES]), nw = (double)std::max(1ull, h[oa::TRI_STAT_WAVES]);
+            fprintf(stderr, "[oa] tri grid stats: queries %llu | per query: rows %.2f entries %.2f survivors %.2f evals %.2f | per wave: "
+                            "eval trips %.1f max-lane entries %.1f max-lane rows %.1f | ring>=2 %.1f%% ring>=3 %.1f%% unsettled %.1f%% over budget %.1f%%\n",
+                    h[oa::TRI_STAT_QUERIES], h[oa::TRI_STAT_ROWS] / nq, h[oa::TRI_STAT_ENTRIES] / nq, h[oa::TRI_STAT_SURVIVORS] / nq,
+                    h[oa::TRI_STAT_EVALS] / nq, h[oa::TRI_STAT_WAVE_TRIPS] / nw, h[oa::TRI_STAT_WAVE_MAX_ENTRIES] / nw,
+                    h[oa::TRI_STAT_WAVE_MAX_ROWS] / nw, 100.0 * h[oa::TRI_STAT_RING2] / nq, 100.0 * h[oa::TRI_STAT_RING3] / nq,
+                    100.0 * h[oa::TRI_STAT_UNSETTLED] / nq, 100.0 * h[oa::TRI_STAT_OVER] / nq);
+        }
         else hipLaunchKernelGGL(oa::k_tri_search_grid<1>, gblocks, dim3(256), 0, c->stream, OA_TGRID_ARGS);
 #undef OA_TGRID_ARGS
         HIPCHK(hipGetLastError());

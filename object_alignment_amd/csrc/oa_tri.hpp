@@ -73,30 +73,73 @@ __device__ __forceinline__ void tri_cell_range(const float4 *__restrict__ tri9, 
     }
 }
 
-// bounding sphere of a triangle for the cell lists: centre = centre of its bounding box, radius rounded UP, so that
-// every point of the triangle is within r of the centre (the search subtracts r from the distance to the centre)
-__device__ __forceinline__ float4 tri_sphere(const float *a, const float *b, const float *c)
+// Cell-list record of a triangle: two float4 {cx, cy, cz, r} {nx, ny, nz, bits(triangle index)}.
+//   (c, r)  smallest enclosing disc of the triangle in its own plane (centre rounded to float, radius measured from
+//           the rounded centre and rounded UP): every point of the triangle is within r of c
+//   n       unit normal scaled by (1 - 1e-6) (so |n| <= 1 after rounding), or 0 when the triangle is degenerate or its
+//           corners deviate from the plane through c by more than eps_plane (then the record is a plain sphere)
+// For x in the triangle:  |n . (p - x)| >= |n . (p - c)| - eps_plane   and   |perp(p - x)| >= |perp(p - c)| - r,
+// which gives the lower bound tri_record_bound2() -- tight where the bounding sphere is not: for a query far (compared
+// with the triangle size) from a smooth surface, dozens of triangles have spheres within reach but only the handful
+// around the foot point pass this test.  NaN corners give NaN records: never skipped, never selected.
+__device__ __forceinline__ void tri_record(const float *a, const float *b, const float *c, double eps_plane, uint32_t t,
+                                           float4 &rec0, float4 &rec1)
 {
-    float ctr[3];
-    for (int k = 0; k < 3; ++k)
-        ctr[k] = 0.5f * fminf(fminf(a[k], b[k]), c[k]) + 0.5f * fmaxf(fmaxf(a[k], b[k]), c[k]);
-    double r2 = 0.0;
-    const float *v[3] = { a, b, c };
-    for (int i = 0; i < 3; ++i) {
-        double s = 0.0;
-        for (int k = 0; k < 3; ++k) { const double d = (double)v[i][k] - (double)ctr[k]; s += d * d; }
-        r2 = s > r2 ? s : r2;
+    const double A[3] = { a[0], a[1], a[2] }, B[3] = { b[0], b[1], b[2] }, C[3] = { c[0], c[1], c[2] };
+    double ab[3], ac[3], bc[3];
+    for (int k = 0; k < 3; ++k) { ab[k] = B[k] - A[k]; ac[k] = C[k] - A[k]; bc[k] = C[k] - B[k]; }
+    const double ab2 = ab[0] * ab[0] + ab[1] * ab[1] + ab[2] * ab[2], ac2 = ac[0] * ac[0] + ac[1] * ac[1] + ac[2] * ac[2],
+                 bc2 = bc[0] * bc[0] + bc[1] * bc[1] + bc[2] * bc[2];
+    const double N[3] = { ab[1] * ac[2] - ab[2] * ac[1], ab[2] * ac[0] - ab[0] * ac[2], ab[0] * ac[1] - ab[1] * ac[0] };
+    const double n2 = N[0] * N[0] + N[1] * N[1] + N[2] * N[2];
+    double ctr[3];
+    if (ab2 >= ac2 + bc2 || !(n2 > 0.0)) for (int k = 0; k < 3; ++k) ctr[k] = 0.5 * (A[k] + B[k]);       // right / obtuse at C, or degenerate
+    else if (ac2 >= ab2 + bc2) for (int k = 0; k < 3; ++k) ctr[k] = 0.5 * (A[k] + C[k]);
+    else if (bc2 >= ab2 + ac2) for (int k = 0; k < 3; ++k) ctr[k] = 0.5 * (B[k] + C[k]);
+    else {                                                          // acute: circumcentre = A + (|ac|^2 (N x ab) + |ab|^2 (ac x N)) / (2 |N|^2)
+        const double u[3] = { N[1] * ab[2] - N[2] * ab[1], N[2] * ab[0] - N[0] * ab[2], N[0] * ab[1] - N[1] * ab[0] };
+        const double v[3] = { ac[1] * N[2] - ac[2] * N[1], ac[2] * N[0] - ac[0] * N[2], ac[0] * N[1] - ac[1] * N[0] };
+        for (int k = 0; k < 3; ++k) ctr[k] = A[k] + (ac2 * u[k] + ab2 * v[k]) / (2.0 * n2);
     }
+    if (!(n2 > 0.0)) {                                              // degenerate: the longest edge's midpoint
+        if (ac2 >= ab2 && ac2 >= bc2) for (int k = 0; k < 3; ++k) ctr[k] = 0.5 * (A[k] + C[k]);
+        else if (bc2 >= ab2 && bc2 >= ac2) for (int k = 0; k < 3; ++k) ctr[k] = 0.5 * (B[k] + C[k]);
+    }
+    const float cf[3] = { (float)ctr[0], (float)ctr[1], (float)ctr[2] };
+    double r2 = 0.0;
+    const double *V[3] = { A, B, C };
+    for (int i = 0; i < 3; ++i) {
+        double sdist = 0.0;
+        for (int k = 0; k < 3; ++k) { const double d = V[i][k] - (double)cf[k]; sdist += d * d; }
+        r2 = sdist > r2 ? sdist : r2;
+    }
+    if (!(r2 == r2) || A[0] != A[0] || B[0] != B[0] || C[0] != C[0]) r2 = NAN;   // fmax-style selects would hide a NaN corner
     const double r = sqrt(r2) * (1.0 + 1e-6) + 1e-37;
-    return make_float4(ctr[0], ctr[1], ctr[2], r < 3.0e38 ? (float)r : INFINITY);   // NaN stays NaN: never skipped, never selected
+    float rf = r < 3.0e38 ? (float)r : INFINITY;                    // NaN stays NaN
+    if ((double)rf < r) rf = nextafterf(rf, INFINITY);
+    float nf[3] = { 0.f, 0.f, 0.f };
+    if (n2 > 0.0 && n2 < 1e300) {
+        const double inv = (1.0 - 1e-6) / sqrt(n2);
+        const float cand[3] = { (float)(N[0] * inv), (float)(N[1] * inv), (float)(N[2] * inv) };
+        double e = 0.0;
+        for (int i = 0; i < 3; ++i) {
+            double dd = 0.0;
+            for (int k = 0; k < 3; ++k) dd += (double)cand[k] * (V[i][k] - (double)cf[k]);
+            e = fabs(dd) > e ? fabs(dd) : e;
+        }
+        const double len2 = (double)cand[0] * cand[0] + (double)cand[1] * cand[1] + (double)cand[2] * cand[2];
+        if (e <= eps_plane && len2 <= 1.0 && len2 >= 1.0 - 1e-5) { nf[0] = cand[0]; nf[1] = cand[1]; nf[2] = cand[2]; }
+    }
+    rec0 = make_float4(cf[0], cf[1], cf[2], rf);
+    rec1 = make_float4(nf[0], nf[1], nf[2], __uint_as_float(t));
 }
 
-// pass 0: counts[cell] += 1 for every cell overlapped; pass 1: write the triangle id (and its bounding sphere, so the
-// search can discard most candidates from one contiguous 16-byte record) at cell_start[cell] + cursor++
+// pass 0: counts[cell] += 1 for every cell overlapped; pass 1: write the triangle's record (disc, normal, index -- the
+// search discards most candidates from these 32 contiguous bytes) at cell_start[cell] + cursor++
 template <bool FILL>
 __global__ void k_tri_grid_bin(const float4 *__restrict__ tri9, int n_tris, GridParams gp, int *__restrict__ counts,
-                               const int *__restrict__ cell_start, int *__restrict__ cell_tris,
-                               float4 *__restrict__ cell_sph, unsigned long long *__restrict__ total)
+                               const int *__restrict__ cell_start, float4 *__restrict__ cell_rec,
+                               unsigned long long *__restrict__ total)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_tris) return;
@@ -104,11 +147,11 @@ __global__ void k_tri_grid_bin(const float4 *__restrict__ tri9, int n_tris, Grid
     bool ok;
     tri_cell_range(tri9, t, gp, lo, hi, ok);
     if (!ok) return;
-    float4 sph = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 rec0 = make_float4(0.f, 0.f, 0.f, 0.f), rec1 = rec0;
     if (FILL) {
         float a[3], b[3], c[3];
         load_tri(tri9, t, a, b, c);
-        sph = tri_sphere(a, b, c);
+        tri_record(a, b, c, (double)gp.eps_plane, (uint32_t)t, rec0, rec1);
     }
     unsigned long long n = 0;
     for (int z = lo[2]; z <= hi[2]; ++z)
@@ -116,9 +159,9 @@ __global__ void k_tri_grid_bin(const float4 *__restrict__ tri9, int n_tris, Grid
             for (int x = lo[0]; x <= hi[0]; ++x) {
                 const int cidx = (z * gp.n[1] + y) * gp.n[0] + x;
                 if (FILL) {
-                    const int pos = cell_start[cidx] + atomicAdd(&counts[cidx], 1);
-                    cell_tris[pos] = t;
-                    cell_sph[pos] = sph;
+                    const long long pos = cell_start[cidx] + atomicAdd(&counts[cidx], 1);
+                    cell_rec[2 * pos] = rec0;
+                    cell_rec[2 * pos + 1] = rec1;
                 } else atomicAdd(&counts[cidx], 1);
                 ++n;
             }
@@ -157,6 +200,7 @@ struct TriSearchState {
     float best; uint32_t bidx;
     float lim, thr, reach;    // lim = min(best, search radius^2); thr = squared-gap threshold; reach = sqrt(thr), rounded up
     double reach2;            // (delta + sqrt((lim + 1e-30) / (1 - 1e-5)))^2: rows / rings whose squared gap exceeds it are out
+    float reach2f;            // the same as a float, rounded up (the per-row arithmetic is float, GridQuery)
 };
 
 // everything derived from `lim` (called when the best improves: rare)
@@ -167,83 +211,177 @@ __device__ __forceinline__ void tri_state_refresh(TriSearchState &s, double delt
     if (s.lim < INFINITY) {
         const double r = (delta + sqrt(((double)s.lim + 1e-30) / (1.0 - 1e-5))) * (1.0 + 1e-9);
         s.reach2 = r * r;
-    } else s.reach2 = INFINITY;
+        const double rf = s.reach2 * (1.0 + 1e-6);
+        s.reach2f = rf < 3.0e38 ? (float)rf : INFINITY;
+    } else { s.reach2 = INFINITY; s.reach2f = INFINITY; }
 }
 
 // Cell-list candidates go through two phases so that divergence does not multiply the expensive part.  Phase 1
-// (tri_candidate): sphere test on the contiguous 16-byte record; survivors' triangle ids are pushed on a per-thread
-// queue in LDS.  Phase 2 (tri_queue_flush): every lane evaluates ITS k-th survivor in the same trip, so a wave pays
-// max-over-lanes(survivors) closest-point evaluations instead of one per candidate slot in which any lane survived
-// (measured with SQ_INSTS_VALU: 18.5k -> 9.5k instructions per wave, profiles/r01g_surface_1M_pmc_summary.txt).
-constexpr int TRI_QUEUE = 16;
+// (tri_candidate): two tests on the contiguous 32-byte record -- the bounding sphere, then for its survivors the
+// plane / in-plane-disc bound -- and what is left goes on a per-thread queue in LDS with its bound as the key.  Phase 2
+// (tri_queue_flush): every lane first evaluates its MOST PROMISING survivor (smallest key); the rest of its queue is
+// then re-tested against the improved best (LDS only), compacted, and evaluated one survivor per wave trip, so a wave
+// pays max-over-lanes(real contenders) closest-point evaluations.
+constexpr int TRI_QUEUE = 10;      // survivors a lane may hold before the wave flushes (phase 2)
+constexpr int TRI_SEGS = 10;       // cell-list ranges of one batch of rows (9 rows of the first block, or 5 rows x 2 end cells)
 
-__device__ __forceinline__ void tri_candidate(const float *p, const float4 sph, int tid, const TriSearchState &s,
-                                              int (*queue)[256], int &nq)
+// Lower bound of the squared distance from p to a triangle with record (rec0, rec1), given D2 = |p - c|^2 (float).
+// Derivation in tri_record's comment; every rounding is covered: products and sums of floats are within 4u of their
+// operands' magnitudes (u = 2^-24), the margins below are 1e-6 relative plus eps_plane + 8u rs absolute, where
+// rs >= |p - c| (the caller passed the sphere test D2 <= rs^2 (1 + 3e-6)).
+__device__ __forceinline__ float tri_record_bound2(const float *p, const float4 rec0, const float4 rec1, float D2, float rs,
+                                                   float eps_plane)
 {
-    const float dx = sph.x - p[0], dy = sph.y - p[1], dz = sph.z - p[2];
+    const float dx = p[0] - rec0.x, dy = p[1] - rec0.y, dz = p[2] - rec0.z;
+    const float pdc = dx * rec1.x + dy * rec1.y + dz * rec1.z;                   // n . (p - c), |n| <= 1
+    const float pd = fmaxf(fabsf(pdc) - (eps_plane + 4.8e-7f * rs), 0.f);         // >= 0, <= plane distance of every point
+    // |perp(p - c)|^2 >= D2 - (n^ . (p - c))^2, and (n^ . v)^2 <= (n . v)^2 (1 + 5e-6) because |n| >= 1 - 2.5e-6
+    // (the 2e-6 off D2: 4u for its own rounding, and 2 |pdc| e + e^2 <= 8e-7 D2 for the absolute error e <= 6u |p - c| of pdc)
+    const float t2 = D2 * 0.999998f - pdc * pdc * 1.000006f;
+    float lb = pd * pd;
+    const float rr = rec0.w * rec0.w * 1.000001f;
+    if (t2 > rr) {                                                                // the foot of p lies outside the disc
+        const float tg = __builtin_sqrtf(t2) * 0.9999998f - rec0.w;               // >= 0 here up to rounding
+        if (tg > 0.f) lb = __builtin_fmaf(tg, tg, lb);
+    }
+    return lb * 0.999999f;
+}
+
+// phase 1 for one record; kmin / gmin track the lane's most promising queue entry
+__device__ __forceinline__ void tri_candidate(const float *p, const float4 rec0, const float4 rec1, const TriSearchState &s,
+                                              float eps_plane, int (*queue)[256], float (*qkey)[256], int &nq, int &kmin, float &gmin)
+{
+    const float dx = rec0.x - p[0], dy = rec0.y - p[1], dz = rec0.z - p[2];
     const float D2 = dx * dx + dy * dy + dz * dz;
-    const float rs = sph.w + s.reach;
+    const float rs = rec0.w + s.reach;
     if (D2 > rs * rs * 1.000003f) return;                          // farther than radius + reach: cannot beat or tie
-    queue[nq][threadIdx.x] = tid;                                  // the caller keeps nq <= TRI_QUEUE - 4 before a trip
+    const float lb = tri_record_bound2(p, rec0, rec1, D2, rs, eps_plane);
+    if (lb > s.thr) return;                                        // the plane / disc bound rules it out
+    queue[nq][threadIdx.x] = __float_as_int(rec1.w);               // the caller keeps nq <= TRI_QUEUE - 4 before a trip
+    qkey[nq][threadIdx.x] = lb;
+    if (lb < gmin || nq == 0) { gmin = lb; kmin = nq; }             // (a NaN bound never becomes the minimum)
     ++nq;
 }
 
-// Phase 2.  The triangle of survivor k + 1 is fetched before survivor k is evaluated: a thread's time is a chain of
-// memory round trips, and the ~300-instruction evaluation hides the next fetch instead of following it.
-__device__ __forceinline__ void tri_queue_flush(const float *p, const float4 *__restrict__ tri9, TriSearchState &s,
-                                                int (*queue)[256], int &nq, double delta, float cutf)
+// closest-point evaluation of triangle t (already loaded) against the running best
+__device__ __forceinline__ void tri_consider(const float *p, const float4 u, const float4 v, const float4 w, uint32_t t,
+                                             TriSearchState &s, double delta, float cutf, int *ev)
 {
+    if (t == s.bidx) return;                                       // (already the best: listed in several cells)
+    const float a[3] = { u.x, u.y, u.z }, b[3] = { u.w, v.x, v.y }, c[3] = { v.z, v.w, w.x };
+    float r[3];
+    if (ev) ++*ev;
+    closest_on_tri(p, a, b, c, r);
+    const float d = tri_dist2(p, r);
+    if (d < s.best || (d == s.best && t < s.bidx && d < INFINITY)) {
+        const bool closer = d < s.best;
+        s.best = d; s.bidx = t;
+        if (closer) { s.lim = fminf(s.best, cutf); tri_state_refresh(s, delta); }
+    }
+}
+
+// Phase 2.  (ev / trips: optional counters of the instrumented build -- closest-point evaluations of this lane, wave trips)
+__device__ __forceinline__ void tri_queue_flush(const float *p, const float4 *__restrict__ tri9, TriSearchState &s,
+                                                int (*queue)[256], float (*qkey)[256], int &nq, int &kmin, float &gmin,
+                                                double delta, float cutf, int *ev = nullptr, int *trips = nullptr)
+{
+    if (!__any(nq > 0)) return;
+    // 1) the most promising survivor of every lane
+    if (nq > 0 && !(gmin > s.thr)) {
+        const uint32_t t = (uint32_t)queue[kmin][threadIdx.x];
+        const float4 u = tri9[3ll * t], v = tri9[3ll * t + 1], w = tri9[3ll * t + 2];
+        tri_consider(p, u, v, w, t, s, delta, cutf, ev);
+    }
+    if (trips) ++*trips;
+    // 2) what is still a contender under the improved best, compacted in place (LDS only)
+    int m = 0;
+    for (int k = 0; __any(k < nq); ++k) {
+        if (k < nq && k != kmin) {
+            const float g = qkey[k][threadIdx.x];
+            if (!(g > s.thr)) { queue[m][threadIdx.x] = queue[k][threadIdx.x]; qkey[m][threadIdx.x] = g; ++m; }
+        }
+    }
+    // 3) one contender per wave trip; the triangle of contender k + 1 is fetched before contender k is evaluated (a
+    // thread's time is a chain of memory round trips: the ~300-instruction evaluation hides the next fetch)
     float4 u = make_float4(0.f, 0.f, 0.f, 0.f), v = u, w = u;
     uint32_t t = IDX_NONE;
-    if (nq > 0) { t = (uint32_t)queue[0][threadIdx.x]; u = tri9[3ll * t]; v = tri9[3ll * t + 1]; w = tri9[3ll * t + 2]; }
-    for (int k = 0; __any(k < nq); ++k) {
+    if (m > 0) { t = (uint32_t)queue[0][threadIdx.x]; u = tri9[3ll * t]; v = tri9[3ll * t + 1]; w = tri9[3ll * t + 2]; }
+    for (int k = 0; __any(k < m); ++k) {
         float4 nu = u, nv = v, nw = w;
         uint32_t nt = IDX_NONE;
-        if (k + 1 < nq) { nt = (uint32_t)queue[k + 1][threadIdx.x]; nu = tri9[3ll * nt]; nv = tri9[3ll * nt + 1]; nw = tri9[3ll * nt + 2]; }
-        if (k < nq && t != s.bidx) {                               // (already the best: listed in several cells)
-            const float a[3] = { u.x, u.y, u.z }, b[3] = { u.w, v.x, v.y }, c[3] = { v.z, v.w, w.x };
-            float lb = 0.f;
-#pragma unroll
-            for (int m = 0; m < 3; ++m) {
-                const float lo = fminf(fminf(a[m], b[m]), c[m]), hi = fmaxf(fmaxf(a[m], b[m]), c[m]);
-                const float g = fmaxf(fmaxf(lo - p[m], p[m] - hi), 0.f);
-                lb += g * g;
-            }
-            if (!(lb > s.thr)) {
-                float r[3];
-                closest_on_tri(p, a, b, c, r);
-                const float d = tri_dist2(p, r);
-                if (d < s.best || (d == s.best && t < s.bidx && d < INFINITY)) {
-                    const bool closer = d < s.best;
-                    s.best = d; s.bidx = t;
-                    if (closer) { s.lim = fminf(s.best, cutf); tri_state_refresh(s, delta); }
-                }
-            }
+        if (k + 1 < m && !(qkey[k + 1][threadIdx.x] > s.thr)) {
+            nt = (uint32_t)queue[k + 1][threadIdx.x]; nu = tri9[3ll * nt]; nv = tri9[3ll * nt + 1]; nw = tri9[3ll * nt + 2];
         }
+        if (k < m && t != IDX_NONE && !(qkey[k][threadIdx.x] > s.thr)) tri_consider(p, u, v, w, t, s, delta, cutf, ev);
         t = nt; u = nu; v = nv; w = nw;
+        if (trips) ++*trips;
     }
-    nq = 0;
+    nq = 0; kmin = 0; gmin = INFINITY;
+}
+
+// Phase 1 over the cell-list ranges a lane has collected (seg[0 .. n_seg), [first, last + 1) positions of cell_rec):
+// every lane walks ITS ranges, four records per trip; the wave leaves when every lane is through.
+__device__ __forceinline__ void tri_scan_segments(const float *p, const float4 *__restrict__ cell_rec,
+                                                  const float4 *__restrict__ tri9, TriSearchState &s, float eps_plane,
+                                                  int2 (*seg)[256], int &n_seg, int (*queue)[256], float (*qkey)[256],
+                                                  int &nq, int &kmin, float &gmin, double delta, float cutf,
+                                                  int *surv = nullptr, int *ev = nullptr, int *trips = nullptr)
+{
+    int k = 0, j = 0, end = 0;
+    while (true) {
+        if (j >= end && k < n_seg) { const int2 sg = seg[k][threadIdx.x]; j = sg.x; end = sg.y; ++k; }
+        const bool active = j < end;
+        if (!__any(active)) break;
+        if (__any(nq > TRI_QUEUE - 4)) {
+            if (surv) *surv += nq;
+            tri_queue_flush(p, tri9, s, queue, qkey, nq, kmin, gmin, delta, cutf, ev, trips);
+        }
+        if (active) {
+            // four records (32 bytes each): eight independent loads; the clamped repeats of the last record are not tested
+            const int last = end - 1;
+            const int e1 = min(j + 1, last), e2 = min(j + 2, last), e3 = min(j + 3, last);
+            const float4 a0 = cell_rec[2ll * j], a1 = cell_rec[2ll * j + 1], b0 = cell_rec[2ll * e1], b1 = cell_rec[2ll * e1 + 1],
+                         c0 = cell_rec[2ll * e2], c1 = cell_rec[2ll * e2 + 1], d0 = cell_rec[2ll * e3], d1 = cell_rec[2ll * e3 + 1];
+            tri_candidate(p, a0, a1, s, eps_plane, queue, qkey, nq, kmin, gmin);
+            if (j + 1 < end) tri_candidate(p, b0, b1, s, eps_plane, queue, qkey, nq, kmin, gmin);
+            if (j + 2 < end) tri_candidate(p, c0, c1, s, eps_plane, queue, qkey, nq, kmin, gmin);
+            if (j + 3 < end) tri_candidate(p, d0, d1, s, eps_plane, queue, qkey, nq, kmin, gmin);
+            j += 4;
+        }
+    }
+    n_seg = 0;
 }
 
 // L = 1, 2 or 4 lanes per query, as in k_nn_search_grid: the rows of a ring are dealt out to the lanes, every lane runs
 // both phases on its rows with its own state, and the lanes merge (d2, index) after every batch of rows.
-template <int L>
+// STATS (debug builds of the launch, OA_GRID_STATS=1): per-launch totals of what the queries did, see TRI_STAT_*
+enum { TRI_STAT_QUERIES, TRI_STAT_ROWS, TRI_STAT_ENTRIES, TRI_STAT_SURVIVORS, TRI_STAT_EVALS, TRI_STAT_WAVE_TRIPS,
+       TRI_STAT_WAVE_MAX_ENTRIES, TRI_STAT_WAVE_MAX_ROWS, TRI_STAT_RING2, TRI_STAT_RING3, TRI_STAT_UNSETTLED, TRI_STAT_OVER,
+       TRI_STAT_WAVES, TRI_STAT_N };
+
+template <int L, bool STATS = false>
 __global__ __launch_bounds__(256, 4) void k_tri_search_grid(const DevState *__restrict__ st,
                                                          const float4 *__restrict__ src4, int ns, GridParams gp,
                                                          const int *__restrict__ cell_start,
-                                                         const int *__restrict__ cell_tris,
-                                                         const float4 *__restrict__ cell_sph,
+                                                         const float4 *__restrict__ cell_rec,
                                                          const float4 *__restrict__ tri9,
                                                          const int *__restrict__ prev,
                                                          unsigned long long *__restrict__ keys,
-                                                         int *__restrict__ todo_list, int *__restrict__ todo_count, int turn)
+                                                         int *__restrict__ todo_list, int *__restrict__ todo_count, int turn,
+                                                         unsigned long long *__restrict__ stats = nullptr)
 {
-    constexpr int RPL = (9 + L - 1) / L;                            // rows per lane and batch
-    constexpr int BATCH = RPL * L;
+    // rows per lane and batch: the first block of a search (its rows are whole ranges: one per row) nine rows at a time,
+    // later rings (interior rows contribute their two end cells: up to two ranges per row) five at a time
+    constexpr int RPL = (9 + L - 1) / L, RPLX = (5 + L - 1) / L;
+    static_assert(RPL <= TRI_SEGS && 2 * RPLX <= TRI_SEGS, "a batch of rows must fit the per-thread range list");
     if (st->halt) return;
     if (turn >= 0 && (st->tree_turn != 0) != (turn != 0)) return;  // not this kernel's turn (DevState::tree_turn)
     __shared__ int queue[TRI_QUEUE][256];
-    int nq = 0;
+    __shared__ float qkey[TRI_QUEUE][256];
+    __shared__ int2 seg[TRI_SEGS][256];
+    int nq = 0, kmin = 0, n_seg = 0;
+    float gmin = INFINITY;
+    int n_rows_loaded = 0, n_entries = 0, n_surv = 0, n_evals = 0, n_trips = 0, max_ring = 0;
     const int gt = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = gt / L, sub = gt % L;                             // the L lanes of a query are neighbours in a wave
     if (i >= ns) return;
@@ -257,18 +395,9 @@ __global__ __launch_bounds__(256, 4) void k_tri_search_grid(const DevState *__re
     const int s = prev ? prev[i] : -1;
     if (s >= 0) tri_eval(pf, tri9, (uint32_t)s, best, bidx);
 
-    const double p[3] = { (double)pf[0], (double)pf[1], (double)pf[2] };
-    double pc[3], off2 = 0.0, pabs = 0.0;
-    int c[3];
-    bool finite = true;
-    for (int a = 0; a < 3; ++a) {
-        if (!(fabs(p[a]) < INFINITY)) finite = false;
-        pabs += fabs(p[a]);
-        pc[a] = p[a] < gp.lo[a] ? gp.lo[a] : (p[a] > gp.hi[a] ? gp.hi[a] : p[a]);
-        const double d = p[a] - pc[a];
-        off2 += d * d;
-        c[a] = grid_cell_coord(pc[a], gp.lo[a], gp.inv_h, gp.n[a]);
-    }
+    double pabs = 0.0;
+    const GridQuery q = grid_locate(gp, pf[0], pf[1], pf[2], &pabs);
+    const float h = gp.hf, inv_h = gp.inv_hf, slack = gp.slackf;
     // float32 closest-point evaluation can undershoot the real distance by at most delta
     const double delta = 64.0 * 5.9604644775390625e-08 * (gp.scale + pabs) + gp.slack;
     // `lim`: the best so far or the search radius (search_cutoff2), whichever is smaller -- see k_nn_search_grid
@@ -290,70 +419,66 @@ __global__ __launch_bounds__(256, 4) void k_tri_search_grid(const DevState *__re
         if (L > 1) budget = budget / L + 8;
     }
     const int r_start = (S.bidx != IDX_NONE && gp.seeded_start) ? 1 : 0;   // as in k_nn_search_grid
-    if (finite) {
+    if (q.finite) {
         for (int r = r_start; r <= gp.r_max && !settled && !over; ++r) {
-            const int x0 = max(c[0] - r, 0), x1 = min(c[0] + r, gp.n[0] - 1);
             // rows of the ring nine at a time: cell ranges first (independent loads), then the candidates -- as in
-            // k_nn_search_grid
+            // k_nn_search_grid; per-row arithmetic in float on the query's frame (GridQuery)
             const int side = 2 * r + 1, n_rows = side * side;
             const unsigned div_mul = 65536u / (unsigned)side + 1u;
-            for (int b0 = 0; b0 < n_rows && !over; b0 += BATCH) {
-                int ja[RPL], jb[RPL], jc[RPL], jd[RPL];
+            const bool first = (r == r_start);
+            const int rpl = first ? RPL : RPLX, batch = rpl * L;
+            for (int b0 = 0; b0 < n_rows && !over; b0 += batch) {
+                int ja[RPL], jb[RPL], jc[RPLX], jd[RPLX];
 #pragma unroll
                 for (int k = 0; k < RPL; ++k) {
-                    ja[k] = jb[k] = jc[k] = jd[k] = 0;
+                    ja[k] = jb[k] = 0;
+                    if (k < RPLX) jc[k] = jd[k] = 0;
                     const int kk = b0 + sub + L * k;
-                    if (kk >= n_rows) continue;
+                    if (k >= rpl || kk >= n_rows) continue;
                     const int qz = (int)(((unsigned)kk * div_mul) >> 16);
                     const int dzi = qz - r, dyi = kk - qz * side - r;
-                    const int z = c[2] + dzi, y = c[1] + dyi;
+                    const int z = q.c[2] + dzi, y = q.c[1] + dyi;
                     if (z < 0 || z >= gp.n[2] || y < 0 || y >= gp.n[1]) continue;
-                    const double dz = grid_axis_gap(pc[2], gp.lo[2], gp.h, z, gp.slack);
-                    const double dy = grid_axis_gap(pc[1], gp.lo[1], gp.h, y, gp.slack);
-                    const double row2 = off2 + dz * dz + dy * dy;
+                    const float gz = grid_gap(q.f[2], h, slack, dzi), gy = grid_gap(q.f[1], h, slack, dyi);
+                    const float row2 = __builtin_fmaf(gy, gy, __builtin_fmaf(gz, gz, q.off2));
                     // (sqrt(row2) - delta)^2 (1 - 1e-5) - 1e-30 > lim  <=>  row2 > reach2: nothing in this row can matter
-                    if (row2 * (1.0 - 1e-9) > S.reach2) continue;
-                    // cells of the row whose slab along x can still hold a triangle within reach: |x - pc.x| <= w
-                    int xa = x0, xb = x1;
-                    if (S.reach2 < 1e300) {
-                        const double w2 = S.reach2 - row2 * (1.0 - 1e-9);
-                        const double w = (double)grid_sqrt_up((float)(w2 > 0.0 ? w2 * (1.0 + 1e-6) : 0.0)) + gp.slack;
-                        xa = max(xa, grid_cell_coord(pc[0] - w, gp.lo[0], gp.inv_h, gp.n[0]));
-                        xb = min(xb, grid_cell_coord(pc[0] + w, gp.lo[0], gp.inv_h, gp.n[0]));
-                    }
+                    if (row2 * 0.999998f > S.reach2f) continue;
+                    // cells of the row whose slab along x can still hold a triangle within reach
+                    int dl, dr;
+                    grid_row_span(q.f[0], h, inv_h, slack, S.reach2f - row2 * 0.999998f, r, dl, dr);
+                    const int xa = max(q.c[0] - dl, 0), xb = min(q.c[0] + dr, gp.n[0] - 1);
                     const int row = (z * gp.n[1] + y) * gp.n[0];
-                    const bool shell_row = (r == r_start) || dzi == -r || dzi == r || dyi == -r || dyi == r;
+                    const bool shell_row = first || dzi == -r || dzi == r || dyi == -r || dyi == r;
+                    if (STATS) ++n_rows_loaded;
                     if (shell_row) {
-                        if (xa <= xb) { ja[k] = cell_start[row + xa]; jb[k] = cell_start[row + xb + 1]; }
-                    } else {
-                        const int xl = c[0] - r, xr = c[0] + r;
-                        if (xl >= xa && xl <= xb) { ja[k] = cell_start[row + xl]; jb[k] = cell_start[row + xl + 1]; }
-                        if (xr >= xa && xr <= xb) { jc[k] = cell_start[row + xr]; jd[k] = cell_start[row + xr + 1]; }
+                        ja[k] = cell_start[row + xa]; jb[k] = cell_start[row + xb + 1];
+                    } else if (k < RPLX) {
+                        const int xl = q.c[0] - r, xr = q.c[0] + r;
+                        if (dl == r && xl >= 0) { ja[k] = cell_start[row + xl]; jb[k] = cell_start[row + xl + 1]; }
+                        if (dr == r && xr < gp.n[0]) { jc[k] = cell_start[row + xr]; jd[k] = cell_start[row + xr + 1]; }
                     }
                 }
+                // The non-empty cell-list ranges of this lane's rows go on a per-thread list in LDS and are scanned in ONE
+                // flattened loop (tri_scan_segments): every lane walks its own ranges four records per trip, so a wave
+                // pays max-over-lanes(records) trips.  Walking the rows in lockstep instead -- range m of every lane
+                // together -- pays the sum over m of the longest range m, several times more when cells hold ~20 records
+                // (PMC before: 41k VALU instructions per wave in the first iterations of a run).
 #pragma unroll
                 for (int k = 0; k < RPL; ++k) {
 #pragma unroll
                     for (int sg = 0; sg < 2; ++sg) {
-                        const int j0 = sg ? jc[k] : ja[k], j1 = sg ? jd[k] : jb[k];
-                        if (j1 <= j0) continue;
-                        budget -= j1 - j0;
-                        if (budget < 0) break;                       // crowded cells: one wave of the tree search is faster
-                        const int last = j1 - 1;
-                        for (int j = j0; j < j1; j += 4) {
-                            if (__any(nq > TRI_QUEUE - 4)) tri_queue_flush(pf, tri9, S, queue, nq, delta, cutf);
-                            // the records and (whether or not they pass) their triangle ids: eight independent loads
-                            const int e1 = min(j + 1, last), e2 = min(j + 2, last), e3 = min(j + 3, last);
-                            const float4 s0 = cell_sph[j], s1 = cell_sph[e1], s2 = cell_sph[e2], s3 = cell_sph[e3];
-                            const int t0 = cell_tris[j], t1 = cell_tris[e1], t2 = cell_tris[e2], t3 = cell_tris[e3];
-                            tri_candidate(pf, s0, t0, S, queue, nq);
-                            if (j + 1 < j1) tri_candidate(pf, s1, t1, S, queue, nq);
-                            if (j + 2 < j1) tri_candidate(pf, s2, t2, S, queue, nq);
-                            if (j + 3 < j1) tri_candidate(pf, s3, t3, S, queue, nq);
+                        if (sg == 1 && k >= RPLX) continue;
+                        const int j0 = sg ? jc[k < RPLX ? k : 0] : ja[k], j1 = sg ? jd[k < RPLX ? k : 0] : jb[k];
+                        if (j1 > j0 && budget >= 0) {
+                            budget -= j1 - j0;                       // crowded cells: one wave of the tree search is faster
+                            if (budget >= 0) { seg[n_seg][threadIdx.x] = make_int2(j0, j1); ++n_seg; if (STATS) n_entries += j1 - j0; }
                         }
                     }
                 }
-                tri_queue_flush(pf, tri9, S, queue, nq, delta, cutf);   // a better best prunes the next batch of rows
+                tri_scan_segments(pf, cell_rec, tri9, S, gp.eps_plane, seg, n_seg, queue, qkey, nq, kmin, gmin, delta, cutf,
+                                  STATS ? &n_surv : nullptr, STATS ? &n_evals : nullptr, STATS ? &n_trips : nullptr);
+                if (STATS) n_surv += nq;
+                tri_queue_flush(pf, tri9, S, queue, qkey, nq, kmin, gmin, delta, cutf, STATS ? &n_evals : nullptr, STATS ? &n_trips : nullptr);   // a better best prunes the next batch of rows
                 over = budget < 0;
                 if (L > 1) {                                         // the lanes of the query agree on the best so far
                     bool changed = false;
@@ -368,18 +493,30 @@ __global__ __launch_bounds__(256, 4) void k_tri_search_grid(const DevState *__re
                     if (changed) { S.lim = fminf(S.best, cutf); tri_state_refresh(S, delta); }
                 }
             }
+            if (STATS) max_ring = r;
             if (over) break;
-            double m = INFINITY;
-            for (int a = 0; a < 3; ++a) {
-                if (c[a] - r > 0) { const double f = pc[a] - (gp.lo[a] + (double)(c[a] - r) * gp.h); m = f < m ? f : m; }
-                if (c[a] + r + 1 < gp.n[a]) { const double f = (gp.lo[a] + (double)(c[a] + r + 1) * gp.h) - pc[a]; m = f < m ? f : m; }
-            }
-            if (!(m < INFINITY)) settled = true;
-            else {
-                m -= gp.slack;
-                m = m > 0.0 ? m : 0.0;
-                if ((off2 + m * m) * (1.0 - 1e-9) > S.reach2) settled = true;   // same test as for a row
-            }
+            const float bound = grid_cube_bound2(gp, q, r);            // everything outside the cube of radius r
+            if (!(bound < INFINITY) || bound * 0.999998f > S.reach2f) settled = true;   // same test as for a row
+        }
+    }
+    if (STATS && stats) {
+        atomicAdd(&stats[TRI_STAT_QUERIES], 1ull);
+        atomicAdd(&stats[TRI_STAT_ROWS], (unsigned long long)n_rows_loaded);
+        atomicAdd(&stats[TRI_STAT_ENTRIES], (unsigned long long)n_entries);
+        atomicAdd(&stats[TRI_STAT_SURVIVORS], (unsigned long long)n_surv);
+        atomicAdd(&stats[TRI_STAT_EVALS], (unsigned long long)n_evals);
+        if (max_ring >= 2) atomicAdd(&stats[TRI_STAT_RING2], 1ull);
+        if (max_ring >= 3) atomicAdd(&stats[TRI_STAT_RING3], 1ull);
+        if (!settled) atomicAdd(&stats[TRI_STAT_UNSETTLED], 1ull);
+        if (over) atomicAdd(&stats[TRI_STAT_OVER], 1ull);
+        int me = n_entries, mr = n_rows_loaded;
+        for (int o = 32; o > 0; o >>= 1) { me = max(me, __shfl_xor(me, o, 64)); mr = max(mr, __shfl_xor(mr, o, 64)); }
+        const unsigned long long act = __ballot(1);
+        if ((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1) {
+            atomicAdd(&stats[TRI_STAT_WAVE_TRIPS], (unsigned long long)n_trips);
+            atomicAdd(&stats[TRI_STAT_WAVE_MAX_ENTRIES], (unsigned long long)me);
+            atomicAdd(&stats[TRI_STAT_WAVE_MAX_ROWS], (unsigned long long)mr);
+            atomicAdd(&stats[TRI_STAT_WAVES], 1ull);
         }
     }
     if (sub != 0) return;
