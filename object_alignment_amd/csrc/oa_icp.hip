@@ -1559,8 +1559,8 @@ int build_tri_grid(oa_ctx *c)
     }
     double h = env_double("OA_TRI_CELL", 1.5) * diag_sum / (double)c->n_tris;   // ~1.5 mean triangle bbox diagonals per cell
     if (!(h > 0.0) || !(h < INFINITY)) h = max_ext > 0.0 ? max_ext / 64.0 : 1.0;
-    h = std::max(h, max_ext / 512.0);
-    const long long max_cells = 1ll << 24;
+    h = std::max(h, max_ext / 1023.0);
+    const long long max_cells = 1ll << std::max(16, std::min(29, env_int("OA_TRI_MAX_CELLS_LOG2", 24)));
     DevTmp<int> d_counts;
     DevTmp<long long> d_off;
     DevTmp<unsigned long long> d_total;
@@ -1572,7 +1572,7 @@ int build_tri_grid(oa_ctx *c)
         long long total = 1;
         for (int a = 0; a < 3; ++a) {
             long long n = ext[a] > 0.0 ? (long long)floor(ext[a] / h) + 1 : 1;
-            n = std::max(1ll, std::min(n, 512ll));
+            n = std::max(1ll, std::min(n, 1024ll));
             gp.n[a] = (int)n;
             total *= n;
             gp.lo[a] = c->bb_lo[a]; gp.hi[a] = c->bb_hi[a];

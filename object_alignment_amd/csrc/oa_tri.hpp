@@ -216,14 +216,32 @@ __device__ __forceinline__ void tri_state_refresh(TriSearchState &s, double delt
     } else { s.reach2 = INFINITY; s.reach2f = INFINITY; }
 }
 
-// Cell-list candidates go through two phases so that divergence does not multiply the expensive part.  Phase 1
-// (tri_candidate): two tests on the contiguous 32-byte record -- the bounding sphere, then for its survivors the
-// plane / in-plane-disc bound -- and what is left goes on a per-thread queue in LDS with its bound as the key.  Phase 2
-// (tri_queue_flush): every lane first evaluates its MOST PROMISING survivor (smallest key); the rest of its queue is
-// then re-tested against the improved best (LDS only), compacted, and evaluated one survivor per wave trip, so a wave
-// pays max-over-lanes(real contenders) closest-point evaluations.
-constexpr int TRI_QUEUE = 10;      // survivors a lane may hold before the wave flushes (phase 2)
+// Cell-list candidates go through two phases so that divergence does not multiply the expensive part.
+//
+// Phase 1 (tri_candidate): two tests on the contiguous 32-byte record -- the bounding sphere, then for its survivors the
+// plane / in-plane-disc bound.  What is left goes into a POOL SHARED BY THE WAVE (LDS): (owner lane, triangle, bound).
+//
+// Phase 2 (tri_pool_flush), when the pool fills up and at the end of every batch of rows:
+//   A  every lane evaluates its own most promising survivor (smallest bound) -- that alone usually brings its best
+//      within a hair of the final answer;
+//   B  the pool is re-tested against the owners' improved thresholds and compacted (LDS only);
+//   C  the remaining contenders are evaluated 64 at a time by WHOEVER IS FREE: lane e takes pool entry e, fetches the
+//      owner's query point with a cross-lane read, and merges (d2, triangle) into the owner's slot with a 64-bit LDS
+//      atomic min -- lexicographic, i.e. nearest triangle, lowest index on ties, whatever the order.
+// A wave therefore pays ceil(contenders of all its lanes / 64) closest-point evaluations instead of the maximum over
+// its lanes per flush (PMC before: 65-80 evaluation trips per wave in the first iterations of a run, for 10-12
+// evaluations per query).
+constexpr int TRI_POOL = 320;      // pool entries per wave; a flush is due above TRI_POOL - 128
 constexpr int TRI_SEGS = 10;       // cell-list ranges of one batch of rows (9 rows of the first block, or 5 rows x 2 end cells)
+
+struct TriPool {                   // this wave's part of the workgroup's LDS
+    int *tid, *own;
+    float *key;
+    unsigned long long *slot;      // one per lane: (bits(d2) << 32) | triangle of what others evaluated for it
+    int n;                         // entries (wave-uniform)
+    int kslot;                     // this lane's most promising entry (-1: none)
+    float gmin;                    // its bound
+};
 
 // Lower bound of the squared distance from p to a triangle with record (rec0, rec1), given D2 = |p - c|^2 (float).
 // Derivation in tri_record's comment; every rounding is covered: products and sums of floats are within 4u of their
@@ -247,20 +265,32 @@ __device__ __forceinline__ float tri_record_bound2(const float *p, const float4 
     return lb * 0.999999f;
 }
 
-// phase 1 for one record; kmin / gmin track the lane's most promising queue entry
-__device__ __forceinline__ void tri_candidate(const float *p, const float4 rec0, const float4 rec1, const TriSearchState &s,
-                                              float eps_plane, int (*queue)[256], float (*qkey)[256], int &nq, int &kmin, float &gmin)
+// phase 1 for one record per lane (valid = this lane has one); called by the whole wave
+__device__ __forceinline__ void tri_candidate(const float *p, const float4 rec0, const float4 rec1, bool valid,
+                                              const TriSearchState &s, float eps_plane, TriPool &pool, int *surv = nullptr)
 {
-    const float dx = rec0.x - p[0], dy = rec0.y - p[1], dz = rec0.z - p[2];
-    const float D2 = dx * dx + dy * dy + dz * dz;
-    const float rs = rec0.w + s.reach;
-    if (D2 > rs * rs * 1.000003f) return;                          // farther than radius + reach: cannot beat or tie
-    const float lb = tri_record_bound2(p, rec0, rec1, D2, rs, eps_plane);
-    if (lb > s.thr) return;                                        // the plane / disc bound rules it out
-    queue[nq][threadIdx.x] = __float_as_int(rec1.w);               // the caller keeps nq <= TRI_QUEUE - 4 before a trip
-    qkey[nq][threadIdx.x] = lb;
-    if (lb < gmin || nq == 0) { gmin = lb; kmin = nq; }             // (a NaN bound never becomes the minimum)
-    ++nq;
+    bool keep = false;
+    float lb = 0.f;
+    if (valid) {
+        const float dx = rec0.x - p[0], dy = rec0.y - p[1], dz = rec0.z - p[2];
+        const float D2 = dx * dx + dy * dy + dz * dz;
+        const float rs = rec0.w + s.reach;
+        if (!(D2 > rs * rs * 1.000003f)) {                         // else: farther than radius + reach, cannot beat or tie
+            lb = tri_record_bound2(p, rec0, rec1, D2, rs, eps_plane);
+            keep = !(lb > s.thr);                                  // else: the plane / disc bound rules it out
+        }
+    }
+    const unsigned long long m = __ballot(keep);
+    if (keep) {
+        if (surv) ++*surv;
+        const int lane = threadIdx.x & 63;
+        const int dst = pool.n + __popcll(m & ((1ull << lane) - 1ull));
+        pool.tid[dst] = __float_as_int(rec1.w);
+        pool.own[dst] = lane;
+        pool.key[dst] = lb;
+        if (pool.kslot < 0 || lb < pool.gmin || pool.gmin != pool.gmin) { pool.gmin = lb; pool.kslot = dst; }
+    }
+    pool.n += __popcll(m);
 }
 
 // closest-point evaluation of triangle t (already loaded) against the running best
@@ -280,51 +310,79 @@ __device__ __forceinline__ void tri_consider(const float *p, const float4 u, con
     }
 }
 
-// Phase 2.  (ev / trips: optional counters of the instrumented build -- closest-point evaluations of this lane, wave trips)
-__device__ __forceinline__ void tri_queue_flush(const float *p, const float4 *__restrict__ tri9, TriSearchState &s,
-                                                int (*queue)[256], float (*qkey)[256], int &nq, int &kmin, float &gmin,
-                                                double delta, float cutf, int *ev = nullptr, int *trips = nullptr)
+// Phase 2 (see above).  Called by the whole wave.  (ev / trips: counters of the instrumented build)
+__device__ __forceinline__ void tri_pool_flush(const float *p, const float4 *__restrict__ tri9, TriSearchState &s,
+                                               TriPool &pool, double delta, float cutf, int *ev = nullptr, int *trips = nullptr)
 {
-    if (!__any(nq > 0)) return;
-    // 1) the most promising survivor of every lane
-    if (nq > 0 && !(gmin > s.thr)) {
-        const uint32_t t = (uint32_t)queue[kmin][threadIdx.x];
+    pool.n = __builtin_amdgcn_readfirstlane(pool.n);              // the same in every lane: the pool is the wave's
+    if (pool.n == 0) return;
+    const int lane = threadIdx.x & 63;
+    // A) the most promising survivor of every lane
+    if (pool.kslot >= 0 && !(pool.gmin > s.thr)) {
+        const uint32_t t = (uint32_t)pool.tid[pool.kslot];
         const float4 u = tri9[3ll * t], v = tri9[3ll * t + 1], w = tri9[3ll * t + 2];
         tri_consider(p, u, v, w, t, s, delta, cutf, ev);
     }
     if (trips) ++*trips;
-    // 2) what is still a contender under the improved best, compacted in place (LDS only)
-    int m = 0;
-    for (int k = 0; __any(k < nq); ++k) {
-        if (k < nq && k != kmin) {
-            const float g = qkey[k][threadIdx.x];
-            if (!(g > s.thr)) { queue[m][threadIdx.x] = queue[k][threadIdx.x]; qkey[m][threadIdx.x] = g; ++m; }
+    // B) what is still a contender under its owner's improved best, compacted in place
+    int n2 = 0;
+    for (int base = 0; base < pool.n; base += 64) {
+        const int e = base + lane;
+        bool c = false;
+        int own = 0, t = 0;
+        float key = 0.f;
+        if (e < pool.n) { own = pool.own[e]; t = pool.tid[e]; key = pool.key[e]; }
+        const float othr = __shfl(s.thr, own, 64);
+        const int oks = __shfl(pool.kslot, own, 64), obi = __shfl((int)s.bidx, own, 64);
+        if (e < pool.n) c = e != oks && t != obi && !(key > othr);
+        const unsigned long long m = __ballot(c);
+        if (c) {                                                   // dst <= e, and this trip's reads are done: in place is safe
+            const int dst = n2 + __popcll(m & ((1ull << lane) - 1ull));
+            pool.own[dst] = own; pool.tid[dst] = t; pool.key[dst] = key;
+        }
+        n2 += __popcll(m);
+    }
+    // C) the contenders, 64 per trip, evaluated by whoever is free
+    if (n2 > 0) {
+        __hip_atomic_store(&pool.slot[lane], ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        for (int base = 0; base < n2; base += 64) {
+            const int e = base + lane;
+            int own = 0;
+            uint32_t t = 0;
+            if (e < n2) { own = pool.own[e]; t = (uint32_t)pool.tid[e]; }
+            const float q0 = __shfl(p[0], own, 64), q1 = __shfl(p[1], own, 64), q2 = __shfl(p[2], own, 64);
+            if (e < n2) {
+                const float4 u = tri9[3ll * t], v = tri9[3ll * t + 1], w = tri9[3ll * t + 2];
+                const float qo[3] = { q0, q1, q2 };
+                const float a[3] = { u.x, u.y, u.z }, b[3] = { u.w, v.x, v.y }, c[3] = { v.z, v.w, w.x };
+                float r[3];
+                if (ev) ++*ev;
+                closest_on_tri(qo, a, b, c, r);
+                const float d = tri_dist2(qo, r);
+                if (d < INFINITY)                                   // d >= +0: its bits order like the value; NaN / inf never win
+                    atomicMin(&pool.slot[own], ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)t);
+            }
+            if (trips) ++*trips;
+        }
+        const unsigned long long k = __hip_atomic_load(&pool.slot[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        if (k != ~0ull) {
+            const float d = __uint_as_float((uint32_t)(k >> 32));
+            const uint32_t t = (uint32_t)k;
+            if (d < s.best || (d == s.best && t < s.bidx)) {
+                const bool closer = d < s.best;
+                s.best = d; s.bidx = t;
+                if (closer) { s.lim = fminf(s.best, cutf); tri_state_refresh(s, delta); }
+            }
         }
     }
-    // 3) one contender per wave trip; the triangle of contender k + 1 is fetched before contender k is evaluated (a
-    // thread's time is a chain of memory round trips: the ~300-instruction evaluation hides the next fetch)
-    float4 u = make_float4(0.f, 0.f, 0.f, 0.f), v = u, w = u;
-    uint32_t t = IDX_NONE;
-    if (m > 0) { t = (uint32_t)queue[0][threadIdx.x]; u = tri9[3ll * t]; v = tri9[3ll * t + 1]; w = tri9[3ll * t + 2]; }
-    for (int k = 0; __any(k < m); ++k) {
-        float4 nu = u, nv = v, nw = w;
-        uint32_t nt = IDX_NONE;
-        if (k + 1 < m && !(qkey[k + 1][threadIdx.x] > s.thr)) {
-            nt = (uint32_t)queue[k + 1][threadIdx.x]; nu = tri9[3ll * nt]; nv = tri9[3ll * nt + 1]; nw = tri9[3ll * nt + 2];
-        }
-        if (k < m && t != IDX_NONE && !(qkey[k][threadIdx.x] > s.thr)) tri_consider(p, u, v, w, t, s, delta, cutf, ev);
-        t = nt; u = nu; v = nv; w = nw;
-        if (trips) ++*trips;
-    }
-    nq = 0; kmin = 0; gmin = INFINITY;
+    pool.n = 0; pool.kslot = -1; pool.gmin = INFINITY;
 }
 
 // Phase 1 over the cell-list ranges a lane has collected (seg[0 .. n_seg), [first, last + 1) positions of cell_rec):
 // every lane walks ITS ranges, four records per trip; the wave leaves when every lane is through.
 __device__ __forceinline__ void tri_scan_segments(const float *p, const float4 *__restrict__ cell_rec,
                                                   const float4 *__restrict__ tri9, TriSearchState &s, float eps_plane,
-                                                  int2 (*seg)[256], int &n_seg, int (*queue)[256], float (*qkey)[256],
-                                                  int &nq, int &kmin, float &gmin, double delta, float cutf,
+                                                  int2 (*seg)[256], int &n_seg, TriPool &pool, double delta, float cutf,
                                                   int *surv = nullptr, int *ev = nullptr, int *trips = nullptr)
 {
     int k = 0, j = 0, end = 0;
@@ -332,22 +390,22 @@ __device__ __forceinline__ void tri_scan_segments(const float *p, const float4 *
         if (j >= end && k < n_seg) { const int2 sg = seg[k][threadIdx.x]; j = sg.x; end = sg.y; ++k; }
         const bool active = j < end;
         if (!__any(active)) break;
-        if (__any(nq > TRI_QUEUE - 4)) {
-            if (surv) *surv += nq;
-            tri_queue_flush(p, tri9, s, queue, qkey, nq, kmin, gmin, delta, cutf, ev, trips);
-        }
+        // four records (32 bytes each) per lane: eight independent loads; the clamped repeats of the last record are not tested
+        const int last = active ? end - 1 : 0, jj = active ? j : 0;
+        const int e1 = min(jj + 1, last), e2 = min(jj + 2, last), e3 = min(jj + 3, last);
+        float4 a0, a1, b0, b1, c0, c1, d0, d1;
+        a0 = a1 = b0 = b1 = c0 = c1 = d0 = d1 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (active) {
-            // four records (32 bytes each): eight independent loads; the clamped repeats of the last record are not tested
-            const int last = end - 1;
-            const int e1 = min(j + 1, last), e2 = min(j + 2, last), e3 = min(j + 3, last);
-            const float4 a0 = cell_rec[2ll * j], a1 = cell_rec[2ll * j + 1], b0 = cell_rec[2ll * e1], b1 = cell_rec[2ll * e1 + 1],
-                         c0 = cell_rec[2ll * e2], c1 = cell_rec[2ll * e2 + 1], d0 = cell_rec[2ll * e3], d1 = cell_rec[2ll * e3 + 1];
-            tri_candidate(p, a0, a1, s, eps_plane, queue, qkey, nq, kmin, gmin);
-            if (j + 1 < end) tri_candidate(p, b0, b1, s, eps_plane, queue, qkey, nq, kmin, gmin);
-            if (j + 2 < end) tri_candidate(p, c0, c1, s, eps_plane, queue, qkey, nq, kmin, gmin);
-            if (j + 3 < end) tri_candidate(p, d0, d1, s, eps_plane, queue, qkey, nq, kmin, gmin);
-            j += 4;
+            a0 = cell_rec[2ll * jj]; a1 = cell_rec[2ll * jj + 1]; b0 = cell_rec[2ll * e1]; b1 = cell_rec[2ll * e1 + 1];
+            c0 = cell_rec[2ll * e2]; c1 = cell_rec[2ll * e2 + 1]; d0 = cell_rec[2ll * e3]; d1 = cell_rec[2ll * e3 + 1];
         }
+        tri_candidate(p, a0, a1, active, s, eps_plane, pool, surv);
+        tri_candidate(p, b0, b1, active && j + 1 < end, s, eps_plane, pool, surv);
+        if (pool.n > TRI_POOL - 128) tri_pool_flush(p, tri9, s, pool, delta, cutf, ev, trips);      // each test adds <= 64 entries
+        tri_candidate(p, c0, c1, active && j + 2 < end, s, eps_plane, pool, surv);
+        tri_candidate(p, d0, d1, active && j + 3 < end, s, eps_plane, pool, surv);
+        if (pool.n > TRI_POOL - 128) tri_pool_flush(p, tri9, s, pool, delta, cutf, ev, trips);
+        if (active) j += 4;
     }
     n_seg = 0;
 }
@@ -376,15 +434,25 @@ __global__ __launch_bounds__(256, 4) void k_tri_search_grid(const DevState *__re
     static_assert(RPL <= TRI_SEGS && 2 * RPLX <= TRI_SEGS, "a batch of rows must fit the per-thread range list");
     if (st->halt) return;
     if (turn >= 0 && (st->tree_turn != 0) != (turn != 0)) return;  // not this kernel's turn (DevState::tree_turn)
-    __shared__ int queue[TRI_QUEUE][256];
-    __shared__ float qkey[TRI_QUEUE][256];
+    __shared__ int pool_tid[4][TRI_POOL], pool_own[4][TRI_POOL];
+    __shared__ float pool_key[4][TRI_POOL];
+    __shared__ unsigned long long pool_slot[256];
     __shared__ int2 seg[TRI_SEGS][256];
-    int nq = 0, kmin = 0, n_seg = 0;
-    float gmin = INFINITY;
+    int n_seg = 0;
+    TriPool pool;
+    {
+        const int wv = threadIdx.x >> 6;
+        pool.tid = pool_tid[wv]; pool.own = pool_own[wv]; pool.key = pool_key[wv]; pool.slot = pool_slot + 64 * wv;
+        pool.n = 0; pool.kslot = -1; pool.gmin = INFINITY;
+    }
     int n_rows_loaded = 0, n_entries = 0, n_surv = 0, n_evals = 0, n_trips = 0, max_ring = 0;
     const int gt = blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = gt / L, sub = gt % L;                             // the L lanes of a query are neighbours in a wave
-    if (i >= ns) return;
+    int i = gt / L;
+    const int sub = gt % L;                                         // the L lanes of a query are neighbours in a wave
+    // Lanes past the last query stay: phase 2 deals pool entries to ALL 64 lanes of the wave (entry e to lane e mod 64),
+    // so a lane that left would take its share of the entries with it.  They repeat the last query without any say.
+    const bool alive = i < ns;
+    if (!alive) i = ns - 1;
     const float4 p4 = src4[i];
     float wx, wy, wz, pf[3];
     m4_mul_v3(st->mx1, p4.x, p4.y, p4.z, wx, wy, wz);
@@ -419,87 +487,100 @@ __global__ __launch_bounds__(256, 4) void k_tri_search_grid(const DevState *__re
         if (L > 1) budget = budget / L + 8;
     }
     const int r_start = (S.bidx != IDX_NONE && gp.seeded_start) ? 1 : 0;   // as in k_nn_search_grid
-    if (q.finite) {
-        for (int r = r_start; r <= gp.r_max && !settled && !over; ++r) {
-            // rows of the ring nine at a time: cell ranges first (independent loads), then the candidates -- as in
-            // k_nn_search_grid; per-row arithmetic in float on the query's frame (GridQuery)
-            const int side = 2 * r + 1, n_rows = side * side;
-            const unsigned div_mul = 65536u / (unsigned)side + 1u;
+    // ONE wave-uniform loop: every trip, every lane that still has work lists the cell ranges of its next batch of rows
+    // (its own ring, its own batch), then the whole wave scans and flushes together.  The pool is shared by the wave,
+    // so phase 1 and phase 2 must be reached by all of its lanes at the same time -- hence no per-lane loops around
+    // them: a lane's ring / batch counters are plain state, and the only loop condition is __any(busy).
+    int r = r_start, b0 = 0;
+    bool busy = q.finite && alive;
+    while (__any(busy)) {
+        bool ring_done = false;
+        if (busy) {
             const bool first = (r == r_start);
-            const int rpl = first ? RPL : RPLX, batch = rpl * L;
-            for (int b0 = 0; b0 < n_rows && !over; b0 += batch) {
-                int ja[RPL], jb[RPL], jc[RPLX], jd[RPLX];
+            const int side = 2 * r + 1, n_rows = side * side;
+            const unsigned div_mul = 65536u / (unsigned)side + 1u;  // k / side == (k * div_mul) >> 16 for k < 256, side <= 15
+            const int rpl = first ? RPL : RPLX;
+            // rows of the ring: cell ranges first (independent loads), then the candidates -- as in k_nn_search_grid;
+            // per-row arithmetic in float on the query's frame (GridQuery)
+            int ja[RPL], jb[RPL], jc[RPLX], jd[RPLX];
 #pragma unroll
-                for (int k = 0; k < RPL; ++k) {
-                    ja[k] = jb[k] = 0;
-                    if (k < RPLX) jc[k] = jd[k] = 0;
-                    const int kk = b0 + sub + L * k;
-                    if (k >= rpl || kk >= n_rows) continue;
-                    const int qz = (int)(((unsigned)kk * div_mul) >> 16);
-                    const int dzi = qz - r, dyi = kk - qz * side - r;
-                    const int z = q.c[2] + dzi, y = q.c[1] + dyi;
-                    if (z < 0 || z >= gp.n[2] || y < 0 || y >= gp.n[1]) continue;
-                    const float gz = grid_gap(q.f[2], h, slack, dzi), gy = grid_gap(q.f[1], h, slack, dyi);
-                    const float row2 = __builtin_fmaf(gy, gy, __builtin_fmaf(gz, gz, q.off2));
-                    // (sqrt(row2) - delta)^2 (1 - 1e-5) - 1e-30 > lim  <=>  row2 > reach2: nothing in this row can matter
-                    if (row2 * 0.999998f > S.reach2f) continue;
-                    // cells of the row whose slab along x can still hold a triangle within reach
-                    int dl, dr;
-                    grid_row_span(q.f[0], h, inv_h, slack, S.reach2f - row2 * 0.999998f, r, dl, dr);
-                    const int xa = max(q.c[0] - dl, 0), xb = min(q.c[0] + dr, gp.n[0] - 1);
-                    const int row = (z * gp.n[1] + y) * gp.n[0];
-                    const bool shell_row = first || dzi == -r || dzi == r || dyi == -r || dyi == r;
-                    if (STATS) ++n_rows_loaded;
-                    if (shell_row) {
-                        ja[k] = cell_start[row + xa]; jb[k] = cell_start[row + xb + 1];
-                    } else if (k < RPLX) {
-                        const int xl = q.c[0] - r, xr = q.c[0] + r;
-                        if (dl == r && xl >= 0) { ja[k] = cell_start[row + xl]; jb[k] = cell_start[row + xl + 1]; }
-                        if (dr == r && xr < gp.n[0]) { jc[k] = cell_start[row + xr]; jd[k] = cell_start[row + xr + 1]; }
-                    }
-                }
-                // The non-empty cell-list ranges of this lane's rows go on a per-thread list in LDS and are scanned in ONE
-                // flattened loop (tri_scan_segments): every lane walks its own ranges four records per trip, so a wave
-                // pays max-over-lanes(records) trips.  Walking the rows in lockstep instead -- range m of every lane
-                // together -- pays the sum over m of the longest range m, several times more when cells hold ~20 records
-                // (PMC before: 41k VALU instructions per wave in the first iterations of a run).
-#pragma unroll
-                for (int k = 0; k < RPL; ++k) {
-#pragma unroll
-                    for (int sg = 0; sg < 2; ++sg) {
-                        if (sg == 1 && k >= RPLX) continue;
-                        const int j0 = sg ? jc[k < RPLX ? k : 0] : ja[k], j1 = sg ? jd[k < RPLX ? k : 0] : jb[k];
-                        if (j1 > j0 && budget >= 0) {
-                            budget -= j1 - j0;                       // crowded cells: one wave of the tree search is faster
-                            if (budget >= 0) { seg[n_seg][threadIdx.x] = make_int2(j0, j1); ++n_seg; if (STATS) n_entries += j1 - j0; }
-                        }
-                    }
-                }
-                tri_scan_segments(pf, cell_rec, tri9, S, gp.eps_plane, seg, n_seg, queue, qkey, nq, kmin, gmin, delta, cutf,
-                                  STATS ? &n_surv : nullptr, STATS ? &n_evals : nullptr, STATS ? &n_trips : nullptr);
-                if (STATS) n_surv += nq;
-                tri_queue_flush(pf, tri9, S, queue, qkey, nq, kmin, gmin, delta, cutf, STATS ? &n_evals : nullptr, STATS ? &n_trips : nullptr);   // a better best prunes the next batch of rows
-                over = budget < 0;
-                if (L > 1) {                                         // the lanes of the query agree on the best so far
-                    bool changed = false;
-#pragma unroll
-                    for (int o = 1; o < L; o <<= 1) {
-                        const float ob = __shfl_xor(S.best, o, 64);
-                        const uint32_t oi = (uint32_t)__shfl_xor((int)S.bidx, o, 64);
-                        if (ob < S.best) { S.best = ob; S.bidx = oi; changed = true; }
-                        else if (ob == S.best && oi < S.bidx) S.bidx = oi;
-                        over = (__shfl_xor((int)over, o, 64) != 0) || over;
-                    }
-                    if (changed) { S.lim = fminf(S.best, cutf); tri_state_refresh(S, delta); }
+            for (int k = 0; k < RPL; ++k) {
+                ja[k] = jb[k] = 0;
+                if (k < RPLX) jc[k] = jd[k] = 0;
+                const int kk = b0 + sub + L * k;
+                if (k >= rpl || kk >= n_rows) continue;
+                const int qz = (int)(((unsigned)kk * div_mul) >> 16);
+                const int dzi = qz - r, dyi = kk - qz * side - r;
+                const int z = q.c[2] + dzi, y = q.c[1] + dyi;
+                if (z < 0 || z >= gp.n[2] || y < 0 || y >= gp.n[1]) continue;
+                const float gz = grid_gap(q.f[2], h, slack, dzi), gy = grid_gap(q.f[1], h, slack, dyi);
+                const float row2 = __builtin_fmaf(gy, gy, __builtin_fmaf(gz, gz, q.off2));
+                // (sqrt(row2) - delta)^2 (1 - 1e-5) - 1e-30 > lim  <=>  row2 > reach2: nothing in this row can matter
+                if (row2 * 0.999998f > S.reach2f) continue;
+                // cells of the row whose slab along x can still hold a triangle within reach
+                int dl, dr;
+                grid_row_span(q.f[0], h, inv_h, slack, S.reach2f - row2 * 0.999998f, r, dl, dr);
+                const int xa = max(q.c[0] - dl, 0), xb = min(q.c[0] + dr, gp.n[0] - 1);
+                const int row = (z * gp.n[1] + y) * gp.n[0];
+                // interior rows were fully covered by ring r-1: only their two end cells are new
+                const bool shell_row = first || dzi == -r || dzi == r || dyi == -r || dyi == r;
+                if (STATS) ++n_rows_loaded;
+                if (shell_row) {
+                    ja[k] = cell_start[row + xa]; jb[k] = cell_start[row + xb + 1];
+                } else if (k < RPLX) {
+                    const int xl = q.c[0] - r, xr = q.c[0] + r;
+                    if (dl == r && xl >= 0) { ja[k] = cell_start[row + xl]; jb[k] = cell_start[row + xl + 1]; }
+                    if (dr == r && xr < gp.n[0]) { jc[k] = cell_start[row + xr]; jd[k] = cell_start[row + xr + 1]; }
                 }
             }
-            if (STATS) max_ring = r;
-            if (over) break;
-            const float bound = grid_cube_bound2(gp, q, r);            // everything outside the cube of radius r
-            if (!(bound < INFINITY) || bound * 0.999998f > S.reach2f) settled = true;   // same test as for a row
+            // The non-empty cell-list ranges of this lane's rows go on a per-thread list in LDS and are scanned in ONE
+            // flattened loop (tri_scan_segments): every lane walks its own ranges four records per trip, so a wave
+            // pays max-over-lanes(records) trips.  Walking the rows in lockstep instead -- range m of every lane
+            // together -- pays the sum over m of the longest range m, several times more when cells hold ~20 records
+            // (PMC before: 41k VALU instructions per wave in the first iterations of a run).
+#pragma unroll
+            for (int k = 0; k < RPL; ++k) {
+#pragma unroll
+                for (int sg = 0; sg < 2; ++sg) {
+                    if (sg == 1 && k >= RPLX) continue;
+                    const int j0 = sg ? jc[k < RPLX ? k : 0] : ja[k], j1 = sg ? jd[k < RPLX ? k : 0] : jb[k];
+                    if (j1 > j0 && budget >= 0) {
+                        budget -= j1 - j0;                           // crowded cells: one wave of the tree search is faster
+                        if (budget >= 0) { seg[n_seg][threadIdx.x] = make_int2(j0, j1); ++n_seg; if (STATS) n_entries += j1 - j0; }
+                    }
+                }
+            }
+            b0 += rpl * L;
+            ring_done = b0 >= n_rows;
+        }
+        // phase 1 and phase 2: the whole wave, every trip
+        tri_scan_segments(pf, cell_rec, tri9, S, gp.eps_plane, seg, n_seg, pool, delta, cutf,
+                          STATS ? &n_surv : nullptr, STATS ? &n_evals : nullptr, STATS ? &n_trips : nullptr);
+        tri_pool_flush(pf, tri9, S, pool, delta, cutf, STATS ? &n_evals : nullptr, STATS ? &n_trips : nullptr);   // a better best prunes the next batch of rows
+        over = busy && budget < 0;
+        if (L > 1) {                                             // the lanes of the query agree on the best so far
+            bool changed = false;
+#pragma unroll
+            for (int o = 1; o < L; o <<= 1) {
+                const float ob = __shfl_xor(S.best, o, 64);
+                const uint32_t oi = (uint32_t)__shfl_xor((int)S.bidx, o, 64);
+                if (ob < S.best) { S.best = ob; S.bidx = oi; changed = true; }
+                else if (ob == S.best && oi < S.bidx) S.bidx = oi;
+                over = (__shfl_xor((int)over, o, 64) != 0) || over;
+            }
+            if (changed) { S.lim = fminf(S.best, cutf); tri_state_refresh(S, delta); }
+        }
+        if (busy) {
+            if (over) busy = false;
+            else if (ring_done) {
+                if (STATS) max_ring = r;
+                const float bound = grid_cube_bound2(gp, q, r);        // everything outside the cube of radius r
+                if (!(bound < INFINITY) || bound * 0.999998f > S.reach2f) { settled = true; busy = false; }   // same test as for a row
+                else { ++r; b0 = 0; if (r > gp.r_max) busy = false; }
+            }
         }
     }
-    if (STATS && stats) {
+    if (STATS && stats && alive) {
         atomicAdd(&stats[TRI_STAT_QUERIES], 1ull);
         atomicAdd(&stats[TRI_STAT_ROWS], (unsigned long long)n_rows_loaded);
         atomicAdd(&stats[TRI_STAT_ENTRIES], (unsigned long long)n_entries);
@@ -519,7 +600,7 @@ __global__ __launch_bounds__(256, 4) void k_tri_search_grid(const DevState *__re
             atomicAdd(&stats[TRI_STAT_WAVES], 1ull);
         }
     }
-    if (sub != 0) return;
+    if (sub != 0 || !alive) return;
     keys[i] = ((unsigned long long)__float_as_uint(S.best) << 32) | S.bidx;
     if (!settled) todo_list[atomicAdd(todo_count, 1)] = i;
 }

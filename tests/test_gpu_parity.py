@@ -814,6 +814,28 @@ def test_surface_search_bit_exact(orc, case, mode):
     assert np.array_equal(idx2, f2) and np.array_equal(gd22, d22), (case, mode, "seeded")
 
 
+@pytest.mark.parametrize("lanes", ["1", "2", "4"])
+def test_surface_grid_lane_variants_and_ragged_last_wave(orc, lanes, monkeypatch):
+    """k_tri_search_grid<L> for every L on a query count that leaves the last wave partly empty: phase 2 of the
+    triangle grid search deals its pool of survivors to all 64 lanes of a wave, so the lanes past the last query must
+    keep working (a round-2 bug: they left, and took their share of the candidates with them)."""
+    from object_alignment_amd.engine import IcpEngine
+    v, t, q = _surface_cases()["lattice"]
+    q = np.concatenate([q, (q[:37] * np.float32(1.002)).astype(np.float32)])        # 12037 queries: ragged in every L
+    eye = np.identity(4, dtype=np.float32)
+    monkeypatch.setenv("OA_GRID_LANES", lanes)
+    with IcpEngine(0) as e:
+        e.set_search_mode("grid")
+        e.set_target_mesh(v, t)
+        e.set_source(q)
+        e.set_matrices(eye, eye)
+        idx, d2, _ = e.nn_search()
+        idx2, d22, _ = e.nn_search()                                                 # seeded
+    ridx, _, rd2 = orc.nn_tri_brute(q, v, t)
+    assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2)
+    assert np.array_equal(idx2, ridx) and np.array_equal(d22, rd2)
+
+
 def test_surface_make_pairs_and_loop(orc):
     """make_pairs / the ICP loop in surface mode against the oracle's mesh-mode restatement."""
     from object_alignment_amd import synth
