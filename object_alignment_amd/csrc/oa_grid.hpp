@@ -197,8 +197,16 @@ __device__ __forceinline__ void grid_candidate(float px, float py, float pz, con
 // lanes (row k of a batch goes to lane k mod L), every lane scans its rows with its own running best, and the lanes
 // merge (d2, index) lexicographically after every batch -- the same candidates as one lane would see or more (a lane
 // prunes with its own, looser, `lim`), so the same answer, in a chain 1/L as long.
+//
+// Structure (as k_tri_search_grid): ONE wave-uniform loop.  Every trip, each lane that still has work lists the cell
+// ranges of its next batch of rows (its own ring, its own batch) on a small per-thread list in LDS, then all lanes walk
+// their lists in one flattened loop, four vertices per trip.  No range sits in registers across the scan (the kernel
+// fits 6 waves per SIMD), and a wave pays max-over-lanes(vertices) trips instead of the sum over the 18 range slots of
+// the longest range in each.
+constexpr int GRID_SEGS = 10;      // ranges of one batch: 9 rows of the first block (one each), or as many later rows (two each) as fit
+
 template <int L>
-__global__ __launch_bounds__(256, 5) void k_nn_search_grid(const DevState *__restrict__ st,
+__global__ __launch_bounds__(256, 6) void k_nn_search_grid(const DevState *__restrict__ st,
                                                         const float4 *__restrict__ src4, int ns, GridParams gp,
                                                         const int *__restrict__ cell_start,
                                                         const float4 *__restrict__ sorted,
@@ -207,12 +215,15 @@ __global__ __launch_bounds__(256, 5) void k_nn_search_grid(const DevState *__res
                                                         int *__restrict__ todo_list, int *__restrict__ todo_count, int turn)
 {
     constexpr int RPL = (9 + L - 1) / L;                            // rows per lane and batch
-    constexpr int BATCH = RPL * L;                                  // 9, 10, 12 rows per batch
+    static_assert(RPL <= GRID_SEGS && (L == 1 || 2 * RPL <= GRID_SEGS), "a batch of rows must fit the per-thread range list");
     if (st->halt) return;
     if (turn >= 0 && (st->tree_turn != 0) != (turn != 0)) return;  // not this kernel's turn (DevState::tree_turn)
+    __shared__ int2 seg[GRID_SEGS][256];
     const int gt = blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = gt / L, sub = gt % L;                             // the L lanes of a query are neighbours in a wave
-    if (i >= ns) return;
+    int i = gt / L;
+    const int sub = gt % L;                                         // the L lanes of a query are neighbours in a wave
+    const bool alive = i < ns;                                      // (lanes past the last query repeat it, silently)
+    if (!alive) i = ns - 1;
     const float4 p4 = src4[i];
     const float4 sw = win[i];                                       // seed: this slot's winner record, see below
     float wx, wy, wz, px, py, pz;
@@ -251,87 +262,105 @@ __global__ __launch_bounds__(256, 5) void k_nn_search_grid(const DevState *__res
     // loads its own cell only -- and a query near a face (a quarter of them at 1M <-> 1M) saves the separate pass,
     // i.e. two round trips of the wave it shares with 63 others.
     const int r_start = (bidx != IDX_NONE && gp.seeded_start) ? 1 : 0;
-    if (q.finite) {
-        for (int r = r_start; r <= gp.r_max && !settled && !over; ++r) {
-            // The (2r+1)^2 rows (y, z) of the ring are handled BATCH at a time: first the cell ranges of a lane's rows
-            // are fetched (up to 36 independent loads in flight), then their vertices are scanned four per trip.  A
-            // thread's time is a chain of memory round trips; this keeps the chain at ~2 + (vertices / 4) per batch
-            // instead of 2 per row + 1 per vertex.
+    int r = r_start, b0 = 0, n_seg = 0;
+    bool busy = q.finite && alive;
+    while (__any(busy)) {
+        bool ring_done = false;
+        if (busy) {
+            // The (2r+1)^2 rows (y, z) of the ring, RPL per lane at a time: first the cell ranges of the rows are
+            // fetched (independent loads, all in flight together), then their vertices are scanned four per trip.
+            const bool first = (r == r_start);
             const int side = 2 * r + 1, n_rows = side * side;
             const unsigned div_mul = 65536u / (unsigned)side + 1u;  // k / side == (k * div_mul) >> 16 for k < 256, side <= 15
-            for (int b0 = 0; b0 < n_rows && !over; b0 += BATCH) {
-                int ja[RPL], jb[RPL], jc[RPL], jd[RPL];             // row m: vertices [ja, jb) and [jc, jd) of `sorted`
+            int ja[RPL], jb[RPL], jc[RPL], jd[RPL];                 // row m: vertices [ja, jb) and [jc, jd) of `sorted`
 #pragma unroll
-                for (int m = 0; m < RPL; ++m) {
-                    ja[m] = jb[m] = jc[m] = jd[m] = 0;
-                    const int kk = b0 + sub + L * m;
-                    if (kk >= n_rows) continue;
-                    const int qz = (int)(((unsigned)kk * div_mul) >> 16);
-                    const int dzi = qz - r, dyi = kk - qz * side - r;
-                    const int z = q.c[2] + dzi, y = q.c[1] + dyi;
-                    if (z < 0 || z >= gp.n[2] || y < 0 || y >= gp.n[1]) continue;
-                    // every vertex of this row of cells is at real distance^2 >= off2 + gy^2 + gz^2 from the query
-                    const float gz = grid_gap(q.f[2], h, slack, dzi), gy = grid_gap(q.f[1], h, slack, dyi);
-                    const float row2 = __builtin_fmaf(gy, gy, __builtin_fmaf(gz, gz, q.off2));
-                    if (row2 * 0.99999f - 1e-30f > lim) continue;                   // cannot beat or tie
-                    // cells of the row that can still matter: x-gap^2 <= lim' - row2
-                    int dl, dr;
-                    grid_row_span(q.f[0], h, inv_h, slack, lim * 1.00001f + 1e-30f - row2 * 0.99999f, r, dl, dr);
-                    const int xa = max(q.c[0] - dl, 0), xb = min(q.c[0] + dr, gp.n[0] - 1);
-                    const int row = (z * gp.n[1] + y) * gp.n[0];
-                    // interior rows were fully covered by ring r-1: only their two end cells are new
-                    const bool shell_row = (r == r_start) || dzi == -r || dzi == r || dyi == -r || dyi == r;
-                    if (shell_row) {
-                        ja[m] = cell_start[row + xa]; jb[m] = cell_start[row + xb + 1];
-                    } else {
-                        const int xl = q.c[0] - r, xr = q.c[0] + r;
-                        if (dl == r && xl >= 0) { ja[m] = cell_start[row + xl]; jb[m] = cell_start[row + xl + 1]; }
-                        if (dr == r && xr < gp.n[0]) { jc[m] = cell_start[row + xr]; jd[m] = cell_start[row + xr + 1]; }
-                    }
-                }
-#pragma unroll
-                for (int m = 0; m < RPL; ++m) {
-#pragma unroll
-                    for (int sg = 0; sg < 2; ++sg) {
-                        const int j0 = sg ? jc[m] : ja[m], j1 = sg ? jd[m] : jb[m];
-                        if (j1 <= j0) continue;
-                        budget -= j1 - j0;
-                        if (budget < 0) break;                       // crowded cells: one wave of the tree search is faster
-                        const int last = j1 - 1;
-                        for (int j = j0; j < j1; j += 4) {           // the clamped repeats of the last vertex change nothing
-                            const float4 q0 = sorted[j], q1 = sorted[min(j + 1, last)], q2 = sorted[min(j + 2, last)],
-                                         q3 = sorted[min(j + 3, last)];
-                            grid_candidate(px, py, pz, q0, j, best, bidx, bj);
-                            grid_candidate(px, py, pz, q1, min(j + 1, last), best, bidx, bj);
-                            grid_candidate(px, py, pz, q2, min(j + 2, last), best, bidx, bj);
-                            grid_candidate(px, py, pz, q3, min(j + 3, last), best, bidx, bj);
-                        }
-                        lim = fminf(best, cutf);
-                    }
-                }
-                if (L > 1) {                                         // the lanes of the query agree on the best so far
-#pragma unroll
-                    for (int o = 1; o < L; o <<= 1) {
-                        const float ob = __shfl_xor(best, o, 64);
-                        const uint32_t oi = (uint32_t)__shfl_xor((int)bidx, o, 64);
-                        const int oj = __shfl_xor(bj, o, 64);
-                        if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; bj = oj; }
-                    }
-                    lim = fminf(best, cutf);
-                }
-                over = budget < 0;
-                if (L > 1) {
-#pragma unroll
-                    for (int o = 1; o < L; o <<= 1) over = (__shfl_xor((int)over, o, 64) != 0) || over;
+            for (int m = 0; m < RPL; ++m) {
+                ja[m] = jb[m] = jc[m] = jd[m] = 0;
+                const int kk = b0 + sub + L * m;
+                if (kk >= n_rows) continue;
+                const int qz = (int)(((unsigned)kk * div_mul) >> 16);
+                const int dzi = qz - r, dyi = kk - qz * side - r;
+                const int z = q.c[2] + dzi, y = q.c[1] + dyi;
+                if (z < 0 || z >= gp.n[2] || y < 0 || y >= gp.n[1]) continue;
+                // every vertex of this row of cells is at real distance^2 >= off2 + gy^2 + gz^2 from the query
+                const float gz = grid_gap(q.f[2], h, slack, dzi), gy = grid_gap(q.f[1], h, slack, dyi);
+                const float row2 = __builtin_fmaf(gy, gy, __builtin_fmaf(gz, gz, q.off2));
+                if (row2 * 0.99999f - 1e-30f > lim) continue;                   // cannot beat or tie
+                // cells of the row that can still matter: x-gap^2 <= lim' - row2
+                int dl, dr;
+                grid_row_span(q.f[0], h, inv_h, slack, lim * 1.00001f + 1e-30f - row2 * 0.99999f, r, dl, dr);
+                const int xa = max(q.c[0] - dl, 0), xb = min(q.c[0] + dr, gp.n[0] - 1);
+                const int row = (z * gp.n[1] + y) * gp.n[0];
+                // interior rows were fully covered by ring r-1: only their two end cells are new
+                const bool shell_row = first || dzi == -r || dzi == r || dyi == -r || dyi == r;
+                if (shell_row) {
+                    ja[m] = cell_start[row + xa]; jb[m] = cell_start[row + xb + 1];
+                } else {
+                    const int xl = q.c[0] - r, xr = q.c[0] + r;
+                    if (dl == r && xl >= 0) { ja[m] = cell_start[row + xl]; jb[m] = cell_start[row + xl + 1]; }
+                    if (dr == r && xr < gp.n[0]) { jc[m] = cell_start[row + xr]; jd[m] = cell_start[row + xr + 1]; }
                 }
             }
-            if (over) break;
-            // lower bound for everything outside the cube of radius r (+inf: the cube covers the whole grid)
-            const float bound = grid_cube_bound2(gp, q, r);
-            if (!(bound < INFINITY) || bound * 0.99999f - 1e-30f > lim) settled = true;   // no unseen vertex can beat or tie, or matter
+            int consumed = RPL;                                    // rows of this batch that went on the list (L == 1: as many as fit)
+            bool full = false;
+#pragma unroll
+            for (int m = 0; m < RPL; ++m) {
+                if (L == 1 && !full && n_seg + 2 > GRID_SEGS) { full = true; consumed = m; }
+                if (full) continue;
+#pragma unroll
+                for (int sg = 0; sg < 2; ++sg) {
+                    const int j0 = sg ? jc[m] : ja[m], j1 = sg ? jd[m] : jb[m];
+                    if (j1 > j0 && budget >= 0) {
+                        budget -= j1 - j0;                           // crowded cells: one wave of the tree search is faster
+                        if (budget >= 0) { seg[n_seg][threadIdx.x] = make_int2(j0, j1); ++n_seg; }
+                    }
+                }
+            }
+            b0 += consumed * L;
+            ring_done = b0 >= n_rows;
+        }
+        {   // every lane walks ITS ranges, four vertices per trip (the clamped repeats of the last vertex change nothing)
+            int k = 0, j = 0, end = 0;
+            while (true) {
+                if (j >= end && k < n_seg) { const int2 sgm = seg[k][threadIdx.x]; j = sgm.x; end = sgm.y; ++k; }
+                const bool active = j < end;
+                if (!__any(active)) break;
+                if (active) {
+                    const int last = end - 1;
+                    const int e1 = min(j + 1, last), e2 = min(j + 2, last), e3 = min(j + 3, last);
+                    const float4 q0 = sorted[j], q1 = sorted[e1], q2 = sorted[e2], q3 = sorted[e3];
+                    grid_candidate(px, py, pz, q0, j, best, bidx, bj);
+                    grid_candidate(px, py, pz, q1, e1, best, bidx, bj);
+                    grid_candidate(px, py, pz, q2, e2, best, bidx, bj);
+                    grid_candidate(px, py, pz, q3, e3, best, bidx, bj);
+                    j += 4;
+                }
+            }
+            n_seg = 0;
+        }
+        over = busy && budget < 0;
+        if (L > 1) {                                             // the lanes of the query agree on the best so far
+#pragma unroll
+            for (int o = 1; o < L; o <<= 1) {
+                const float ob = __shfl_xor(best, o, 64);
+                const uint32_t oi = (uint32_t)__shfl_xor((int)bidx, o, 64);
+                const int oj = __shfl_xor(bj, o, 64);
+                if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; bj = oj; }
+                over = (__shfl_xor((int)over, o, 64) != 0) || over;
+            }
+        }
+        lim = fminf(best, cutf);
+        if (busy) {
+            if (over) busy = false;
+            else if (ring_done) {
+                // lower bound for everything outside the cube of radius r (+inf: the cube covers the whole grid)
+                const float bound = grid_cube_bound2(gp, q, r);
+                if (!(bound < INFINITY) || bound * 0.99999f - 1e-30f > lim) { settled = true; busy = false; }   // no unseen vertex can beat or tie, or matter
+                else { ++r; b0 = 0; if (r > gp.r_max) busy = false; }
+            }
         }
     }
-    if (sub != 0) return;
+    if (sub != 0 || !alive) return;
     keys[i] = ((unsigned long long)__float_as_uint(best) << 32) | bidx;
     // the winner record is read by k_pair_accumulate, the tree search and the next search; a winner that is still the
     // seed (the usual case once the loop converges) is already there

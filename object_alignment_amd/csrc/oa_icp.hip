@@ -1581,7 +1581,7 @@ int build_tri_grid(oa_ctx *c)
         gp.h = h; gp.inv_h = 1.0 / h;
         gp.r_max = std::min(env_int("OA_GRID_RMAX", 3), 3);
         gp.seeded_start = env_int("OA_TRI_SEEDED_START", 1) ? 1 : 0;
-        gp.budget = env_int("OA_GRID_BUDGET", 128);
+        gp.budget = env_int("OA_GRID_BUDGET", 192);
         gp.scale = scale;
         gp.slack = 1e-10 * scale + 1e-300;
         oa::grid_params_finish(gp);

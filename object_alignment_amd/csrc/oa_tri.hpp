@@ -428,10 +428,11 @@ __global__ __launch_bounds__(256, 4) void k_tri_search_grid(const DevState *__re
                                                          int *__restrict__ todo_list, int *__restrict__ todo_count, int turn,
                                                          unsigned long long *__restrict__ stats = nullptr)
 {
-    // rows per lane and batch: the first block of a search (its rows are whole ranges: one per row) nine rows at a time,
-    // later rings (interior rows contribute their two end cells: up to two ranges per row) five at a time
-    constexpr int RPL = (9 + L - 1) / L, RPLX = (5 + L - 1) / L;
-    static_assert(RPL <= TRI_SEGS && 2 * RPLX <= TRI_SEGS, "a batch of rows must fit the per-thread range list");
+    // rows per lane and batch: nine rows of a ring at a time (dealt out to the L lanes of the query).  The rows of the
+    // first block of a search are whole ranges (one per row); interior rows of later rings contribute their two end
+    // cells (two ranges per row): with one lane per query a batch then takes as many rows as fit the range list.
+    constexpr int RPL = (9 + L - 1) / L;
+    static_assert(RPL <= TRI_SEGS && (L == 1 || 2 * RPL <= TRI_SEGS), "a batch of rows must fit the per-thread range list");
     if (st->halt) return;
     if (turn >= 0 && (st->tree_turn != 0) != (turn != 0)) return;  // not this kernel's turn (DevState::tree_turn)
     __shared__ int pool_tid[4][TRI_POOL], pool_own[4][TRI_POOL];
@@ -499,14 +500,14 @@ __global__ __launch_bounds__(256, 4) void k_tri_search_grid(const DevState *__re
             const bool first = (r == r_start);
             const int side = 2 * r + 1, n_rows = side * side;
             const unsigned div_mul = 65536u / (unsigned)side + 1u;  // k / side == (k * div_mul) >> 16 for k < 256, side <= 15
-            const int rpl = first ? RPL : RPLX;
+            const int rpl = RPL;
             // rows of the ring: cell ranges first (independent loads), then the candidates -- as in k_nn_search_grid;
             // per-row arithmetic in float on the query's frame (GridQuery)
-            int ja[RPL], jb[RPL], jc[RPLX], jd[RPLX];
+            int ja[RPL], jb[RPL], jc[RPL], jd[RPL];
 #pragma unroll
             for (int k = 0; k < RPL; ++k) {
                 ja[k] = jb[k] = 0;
-                if (k < RPLX) jc[k] = jd[k] = 0;
+                jc[k] = jd[k] = 0;
                 const int kk = b0 + sub + L * k;
                 if (k >= rpl || kk >= n_rows) continue;
                 const int qz = (int)(((unsigned)kk * div_mul) >> 16);
@@ -527,7 +528,7 @@ __global__ __launch_bounds__(256, 4) void k_tri_search_grid(const DevState *__re
                 if (STATS) ++n_rows_loaded;
                 if (shell_row) {
                     ja[k] = cell_start[row + xa]; jb[k] = cell_start[row + xb + 1];
-                } else if (k < RPLX) {
+                } else {
                     const int xl = q.c[0] - r, xr = q.c[0] + r;
                     if (dl == r && xl >= 0) { ja[k] = cell_start[row + xl]; jb[k] = cell_start[row + xl + 1]; }
                     if (dr == r && xr < gp.n[0]) { jc[k] = cell_start[row + xr]; jd[k] = cell_start[row + xr + 1]; }
@@ -538,25 +539,31 @@ __global__ __launch_bounds__(256, 4) void k_tri_search_grid(const DevState *__re
             // pays max-over-lanes(records) trips.  Walking the rows in lockstep instead -- range m of every lane
             // together -- pays the sum over m of the longest range m, several times more when cells hold ~20 records
             // (PMC before: 41k VALU instructions per wave in the first iterations of a run).
+            int consumed = rpl;                                   // rows of this batch that went on the list (L == 1: as many as fit)
+            bool full = false;
 #pragma unroll
             for (int k = 0; k < RPL; ++k) {
+                if (L == 1 && !full && n_seg + 2 > TRI_SEGS) { full = true; consumed = k; }
+                if (full) continue;
 #pragma unroll
                 for (int sg = 0; sg < 2; ++sg) {
-                    if (sg == 1 && k >= RPLX) continue;
-                    const int j0 = sg ? jc[k < RPLX ? k : 0] : ja[k], j1 = sg ? jd[k < RPLX ? k : 0] : jb[k];
+                    const int j0 = sg ? jc[k] : ja[k], j1 = sg ? jd[k] : jb[k];
                     if (j1 > j0 && budget >= 0) {
                         budget -= j1 - j0;                           // crowded cells: one wave of the tree search is faster
                         if (budget >= 0) { seg[n_seg][threadIdx.x] = make_int2(j0, j1); ++n_seg; if (STATS) n_entries += j1 - j0; }
                     }
                 }
             }
-            b0 += rpl * L;
+            b0 += consumed * L;
             ring_done = b0 >= n_rows;
         }
         // phase 1 and phase 2: the whole wave, every trip
         tri_scan_segments(pf, cell_rec, tri9, S, gp.eps_plane, seg, n_seg, pool, delta, cutf,
                           STATS ? &n_surv : nullptr, STATS ? &n_evals : nullptr, STATS ? &n_trips : nullptr);
-        tri_pool_flush(pf, tri9, S, pool, delta, cutf, STATS ? &n_evals : nullptr, STATS ? &n_trips : nullptr);   // a better best prunes the next batch of rows
+        // phase 2 now if somebody needs its final word on this ring (or gives up), or the pool is filling up; otherwise the
+        // survivors wait for the next batch's (every flush costs the wave at least one evaluation trip)
+        if (__any(busy && (ring_done || budget < 0)) || pool.n > TRI_POOL / 4)
+            tri_pool_flush(pf, tri9, S, pool, delta, cutf, STATS ? &n_evals : nullptr, STATS ? &n_trips : nullptr);
         over = busy && budget < 0;
         if (L > 1) {                                             // the lanes of the query agree on the best so far
             bool changed = false;
