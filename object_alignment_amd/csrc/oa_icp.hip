@@ -501,7 +501,7 @@ int launch_nn_impl(oa_ctx *c)
     if (c->ns_pad / (oa::NN_THREADS * c->R) > 65535)               // only the brute-force launch has this limit (grid.y)
         return fail(OA_E_BAD_ARG, "shard of %d points exceeds the brute-force launch grid (use more shards or OA_NN_R=8)", c->ns);
 #define OA_NN_ARGS c->d_state, c->d_src4, c->d_tg, c->groups_per_split, c->n_groups_pad, c->d_keys
-#define OA_NNF_ARGS c->d_state, c->d_src4, c->d_tg, c->d_tf, c->d_tf3, c->d_tgt_xyz, c->d_prev, c->groups_per_split, c->n_groups_pad, c->d_keys
+#define OA_NNF_ARGS c->d_state, c->d_src4, c->d_tg, c->d_tf, c->d_tf3, (const float4 *)c->d_win, c->groups_per_split, c->n_groups_pad, c->d_keys
     if (c->filter_ok && c->use_filter) {
         const bool small = (c->tile_groups == 64);
 #define OA_LAUNCH_F(RR)                                                                                              \

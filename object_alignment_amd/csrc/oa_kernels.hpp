@@ -683,8 +683,7 @@ __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_filt
                                                                    const float4 *__restrict__ tg,
                                                                    const float4 *__restrict__ tf2,
                                                                    const float4 *__restrict__ tf3,
-                                                                   const float *__restrict__ tgt_xyz,
-                                                                   const int *__restrict__ prev, int groups_per_split,
+                                                                   const float4 *__restrict__ win, int groups_per_split,
                                                                    int n_groups_pad,
                                                                    unsigned long long *__restrict__ keys)
 {
@@ -701,8 +700,8 @@ __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_filt
     const float cx = st->tc[0], cy = st->tc[1], cz = st->tc[2];
     const int au = st->fax[0], av = st->fax[1];
     const int base = blockIdx.y * (NN_THREADS * R);
-    float px[R], py[R], pz[R], hu[R], hv[R], hd[R], best[R], thr2[R], thr3[R];
-    uint32_t bidx[R];
+    float px[R], py[R], pz[R], hu[R], hv[R], hd[R], best[R], thr2[R], thr3[R], seed_d[R];
+    uint32_t bidx[R], seed_idx[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int i = base + r * NN_THREADS + tid;
@@ -718,11 +717,15 @@ __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_filt
         hd[r] = (au + av == 1) ? h2 : ((au + av == 2) ? h1 : h0); // the dropped axis is the remaining one
         best[r] = INFINITY;
         bidx[r] = IDX_NONE;
-        const int s = prev ? prev[i] : -1;
-        if (s >= 0) {                                           // seed: last iteration's nearest vertex
-            const float d = d2_metric(px[r], py[r], pz[r], tgt_xyz[3ll * s], tgt_xyz[3ll * s + 1], tgt_xyz[3ll * s + 2]);
-            if (d < INFINITY) { best[r] = d; bidx[r] = (uint32_t)s; }
+        // seed: the slot's winner record of the last search (coordinates + index, kept current by k_pair_accumulate) --
+        // one coalesced 16-byte read per split where the index alone cost a scattered gather from the target array
+        const float4 sw = win ? win[i] : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+        if (__float_as_int(sw.w) >= 0) {
+            const float d = d2_metric(px[r], py[r], pz[r], sw.x, sw.y, sw.z);
+            if (d < INFINITY) { best[r] = d; bidx[r] = (uint32_t)__float_as_int(sw.w); }
         }
+        seed_idx[r] = bidx[r];
+        seed_d[r] = best[r];
         filter_thresholds(best[r], hu[r], hv[r], hd[r], qmax, thr2[r], thr3[r]);
     }
 
@@ -827,12 +830,21 @@ __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_filt
     }
 #undef OA_STG_EACH
 
+    // A split reports when it has something to say: a better vertex than the seed, or the seed itself when it lies in
+    // this split's range (exactly one split owns it, so the key is never left empty).  With 24 splits and a settled
+    // pose that is one 64-bit atomic per point instead of 24 (PMC: 187 MB of HBM-side writes per launch for 8 MB of keys).
+    const uint32_t own_lo = (uint32_t)g_begin * 4u, own_hi = (uint32_t)g_end * 4u;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const unsigned long long key = ((unsigned long long)__float_as_uint(best[r]) << 32) | bidx[r];
         unsigned long long *dst = keys + base + r * NN_THREADS + tid;
         if (gridDim.x == 1) *dst = key;
-        else atomicMin(dst, key);                                  // (d2, idx) lexicographic: lowest index on ties
+        else {
+            const bool seeded = seed_idx[r] != IDX_NONE;
+            const bool improved = bidx[r] != seed_idx[r] || best[r] != seed_d[r];
+            const bool owner = seeded && seed_idx[r] >= own_lo && seed_idx[r] < own_hi;
+            if (!seeded || improved || owner) atomicMin(dst, key);  // (d2, idx) lexicographic: lowest index on ties
+        }
     }
 }
 
