@@ -33,7 +33,7 @@ SYMBOLS = [
     "oa_set_search_mode",
     "oa_set_target", "oa_set_target_mesh", "oa_set_source", "oa_set_normals", "oa_set_matrices", "oa_get_matrix_world", "oa_num_selected",
     "oa_reset_seeds", "oa_get_stat",
-    "oa_make_pairs", "oa_nn_search", "oa_kabsch", "oa_kabsch_from_sums", "oa_get_pivot",
+    "oa_make_pairs", "oa_nn_search", "oa_kabsch", "oa_affine_from_points", "oa_kabsch_from_sums", "oa_get_pivot",
     "oa_iterate", "oa_run", "oa_get_history", "oa_run_begin", "oa_iter_partial", "oa_iter_finish", "oa_run_end",
 ]
 
@@ -103,6 +103,7 @@ def load():
     L.oa_make_pairs.argtypes = [vp, C.c_double, C.c_int, dp, dp, C.c_int64, ip, dp]
     L.oa_nn_search.argtypes = [vp, ip, fp, dp]
     L.oa_kabsch.argtypes = [vp, dp, dp, C.c_int64, C.c_int64, C.c_int, dp]
+    L.oa_affine_from_points.argtypes = [vp, dp, dp, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, dp]
     L.oa_kabsch_from_sums.argtypes = [vp, dp, dp, C.c_int, dp]
     L.oa_get_pivot.argtypes = [vp, dp]
     L.oa_iterate.argtypes = [vp, C.POINTER(Settings), dp, dp]

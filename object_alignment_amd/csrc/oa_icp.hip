@@ -12,6 +12,7 @@
 #include "oa_grid.hpp"
 #include "oa_tri.hpp"
 #include "oa_bvh.hpp"
+#include "oa_affine.hpp"
 #include "../../include/oa_icp.h"
 
 #include <algorithm>
@@ -2075,6 +2076,46 @@ OA_EXPORT int oa_kabsch(oa_ctx *c, const double *A, const double *B, int64_t K, 
     rc = solve_on_device(c, c->d_sums, pv, with_scale, M);      // synchronises the stream
     if (rc) (void)hipStreamSynchronize(c->stream);
     return rc;
+}
+
+// the reference's full signature: any ndims in 2..8, shear (full affine) or rigid / similarity
+OA_EXPORT int oa_affine_from_points(oa_ctx *c, const double *v0, const double *v1, int ndims, int64_t K, int64_t ld,
+                                    int shear, int with_scale, double *M)
+{
+    if (!c || !M) return fail(OA_E_BAD_ARG, "oa_affine_from_points: null argument");
+    OA_ROUTE_FIRST(c, oa_affine_from_points(sub, v0, v1, ndims, K, ld, shear, with_scale, M));
+    if (ndims < 2 || K < ndims) return fail(OA_E_TOO_FEW_PAIRS, "input arrays are of wrong shape or type");   // general.py:150-157
+    if (ndims > oa::AFF_MAXD) return fail(OA_E_BAD_ARG, "oa_affine_from_points: ndims %d > %d", ndims, oa::AFF_MAXD);
+    if (!v0 || !v1 || ld < K) return fail(OA_E_BAD_ARG, "oa_affine_from_points: bad arrays");
+    int rc = use_device(c);
+    if (rc) return rc;
+    if ((rc = ensure_common(c))) return rc;
+    const int n = ndims, w = n + 1;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(512, (K + 1023) / 1024));
+    const long long cols_per_block = ((K + blocks - 1) / blocks + oa::AFF_TILE - 1) / oa::AFF_TILE * oa::AFF_TILE;
+    const int gblocks = (int)((K + cols_per_block - 1) / cols_per_block);
+    DevTmp<double> d0, d1, p1, p2, d_cs, d_gram, d_out;
+    HIPCHK(d0.alloc((size_t)n * K)); HIPCHK(d1.alloc((size_t)n * K));
+    HIPCHK(p1.alloc((size_t)blocks * oa::AFF_M2)); HIPCHK(p2.alloc((size_t)gblocks * oa::AFF_M2 * oa::AFF_M2));
+    HIPCHK(d_cs.alloc(oa::AFF_M2)); HIPCHK(d_gram.alloc(oa::AFF_M2 * oa::AFF_M2)); HIPCHK(d_out.alloc((size_t)w * w + 1));
+    for (int a = 0; a < n; ++a) {
+        HIPCHK(hipMemcpyAsync(d0.p + (size_t)a * K, v0 + (size_t)a * ld, sizeof(double) * (size_t)K, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(d1.p + (size_t)a * K, v1 + (size_t)a * ld, sizeof(double) * (size_t)K, hipMemcpyHostToDevice, c->stream));
+    }
+    hipLaunchKernelGGL(oa::k_affine_colsums, dim3(blocks), dim3(256), 0, c->stream, (const double *)d0.p, (const double *)d1.p, n,
+                       (long long)K, (long long)K, p1.p);
+    hipLaunchKernelGGL(oa::k_affine_reduce, dim3(1), dim3(64), 0, c->stream, (const double *)p1.p, blocks, oa::AFF_M2, d_cs.p);
+    hipLaunchKernelGGL(oa::k_affine_gram, dim3(gblocks), dim3(256), 0, c->stream, (const double *)d0.p, (const double *)d1.p, n,
+                       (long long)K, (long long)K, (const double *)d_cs.p, cols_per_block, p2.p);
+    hipLaunchKernelGGL(oa::k_affine_reduce, dim3(1), dim3(256), 0, c->stream, (const double *)p2.p, gblocks, oa::AFF_M2 * oa::AFF_M2, d_gram.p);
+    hipLaunchKernelGGL(oa::k_affine_solve, dim3(1), dim3(64), 0, c->stream, (const double *)d_cs.p, (const double *)d_gram.p, n,
+                       (long long)K, shear ? 1 : 0, with_scale ? 1 : 0, d_out.p);
+    HIPCHK(hipGetLastError());
+    std::vector<double> out((size_t)w * w + 1);
+    { int rcr = read_small(c, out.data(), d_out, sizeof(double) * out.size()); if (rcr) return rcr; }
+    if (out[(size_t)w * w] != 1.0) return fail(OA_E_TOO_FEW_PAIRS, "input arrays are of wrong shape or type");
+    memcpy(M, out.data(), sizeof(double) * (size_t)w * w);
+    return OA_OK;
 }
 
 OA_EXPORT int oa_kabsch_from_sums(oa_ctx *c, const double sums[OA_NSUMS], const double pivot[3], int with_scale,

@@ -228,6 +228,19 @@ class IcpEngine:
         capi.check(rc)
         return M
 
+    def affine_from_points(self, v0, v1, shear=True, scale=True) -> np.ndarray:
+        """affine_matrix_from_points in full: any ndims in 2..8, shear (affine) or rigid / similarity."""
+        v0 = np.ascontiguousarray(v0, np.float64)
+        v1 = np.ascontiguousarray(v1, np.float64)
+        n, K = v0.shape
+        M = np.empty((n + 1, n + 1), np.float64)
+        rc = self._L.oa_affine_from_points(self._h, capi.dptr(v0), capi.dptr(v1), n, K, K, int(bool(shear)), int(bool(scale)),
+                                           capi.dptr(M))
+        if rc == capi.OA_E_TOO_FEW_PAIRS:
+            raise ValueError(REF_VALUEERROR)
+        capi.check(rc)
+        return M
+
     def kabsch_from_sums(self, sums, pivot=None, scale=False) -> np.ndarray:
         s = np.ascontiguousarray(sums, np.float64).reshape(capi.OA_NSUMS)
         pv = np.ascontiguousarray(pivot, np.float64).reshape(3) if pivot is not None else None

@@ -244,8 +244,11 @@ def make_pairs(align_obj, base_obj, base_bvh, vlist, thresh, sample=0, calc_stat
 
 
 def affine_matrix_from_points(v0, v1, shear=True, scale=True, usesvd=True):
-    """Same contract as the reference's affine_matrix_from_points (functions/general.py:105-217)
-    for the branch the ICP operators use: 3-D, shear=False (rigid, or similarity when scale=True)."""
+    """Same contract as the reference's affine_matrix_from_points (functions/general.py:105-217), every branch:
+    shear=True (the signature's default) is the affine estimate of Hartley & Zisserman (:168-178); shear=False the
+    rigid (scale=False) or similarity (scale=True) transform through the SVD of the covariance (:179-190, :208-212).
+    v0, v1: (ndims, K) with 2 <= ndims <= 8.  The 3-D rigid / similarity case -- the one the ICP operators use -- takes
+    the 24-sum solve of the loop (oa_kabsch); everything else the general device path (oa_affine_from_points)."""
     v0 = np.asarray(v0, dtype=np.float64)        # the reference copies (:146-147) because it centres in place; nothing
     v1 = np.asarray(v1, dtype=np.float64)        # is modified here
     if v0.ndim != 2 or v1.ndim != 2:
@@ -253,13 +256,13 @@ def affine_matrix_from_points(v0, v1, shear=True, scale=True, usesvd=True):
     ndims = v0.shape[0]
     if ndims < 2 or v0.shape[1] < ndims or v0.shape != v1.shape:       # :150
         raise ValueError(REF_VALUEERROR)                                # :157
-    if shear:
-        raise NotImplementedError("shear=True (full affine) is not on the ICP path; no ICP caller selects it")
-    if ndims != 3:
-        raise NotImplementedError("only 3-D point sets are on the ICP path")
-    # usesvd=False (Horn's quaternion branch, :191-206) minimises the same objective and has the same
+    if ndims > 8:
+        raise ValueError("affine_matrix_from_points: at most 8 dimensions on the device path (got %d)" % ndims)
+    # usesvd=False (Horn's quaternion branch, :191-206, 3-D only) minimises the same objective and has the same
     # optimum; it is served by the same device solve.
-    return default_engine().kabsch(v0, v1, scale=bool(scale))
+    if ndims == 3 and not shear:
+        return default_engine().kabsch(v0, v1, scale=bool(scale))
+    return default_engine().affine_from_points(v0, v1, shear=bool(shear), scale=bool(scale))
 
 
 def calc_target_matrix(A, B, scale=False):

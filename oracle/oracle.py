@@ -257,10 +257,11 @@ def kabsch_c(A, B, scale=False):
 
 
 def affine_matrix_from_points(v0, v1, shear=False, scale=False, usesvd=True):
-    """numpy restatement of the live branch of
-    /root/reference/functions/general.py:105-217 (shear=False, usesvd=True)."""
-    if shear or not usesvd:
-        raise NotImplementedError("oracle restates only shear=False, usesvd=True")
+    """numpy restatement of /root/reference/functions/general.py:105-217: the shear branch (:168-178) and the SVD
+    branch (:179-190, :208-212), any ndims >= 2.  (Horn's quaternion branch, usesvd=False, is not restated: it
+    minimises the same objective; the golden fixtures hold the reference's own Horn results.)"""
+    if not usesvd and not shear and np.shape(v0)[0] == 3:
+        raise NotImplementedError("oracle does not restate the quaternion branch")
     v0 = np.array(v0, dtype=np.float64, copy=True)
     v1 = np.array(v1, dtype=np.float64, copy=True)
     ndims = v0.shape[0]
@@ -270,14 +271,21 @@ def affine_matrix_from_points(v0, v1, shear=False, scale=False, usesvd=True):
     c1 = np.mean(v1, axis=1)                                           # :164
     a = v0 - c0.reshape(ndims, 1)
     b = v1 - c1.reshape(ndims, 1)
-    u, s, vh = np.linalg.svd(b @ a.T)                                  # :181
-    R = u @ vh                                                         # :183
-    if np.linalg.det(R) < 0.0:                                         # :184
-        R = R - np.outer(u[:, ndims - 1], vh[ndims - 1, :] * 2.0)      # :186
     M = np.identity(ndims + 1)
-    M[:ndims, :ndims] = R                                              # :189-190
-    if scale:
-        M[:ndims, :ndims] *= math.sqrt(np.sum(b * b) / np.sum(a * a))  # :208-212
+    if shear:
+        stacked = np.concatenate((a, b), axis=0)                       # :170
+        _, _, vh = np.linalg.svd(stacked.T)                            # :171
+        vh = vh[:ndims].T                                              # :172
+        t = np.dot(vh[ndims:2 * ndims], np.linalg.pinv(vh[:ndims]))    # :173-176
+        M[:ndims, :ndims] = t                                          # :177-178
+    else:
+        u, s, vh = np.linalg.svd(b @ a.T)                              # :181
+        R = u @ vh                                                     # :183
+        if np.linalg.det(R) < 0.0:                                     # :184
+            R = R - np.outer(u[:, ndims - 1], vh[ndims - 1, :] * 2.0)  # :186
+        M[:ndims, :ndims] = R                                          # :189-190
+        if scale:
+            M[:ndims, :ndims] *= math.sqrt(np.sum(b * b) / np.sum(a * a))  # :208-212
     M0 = np.identity(ndims + 1)
     M0[:ndims, ndims] = -c0
     M1inv = np.identity(ndims + 1)

@@ -61,6 +61,28 @@ def test_affine_matrix_from_points_golden(golden_dir):
         assert np.abs(got - g[p + "M"]).max() < 1e-9
 
 
+def test_affine_matrix_from_points_full_signature_golden(golden_dir):
+    """The rest of the reference's signature through the GPU path: shear=True (the default arguments, incl. the doctest
+    at functions/general.py:125-130), 2-D and 4-D point sets -- against outputs of the imported reference."""
+    from object_alignment_amd.functions import affine_matrix_from_points
+    g = _load(golden_dir, "affine_general")
+    n = int(g["n_cases"])
+    assert n >= 40
+    for k in range(n):
+        name = str(g["c%02d_name" % k])
+        v0, v1, ref = g["c%02d_v0" % k], g["c%02d_v1" % k], g["c%02d_M" % k]
+        M = affine_matrix_from_points(v0, v1, shear=bool(g["c%02d_shear" % k]), scale=bool(g["c%02d_scale" % k]))
+        assert M.shape == ref.shape, name
+        tol = 1e-9 * max(1.0, float(np.abs(ref).max()))
+        assert np.abs(M - ref).max() <= tol, (name, float(np.abs(M - ref).max()))
+    # the doctest itself, with default arguments, to the digits the reference prints
+    M = affine_matrix_from_points([[0, 1031, 1031, 0], [0, 0, 1600, 1600]], [[675, 826, 826, 677], [55, 52, 281, 277]])
+    want = np.array([[0.14549, 0.00062, 675.50008], [0.00048, 0.14094, 53.24971], [0.0, 0.0, 1.0]])
+    assert np.allclose(M, want, atol=1e-5)
+    with pytest.raises(ValueError):
+        affine_matrix_from_points(np.zeros((2, 1)), np.zeros((2, 1)))
+
+
 def test_kabsch_properties(eng):
     from object_alignment_amd import synth
     rng = np.random.default_rng(0)

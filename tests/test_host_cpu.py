@@ -72,8 +72,14 @@ def test_affine_matrix_from_points_validation_matches_reference(built):
         affine_matrix_from_points(np.zeros((3, 5)), np.zeros((3, 6)), shear=False)       # shape mismatch
     with pytest.raises(ValueError, match=msg):
         affine_matrix_from_points(np.zeros((1, 5)), np.zeros((1, 5)), shear=False)       # ndims < 2
-    with pytest.raises(NotImplementedError):
-        affine_matrix_from_points(np.zeros((3, 5)), np.zeros((3, 5)))                    # shear=True default
+    with pytest.raises(ValueError, match=msg):
+        affine_matrix_from_points(np.zeros((2, 1)), np.zeros((2, 1)))                    # default arguments, K < ndims
+    # the default arguments (shear=True) reach the device path now: without a GPU that fails loudly, never quietly
+    from object_alignment_amd import _capi
+    if _capi.load().oa_device_count() == 0:
+        with pytest.raises((_capi.OaError, RuntimeError)):
+            affine_matrix_from_points(np.ones((3, 5)), np.ones((3, 5)))
+    assert "NotImplementedError" not in open(os.path.join(ROOT, "object_alignment_amd", "functions", "general.py")).read()
 
 
 def test_make_pairs_thresh_zero_returns_none(built):
