@@ -424,17 +424,17 @@ int check_ready(oa_ctx *c)
 bool grid_active(const oa_ctx *c);
 // every query through the tree: on request, and in auto mode for shards of up to `auto_max` points -- one wave per
 // query has far lower latency than the one-thread-per-query grid kernels until the waves no longer fit the chip
-// (measured crossover: 1.2e4 .. 2.4e4 points for vertices -- the grid kernel spreads a query over 2 or 4 lanes when the
-// shard is small --, 2.8e4 .. 4e4 for triangles, later for big targets whose grid no longer sits in cache;
-// profiles/r01h_search_mode_crossover.txt)
-inline int vertex_tree_max(const oa_ctx *c) { return c->nt >= 500000 ? 24576 : 12288; }
-inline int tri_tree_max(const oa_ctx *c) { return c->n_tris >= 1000000 ? 40960 : (c->n_tris >= 250000 ? 36864 : 28672); }
+// (measured crossover after the round-2 grid kernels: 3e3 .. 1.4e4 points for vertices -- the grid kernel spreads a
+// query over 2 or 4 lanes when the shard is small --, 1.5e4 .. 2e4 for triangles, later for big targets whose grid no
+// longer sits in cache; profiles/r02l_search_mode_crossover.txt.  Round 1: 1.2e4 .. 2.4e4 and 2.8e4 .. 4e4.)
+inline int vertex_tree_max(const oa_ctx *c) { return c->nt >= 500000 ? 14336 : 3072; }
+inline int tri_tree_max(const oa_ctx *c) { return c->n_tris >= 1000000 ? 20480 : (c->n_tris >= 250000 ? 18432 : 15360); }
 // ... and while the pose still moves by a good part of a cell per iteration (stale seeds, long reach: the first
 // iterations of a run, i.e. ALL of a typical early-exit run) the tree wins up to much larger shards (5-iteration runs
-// from a cold start, profiles/r01h_search_mode_crossover_short_runs.txt): shards between the two limits get both
+// from a cold start, profiles/r02l_search_mode_crossover_short_runs.txt): shards between the two limits get both
 // searches enqueued and DevState::tree_turn decides on the device
-inline int vertex_tree_early(const oa_ctx *c) { return c->nt >= 500000 ? 49152 : 14336; }
-inline int tri_tree_early(const oa_ctx *c) { return c->n_tris >= 1000000 ? 393216 : (c->n_tris >= 250000 ? 163840 : 57344); }
+inline int vertex_tree_early(const oa_ctx *c) { return c->nt >= 500000 ? 28672 : 8192; }
+inline int tri_tree_early(const oa_ctx *c) { return c->n_tris >= 1000000 ? 57344 : (c->n_tris >= 250000 ? 40960 : 22528); }
 inline bool bvh_whole(const oa_ctx *c, bool ok, int auto_max)
 {
     if (!ok) return false;

@@ -1378,7 +1378,7 @@ def test_tree_then_grid_turns(surface):
     from object_alignment_amd import synth
     from object_alignment_amd.engine import IcpEngine
     tv, tt = synth.bumpy_icosphere_mesh(5)                              # 10k vertices, 20k triangles
-    ns = 40_000 if surface else 13_500                                  # inside (late, early] for either mode
+    ns = 19_000 if surface else 6_000                                   # inside (late, early] for either mode
     src = synth.bunny_surface(ns, offset=0.41).astype(np.float32)
     src *= np.float32(np.linalg.norm(tv, axis=1).mean() / np.linalg.norm(src, axis=1).mean())
     pose = synth.rigid4(synth.rotation_from_rotvec([0.05, -0.04, 0.06]), [0.03, -0.02, 0.025])
