@@ -1,17 +1,23 @@
 #!/usr/bin/env python3
-"""Turn the raw output of tools/profile.sh (gpurun_out/prof_stats, prof_pmc_*) into the committed artefacts:
-profiles/<tag>_bench_1Mx1M_kernel_stats.csv, profiles/<tag>_bench_1Mx1M_pmc_summary.txt and the
-"1000000x1000000_n1" / "grid_..." entries of profiles/hbm_traffic.json that bench.py reports as roofline.traffic.
+"""Turn the raw output of tools/profile.sh (gpurun_out/prof_*) into the committed artefacts:
+  profiles/<tag>_bench_1Mx1M_kernel_stats.csv, profiles/<tag>_bench_1Mx1M_pmc_summary.txt,
+  profiles/<tag>_surface_1M_kernel_stats.csv,  profiles/<tag>_surface_1M_pmc_summary.txt
+and the entries of profiles/hbm_traffic.json that bench.py reports as roofline.traffic /
+roofline.valu_instructions_per_pair -- each stamped with the kernel it was measured on, the commit and a fingerprint of
+the kernel sources (bench.py withholds a figure whose kernel name no longer matches, and marks one from other sources
+stale).
 
 HBM-side bytes follow MI355X_MICROARCH.md's HBM section: FETCH_SIZE and WRITE_SIZE are collected in separate passes,
 are in KB, and FETCH_SIZE counts half of the wide coalesced bytes on gfx950 (hence 2 x FETCH_SIZE + WRITE_SIZE).
-Usage: python tools/summarize_profile.py <tag> ["header line"]"""
+Usage (here, after gpurun merged gpurun_out/): python tools/summarize_profile.py <tag> ["header line"]"""
 import collections
 import csv
 import glob
+import hashlib
 import json
 import os
 import shutil
+import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -29,55 +35,104 @@ def short(name):
     return n.replace("void ", "").replace("oa::", "")
 
 
-def main():
-    tag = sys.argv[1]
-    header = sys.argv[2] if len(sys.argv) > 2 else ""
-    stats = newest(os.path.join(OUT, "prof_stats", "*", "*_kernel_stats.csv"))
-    shutil.copy(stats, os.path.join(PROF, "%s_bench_1Mx1M_kernel_stats.csv" % tag))
+def csrc_sha16():
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "object_alignment_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def collect(subdirs, want):
     agg = collections.defaultdict(list)
-    for sub in ("prof_pmc_FETCH_SIZE", "prof_pmc_WRITE_SIZE", "prof_pmc_SQ"):
+    for sub in subdirs:
         f = newest(os.path.join(OUT, sub, "*", "*_counter_collection.csv"))
         if not f:
             continue
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
-            if k.startswith("k_nn_search"):
+            if want(k):
                 agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
-    lines = ["# %s: %s" % (tag, header),
-             "# rocprofv3 PMC passes of `python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-surface` (tools/profile.sh); per-dispatch means", ""]
+    return agg
+
+
+def table(agg, lines):
     mean = {}
     order = {"FETCH_SIZE": 0, "WRITE_SIZE": 1}
     for (k, c), v in sorted(agg.items(), key=lambda kv: (order.get(kv[0][1], 2), kv[0][1] if kv[0][1] not in order else "", kv[0][0])):
         mean[(k, c)] = sum(v) / len(v)
-        lines.append("%-40s %-22s calls=%d mean=%g" % (k, c, len(v), mean[(k, c)]))
+        lines.append("%-44s %-22s calls=%d mean=%g" % (k, c, len(v), mean[(k, c)]))
     lines.append("")
     traffic = {}
     for k in sorted({k for k, _ in mean}):
         if (k, "FETCH_SIZE") in mean and (k, "WRITE_SIZE") in mean:
             b = (2.0 * mean[(k, "FETCH_SIZE")] + mean[(k, "WRITE_SIZE")]) * 1024.0
             traffic[k] = b
-            lines.append("%s: HBM-side traffic per launch = (2*FETCH_SIZE + WRITE_SIZE) KB = %.3g GB" % (k, b / 1e9))
+            lines.append("%s: HBM-side traffic per launch = (2*FETCH_SIZE + WRITE_SIZE) KB = %.4g GB" % (k, b / 1e9))
+    return mean, traffic
+
+
+def main():
+    tag = sys.argv[1]
+    header = sys.argv[2] if len(sys.argv) > 2 else ""
+    try:
+        commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], text=True).strip()
+    except Exception:
+        commit = None
+    stamp = {"commit": commit, "csrc_sha16": csrc_sha16()}
+    jf = os.path.join(PROF, "hbm_traffic.json")
+    tr = json.load(open(jf)) if os.path.exists(jf) else {}
+
+    # ---- the bench command
+    stats = newest(os.path.join(OUT, "prof_stats", "*", "*_kernel_stats.csv"))
+    if stats:
+        shutil.copy(stats, os.path.join(PROF, "%s_bench_1Mx1M_kernel_stats.csv" % tag))
+    agg = collect(("prof_pmc_FETCH_SIZE", "prof_pmc_WRITE_SIZE", "prof_pmc_SQ", "prof_pmc_SQ2"), lambda k: k.startswith("k_nn_search"))
+    lines = ["# %s: %s" % (tag, header),
+             "# rocprofv3 PMC passes of `python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-surface` (tools/profile.sh); per-dispatch means",
+             "# commit %s, kernel sources sha16 %s" % (commit, stamp["csrc_sha16"]), ""]
+    mean, traffic = table(agg, lines)
     brute = [k for k in traffic if k.startswith("k_nn_search_filtered")]
     per_pair = None
     if brute and (brute[0], "SQ_INSTS_VALU") in mean:
         per_pair = mean[(brute[0], "SQ_INSTS_VALU")] * 64.0 / 1e12
-        lines.append("%s: SQ_INSTS_VALU*64/1e12 pairs = %.3g VALU instructions per pair (8 algorithmic flop per pair)" % (brute[0], per_pair))
+        lines.append("%s: SQ_INSTS_VALU*64/1e12 pairs = %.4g VALU instructions per pair (8 algorithmic flop per pair)" % (brute[0], per_pair))
     summ = os.path.join(PROF, "%s_bench_1Mx1M_pmc_summary.txt" % tag)
     open(summ, "w").write("\n".join(lines) + "\n")
-    jf = os.path.join(PROF, "hbm_traffic.json")
-    tr = json.load(open(jf)) if os.path.exists(jf) else {}
     rel = os.path.relpath(summ, ROOT)
     if brute:
         k = brute[0]
-        tr["1000000x1000000_n1"] = {"bytes_per_launch": traffic[k], "fetch_size_kb": mean[(k, "FETCH_SIZE")],
-                                    "write_size_kb": mean[(k, "WRITE_SIZE")], "source": rel}
+        tr["1000000x1000000_n1"] = dict(stamp, kernel=k, bytes_per_launch=traffic[k], fetch_size_kb=mean[(k, "FETCH_SIZE")],
+                                        write_size_kb=mean[(k, "WRITE_SIZE")], source=rel)
         if per_pair is not None:
             tr["1000000x1000000_n1"]["valu_instructions_per_pair"] = per_pair
     gk = [k for k in traffic if k.startswith("k_nn_search_grid")]          # k_nn_search_grid<1> at this size
     if gk:
-        tr["grid_1000000x1000000_n1"] = {"bytes_per_launch": traffic[gk[0]], "source": rel}
-    json.dump(tr, open(jf, "w"), indent=1)
+        tr["grid_1000000x1000000_n1"] = dict(stamp, kernel=gk[0], bytes_per_launch=traffic[gk[0]], source=rel)
     print("\n".join(lines))
+
+    # ---- the surface loop
+    sstats = newest(os.path.join(OUT, "prof_surf_stats", "*", "*_kernel_stats.csv"))
+    if sstats:
+        shutil.copy(sstats, os.path.join(PROF, "%s_surface_1M_kernel_stats.csv" % tag))
+    sagg = collect(("prof_surf_FETCH_SIZE", "prof_surf_WRITE_SIZE", "prof_surf_SQ"),
+                   lambda k: "search_grid" in k or k.startswith("k_bvh_search") or k.startswith("k_pair_accumulate"))
+    if sagg:
+        sl = ["# %s: %s" % (tag, header),
+              "# rocprofv3 PMC passes of `ONLY=surface:auto python tools/time_surface.py` (1M points, 980k-vertex / 1.96M-triangle mesh: a 5-",
+              "# and a 30-iteration run from a cold start); per-dispatch means over all launches",
+              "# commit %s, kernel sources sha16 %s" % (commit, stamp["csrc_sha16"]), ""]
+        smean, straffic = table(sagg, sl)
+        ssumm = os.path.join(PROF, "%s_surface_1M_pmc_summary.txt" % tag)
+        open(ssumm, "w").write("\n".join(sl) + "\n")
+        tk = [k for k in straffic if k.startswith("k_tri_search_grid")]
+        if tk:
+            tr["surface_1000000x1957200_n1"] = dict(stamp, kernel=tk[0], bytes_per_launch=straffic[tk[0]],
+                                                    source=os.path.relpath(ssumm, ROOT),
+                                                    note="mean over the launches of a 5- and a 30-iteration run from a cold start")
+        print("\n".join(sl))
+    json.dump(tr, open(jf, "w"), indent=1)
 
 
 if __name__ == "__main__":
