@@ -69,18 +69,19 @@ int fail(int code, const char *fmt, ...)
 // size; blocks that sit unused for CACHE_MAX_AGE releases, or push the cache past its cap, are really freed.
 // The library is a guest in somebody else's process (Blender): the cap is 256 MiB by default (OA_DEV_CACHE_MB raises
 // or lowers it, OA_DEV_CACHE=0 switches the cache off), and when the last context is destroyed everything is freed.
-// Releases are STREAM ORDERED, not device-synchronising: a block goes back with an event recorded on the stream of the
-// context that used it (tl_stream, set by use_device); the next owner on the same stream needs no wait at all (stream
-// order), another stream waits for the event on the device.  Only a real hipFree synchronises (the runtime's own rule).
+// Releases are STREAM ORDERED, not device-synchronising: a block goes back tagged with the stream of the context that
+// used it (tl_stream, set by use_device).  The next owner on the same stream needs no wait at all (stream order); an
+// owner on another stream first waits for the releasing stream (rare: two contexts trading blocks).  Only a real hipFree
+// synchronises (the runtime's own rule).  No events: recording one per release cost more than the device synchronisation
+// it replaced on an idle device (a whole alignment call of 2562 points: 0.46 -> 0.64 ms).
 thread_local hipStream_t tl_stream = nullptr;
 thread_local bool tl_stream_known = false;
 
 struct DevCache {
-    struct Block { void *p; size_t bytes; int device; unsigned long long stamp; hipEvent_t ev; hipStream_t stream; };
+    struct Block { void *p; size_t bytes; int device; unsigned long long stamp; hipStream_t stream; bool settled; };
     std::mutex mu;
     std::vector<Block> free_blocks;
     std::unordered_map<void *, std::pair<size_t, int>> live;    // pointer -> (bytes, device)
-    std::vector<hipEvent_t> spare_events;
     size_t cached_bytes = 0;
     unsigned long long clock = 0;
     int contexts = 0;                                           // live oa_ctx objects (single-device ones)
@@ -105,15 +106,11 @@ struct DevCache {
                     free_blocks[i] = free_blocks.back();
                     free_blocks.pop_back();
                     live[*out] = { bytes, dev };
-                    if (b.ev) {
-                        // same stream: stream order is enough; another stream waits for the releasing stream's event
-                        // on the device; unknown stream (no context in use on this thread): wait on the host
-                        hipError_t e = hipSuccess;
-                        if (!(tl_stream_known && b.stream == tl_stream))
-                            e = tl_stream_known ? hipStreamWaitEvent(tl_stream, b.ev, 0) : hipEventSynchronize(b.ev);
-                        spare_events.push_back(b.ev);
-                        if (e != hipSuccess) return e;
-                    }
+                    lk.unlock();
+                    // same stream: stream order is enough.  Another stream (or none known): whatever the releasing
+                    // stream still has in flight must finish first
+                    if (!b.settled && !(tl_stream_known && b.stream == tl_stream))
+                        if (hipStreamSynchronize(b.stream) != hipSuccess) { (void)hipGetLastError(); (void)hipDeviceSynchronize(); }
                     return hipSuccess;
                 }
         }
@@ -127,29 +124,28 @@ struct DevCache {
         return e;
     }
 
-    // synced: the caller has already synchronised the device (oa_destroy) -- no event needed
-    void release(void *p, bool synced = false)
+    // settled: the caller has already synchronised the device (oa_destroy) -- nothing can still be using the block
+    void release(void *p, bool settled = false)
     {
         if (!p) return;
         if (!enabled) { (void)hipFree(p); return; }
         std::lock_guard<std::mutex> lk(mu);
         auto it = live.find(p);
         if (it == live.end()) { (void)hipFree(p); return; }
-        Block b{ p, it->second.first, it->second.second, ++clock, nullptr, nullptr };
+        Block b{ p, it->second.first, it->second.second, ++clock, tl_stream, settled };
         live.erase(it);
         if (b.bytes > max_bytes) { (void)hipFree(p); return; }     // would not fit under the cap anyway (hipFree synchronises)
-        if (!synced) {
-            if (tl_stream_known) {
-                if (!spare_events.empty()) { b.ev = spare_events.back(); spare_events.pop_back(); }
-                else if (hipEventCreateWithFlags(&b.ev, hipEventDisableTiming) != hipSuccess) b.ev = nullptr;
-                if (b.ev && hipEventRecord(b.ev, tl_stream) != hipSuccess) { spare_events.push_back(b.ev); b.ev = nullptr; }
-                b.stream = tl_stream;
-            }
-            if (!b.ev) (void)hipDeviceSynchronize();               // no stream to order against: what hipFree would have done
-        }
+        if (!settled && !tl_stream_known) { (void)hipDeviceSynchronize(); b.settled = true; }   // no stream to order against
         free_blocks.push_back(b);
         cached_bytes += b.bytes;
         trim_locked(max_bytes, CACHE_MAX_AGE);
+    }
+
+    // a stream is about to be destroyed (its device has been synchronised): its blocks have nothing in flight any more
+    void stream_gone(hipStream_t s)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (Block &b : free_blocks) if (b.stream == s) { b.settled = true; b.stream = nullptr; }
     }
 
     void trim(size_t cap, unsigned long long max_age) { std::lock_guard<std::mutex> lk(mu); trim_locked(cap, max_age); }
@@ -162,12 +158,7 @@ struct DevCache {
         while (i < free_blocks.size()) {
             const bool old = clock - free_blocks[i].stamp > max_age;
             if (old || cached_bytes > cap) {
-                int cur = 0;
-                (void)hipGetDevice(&cur);
-                if (cur != free_blocks[i].device) (void)hipSetDevice(free_blocks[i].device);
-                (void)hipFree(free_blocks[i].p);                   // synchronises the device: pending events are done
-                if (cur != free_blocks[i].device) (void)hipSetDevice(cur);
-                if (free_blocks[i].ev) spare_events.push_back(free_blocks[i].ev);
+                (void)hipFree(free_blocks[i].p);                   // synchronises the device
                 cached_bytes -= free_blocks[i].bytes;
                 free_blocks.erase(free_blocks.begin() + (long)i);
             } else ++i;
@@ -181,8 +172,6 @@ struct DevCache {
         if (--contexts > 0) return;
         contexts = 0;
         trim_locked(0, 0);                                         // last context gone: give everything back
-        for (hipEvent_t e : spare_events) (void)hipEventDestroy(e);
-        spare_events.clear();
     }
 };
 
@@ -1143,7 +1132,7 @@ OA_EXPORT void oa_destroy(oa_ctx *c)
     if (c->ev_loop0) (void)hipEventDestroy(c->ev_loop0);
     if (c->h_poll) (void)hipHostFree(c->h_poll);
     if (c->ev_loop1) (void)hipEventDestroy(c->ev_loop1);
-    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    if (c->own_stream) { dev_cache().stream_gone(c->own_stream); (void)hipStreamDestroy(c->own_stream); }
     delete c;
     dev_cache().context_destroyed();                                // the last context gives the cached blocks back
 }
