@@ -433,7 +433,6 @@ int build_grid(oa_ctx *c);
 int build_tri_grid(oa_ctx *c);
 int build_bvh(oa_ctx *c, bool tri);
 int scan_counts(oa_ctx *c, const int *d_counts, int n, long long *d_off);
-int scan_tri_list_lengths(oa_ctx *c, const int *d_counts, int n, long long *d_off);
 int launch_tri_search(oa_ctx *c);
 
 // one wave per query: 4 queries per workgroup, workgroups loop when there are more queries than that
@@ -1347,22 +1346,8 @@ OA_EXPORT int oa_set_target(oa_ctx *c, const float *xyz, int64_t n, int on_devic
 
 namespace {
 struct IntToLL { __host__ __device__ long long operator()(int v) const { return (long long)v; } };
-struct TriListLen { __host__ __device__ long long operator()(int v) const { return oa::tri_cell_list_len(v); } };
 
 // offsets[0..n] = exclusive prefix sums of counts[0..n-1] (offsets[n] = total); counts must hold n + 1 ints, the last 0
-// the same over the triangle grid's list lengths (header + triangles, padded to a multiple of four records)
-int scan_tri_list_lengths(oa_ctx *c, const int *d_counts, int n, long long *d_off)
-{
-    auto in = rocprim::make_transform_iterator(d_counts, TriListLen{});
-    size_t bytes = 0;
-    HIPCHK(rocprim::exclusive_scan(nullptr, bytes, in, d_off, 0ll, (size_t)n + 1, rocprim::plus<long long>(), c->stream));
-    DevTmp<char> tmp;
-    HIPCHK(tmp.alloc(bytes));
-    HIPCHK(rocprim::exclusive_scan((void *)tmp.p, bytes, in, d_off, 0ll, (size_t)n + 1, rocprim::plus<long long>(), c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));                      // tmp is released on return
-    return OA_OK;
-}
-
 int scan_counts(oa_ctx *c, const int *d_counts, int n, long long *d_off)
 {
     auto in = rocprim::make_transform_iterator(d_counts, IntToLL{});
@@ -1606,22 +1591,15 @@ int build_tri_grid(oa_ctx *c)
     if (n_cells <= 0 || entries == 0) return OA_OK;
     HIPCHK(d_off.alloc((size_t)n_cells + 1));
     HIPCHK(dev_malloc(&c->d_tcell_start, sizeof(int) * (size_t)(n_cells + 1)));
-    // a cell's list = its header + its triangles, padded to a multiple of four records (oa_tri.hpp: tri_cell_list_len)
-    { int rcs = scan_tri_list_lengths(c, d_counts.p, n_cells, d_off.p); if (rcs) return rcs; }
-    long long records = 0;
-    { int rcr = read_small(c, &records, d_off.p + n_cells, sizeof records); if (rcr) return rcr; }
-    if (records <= 0 || records > 0x7FFFFFF0ll) return OA_OK;
-    HIPCHK(dev_malloc(&c->d_tcell_rec, sizeof(float4) * 2 * (size_t)records));
-    HIPCHK(hipMemsetAsync(c->d_tcell_rec, 0xBF, sizeof(float4) * 2 * (size_t)records, c->stream));   // padding: every field negative
+    HIPCHK(dev_malloc(&c->d_tcell_rec, sizeof(float4) * 2 * (size_t)entries));
+    { int rcs = scan_counts(c, d_counts.p, n_cells, d_off.p); if (rcs) return rcs; }
     hipLaunchKernelGGL(oa::k_grid_starts, dim3((n_cells + 256) / 256), dim3(256), 0, c->stream, d_off.p, n_cells, c->d_tcell_start, d_counts.p);
     hipLaunchKernelGGL(oa::k_tri_grid_bin<true>, dim3((c->n_tris + 255) / 256), dim3(256), 0, c->stream, c->d_tri9, c->n_tris,
                        gp, d_counts.p, (const int *)c->d_tcell_start, c->d_tcell_rec, (unsigned long long *)nullptr);
-    hipLaunchKernelGGL(oa::k_tri_cell_headers, dim3((n_cells + 255) / 256), dim3(256), 0, c->stream, (const float4 *)c->d_tri9, gp,
-                       n_cells, (const int *)c->d_tcell_start, (const int *)d_counts.p, c->d_tcell_rec);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     c->tgp = gp;
-    c->n_tri_entries = records;
+    c->n_tri_entries = (long long)entries;
     c->tri_grid_ok = true;
     if (c->debug)
         fprintf(stderr, "[oa] tri grid: h=%g cells=%dx%dx%d entries=%llu (%.2f per triangle)\n", gp.h, gp.n[0], gp.n[1], gp.n[2],

@@ -16,7 +16,6 @@
 // surface, or in crowded cells -- are finished by the triangle tree (oa_bvh.hpp); k_tri_search_all (every triangle
 // for every query) is what OA_SEARCH_BRUTE runs.
 #pragma once
-#include <hip/hip_fp16.h>
 #include "oa_grid.hpp"
 
 namespace oa {
@@ -159,110 +158,14 @@ __global__ void k_tri_grid_bin(const float4 *__restrict__ tri9, int n_tris, Grid
         for (int y = lo[1]; y <= hi[1]; ++y)
             for (int x = lo[0]; x <= hi[0]; ++x) {
                 const int cidx = (z * gp.n[1] + y) * gp.n[0] + x;
-                if (FILL) {                                         // position 0 of a cell's list is its header (k_tri_cell_headers)
-                    const long long pos = (long long)cell_start[cidx] + 1 + atomicAdd(&counts[cidx], 1);
+                if (FILL) {
+                    const long long pos = cell_start[cidx] + atomicAdd(&counts[cidx], 1);
                     cell_rec[2 * pos] = rec0;
                     cell_rec[2 * pos + 1] = rec1;
                 } else atomicAdd(&counts[cidx], 1);
                 ++n;
             }
     if (!FILL && total) atomicAdd(total, n);
-}
-
-// Length of a cell's list in records: header + triangles, padded to a multiple of four (the scan reads four records per
-// trip and looks for a header in the first of them only: with this padding a header can be nowhere else)
-__host__ __device__ inline long long tri_cell_list_len(int n_tris_in_cell)
-{
-    return n_tris_in_cell > 0 ? (((long long)n_tris_in_cell + 1 + 3) & ~3ll) : 0ll;
-}
-
-__device__ __forceinline__ float tri_half_bits_to_float(unsigned h) { return __half2float(__ushort_as_half((unsigned short)h)); }
-
-// Header of a non-empty cell: a bound on the part of the surface INSIDE the cell -- for every triangle T listed in the
-// cell and every x in T that lies in the cell's box:  |x - c| <= rc  and  |n . (x - c)| <= eps.
-//   c    mean of the triangles' disc centres (a point on the patch);   n    their mean normal, normalised, x (1 - 1e-6);
-//   rc   max over T of min(|c_T - c| + r_T, distance from c to the farthest corner of the box);
-//   eps  max over T of the largest |n . (x - c)| the triangle's corners AND the box allow (a linear function over T and
-//        over the box: its range over the intersection lies inside both ranges).
-// Record: {cx, cy, cz, -rc} {nx, ny, nz, bits(eps as a half rounded up | list length / 4 << 16)}; -rc < 0 marks the record
-// as "not a triangle" (so do the padding records: all bytes 0xBF).  The search skips the whole list when the bound
-// tri_record_bound2-style from (c, rc, n, eps) exceeds its threshold -- valid because a point of a triangle within reach
-// lies in SOME cell, and in that cell it is part of the bounded content.  n = 0 (cancelling normals, a non-finite
-// triangle) degrades the bound to the sphere (c, rc); a list longer than 4 x 65535 records is never skipped.
-__global__ void k_tri_cell_headers(const float4 *__restrict__ tri9, GridParams gp, int n_cells, const int *__restrict__ cell_start,
-                                   const int *__restrict__ cell_count, float4 *__restrict__ cell_rec)
-{
-    const int cidx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (cidx >= n_cells) return;
-    const int nt = cell_count[cidx];
-    if (nt <= 0) return;
-    const long long j0 = cell_start[cidx];
-    double cs[3] = { 0, 0, 0 }, ns[3] = { 0, 0, 0 };
-    int good = 0;
-    for (int k = 0; k < nt; ++k) {
-        const float4 r0 = cell_rec[2 * (j0 + 1 + k)], r1 = cell_rec[2 * (j0 + 1 + k) + 1];
-        if (!(r0.w >= 0.f) || !(fabsf(r0.x) < INFINITY) || !(fabsf(r0.y) < INFINITY) || !(fabsf(r0.z) < INFINITY)) continue;   // non-finite triangle
-        cs[0] += r0.x; cs[1] += r0.y; cs[2] += r0.z;
-        ns[0] += r1.x; ns[1] += r1.y; ns[2] += r1.z;
-        ++good;
-    }
-    const int cx = cidx % gp.n[0], cy = (cidx / gp.n[0]) % gp.n[1], cz = cidx / (gp.n[0] * gp.n[1]);
-    const int cc[3] = { cx, cy, cz };
-    double blo[3], bhi[3];
-    for (int a = 0; a < 3; ++a) { blo[a] = gp.lo[a] + (double)cc[a] * gp.h - gp.slack; bhi[a] = gp.lo[a] + (double)(cc[a] + 1) * gp.h + gp.slack; }
-    // the last cell of an axis also holds what lies beyond the box's edge by rounding (grid_cell_coord clamps)
-    for (int a = 0; a < 3; ++a) { if (cc[a] == 0) blo[a] = -INFINITY; if (cc[a] == gp.n[a] - 1) bhi[a] = INFINITY; }
-    float cf[3] = { 0.f, 0.f, 0.f }, nf[3] = { 0.f, 0.f, 0.f };
-    float rcf = INFINITY, epsf = INFINITY;
-    bool usable = good > 0;
-    for (int a = 0; a < 3 && usable; ++a) if (!(blo[a] > -INFINITY) || !(bhi[a] < INFINITY)) usable = false;   // edge cells: never skipped
-    if (usable) {
-        for (int a = 0; a < 3; ++a) cf[a] = (float)(cs[a] / good);
-        const double nl = sqrt(ns[0] * ns[0] + ns[1] * ns[1] + ns[2] * ns[2]);
-        if (nl > 1e-3 * good) for (int a = 0; a < 3; ++a) nf[a] = (float)(ns[a] / nl * (1.0 - 1e-6));
-        const double n2 = (double)nf[0] * nf[0] + (double)nf[1] * nf[1] + (double)nf[2] * nf[2];
-        if (!(n2 <= 1.0)) { nf[0] = nf[1] = nf[2] = 0.f; }
-        // farthest corner of the box from c, and the box's range of n . (x - c)
-        double corner2 = 0.0, box_lo = 0.0, box_hi = 0.0;
-        for (int a = 0; a < 3; ++a) {
-            const double dl = blo[a] - (double)cf[a], dh = bhi[a] - (double)cf[a];
-            corner2 += fmax(dl * dl, dh * dh);
-            const double na = (double)nf[a];
-            box_lo += fmin(na * dl, na * dh); box_hi += fmax(na * dl, na * dh);
-        }
-        double rc = 0.0, eps = 0.0;
-        for (int k = 0; k < nt; ++k) {
-            const float4 r0 = cell_rec[2 * (j0 + 1 + k)], r1 = cell_rec[2 * (j0 + 1 + k) + 1];
-            if (!(r0.w >= 0.f) || !(fabsf(r0.x) < INFINITY) || !(fabsf(r0.y) < INFINITY) || !(fabsf(r0.z) < INFINITY)) continue;
-            const double dx = (double)r0.x - cf[0], dy = (double)r0.y - cf[1], dz = (double)r0.z - cf[2];
-            rc = fmax(rc, fmin(sqrt(dx * dx + dy * dy + dz * dz) + (double)r0.w, sqrt(corner2)));
-            float a[3], b[3], c[3];
-            load_tri(tri9, __float_as_uint(r1.w), a, b, c);
-            const float *V[3] = { a, b, c };
-            double tlo = INFINITY, thi = -INFINITY;
-            for (int v = 0; v < 3; ++v) {
-                const double d = (double)nf[0] * ((double)V[v][0] - cf[0]) + (double)nf[1] * ((double)V[v][1] - cf[1]) + (double)nf[2] * ((double)V[v][2] - cf[2]);
-                tlo = fmin(tlo, d); thi = fmax(thi, d);
-            }
-            const double lo = fmax(tlo, box_lo), hi = fmin(thi, box_hi);
-            if (lo <= hi) eps = fmax(eps, fmax(fabs(lo), fabs(hi)));
-        }
-        rc = rc * (1.0 + 1e-6) + 1e-37;
-        eps = eps * (1.0 + 1e-6) + (double)gp.eps_plane;
-        rcf = rc < 3.0e38 ? (float)rc : INFINITY;
-        if ((double)rcf < rc) rcf = nextafterf(rcf, INFINITY);
-        epsf = eps < 6.0e4 ? (float)eps : INFINITY;
-    }
-    // eps as a half, rounded UP
-    unsigned short hb = 0x7C00;                                          // +inf: the plane term contributes nothing
-    if (epsf < 6.0e4f) {
-        __half hh = __float2half_ru(epsf);
-        hb = __half_as_ushort(hh);
-    }
-    const long long len = tri_cell_list_len(nt);
-    const unsigned len4 = (usable && rcf < INFINITY && len / 4 <= 65535) ? (unsigned)(len / 4) : 0u;   // 0: never skipped
-    cell_rec[2 * j0] = make_float4(cf[0], cf[1], cf[2], -(rcf < INFINITY ? rcf : 3.0e38f));
-    cell_rec[2 * j0 + 1] = make_float4(nf[0], nf[1], nf[2], __uint_as_float((unsigned)hb | (len4 << 16)));
 }
 
 __device__ __forceinline__ void tri_eval(const float *p, const float4 *__restrict__ tri9, uint32_t t, float &best, uint32_t &bidx)
@@ -476,57 +379,33 @@ __device__ __forceinline__ void tri_pool_flush(const float *p, const float4 *__r
 }
 
 // Phase 1 over the cell-list ranges a lane has collected (seg[0 .. n_seg), [first, last + 1) positions of cell_rec):
-// every lane walks ITS ranges, four records per trip; the wave leaves when every lane is through.  A range is a run of
-// whole cell lists, each a multiple of four records long and led by its header: a header can only be the FIRST record of
-// a trip, and when the cell's content bound (k_tri_cell_headers) exceeds the lane's threshold the lane steps over the
-// whole list.  `budget` counts the records a lane really looks at; a lane that runs out stops scanning (the tree takes
-// the query over).
+// every lane walks ITS ranges, four records per trip; the wave leaves when every lane is through.
 __device__ __forceinline__ void tri_scan_segments(const float *p, const float4 *__restrict__ cell_rec,
                                                   const float4 *__restrict__ tri9, TriSearchState &s, float eps_plane,
                                                   int2 (*seg)[256], int &n_seg, TriPool &pool, double delta, float cutf,
-                                                  int &budget, int *n_ent = nullptr, int *surv = nullptr, int *ev = nullptr,
-                                                  int *trips = nullptr)
+                                                  int *surv = nullptr, int *ev = nullptr, int *trips = nullptr)
 {
     int k = 0, j = 0, end = 0;
     while (true) {
         if (j >= end && k < n_seg) { const int2 sg = seg[k][threadIdx.x]; j = sg.x; end = sg.y; ++k; }
-        const bool active = j < end && budget >= 0;
+        const bool active = j < end;
         if (!__any(active)) break;
-        // four records (32 bytes each) per lane: eight independent loads
-        const int jj = active ? j : 0;
+        // four records (32 bytes each) per lane: eight independent loads; the clamped repeats of the last record are not tested
+        const int last = active ? end - 1 : 0, jj = active ? j : 0;
+        const int e1 = min(jj + 1, last), e2 = min(jj + 2, last), e3 = min(jj + 3, last);
         float4 a0, a1, b0, b1, c0, c1, d0, d1;
-        a0 = a1 = b0 = b1 = c0 = c1 = d0 = d1 = make_float4(0.f, 0.f, 0.f, -1.f);
+        a0 = a1 = b0 = b1 = c0 = c1 = d0 = d1 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (active) {
-            a0 = cell_rec[2ll * jj]; a1 = cell_rec[2ll * jj + 1]; b0 = cell_rec[2ll * jj + 2]; b1 = cell_rec[2ll * jj + 3];
-            c0 = cell_rec[2ll * jj + 4]; c1 = cell_rec[2ll * jj + 5]; d0 = cell_rec[2ll * jj + 6]; d1 = cell_rec[2ll * jj + 7];
+            a0 = cell_rec[2ll * jj]; a1 = cell_rec[2ll * jj + 1]; b0 = cell_rec[2ll * e1]; b1 = cell_rec[2ll * e1 + 1];
+            c0 = cell_rec[2ll * e2]; c1 = cell_rec[2ll * e2 + 1]; d0 = cell_rec[2ll * e3]; d1 = cell_rec[2ll * e3 + 1];
         }
-        bool look = active;
-        if (active && a0.w < 0.f) {                                 // a cell's list starts here: its content bound first
-            const unsigned wbits = __float_as_uint(a1.w);
-            const unsigned len4 = wbits >> 16;
-            const float rc = -a0.w, eps = tri_half_bits_to_float(wbits & 0xFFFFu);
-            const float dx = p[0] - a0.x, dy = p[1] - a0.y, dz = p[2] - a0.z;
-            const float D2 = dx * dx + dy * dy + dz * dz;
-            const float Dub = __builtin_sqrtf(D2) * 1.000001f;
-            const float pdc = dx * a1.x + dy * a1.y + dz * a1.z;
-            const float pd = fmaxf(fabsf(pdc) - (eps + 4.8e-7f * Dub), 0.f);       // eps = +inf (no usable plane): 0
-            const float t2 = D2 * 0.999998f - pdc * pdc * 1.000006f;
-            float lb = pd * pd;
-            if (t2 > rc * rc * 1.000001f) {
-                const float tg = __builtin_sqrtf(t2) * 0.9999998f - rc;
-                if (tg > 0.f) lb = __builtin_fmaf(tg, tg, lb);
-            }
-            if (len4 != 0u && lb * 0.999999f > s.thr) { j += 4 * (int)len4; look = false; }   // nothing in this cell can beat or tie
-        }
-        if (look) budget -= 4;
-        if (look && n_ent) *n_ent += 4;
-        tri_candidate(p, a0, a1, look && a0.w >= 0.f, s, eps_plane, pool, surv);
-        tri_candidate(p, b0, b1, look && b0.w >= 0.f, s, eps_plane, pool, surv);
+        tri_candidate(p, a0, a1, active, s, eps_plane, pool, surv);
+        tri_candidate(p, b0, b1, active && j + 1 < end, s, eps_plane, pool, surv);
         if (pool.n > TRI_POOL - 128) tri_pool_flush(p, tri9, s, pool, delta, cutf, ev, trips);      // each test adds <= 64 entries
-        tri_candidate(p, c0, c1, look && c0.w >= 0.f, s, eps_plane, pool, surv);
-        tri_candidate(p, d0, d1, look && d0.w >= 0.f, s, eps_plane, pool, surv);
+        tri_candidate(p, c0, c1, active && j + 2 < end, s, eps_plane, pool, surv);
+        tri_candidate(p, d0, d1, active && j + 3 < end, s, eps_plane, pool, surv);
         if (pool.n > TRI_POOL - 128) tri_pool_flush(p, tri9, s, pool, delta, cutf, ev, trips);
-        if (look) j += 4;
+        if (active) j += 4;
     }
     n_seg = 0;
 }
@@ -669,15 +548,18 @@ __global__ __launch_bounds__(256, 4) void k_tri_search_grid(const DevState *__re
 #pragma unroll
                 for (int sg = 0; sg < 2; ++sg) {
                     const int j0 = sg ? jc[k] : ja[k], j1 = sg ? jd[k] : jb[k];
-                    if (j1 > j0 && budget >= 0) { seg[n_seg][threadIdx.x] = make_int2(j0, j1); ++n_seg; }
+                    if (j1 > j0 && budget >= 0) {
+                        budget -= j1 - j0;                           // crowded cells: one wave of the tree search is faster
+                        if (budget >= 0) { seg[n_seg][threadIdx.x] = make_int2(j0, j1); ++n_seg; if (STATS) n_entries += j1 - j0; }
+                    }
                 }
             }
             b0 += consumed * L;
             ring_done = b0 >= n_rows;
         }
         // phase 1 and phase 2: the whole wave, every trip
-        tri_scan_segments(pf, cell_rec, tri9, S, gp.eps_plane, seg, n_seg, pool, delta, cutf, budget,     // (crowded cells: the budget)
-                          STATS ? &n_entries : nullptr, STATS ? &n_surv : nullptr, STATS ? &n_evals : nullptr, STATS ? &n_trips : nullptr);
+        tri_scan_segments(pf, cell_rec, tri9, S, gp.eps_plane, seg, n_seg, pool, delta, cutf,
+                          STATS ? &n_surv : nullptr, STATS ? &n_evals : nullptr, STATS ? &n_trips : nullptr);
         // phase 2 now if somebody needs its final word on this ring (or gives up), or the pool is filling up; otherwise the
         // survivors wait for the next batch's (every flush costs the wave at least one evaluation trip)
         if (__any(busy && (ring_done || budget < 0)) || pool.n > TRI_POOL / 4)
