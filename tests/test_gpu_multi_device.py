@@ -109,6 +109,55 @@ def test_multi_iterate_equals_run(surface):
     assert np.array_equal(mw, res.matrix_world)
 
 
+def test_multi_more_devices_than_points(orc):
+    """Empty shards (16 children, 10 selected points) post zero sums and do not disturb the others."""
+    from object_alignment_amd.engine import IcpEngine
+    rng = np.random.default_rng(4)
+    tgt = rng.uniform(-1, 1, size=(500, 3)).astype(np.float32)
+    src = (tgt[:10] + np.float32(0.01)).astype(np.float32)
+    eye = np.identity(4, dtype=np.float32)
+    with IcpEngine(devices=[0] * 16) as m:
+        m.set_target(tgt)
+        m.set_source(src)
+        assert m.n_selected == 10
+        m.set_matrices(eye, eye)
+        res = m.run(iters=3, thresh=0.5, use_target=True, early_exit=False)
+    ref = orc.icp_run(src, tgt, eye, eye, iters=3, sample=1, thresh=0.5, target_d=1e-300, use_target=True)
+    assert np.array_equal(res.step_K, ref["step_K"])
+    assert np.abs(res.step_M - ref["step_M"]).max() < 1e-9
+
+
+@pytest.mark.parametrize("surface", [False, True])
+def test_multi_normals_and_too_few_pairs(orc, surface):
+    """The normal-angle extension and the K < 3 error travel through a multi-device context like through a single one."""
+    from object_alignment_amd import synth
+    from object_alignment_amd.engine import IcpEngine
+    v, t = synth.bumpy_icosphere_mesh(4)
+    src, nrm = synth.bunny_surface_with_normals(3000, 0.3)
+    src = (src * np.float32(np.linalg.norm(v, axis=1).mean() / np.linalg.norm(src, axis=1).mean())).astype(np.float32)
+    tn = (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+    mxa = synth.rigid4(synth.rotation_from_rotvec([0.03, -0.02, 0.04]), [0.02, -0.01, 0.015])
+    eye = np.identity(4, dtype=np.float32)
+    out = []
+    for devs in (None, [0, 0, 0]):
+        with (IcpEngine(0) if devs is None else IcpEngine(devices=devs)) as e:
+            if surface:
+                e.set_target_mesh(v, t)
+            else:
+                e.set_target(v)
+            e.set_source(src)
+            e.set_normals(nrm, None if surface else tn, 30.0)
+            e.set_matrices(mxa, eye)
+            out.append(e.run(iters=4, thresh=0.5, early_exit=False))
+            e.set_matrices(mxa, eye)
+            with pytest.raises(ValueError) as ei:                                  # nothing within 1e-9: K = 0
+                e.run(iters=4, thresh=1e-9, early_exit=False)
+            assert getattr(ei.value, "partial", None) is not None and ei.value.partial.iters_done == 0
+    assert np.array_equal(out[0].step_K, out[1].step_K)
+    assert np.abs(out[0].step_M - out[1].step_M).max() < 1e-9
+    assert np.abs(out[0].matrix_world - out[1].matrix_world).max() <= F32_ULP
+
+
 def test_rccl_exchange_world_of_one(golden_dir):
     """OA_EXCHANGE_RCCL on one GPU: librccl is loaded by the library, ncclCommInitAll builds a communicator of one
     and ncclAllReduce runs on the context's stream every iteration.  Identity for one rank: same bits as the mailbox."""
