@@ -471,13 +471,14 @@ int launch_nn_impl(oa_ctx *c)
         if (dual) { int rcb = launch_bvh<false>(c, nullptr, nullptr, 1); if (rcb) return rcb; }   // runs when DevState::tree_turn
         const int turn = dual ? 0 : -1;
         // lanes per query: shards too small to fill the chip's wave slots split every query's rows between 2 or 4
-        // lanes.  Measured on 256 CUs (profiles/r01h_grid_lanes_sweep.txt): against a target that sits in cache 4 lanes
-        // win up to ~65k queries and 2 up to ~200k; against >= 500k vertices every round trip is longer and the lanes
-        // pay for longer: 4 up to ~200k queries, 2 up to ~600k; 1M queries lose 15 % with 2
+        // lanes.  Measured on 256 CUs with the round-2 kernel (profiles/r02n_grid_lanes_sweep.txt; round 1:
+        // r01h_grid_lanes_sweep.txt): against a target that sits in cache 4 lanes win up to ~20k queries and 2 up to
+        // ~350k; against >= 500k vertices every round trip is longer and the lanes pay for longer: 4 up to ~100k
+        // queries, 2 up to ~700k; 1M queries lose 7 % with 2
         int lanes = c->grid_lanes;
         if (lanes != 1 && lanes != 2 && lanes != 4) {
             const bool big = c->nt >= 500000;
-            lanes = (c->ns <= (big ? 768 : 256) * c->n_cu) ? 4 : ((c->ns <= (big ? 2400 : 800) * c->n_cu) ? 2 : 1);
+            lanes = (c->ns <= (big ? 400 : 80) * c->n_cu) ? 4 : ((c->ns <= (big ? 2800 : 1400) * c->n_cu) ? 2 : 1);
         }
 #define OA_GRID_ARGS c->d_state, c->d_src4, c->ns, c->gp, c->d_cell_start, c->d_sorted, c->d_win, c->d_keys, c->d_todo_list, c->d_todo_count, turn
         const dim3 gblocks((unsigned)(((long long)c->ns * lanes + 255) / 256));
@@ -1620,10 +1621,14 @@ int launch_tri_search(oa_ctx *c)
         const bool dual = c->grid_mode == -1 && c->turns_on && c->ns <= tri_tree_early(c);
         if (dual) { int rcb = launch_bvh<true>(c, nullptr, nullptr, 1); if (rcb) return rcb; }    // runs when DevState::tree_turn
         const int turn = dual ? 0 : -1;
-        // lanes per query, as for the vertex grid; these chains are longer, so more lanes pay for longer (measured on
-        // 256 CUs: 4 lanes win up to ~128k queries, 2 lanes up to ~600k)
+        // lanes per query, as for the vertex grid (measured on 256 CUs with the round-2 kernel,
+        // profiles/r02n_grid_lanes_sweep.txt: small meshes 4 lanes up to ~32k queries, 2 up to ~180k; >= 250k triangles
+        // 4 up to ~100k, 2 up to ~800k)
         int lanes = c->grid_lanes;
-        if (lanes != 1 && lanes != 2 && lanes != 4) lanes = (c->ns <= 512 * c->n_cu) ? 4 : ((c->ns <= 2400 * c->n_cu) ? 2 : 1);
+        if (lanes != 1 && lanes != 2 && lanes != 4) {
+            const bool big = c->n_tris >= 250000;
+            lanes = (c->ns <= (big ? 400 : 128) * c->n_cu) ? 4 : ((c->ns <= (big ? 3200 : 700) * c->n_cu) ? 2 : 1);
+        }
 #define OA_TGRID_ARGS c->d_state, c->d_src4, c->ns, c->tgp, c->d_tcell_start, c->d_tcell_rec, c->d_tri9, c->d_prev, c->d_keys, c->d_todo_list, c->d_todo_count, turn
         const dim3 gblocks((unsigned)(((long long)c->ns * lanes + 255) / 256));
         if (lanes == 4) hipLaunchKernelGGL(oa::k_tri_search_grid<4>, gblocks, dim3(256), 0, c->stream, OA_TGRID_ARGS);
