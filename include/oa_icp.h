@@ -178,6 +178,8 @@ int oa_reset_seeds(oa_ctx *ctx);
 #define OA_STAT_N_TRIS            4
 #define OA_STAT_SURFACE           5   /* 1 = surface mode (oa_set_target_mesh) */
 #define OA_STAT_CACHE_BYTES       6   /* device bytes currently held by the process-wide allocation cache */
+#define OA_STAT_BRUTE_KERNEL      7   /* what OA_SEARCH_BRUTE launches for the current shard: 0 = k_nn_search (exact only), 1 =
+                                       * k_nn_search_filtered (default), 2 = k_nn_search_mfma (experiment, env OA_NN_MFMA=1) */
 int oa_get_stat(oa_ctx *ctx, int what, double *value);
 int64_t oa_num_selected(oa_ctx *ctx);     /* selected source points held by this context (its shard) */
 

@@ -13,6 +13,7 @@
 #include "oa_tri.hpp"
 #include "oa_bvh.hpp"
 #include "oa_affine.hpp"
+#include "oa_mfma.hpp"
 #include "../../include/oa_icp.h"
 
 #include <algorithm>
@@ -249,6 +250,9 @@ struct oa_ctx {
     bool filter_ok = false;
     float tc[3] = { 0, 0, 0 };
     double qmax = 0.0;
+    int nn_mfma = 0;                 // OA_NN_MFMA=1 (experiment): first filter level of the brute-force search on the matrix cores (oa_mfma.hpp)
+    oa::half8 *d_tfm = nullptr;      // its image of the target
+    double mfma_sigma = 1.0;
     // source (this shard)
     int ns = 0, ns_pad = 0, R = 4;
     float4 *d_src4 = nullptr;
@@ -493,7 +497,10 @@ int launch_nn_impl(oa_ctx *c)
         return fail(OA_E_BAD_ARG, "shard of %d points exceeds the brute-force launch grid (use more shards or OA_NN_R=8)", c->ns);
 #define OA_NN_ARGS c->d_state, c->d_src4, c->d_tg, c->groups_per_split, c->n_groups_pad, c->d_keys
 #define OA_NNF_ARGS c->d_state, c->d_src4, c->d_tg, c->d_tf, c->d_tf3, (const float4 *)c->d_win, c->groups_per_split, c->n_groups_pad, c->d_keys
-    if (c->filter_ok && c->use_filter) {
+    if (c->filter_ok && c->use_filter && c->nn_mfma && c->d_tfm && c->R == 4 && c->tile_groups == oa::FTILE_GROUPS) {
+        hipLaunchKernelGGL(oa::k_nn_search_mfma, grid, block, 0, c->stream, c->d_state, c->d_src4, c->d_tg, c->d_tf, c->d_tf3,
+                           (const oa::half8 *)c->d_tfm, (const float4 *)c->d_win, c->groups_per_split, c->n_groups_pad, c->mfma_sigma, c->d_keys);
+    } else if (c->filter_ok && c->use_filter) {
         const bool small = (c->tile_groups == 64);
 #define OA_LAUNCH_F(RR)                                                                                              \
         do {                                                                                                         \
@@ -1032,6 +1039,7 @@ OA_EXPORT int oa_create(oa_ctx **out, int device)
     c->grid_stats = env_int("OA_GRID_STATS", 0) != 0;
     c->turn_frac = env_double("OA_TURN_FRAC", 0.1);
     c->use_filter = env_int("OA_NN_FILTER", 1) != 0;
+    c->nn_mfma = env_int("OA_NN_MFMA", 0);
     c->grid_mode = env_int("OA_NN_GRID", -1);
     dev_cache().context_created();
     *out = c;
@@ -1118,7 +1126,7 @@ OA_EXPORT void oa_destroy(oa_ctx *c)
     (void)hipDeviceSynchronize();
     tl_stream_known = false;                                        // the stream below is about to go away
 #define OA_FREE(x) dev_free(c->x, true)
-    OA_FREE(d_tgt_xyz); OA_FREE(d_tg); OA_FREE(d_tf); OA_FREE(d_tf3); OA_FREE(d_prev); OA_FREE(d_win); OA_FREE(d_cell_start);
+    OA_FREE(d_tgt_xyz); OA_FREE(d_tg); OA_FREE(d_tf); OA_FREE(d_tf3); OA_FREE(d_tfm); OA_FREE(d_prev); OA_FREE(d_win); OA_FREE(d_cell_start);
     OA_FREE(d_sorted); OA_FREE(d_todo_list); OA_FREE(d_todo_count); OA_FREE(d_src4); OA_FREE(d_keys); OA_FREE(d_state);
     OA_FREE(d_partials); OA_FREE(d_sums); OA_FREE(d_solve);
     OA_FREE(d_valid); OA_FREE(d_b); OA_FREE(d_dist); OA_FREE(d_counts); OA_FREE(d_offsets); OA_FREE(d_A); OA_FREE(d_B);
@@ -1214,6 +1222,17 @@ int build_filter(oa_ctx *c)
     for (double v : mx) if (v > m) m = v;
     c->qmax = sqrt(m) * (1.0 + 1e-6);
     c->filter_ok = (c->qmax < 1e18);
+    dev_free(c->d_tfm);
+    if (c->filter_ok && c->nn_mfma) {                            // experiment: the MFMA image (32 B per target)
+        int e = 0;
+        if (c->qmax > 0.0) { frexp(c->qmax, &e); }               // qmax = f 2^e, f in [0.5, 1)  ->  qmax 2^-e < 1
+        c->mfma_sigma = ldexp(1.0, -e);
+        const int n_targets_pad = c->n_groups_pad * 4;
+        HIPCHK(dev_malloc(&c->d_tfm, sizeof(oa::half8) * 2 * (size_t)n_targets_pad));
+        hipLaunchKernelGGL(oa::k_pack_filter_mfma, dim3((unsigned)((n_targets_pad + 255) / 256)), dim3(256), 0, c->stream, c->d_tgt_xyz,
+                           c->nt, n_targets_pad, c->tc[0], c->tc[1], c->tc[2], c->fax[0], c->fax[1], c->fax[2], c->mfma_sigma, c->d_tfm);
+        HIPCHK(hipGetLastError());
+    }
     return OA_OK;
 }
 
@@ -1302,7 +1321,7 @@ int set_target_common(oa_ctx *c, const float *xyz, int64_t n, int on_device, boo
     int rc = use_device(c);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
-    dev_free(c->d_tgt_xyz); dev_free(c->d_tg); dev_free(c->d_tf); dev_free(c->d_tf3);
+    dev_free(c->d_tgt_xyz); dev_free(c->d_tg); dev_free(c->d_tf); dev_free(c->d_tf3); dev_free(c->d_tfm);
     dev_free(c->d_tri9); dev_free(c->d_tcell_start); dev_free(c->d_tcell_rec);
     dev_free(c->d_bvh_box); dev_free(c->d_bvh_prims); dev_free(c->d_tbvh_box); dev_free(c->d_tbvh_prims);
     c->surface = false; c->tri_grid_ok = false; c->n_tris = 0; c->bvh_ok = false; c->tbvh_ok = false;
@@ -1872,6 +1891,10 @@ OA_EXPORT int oa_get_stat(oa_ctx *c, int what, double *value)
     case OA_STAT_TRI_GRID_ENTRIES: *value = c->tri_grid_ok ? (double)c->n_tri_entries : 0.0; return OA_OK;
     case OA_STAT_N_TRIS: *value = (double)c->n_tris; return OA_OK;
     case OA_STAT_SURFACE: *value = c->surface ? 1.0 : 0.0; return OA_OK;
+    case OA_STAT_BRUTE_KERNEL:
+        *value = !(c->filter_ok && c->use_filter) ? 0.0
+                 : ((c->nn_mfma && c->d_tfm && c->R == 4 && c->tile_groups == oa::FTILE_GROUPS) ? 2.0 : 1.0);
+        return OA_OK;
     default: return fail(OA_E_BAD_ARG, "oa_get_stat: unknown key %d", what);
     }
 }

@@ -176,7 +176,8 @@ class IcpEngine:
         """Forget the previous searches' answers (the next search starts cold; results are unaffected)."""
         capi.check(self._L.oa_reset_seeds(self._h))
 
-    STATS = {"grid_cells": 1, "tri_grid_cells": 2, "tri_grid_entries": 3, "n_tris": 4, "surface": 5, "cache_bytes": 6}
+    STATS = {"grid_cells": 1, "tri_grid_cells": 2, "tri_grid_entries": 3, "n_tris": 4, "surface": 5, "cache_bytes": 6,
+             "brute_kernel": 7}
 
     def stat(self, name) -> float:
         v = C.c_double(0.0)
