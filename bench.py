@@ -50,6 +50,7 @@ import numpy as np  # noqa: E402
 VALU_PEAK_TLANEOPS = 78.6            # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (MI355X_MICROARCH.md), T lane-ops/s
 FP32_VECTOR_PEAK_TFLOPS = 157.3      # the same peak counting an FMA as 2 flop
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F16_PEAK_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense f16 / bf16 MFMA (the experiment leg only)
 FLOP_PER_PAIR = 8                    # 3 sub, 3 mul, 2 add (difference-form squared distance), SURVEY.md 8d
 VALU_PER_PAIR_ISA = 3.0              # hot loop of k_nn_search_filtered: (64 FMA + 16 min3 [2 slots] + 4 cmp) / 32 pairs
 KERNELS = {"brute": "k_nn_search_filtered", "grid": "k_nn_search_grid", "surface_grid": "k_tri_search_grid",
@@ -67,6 +68,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-surface", action="store_true", help="skip the surface-mode leg (1M points vs a 2M-triangle mesh)")
     ap.add_argument("--no-grid", action="store_true", help="skip the grid-search leg")
+    ap.add_argument("--no-mfma", action="store_true", help="skip the OA_NN_MFMA=1 experiment leg")
     return ap.parse_args()
 
 
@@ -197,8 +199,49 @@ def surface_leg(args, local_rank):
                          "cell_list_entries": entries, "cells": cells}}
 
 
+def mfma_leg(args, local_rank, src, tgt, mxa, mxb, kw, ref_matrix):
+    """EXPERIMENT, reported beside the headline and never instead of it (BASELINE.json's north-star describes the
+    brute-force search without MFMA): the same cold run with OA_NN_MFMA=1 -- the first filter level of the brute-force
+    search as one v_mfma_f32_32x32x16_f16 per 32 targets x 32 points (object_alignment_amd/csrc/oa_mfma.hpp)."""
+    from object_alignment_amd.engine import IcpEngine
+    os.environ["OA_NN_MFMA"] = "1"
+    try:
+        with IcpEngine(local_rank) as e:
+            e.set_search_mode("brute")
+            e.set_target(tgt)
+            e.set_source(src, stride=1)
+            if e.stat("brute_kernel") != 2.0:
+                return {"error": "k_nn_search_mfma does not take this shard (needs >= 65536 points and > 65536 target vertices)"}
+            e.set_matrices(mxa, mxb)
+            e.run(iters=1, **kw)
+            e.set_matrices(mxa, mxb)
+            e.reset_seeds()
+            t0 = time.perf_counter()
+            r = e.run(iters=args.steps, **kw)
+            dt = time.perf_counter() - t0
+    finally:
+        os.environ.pop("OA_NN_MFMA", None)
+    nn_ms = r.nn_ms_total / max(1, args.steps)
+    pairs = float(args.n_source) * float(args.n_target)
+    mfma_tflops = 32.0 * pairs / (nn_ms * 1e-3) / 1e12           # 2 x K = 16 flop per pair and MFMA, all executed
+    return {
+        "what": "EXPERIMENT (env OA_NN_MFMA=1, off by default): k_nn_search_mfma, filter levels 1-2 of the brute-force search "
+                "on the matrix cores (binary16 hi/lo split, sign test); same correspondences",
+        "value": args.steps / dt, "unit": "iterations/s", "steps": args.steps, "ms_per_step": 1e3 * dt / args.steps,
+        "ms_per_nn_search": nn_ms, "final_matrix_bitwise_equal_to_default_kernel": bool(np.array_equal(r.matrix_world, ref_matrix)),
+        "roofline": {"bound": "mfma", "achieved": mfma_tflops, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": mfma_tflops / MFMA_F16_PEAK_TFLOPS, "kernel": "k_nn_search_mfma",
+                     "formula": "32 flop (2 x K = 16) x N_s x N_t / search time / 2500 TFLOP/s (dense f16 MFMA peak, "
+                                "MI355X_MICROARCH.md)",
+                     "note": "the loop issues 8 v_or3_b32 per MFMA to look at the signs of its 1024 results; those half-rate "
+                             "VALU instructions, not the matrix pipe, bound it (tools/mfma_microbench.hip: MFMA alone 17 ms per "
+                             "1e12 pairs, with the sign test 25.5 ms)"},
+    }
+
+
 def main():
     args = parse()
+    os.environ.pop("OA_NN_MFMA", None)                            # the headline is the north-star kernel, never the experiment
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -301,6 +344,13 @@ def main():
         except Exception as exc:                                  # never lose the headline line
             grid = ("error: %r" % (exc,),)
 
+    mfma = None
+    if n_gpus == 1 and not args.no_mfma:
+        try:
+            mfma = mfma_leg(args, local_rank, src, tgt, mxa, mxb, kw, res.matrix_world)
+        except Exception as exc:                                  # never lose the headline line
+            mfma = {"error": repr(exc)}
+
     surf = None
     if n_gpus == 1 and not args.no_surface:
         try:
@@ -385,6 +435,8 @@ def main():
             }
         elif grid is not None:
             out["grid_path"] = {"error": grid[0]}
+        if mfma is not None:
+            out["mfma_experiment"] = mfma
         if surf is not None:
             out["surface_path"] = surf
         if n_gpus == 1 and not args.no_cpu_baseline and args.cpu_iters > 0:

@@ -498,7 +498,7 @@ int launch_nn_impl(oa_ctx *c)
 #define OA_NN_ARGS c->d_state, c->d_src4, c->d_tg, c->groups_per_split, c->n_groups_pad, c->d_keys
 #define OA_NNF_ARGS c->d_state, c->d_src4, c->d_tg, c->d_tf, c->d_tf3, (const float4 *)c->d_win, c->groups_per_split, c->n_groups_pad, c->d_keys
     if (c->filter_ok && c->use_filter && c->nn_mfma && c->d_tfm && c->R == 4 && c->tile_groups == oa::FTILE_GROUPS) {
-        hipLaunchKernelGGL(oa::k_nn_search_mfma, grid, block, 0, c->stream, c->d_state, c->d_src4, c->d_tg, c->d_tf, c->d_tf3,
+        hipLaunchKernelGGL(oa::k_nn_search_mfma, grid, block, 0, c->stream, c->d_state, c->d_src4, c->d_tg,
                            (const oa::half8 *)c->d_tfm, (const float4 *)c->d_win, c->groups_per_split, c->n_groups_pad, c->mfma_sigma, c->d_keys);
     } else if (c->filter_ok && c->use_filter) {
         const bool small = (c->tile_groups == 64);

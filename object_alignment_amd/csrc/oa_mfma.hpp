@@ -6,9 +6,9 @@
 // pair.  VERDICT r1 item 8 asked what a low-precision MFMA pre-filter would buy; this file is the answer, behind a flag.
 //
 // Same structure as k_nn_search_filtered (a conservative score that can only PROVE LOSERS; everything it cannot rule out
-// goes through that kernel's own level 2 (fp32 3-D score) and level 3 (exact metric, lexicographic (d2, index))), with
-// level 1 replaced: one v_mfma_f32_32x32x16_f16 scores 32 targets x 32 points -- 1024 pairs -- and the sign of each of
-// its results says "cannot win or tie" (+) or "look closer" (-).
+// goes through that kernel's level 3: the exact metric, lexicographic (d2, index)), with levels 1 and 2 replaced: one
+// v_mfma_f32_32x32x16_f16 scores 32 targets x 32 points -- 1024 pairs -- and the sign of each of its results says
+// "cannot win or tie" (+) or "look closer" (-).
 //
 //   scaled centred coordinates   x = sigma * fl32(q - c) (targets, |x| <= 1),  y = sigma * fl32(p - c) (points),  sigma = 2^e
 //   target row   U = [ah0 al0 ah0 | ah1 al1 ah1 | ah2 al2 ah2 | wh wm wl | -1 -1 -1 | 0]     a = -2x = ah + al (+ r_a),
@@ -134,14 +134,12 @@ __device__ __forceinline__ half8 shfl_xor32_half8(half8 v)
     return __builtin_bit_cast(half8, w);
 }
 
-// Same launch geometry, same arguments and the same reporting as k_nn_search_filtered<4, 256>; `tfm` is the MFMA image,
-// tf2 / tf3 / tg serve levels 2 and 3 from global memory.  A wave's 256 points form 8 blocks of 32 columns: block
+// Same launch geometry and the same reporting as k_nn_search_filtered<4, 256>; `tfm` is the MFMA image (through LDS),
+// `tg` the exact target image (read from global memory by the slow path).  A wave's 256 points form 8 blocks of 32 columns: block
 // (r, h) = register r of lanes 32 h .. 32 h + 31.
 __global__ __launch_bounds__(NN_THREADS, 4) void k_nn_search_mfma(const DevState *__restrict__ st,
                                                                 const float4 *__restrict__ src4,
                                                                 const float4 *__restrict__ tg,
-                                                                const float4 *__restrict__ tf2,
-                                                                const float4 *__restrict__ tf3,
                                                                 const half8 *__restrict__ tfm,
                                                                 const float4 *__restrict__ win, int groups_per_split,
                                                                 int n_groups_pad, double sigma,
@@ -157,7 +155,7 @@ __global__ __launch_bounds__(NN_THREADS, 4) void k_nn_search_mfma(const DevState
     const int base = blockIdx.y * (NN_THREADS * R);
     // (the point itself and its seed are re-read where they are needed -- the slow path and the report -- instead of
     //  living in registers through the hot loop: 8 column blocks x 4 VGPRs + 16 results leave no room for them)
-    float hu[R], hv[R], hd[R], best[R], thr3[R];
+    float hu[R], hv[R], hd[R], best[R];
     uint32_t bidx[R];
     half8 Bf[2 * R];
 #define OA_MF_POINT(r, X, Y, Z)                                                                                     \
@@ -190,8 +188,6 @@ __global__ __launch_bounds__(NN_THREADS, 4) void k_nn_search_mfma(const DevState
         OA_MF_SEED(r, qx, qy, qz, sd, si);
         best[r] = sd;
         bidx[r] = si;
-        float t2;
-        filter_thresholds(best[r], hu[r], hv[r], hd[r], qmax, t2, thr3[r]);
     }
     // the columns of block (r, 0) belong to lanes 0..31, of block (r, 1) to lanes 32..63; lane l supplies rows
     // k = 8 (l / 32) .. + 7 of column l % 32
@@ -211,79 +207,94 @@ __global__ __launch_bounds__(NN_THREADS, 4) void k_nn_search_mfma(const DevState
     if (g_end > n_groups_pad) g_end = n_groups_pad;
     const int n_bufs = (g_end - g_begin) / MF_GROUPS;              // groups_per_split is a multiple of 256
     const half8 *tsrc = tfm + (long long)(g_begin / 8) * 64;       // 8 groups per MFMA tile
+    // Tiles go global -> LDS directly (LDS-DMA, 16 B per lane: the destination is the wave's base + lane x 16, which is
+    // exactly this image's layout).  Staging them through registers cost 16 VGPRs the hot loop does not have: the
+    // compiler parked them in scratch (PMC: 28 GB of HBM-side writes per launch) and waited for every load at once.
     constexpr int LOADS = MF_TILES * 64 / NN_THREADS;              // 4 x 16 B per thread and buffer
-    half8 stg[LOADS];
-#pragma unroll
-    for (int k = 0; k < LOADS; ++k) { stg[k] = tsrc[k * NN_THREADS + tid]; tile[0][k * NN_THREADS + tid] = stg[k]; }
+    typedef const void __attribute__((address_space(1))) *gptr_t;
+    typedef void __attribute__((address_space(3))) *lptr_t;
+#define OA_MF_FETCH(buf, src)                                                                                        \
+    do {                                                                                                             \
+        _Pragma("unroll") for (int k_ = 0; k_ < LOADS; ++k_)                                                          \
+            __builtin_amdgcn_global_load_lds((gptr_t)((src) + k_ * NN_THREADS + tid), (lptr_t)&tile[buf][k_ * NN_THREADS + tid], 16, 0, 0); \
+    } while (0)
+    OA_MF_FETCH(0, tsrc);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const float16v zero = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 
     for (int t = 0; t < n_bufs; ++t) {
         const int cur = t & 1;
         const bool more = (t + 1 < n_bufs);
-        if (more) {
-            const half8 *nsrc = tsrc + (long long)(t + 1) * MF_TILES * 64;
-#pragma unroll
-            for (int k = 0; k < LOADS; ++k) stg[k] = nsrc[k * NN_THREADS + tid];
-        }
+        if (more) OA_MF_FETCH(cur ^ 1, tsrc + (long long)(t + 1) * MF_TILES * 64);   // lands while this buffer is consumed
         for (int mt = 0; mt < MF_TILES; ++mt) {
             const half8 a = tile[cur][mt * 64 + lane];
             const int g0 = g_begin + t * MF_GROUPS + mt * 8;       // first of the tile's 8 groups
-            // the next block's MFMA is issued before this block's results are looked at (a column rebuilt by this block's
-            // slow path then meets one more tile with its old, looser threshold: still conservative)
+            // Hot path: the eight MFMAs' results are OR-ed into ONE running word (8 x v_or3_b32 per MFMA, nothing else) and
+            // the sign is tested once per tile.  v_or3 is a half-rate instruction on this part: eight of them take as long
+            // as the MFMA they follow, so each MFMA is issued one step ahead of the ORs that read it.  (Tried, slower: two
+            // tiles per trip, 24.5 vs 23.3 ms; carrying the pipeline across trips -- the compiler then hoists four MFMAs
+            // to the top of the loop and spills their results.)
+            int acc = 0;
             float16v d_next = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, Bf[0], zero, 0, 0, 0);
 #pragma unroll
             for (int blk = 0; blk < 2 * R; ++blk) {
                 const float16v d = d_next;
                 if (blk + 1 < 2 * R) d_next = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, Bf[blk + 1], zero, 0, 0, 0);
+#pragma unroll
+                for (int k = 0; k < 16; k += 2) acc = acc | __float_as_int(d[k]) | __float_as_int(d[k + 1]);
+            }
+            if (!__any(acc < 0)) continue;
+            // Slow path (about one tile per point and search): the tile again, block by block
+#pragma unroll
+            for (int blk = 0; blk < 2 * R; ++blk) {
+                const float16v d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, Bf[blk], zero, 0, 0, 0);
                 const int s = mfma_sign_or(d);
                 if (__any(s < 0)) {
-                    // some (target, point) of this tile and block could not be ruled out: the owner lanes of the flagged
-                    // columns run levels 2 and 3 of k_nn_search_filtered on the tile's 32 targets
+                    // some (target, point) of this tile and block could not be ruled out.  The signs say which: result k of
+                    // lane l is target row (k & 3) + 8 (k >> 2) + 4 (l >> 5) of the tile, column l & 31.  The owner lane
+                    // of a column collects its two halves of the rows and evaluates exactly those targets (level 3 of
+                    // k_nn_search_filtered: the exact metric, lexicographic (d2, index)); the MFMA score is as sharp as
+                    // that kernel's fp32 level 2, which is skipped.
                     const int r = blk >> 1, h = blk & 1;
-                    const int so = s | __shfl_xor(s, 32, 64);      // the two lanes that hold the rows of a column
+                    unsigned m = 0u;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) m |= ((unsigned)__float_as_int(d[k]) >> 31) << k;
+                    const unsigned mo = (unsigned)__shfl_xor((int)m, 32, 64);
                     bool improved = false;
-                    if ((lane >> 5) == h && so < 0) {
+                    if ((lane >> 5) == h && (m | mo) != 0u) {
                         OA_MF_POINT(r, qx, qy, qz);
                         float b = best[r];
                         uint32_t bi = bidx[r];
-                        for (int k = 0; k < 8; ++k) {
-                            const long long g = g0 + k;
-                            const float4 AU = tf2[3 * g], AV = tf2[3 * g + 1];
-                            const float4 AD = tf3[2 * g], W3 = tf3[2 * g + 1];
-                            const float c0 = __builtin_fmaf(hu[r], AU.x, __builtin_fmaf(hv[r], AV.x, __builtin_fmaf(hd[r], AD.x, W3.x)));
-                            const float c1 = __builtin_fmaf(hu[r], AU.y, __builtin_fmaf(hv[r], AV.y, __builtin_fmaf(hd[r], AD.y, W3.y)));
-                            const float c2 = __builtin_fmaf(hu[r], AU.z, __builtin_fmaf(hv[r], AV.z, __builtin_fmaf(hd[r], AD.z, W3.z)));
-                            const float c3 = __builtin_fmaf(hu[r], AU.w, __builtin_fmaf(hv[r], AV.w, __builtin_fmaf(hd[r], AD.w, W3.w)));
-                            const float m3 = __builtin_fminf(__builtin_fminf(c0, c1), __builtin_fminf(c2, c3));
-                            if (!(m3 > thr3[r])) {                    // level 3: cannot be ruled out, exact metric
-                                const float4 *eg = tg + 3 * g;
-                                const float4 X = eg[0], Yv = eg[1], Z = eg[2];
-                                const uint32_t j = (uint32_t)g * 4u;
-                                const float e0 = d2_metric(qx, qy, qz, X.x, Yv.x, Z.x);
-                                const float e1 = d2_metric(qx, qy, qz, X.y, Yv.y, Z.y);
-                                const float e2 = d2_metric(qx, qy, qz, X.z, Yv.z, Z.z);
-                                const float e3 = d2_metric(qx, qy, qz, X.w, Yv.w, Z.w);
-                                if (e0 < b || (e0 == b && j < bi)) { b = e0; bi = j; }
-                                if (e1 < b || (e1 == b && j + 1u < bi)) { b = e1; bi = j + 1u; }
-                                if (e2 < b || (e2 == b && j + 2u < bi)) { b = e2; bi = j + 2u; }
-                                if (e3 < b || (e3 == b && j + 3u < bi)) { b = e3; bi = j + 3u; }
-                                if (b < best[r]) { float t2; filter_thresholds(b, hu[r], hv[r], hd[r], qmax, t2, thr3[r]); improved = true; }
-                                best[r] = b;
-                                bidx[r] = (b < INFINITY) ? bi : IDX_NONE;
-                            }
+                        unsigned long long todo = (unsigned long long)m | ((unsigned long long)mo << 16);   // own rows, then the partner's
+                        while (todo) {
+                            const int bit = __ffsll((long long)todo) - 1;
+                            todo &= todo - 1ull;
+                            const int k = bit & 15, half = (bit < 16) ? h : (h ^ 1);
+                            const int row = (k & 3) + 8 * (k >> 2) + 4 * half;
+                            const long long g = g0 + (row >> 2);
+                            const int comp = row & 3;
+                            const float4 *eg = tg + 3 * g;
+                            const float4 X = eg[0], Yv = eg[1], Z = eg[2];
+                            const float tx = comp == 0 ? X.x : (comp == 1 ? X.y : (comp == 2 ? X.z : X.w));
+                            const float ty = comp == 0 ? Yv.x : (comp == 1 ? Yv.y : (comp == 2 ? Yv.z : Yv.w));
+                            const float tz = comp == 0 ? Z.x : (comp == 1 ? Z.y : (comp == 2 ? Z.z : Z.w));
+                            const uint32_t j = (uint32_t)g * 4u + (uint32_t)comp;
+                            const float e = d2_metric(qx, qy, qz, tx, ty, tz);
+                            if (e < b || (e == b && j < bi)) { b = e; bi = j; }
                         }
+                        improved = b < best[r];
+                        best[r] = b;
+                        bidx[r] = (b < INFINITY) ? bi : IDX_NONE;       // overflowed distances (+inf) never win
                     }
                     if (__any(improved)) OA_MF_REBUILD(r);           // a tighter threshold for the columns that improved
                 }
             }
         }
-        if (more) {
-#pragma unroll
-            for (int k = 0; k < LOADS; ++k) tile[cur ^ 1][k * NN_THREADS + tid] = stg[k];
-        }
-        __syncthreads();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's part of the next buffer has landed ...
+        __syncthreads();                                            // ... and so has everybody else's; nobody still reads this one
     }
+#undef OA_MF_FETCH
 #undef OA_MF_REBUILD
 
     const uint32_t own_lo = (uint32_t)g_begin * 4u, own_hi = (uint32_t)g_end * 4u;

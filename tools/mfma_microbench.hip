@@ -55,6 +55,57 @@ __global__ __launch_bounds__(256, 1) void k_rate(const half8 *__restrict__ img, 
     out[blockIdx.x * 256 + threadIdx.x] = flagged;
 }
 
+// the same loop with other ways to look at the 16 results per lane: FL = 0 v_or3_b32 on the bits (8 per MFMA), 1 the
+// NaN-sticky sum acc = fma(d, +inf, acc) started at +inf (16 full-rate FMAs: a negative d makes -inf, inf - inf = NaN),
+// 2 half and half (8 results through 4 v_or3, 8 through 8 v_fma), 3 v_min3_f32 (8 per MFMA), 4 nothing (MFMA only)
+template <int FL>
+__global__ __launch_bounds__(256, 1) void k_rate_fl(const half8 *__restrict__ img, int iters, int *__restrict__ out)
+{
+    __shared__ half8 tile[TILES * 64];
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < TILES * 64; i += 256) tile[i] = img[i];
+    __syncthreads();
+    half8 B[8];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) B[b] = img[(TILES + b) * 64 + lane];
+    int flagged = 0;
+    const float16_ zero = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    const float inf = __builtin_inff();
+    for (int it = 0; it < iters; ++it) {
+        for (int t = 0; t < TILES; ++t) {
+            const half8 a = tile[t * 64 + lane];
+            int acc = 0;
+            float facc = inf, macc = inf;
+            float16_ d_next = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, B[0], zero, 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const float16_ d = d_next;
+                if (b + 1 < 8) d_next = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, B[b + 1], zero, 0, 0, 0);
+                if (FL == 0) {
+#pragma unroll
+                    for (int k = 0; k < 16; k += 2) acc = acc | __float_as_int(d[k]) | __float_as_int(d[k + 1]);
+                } else if (FL == 1) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) facc = __builtin_fmaf(d[k], inf, facc);
+                } else if (FL == 2) {
+#pragma unroll
+                    for (int k = 0; k < 8; k += 2) acc = acc | __float_as_int(d[k]) | __float_as_int(d[k + 1]);
+#pragma unroll
+                    for (int k = 8; k < 16; ++k) facc = __builtin_fmaf(d[k], inf, facc);
+                } else if (FL == 3) {
+#pragma unroll
+                    for (int k = 0; k < 16; k += 2) macc = __builtin_fminf(macc, __builtin_fminf(d[k], d[k + 1]));
+                } else {
+                    acc |= __float_as_int(d[0]);
+                }
+            }
+            const bool bad = acc < 0 || !(facc == inf) || macc < 0.f;
+            if (__any(bad)) { flagged += 1; B[0][0] += (_Float16)1; }
+        }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = flagged;
+}
+
 // arithmetic probe: one wave, D = A x B for one tile, all 1024 results written out (row = target, col = point)
 __global__ void k_one(const half8 *__restrict__ a, const half8 *__restrict__ b, float *__restrict__ d)
 {
@@ -125,6 +176,26 @@ int main()
             const double pairs = (double)iters * TILES * 8 * 1024.0 * blocks * 4;
             printf("mfma 32x32x16 f16 + sign test, %2d waves/CU: %.3f ms  %.1f cycles per MFMA per SIMD (at max clock)  %.1f T pairs/s  -> 1e12 pairs in %.1f ms\n",
                    wpc, best, best * 1e-3 * clk / mfma_per_simd, pairs / (best * 1e-3) / 1e12, 1e12 / (pairs / (best * 1e-3)) * 1e3);
+        }
+        struct { const char *name; void (*k)(const half8 *, int, int *); } fl[] = {
+            { "8 x v_or3_b32 (running, one test per tile)", k_rate_fl<0> }, { "16 x v_fma_f32 NaN-sticky", k_rate_fl<1> },
+            { "4 x v_or3 + 8 x v_fma", k_rate_fl<2> }, { "8 x v_min3_f32", k_rate_fl<3> }, { "MFMA alone", k_rate_fl<4> } };
+        for (auto &f : fl) {
+            const int wpc = 16, blocks = cus * wpc / 4, iters = 64;
+            hipLaunchKernelGGL(f.k, dim3(blocks), dim3(256), 0, 0, d_img, 2, d_out);
+            CHK(hipDeviceSynchronize());
+            float best = 1e30f;
+            for (int r = 0; r < 3; ++r) {
+                CHK(hipEventRecord(e0));
+                hipLaunchKernelGGL(f.k, dim3(blocks), dim3(256), 0, 0, d_img, iters, d_out);
+                CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
+                float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+                best = ms < best ? ms : best;
+            }
+            const double mfma_per_simd = (double)iters * TILES * 8 * wpc / 4.0;
+            const double pairs = (double)iters * TILES * 8 * 1024.0 * blocks * 4;
+            printf("mfma + %-44s 16 waves/CU: %.1f cycles per MFMA per SIMD (at max clock)  -> 1e12 pairs in %.1f ms\n",
+                   f.name, best * 1e-3 * clk / mfma_per_simd, 1e12 / (pairs / (best * 1e-3)) * 1e3);
         }
         CHK(hipFree(d_img)); CHK(hipFree(d_out));
     }
