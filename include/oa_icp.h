@@ -85,8 +85,9 @@ int         oa_create(oa_ctx **out, int device);
  * oa_run / oa_iterate drive all devices from the calling thread -- one stream per device, no host round trip per
  * iteration -- and every iteration the devices exchange their OA_NSUMS partial sums and perform the identical solve
  * (operators/icp_align.py:96-151 is still ONE call).  A device may be listed more than once (its shards then share
- * one stream); that is how the path is tested on a single GPU.  Not available on such a context: oa_make_pairs,
- * oa_nn_search (per-point outputs), oa_set_stream, and the split-phase calls. */
+ * one stream); that is how the path is tested on a single GPU.  oa_make_pairs and oa_nn_search work on such a context
+ * too: every device answers for its shard and the library merges the answers back into the caller's (vlist) order.
+ * Not available on it: oa_set_stream and the split-phase calls. */
 int         oa_create_multi(oa_ctx **out, const int *devices, int n_dev);
 int         oa_num_devices(oa_ctx *ctx);
 /* How the devices of an oa_create_multi context join their sums (default: OA_EXCHANGE_MAILBOX; env OA_EXCHANGE=rccl):

@@ -250,6 +250,10 @@ struct oa_ctx {
     bool filter_ok = false;
     float tc[3] = { 0, 0, 0 };
     double qmax = 0.0;
+    int *d_members = nullptr;        // shard of a spatially sharded selection: position in the whole selection of every caller-order slot (ascending); nullptr = shard_begin + slot
+    long long shard_begin = 0;
+    int *d_pos = nullptr;            // oa_make_pairs on a shard: whole-selection position of every pair
+    std::vector<int> h_members;      // host copy of d_members (children of a multi-device context)
     int nn_mfma = 0;                 // OA_NN_MFMA=1 (experiment): first filter level of the brute-force search on the matrix cores (oa_mfma.hpp)
     oa::half8 *d_tfm = nullptr;      // its image of the target
     double mfma_sigma = 1.0;
@@ -1126,7 +1130,7 @@ OA_EXPORT void oa_destroy(oa_ctx *c)
     (void)hipDeviceSynchronize();
     tl_stream_known = false;                                        // the stream below is about to go away
 #define OA_FREE(x) dev_free(c->x, true)
-    OA_FREE(d_tgt_xyz); OA_FREE(d_tg); OA_FREE(d_tf); OA_FREE(d_tf3); OA_FREE(d_tfm); OA_FREE(d_prev); OA_FREE(d_win); OA_FREE(d_cell_start);
+    OA_FREE(d_tgt_xyz); OA_FREE(d_tg); OA_FREE(d_tf); OA_FREE(d_tf3); OA_FREE(d_tfm); OA_FREE(d_members); OA_FREE(d_pos); OA_FREE(d_prev); OA_FREE(d_win); OA_FREE(d_cell_start);
     OA_FREE(d_sorted); OA_FREE(d_todo_list); OA_FREE(d_todo_count); OA_FREE(d_src4); OA_FREE(d_keys); OA_FREE(d_state);
     OA_FREE(d_partials); OA_FREE(d_sums); OA_FREE(d_solve);
     OA_FREE(d_valid); OA_FREE(d_b); OA_FREE(d_dist); OA_FREE(d_counts); OA_FREE(d_offsets); OA_FREE(d_A); OA_FREE(d_B);
@@ -1742,7 +1746,9 @@ OA_EXPORT int oa_set_source(oa_ctx *c, const float *xyz, int64_t n_verts, int on
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
     dev_free(c->d_src4); dev_free(c->d_keys); dev_free(c->d_prev); dev_free(c->d_win); dev_free(c->d_sel); dev_free(c->d_src_n);
-    dev_free(c->d_src4o); dev_free(c->d_perm);
+    dev_free(c->d_src4o); dev_free(c->d_perm); dev_free(c->d_members); dev_free(c->d_pos);
+    c->h_members.clear();
+    c->shard_begin = begin;
     c->normals_on = false;
     c->src_n_verts = n_verts;
     dev_free(c->d_valid); dev_free(c->d_b); dev_free(c->d_dist); dev_free(c->d_counts); dev_free(c->d_offsets);
@@ -1796,6 +1802,14 @@ OA_EXPORT int oa_set_source(oa_ctx *c, const float *xyz, int64_t n_verts, int on
         if (shard_count > 1 && c->ns > 0 && n_sel < 0x7FF00000ll && env_int("OA_SORT_SOURCE", 1) && env_int("OA_SHARD_SPATIAL", 1)) {
             int rcm = spatial_shard_members(c, d_xyz, n_verts, (const long long *)d_vlist.p, step, n_sel, begin, c->ns, d_members);
             if (rcm) return rcm;
+            if (d_members.p) {                                      // kept: per-point outputs of a shard go back to vlist order through it
+                HIPCHK(dev_malloc(&c->d_members, sizeof(int) * (size_t)c->ns));
+                HIPCHK(hipMemcpyAsync(c->d_members, d_members.p, sizeof(int) * (size_t)c->ns, hipMemcpyDeviceToDevice, c->stream));
+                if (c->parent) {
+                    c->h_members.resize((size_t)c->ns);
+                    HIPCHK(hipMemcpyAsync(c->h_members.data(), d_members.p, sizeof(int) * (size_t)c->ns, hipMemcpyDeviceToHost, c->stream));
+                }
+            }
         }
         hipLaunchKernelGGL(oa::k_pack_source, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, d_xyz,
                            (const long long *)d_vlist.p, step, begin, (const int *)d_members.p, c->ns, c->ns_pad, c->d_src4, c->d_sel);
@@ -1945,7 +1959,29 @@ int push_state_for_oneshot(oa_ctx *c, double thresh, bool cutoff)
 
 OA_EXPORT int oa_nn_search(oa_ctx *c, int64_t *idx, float *d2, double *kernel_ms)
 {
-    OA_NOT_MULTI(c, "oa_nn_search");
+    if (c && !c->subs.empty()) {
+        // multi-device: every child searches its shard; the answers go back to the caller's (vlist) order through the
+        // shard membership each child kept.  kernel_ms = the slowest child (the children run one after the other here:
+        // this entry point returns host arrays, it is not the loop).
+        if (kernel_ms) *kernel_ms = 0.0;
+        std::vector<int64_t> ic;
+        std::vector<float> dc;
+        for (oa_ctx *sub : c->subs) {
+            const size_t n = (size_t)sub->ns;
+            if (idx) ic.resize(std::max<size_t>(1, n));
+            if (d2) dc.resize(std::max<size_t>(1, n));
+            double ms = 0.0;
+            int rc = oa_nn_search(sub, idx ? ic.data() : nullptr, d2 ? dc.data() : nullptr, &ms);
+            if (rc) return rc;
+            if (kernel_ms && ms > *kernel_ms) *kernel_ms = ms;
+            for (size_t k = 0; k < n; ++k) {
+                const long long g = sub->h_members.empty() ? sub->shard_begin + (long long)k : (long long)sub->h_members[k];
+                if (idx) idx[g] = ic[k];
+                if (d2) d2[g] = dc[k];
+            }
+        }
+        return OA_OK;
+    }
     int rc = check_ready(c);
     if (rc) return rc;
     if ((rc = use_device(c))) return rc;
@@ -1981,7 +2017,61 @@ OA_EXPORT int oa_nn_search(oa_ctx *c, int64_t *idx, float *d2, double *kernel_ms
 OA_EXPORT int oa_make_pairs(oa_ctx *c, double thresh, int calc_stats, double *A, double *B, int64_t cap, int64_t *K,
                             double dstats[2])
 {
-    OA_NOT_MULTI(c, "oa_make_pairs");
+    if (c && !c->subs.empty()) {
+        // multi-device: every child pairs its shard (its pairs come out in ascending selection position, with that
+        // position); the shards are merged back into vlist order on the host.  Statistics: the children's two-pass
+        // means and population deviations combine exactly (K-weighted mean; variance = within + between).
+        if (!K || cap < 0 || (cap > 0 && (!A || !B))) return fail(OA_E_BAD_ARG, "oa_make_pairs: bad output arguments");
+        if (!(thresh > 0.0)) return fail(OA_E_BAD_THRESH, "thresh must be > 0 (the reference's make_pairs returns None)");
+        *K = 0;
+        if (dstats) { dstats[0] = NAN; dstats[1] = NAN; }
+        const size_t n_dev = c->subs.size();
+        std::vector<std::vector<double>> Ac(n_dev), Bc(n_dev);
+        std::vector<std::vector<int>> Pc(n_dev);
+        std::vector<int64_t> Kc(n_dev, 0);
+        std::vector<double> mean(n_dev, 0.0), dev(n_dev, 0.0);
+        int64_t total = 0;
+        for (size_t r = 0; r < n_dev; ++r) {
+            oa_ctx *sub = c->subs[r];
+            const int64_t capc = std::max(1, sub->ns);
+            Ac[r].resize(3 * (size_t)capc); Bc[r].resize(3 * (size_t)capc);
+            double st[2] = { NAN, NAN };
+            int rc = oa_make_pairs(sub, thresh, calc_stats, Ac[r].data(), Bc[r].data(), capc, &Kc[r], st);
+            if (rc) return rc;
+            mean[r] = st[0]; dev[r] = st[1];
+            Pc[r].resize((size_t)std::max<int64_t>(1, Kc[r]));
+            if (Kc[r] > 0) {
+                if ((rc = use_device(sub))) return rc;
+                HIPCHK(hipMemcpyAsync(Pc[r].data(), sub->d_pos, sizeof(int) * (size_t)Kc[r], hipMemcpyDeviceToHost, sub->stream));
+                HIPCHK(hipStreamSynchronize(sub->stream));
+            }
+            total += Kc[r];
+        }
+        if (total > cap) return fail(OA_E_CAPACITY, "oa_make_pairs: %lld pairs but capacity %lld", (long long)total, (long long)cap);
+        std::vector<int64_t> head(n_dev, 0);
+        for (int64_t k = 0; k < total; ++k) {                       // n_dev-way merge on the selection position
+            size_t best = n_dev;
+            for (size_t r = 0; r < n_dev; ++r)
+                if (head[r] < Kc[r] && (best == n_dev || Pc[r][(size_t)head[r]] < Pc[best][(size_t)head[best]])) best = r;
+            const int64_t h = head[best]++, capc = std::max(1, c->subs[best]->ns);
+            for (int a = 0; a < 3; ++a) {
+                A[(size_t)a * cap + k] = Ac[best][(size_t)a * capc + h];
+                B[(size_t)a * cap + k] = Bc[best][(size_t)a * capc + h];
+            }
+        }
+        *K = total;
+        if (calc_stats && dstats && total > 0) {
+            double m = 0.0;
+            for (size_t r = 0; r < n_dev; ++r) if (Kc[r] > 0) m += (double)Kc[r] * mean[r];
+            m /= (double)total;
+            double var = 0.0;
+            for (size_t r = 0; r < n_dev; ++r)
+                if (Kc[r] > 0) var += (double)Kc[r] * (dev[r] * dev[r] + (mean[r] - m) * (mean[r] - m));
+            dstats[0] = m;
+            dstats[1] = sqrt(var / (double)total);
+        }
+        return OA_OK;
+    }
     int rc = check_ready(c);
     if (rc) return rc;
     if (!K || cap < 0 || (cap > 0 && (!A || !B))) return fail(OA_E_BAD_ARG, "oa_make_pairs: bad output arguments");
@@ -2002,6 +2092,8 @@ OA_EXPORT int oa_make_pairs(oa_ctx *c, double thresh, int calc_stats, double *A,
         HIPCHK(dev_malloc(&c->d_offsets, sizeof(long long) * (size_t)(n_blocks + 1)));
         HIPCHK(dev_malloc(&c->d_A, sizeof(double) * 3 * (size_t)c->ns));
         HIPCHK(dev_malloc(&c->d_B, sizeof(double) * 3 * (size_t)c->ns));
+        dev_free(c->d_pos);
+        if (c->parent) HIPCHK(dev_malloc(&c->d_pos, sizeof(int) * (size_t)c->ns));
         c->emit_cap = c->ns;
     }
     c->d_pivot0 = 0.0;
@@ -2027,7 +2119,8 @@ OA_EXPORT int oa_make_pairs(oa_ctx *c, double thresh, int calc_stats, double *A,
     hipLaunchKernelGGL(oa::k_scan_counts, dim3(1), dim3(1024), 0, c->stream, c->d_counts, n_blocks, c->d_offsets);
     hipLaunchKernelGGL(oa::k_scatter_pairs, dim3(n_blocks), dim3(256), 0, c->stream, c->d_valid, c->ns,
                        c->d_perm ? c->d_src4o : c->d_src4,
-                       c->d_b, c->d_offsets, (long long)c->ns, c->d_A, c->d_B);
+                       c->d_b, c->d_offsets, (long long)c->ns, c->d_A, c->d_B, (const int *)c->d_members, c->shard_begin,
+                       c->parent ? c->d_pos : (int *)nullptr);
     HIPCHK(hipGetLastError());
     double sums[oa::NSUMS];
     long long total = 0;

@@ -1333,8 +1333,12 @@ __global__ __launch_bounds__(1024) void k_scan_counts(const int *__restrict__ co
 __global__ __launch_bounds__(256) void k_scatter_pairs(const unsigned char *__restrict__ valid, int ns,
                                                        const float4 *__restrict__ src4, const float *__restrict__ b,
                                                        const long long *__restrict__ offsets, long long cap,
-                                                       double *__restrict__ A, double *__restrict__ B)
+                                                       double *__restrict__ A, double *__restrict__ B,
+                                                       const int *__restrict__ members, long long begin,
+                                                       int *__restrict__ pos)
 {
+    // pos (optional): the pair's position in the WHOLE selection -- members[i] for a spatial shard, begin + i for a
+    // contiguous one -- so that the shards of a multi-device context can be merged back into vlist order
     __shared__ int wsum[4];
     const int i = blockIdx.x * 256 + threadIdx.x;
     const bool v = (i < ns) && valid[i];
@@ -1350,6 +1354,7 @@ __global__ __launch_bounds__(256) void k_scatter_pairs(const unsigned char *__re
     const float4 p = src4[i];
     A[k] = (double)p.x; A[cap + k] = (double)p.y; A[2 * cap + k] = (double)p.z;
     B[k] = (double)b[3ll * i]; B[cap + k] = (double)b[3ll * i + 1]; B[2 * cap + k] = (double)b[3ll * i + 2];
+    if (pos) pos[k] = members ? members[i] : (int)(begin + i);
 }
 
 #endif  // __HIPCC__

@@ -158,9 +158,9 @@ class GpuBVH:
     """
 
     def __init__(self, target_xyz, engine: IcpEngine | None = None, tris=None):
-        self.engine = engine if engine is not None else default_engine(devices=[0])
-        if self.engine.multi:
-            raise ValueError("make_pairs returns per-point outputs: GpuBVH needs a single-device engine")
+        # (a multi-device engine works too: every GPU pairs its shard of the source, the library merges the pairs back
+        #  into vlist order)
+        self.engine = engine if engine is not None else default_engine()
         self.target = np.ascontiguousarray(target_xyz, dtype=np.float32).reshape(-1, 3)
         self.tris = tris
         self._src_key = None

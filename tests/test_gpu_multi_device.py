@@ -109,6 +109,61 @@ def test_multi_iterate_equals_run(surface):
     assert np.array_equal(mw, res.matrix_world)
 
 
+@pytest.mark.parametrize("surface", [False, True])
+@pytest.mark.parametrize("n_dev", [2, 5, 16])
+def test_multi_per_point_outputs_in_vlist_order(surface, n_dev):
+    """make_pairs (functions/general.py:257-329) and nn_search on a multi-device context: every shard answers for its
+    points, the library merges the answers back into the caller's order -- the same arrays as one device gives, pair
+    for pair, with a vlist that is neither sorted nor duplicate-free and a stride."""
+    from object_alignment_amd import synth
+    from object_alignment_amd.engine import IcpEngine
+    rng = np.random.default_rng(100 + n_dev)
+    v, t = synth.bumpy_icosphere_mesh(4)
+    src = (synth.bumpy_icosphere(4) * np.float32(1.02)).astype(np.float32)
+    src[::11] += np.float32(0.4)                                    # some points beyond the threshold
+    vlist = rng.permutation(len(src))[: len(src) * 3 // 4]
+    vlist = np.concatenate([vlist, vlist[:37]])                     # the reference appends per membership: duplicates stay
+    mxa = synth.rigid4(synth.rotation_from_rotvec([0.03, -0.02, 0.04]), [0.02, -0.01, 0.015])
+    eye = np.identity(4, dtype=np.float32)
+    out = []
+    for devs in (None, [0] * n_dev):
+        with (IcpEngine(0) if devs is None else IcpEngine(devices=devs)) as e:
+            if surface:
+                e.set_target_mesh(v, t)
+            else:
+                e.set_target(v)
+            e.set_source(src, vlist=vlist, stride=2)
+            e.set_matrices(mxa, eye)
+            A, B, st = e.make_pairs(0.12, calc_stats=True)
+            idx, d2, _ = e.nn_search()
+            out.append((A, B, np.array(st), idx, d2))
+    assert 0 < out[0][0].shape[1] < (len(vlist) + 1) // 2           # the threshold cuts, so compaction matters
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert np.allclose(out[0][2], out[1][2], rtol=1e-12, atol=0)
+    assert np.array_equal(out[0][3], out[1][3]) and np.array_equal(out[0][4], out[1][4])
+
+
+@pytest.mark.parametrize("n_dev", [2, 8])
+def test_make_pairs_golden_on_a_multi_device_engine(golden_dir, n_dev):
+    """The reference's make_pairs fixtures (generated by its own code) through GpuBVH on a multi-device engine."""
+    from object_alignment_amd.engine import IcpEngine
+    from object_alignment_amd.functions import make_pairs, GpuBVH, AlignObject
+    g = _load(golden_dir, "make_pairs")
+    with IcpEngine(devices=[0] * n_dev) as eng:
+        for i in range(int(g["n_cases"])):
+            p = "c%02d_" % i
+            align = AlignObject(g[p + "src"], g[p + "mx_align"])
+            base = AlignObject(g[p + "tgt"], g[p + "mx_base"])
+            bvh = GpuBVH.FromObject(base, None, engine=eng)
+            A, B, ds = make_pairs(align, base, bvh, g[p + "vlist"].tolist(), float(g[p + "thresh"]),
+                                  int(g[p + "sample"]), calc_stats=bool(g[p + "calc_stats"]))
+            name = str(g[p + "name"])
+            assert np.array_equal(A, g[p + "A"]), name
+            assert np.array_equal(B, g[p + "B"]), name
+            if bool(g[p + "calc_stats"]):
+                assert np.allclose(ds, g[p + "d_stats"], rtol=1e-9, atol=1e-13), name
+
+
 def test_multi_more_devices_than_points(orc):
     """Empty shards (16 children, 10 selected points) post zero sums and do not disturb the others."""
     from object_alignment_amd.engine import IcpEngine
