@@ -233,8 +233,8 @@ __global__ __launch_bounds__(NN_THREADS, 4) void k_nn_search_mfma(const DevState
             // Hot path: the eight MFMAs' results are OR-ed into ONE running word (8 x v_or3_b32 per MFMA, nothing else) and
             // the sign is tested once per tile.  v_or3 is a half-rate instruction on this part: eight of them take as long
             // as the MFMA they follow, so each MFMA is issued one step ahead of the ORs that read it.  (Tried, slower: two
-            // tiles per trip, 24.5 vs 23.3 ms; carrying the pipeline across trips -- the compiler then hoists four MFMAs
-            // to the top of the loop and spills their results.)
+            // tiles per trip, 24.5 vs 23.3 ms; s_setprio(1) around the MFMA, 23.8; carrying the pipeline across trips --
+            // the compiler then hoists four MFMAs to the top of the loop and spills their results.)
             int acc = 0;
             float16v d_next = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, Bf[0], zero, 0, 0, 0);
 #pragma unroll
