@@ -81,7 +81,8 @@ typedef struct oa_report {
 int         oa_device_count(void);
 int         oa_create(oa_ctx **out, int device);
 /* One context over n_dev GPUs of this process (1 <= n_dev <= 64; SURVEY.md 8b's oa_create(&ctx, devices, n_dev)).
- * Every upload goes to all of them (target replicated; source: device i keeps shard i of n_dev, see oa_set_source),
+ * Every upload goes to all of them (target replicated; source: device i keeps shard i of n_dev, see oa_set_source;
+ * children on different GPUs upload and build their search structures concurrently, one host thread each),
  * oa_run / oa_iterate drive all devices from the calling thread -- one stream per device, no host round trip per
  * iteration -- and every iteration the devices exchange their OA_NSUMS partial sums and perform the identical solve
  * (operators/icp_align.py:96-151 is still ONE call).  A device may be listed more than once (its shards then share

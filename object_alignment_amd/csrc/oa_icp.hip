@@ -36,6 +36,9 @@
         for (oa_ctx *sub : (c)->subs) { const int rc_ = (call); if (rc_) return rc_; }         \
         return OA_OK;                                                                          \
     }
+// uploads and index builds: the children work at the same time, one host thread each, when they sit on different GPUs
+#define OA_ROUTE_ALL_PAR(c, call)                                                              \
+    if ((c) && !(c)->subs.empty()) return route_all_parallel((c), [&](oa_ctx *sub) -> int { return (call); });
 #define OA_ROUTE_FIRST(c, call)                                                                \
     if ((c) && !(c)->subs.empty()) { oa_ctx *sub = (c)->subs[0]; return (call); }
 #define OA_NOT_MULTI(c, what)                                                                  \
@@ -213,6 +216,12 @@ double env_double(const char *name, double dflt)
     return (v && *v) ? atof(v) : dflt;
 }
 
+// A multi-device parent's uploads (target: 20+ ms of copies, sorts and index builds per device at 1M) would take n_dev
+// times as long driven one child after the other; every child has its own device and stream, so each gets a host
+// thread.  Children that share a device also share a stream: they stay sequential (OA_MULTI_THREADS=1 forces threads --
+// how the path is tested on a one-GPU box --, 0 forbids them).  The first failing child's code and message win.
+template <typename F> int route_all_parallel(oa_ctx *c, F f);
+
 }  // namespace
 
 struct oa_ctx {
@@ -327,6 +336,32 @@ int use_device(oa_ctx *c)
 {
     HIPCHK(hipSetDevice(c->device));
     tl_stream = c->stream; tl_stream_known = true;              // releases of device blocks are ordered on this stream
+    return OA_OK;
+}
+
+template <typename F> int route_all_parallel(oa_ctx *c, F f)
+{
+    const size_t n = c->subs.size();
+    bool distinct = true;
+    for (size_t i = 0; i < n && distinct; ++i)
+        for (size_t j = i + 1; j < n; ++j)
+            if (c->subs[i]->device == c->subs[j]->device) { distinct = false; break; }
+    const int force = env_int("OA_MULTI_THREADS", -1);
+    if (n < 2 || force == 0 || (force < 0 && !distinct)) {
+        for (oa_ctx *sub : c->subs) { const int rc = f(sub); if (rc) return rc; }
+        return OA_OK;
+    }
+    std::vector<int> rcs(n, OA_OK);
+    std::vector<std::string> errs(n);
+    std::vector<std::thread> workers;
+    workers.reserve(n - 1);
+    for (size_t i = 1; i < n; ++i)
+        workers.emplace_back([&, i]() { rcs[i] = f(c->subs[i]); if (rcs[i]) errs[i] = g_err; });
+    rcs[0] = f(c->subs[0]);
+    if (rcs[0]) errs[0] = g_err;
+    for (std::thread &w : workers) w.join();
+    for (size_t i = 0; i < n; ++i)
+        if (rcs[i]) { g_err = errs[i]; return rcs[i]; }
     return OA_OK;
 }
 
@@ -1364,7 +1399,7 @@ int set_target_common(oa_ctx *c, const float *xyz, int64_t n, int on_device, boo
 }  // namespace
 OA_EXPORT int oa_set_target(oa_ctx *c, const float *xyz, int64_t n, int on_device)
 {
-    OA_ROUTE_ALL(c, oa_set_target(sub, xyz, n, on_device));                 // replicated on every device
+    OA_ROUTE_ALL_PAR(c, oa_set_target(sub, xyz, n, on_device));             // replicated on every device
     return set_target_common(c, xyz, n, on_device, true);
 }
 
@@ -1694,7 +1729,7 @@ OA_EXPORT int oa_set_target_mesh(oa_ctx *c, const float *xyz, int64_t n_verts, i
                                  int64_t n_tris)
 {
     if (!c) return fail(OA_E_BAD_ARG, "null context");
-    OA_ROUTE_ALL(c, oa_set_target_mesh(sub, xyz, n_verts, on_device, tris, n_tris));
+    OA_ROUTE_ALL_PAR(c, oa_set_target_mesh(sub, xyz, n_verts, on_device, tris, n_tris));
     if (n_tris < 1 || !tris) return fail(OA_E_BAD_ARG, "oa_set_target_mesh: no triangles");
     if (n_tris > 0x2AAAAAA0ll) return fail(OA_E_BAD_ARG, "too many triangles");
     int rc = set_target_common(c, xyz, n_verts, on_device, false);  // vertex images + bbox + filter; no vertex grid / tree
@@ -1729,7 +1764,7 @@ OA_EXPORT int oa_set_source(oa_ctx *c, const float *xyz, int64_t n_verts, int on
     if (!c->subs.empty()) {                                         // multi-device: child i keeps shard i of n_dev
         if (shard_count != 1) return fail(OA_E_BAD_ARG, "oa_set_source: a multi-device context shards the source itself (pass shard 0 of 1)");
         const int n_dev = (int)c->subs.size();
-        OA_ROUTE_ALL(c, oa_set_source(sub, xyz, n_verts, on_device, vlist, n_vlist, stride, sub->rank, n_dev));
+        OA_ROUTE_ALL_PAR(c, oa_set_source(sub, xyz, n_verts, on_device, vlist, n_vlist, stride, sub->rank, n_dev));
     }
     const long long step = stride > 1 ? stride : 1;                 // sample > 1 -> vlist[0::sample] (general.py:274)
     const long long n_all = vlist ? n_vlist : n_verts;
@@ -1834,7 +1869,7 @@ OA_EXPORT int oa_set_normals(oa_ctx *c, const float *src_normals, int64_t n_vert
                              double max_angle_deg)
 {
     if (!c) return fail(OA_E_BAD_ARG, "null context");
-    OA_ROUTE_ALL(c, oa_set_normals(sub, src_normals, n_verts, tgt_normals, nt, max_angle_deg));
+    OA_ROUTE_ALL_PAR(c, oa_set_normals(sub, src_normals, n_verts, tgt_normals, nt, max_angle_deg));
     c->normals_on = false;
     if (!src_normals || !(max_angle_deg > 0.0) || !(max_angle_deg < 180.0)) return OA_OK;       // switched off
     if (!c->d_src4 || !c->d_sel) return fail(OA_E_STATE, "oa_set_normals: call oa_set_source first");

@@ -164,6 +164,41 @@ def test_make_pairs_golden_on_a_multi_device_engine(golden_dir, n_dev):
                 assert np.allclose(ds, g[p + "d_stats"], rtol=1e-9, atol=1e-13), name
 
 
+def test_threaded_uploads_give_the_same_context(golden_dir, monkeypatch):
+    """On different GPUs the children of a multi-device context upload and build their indices at the same time, one
+    host thread each.  This box has one GPU (children then share its stream and stay sequential): OA_MULTI_THREADS=1
+    forces the threaded path, which must leave every child exactly as the sequential one does -- same loop, bit for bit,
+    same pairs -- and must report a child's failure."""
+    from object_alignment_amd import synth
+    from object_alignment_amd.engine import IcpEngine
+    v, t = synth.bumpy_icosphere_mesh(4)
+    src = (synth.bumpy_icosphere(4) * np.float32(1.02)).astype(np.float32)
+    nrm = (src / np.linalg.norm(src, axis=1, keepdims=True)).astype(np.float32)
+    mxa = synth.rigid4(synth.rotation_from_rotvec([0.03, -0.02, 0.04]), [0.02, -0.01, 0.015])
+    eye = np.identity(4, dtype=np.float32)
+    out = []
+    for threads in ("0", "1"):
+        monkeypatch.setenv("OA_MULTI_THREADS", threads)
+        with IcpEngine(devices=[0] * 6) as m:
+            for surface in (False, True):
+                if surface:
+                    m.set_target_mesh(v, t)
+                else:
+                    m.set_target(v)
+                m.set_source(src, vlist=np.arange(0, len(src), 3))
+                m.set_normals(nrm, None if surface else (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32), 60.0)
+                m.set_matrices(mxa, eye)
+                r = m.run(iters=5, thresh=0.5, early_exit=False)
+                A, B, _ = m.make_pairs(0.2)
+                out.append((r.step_M.copy(), r.step_K.copy(), r.matrix_world.copy(), A, B))
+            with pytest.raises(Exception):                          # a bad triangle index fails in every child
+                m.set_target_mesh(v, np.array([[0, 1, len(v) + 5]], np.int32))
+    n = len(out) // 2
+    for a, b in zip(out[:n], out[n:]):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+
+
 def test_multi_more_devices_than_points(orc):
     """Empty shards (16 children, 10 selected points) post zero sums and do not disturb the others."""
     from object_alignment_amd.engine import IcpEngine
