@@ -2,7 +2,7 @@
 HIPCC  ?= /opt/rocm/bin/hipcc
 CSRC   := object_alignment_amd/csrc
 LIB    := object_alignment_amd/liboa_icp.so
-FLAGS  := --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form -fPIC -shared -fvisibility=hidden -pthread -Wall
+FLAGS  := --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form -fno-slp-vectorize -fPIC -shared -fvisibility=hidden -pthread -Wall
 
 all: $(LIB) oracle
 
