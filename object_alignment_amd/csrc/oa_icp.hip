@@ -1700,9 +1700,9 @@ int launch_tri_search(oa_ctx *c)
             unsigned long long h[oa::TRI_STAT_N];
             { int rcr = read_small(c, h, d_stats, sizeof h); if (rcr) return rcr; }
             const double nq = (double)std::max(1ull, h[oa::TRI_STAT_QUERIES]), nw = (double)std::max(1ull, h[oa::TRI_STAT_WAVES]);
-            fprintf(stderr, "[oa] tri grid stats: queries %llu | per query: rows %.2f entries %.2f survivors %.2f evals %.2f | per wave: "
+            fprintf(stderr, "[oa] tri grid stats: queries %llu | per query: rows %.2f entries %.2f (sphere passes %.2f) survivors %.2f evals %.2f | per wave: "
                             "eval trips %.1f max-lane entries %.1f max-lane rows %.1f | ring>=2 %.1f%% ring>=3 %.1f%% unsettled %.1f%% over budget %.1f%%\n",
-                    h[oa::TRI_STAT_QUERIES], h[oa::TRI_STAT_ROWS] / nq, h[oa::TRI_STAT_ENTRIES] / nq, h[oa::TRI_STAT_SURVIVORS] / nq,
+                    h[oa::TRI_STAT_QUERIES], h[oa::TRI_STAT_ROWS] / nq, h[oa::TRI_STAT_ENTRIES] / nq, h[oa::TRI_STAT_SPHERE] / nq, h[oa::TRI_STAT_SURVIVORS] / nq,
                     h[oa::TRI_STAT_EVALS] / nq, h[oa::TRI_STAT_WAVE_TRIPS] / nw, h[oa::TRI_STAT_WAVE_MAX_ENTRIES] / nw,
                     h[oa::TRI_STAT_WAVE_MAX_ROWS] / nw, 100.0 * h[oa::TRI_STAT_RING2] / nq, 100.0 * h[oa::TRI_STAT_RING3] / nq,
                     100.0 * h[oa::TRI_STAT_UNSETTLED] / nq, 100.0 * h[oa::TRI_STAT_OVER] / nq);

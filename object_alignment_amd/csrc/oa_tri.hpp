@@ -276,6 +276,7 @@ __device__ __forceinline__ void tri_candidate(const float *p, const float4 rec0,
         const float D2 = dx * dx + dy * dy + dz * dz;
         const float rs = rec0.w + s.reach;
         if (!(D2 > rs * rs * 1.000003f)) {                         // else: farther than radius + reach, cannot beat or tie
+            if (surv) *surv += 1 << 16;                            // (instrumented build: sphere passes in the high half)
             lb = tri_record_bound2(p, rec0, rec1, D2, rs, eps_plane);
             keep = !(lb > s.thr);                                  // else: the plane / disc bound rules it out
         }
@@ -414,7 +415,7 @@ __device__ __forceinline__ void tri_scan_segments(const float *p, const float4 *
 // both phases on its rows with its own state, and the lanes merge (d2, index) after every batch of rows.
 // STATS (debug builds of the launch, OA_GRID_STATS=1): per-launch totals of what the queries did, see TRI_STAT_*
 enum { TRI_STAT_QUERIES, TRI_STAT_ROWS, TRI_STAT_ENTRIES, TRI_STAT_SURVIVORS, TRI_STAT_EVALS, TRI_STAT_WAVE_TRIPS,
-       TRI_STAT_WAVE_MAX_ENTRIES, TRI_STAT_WAVE_MAX_ROWS, TRI_STAT_RING2, TRI_STAT_RING3, TRI_STAT_UNSETTLED, TRI_STAT_OVER,
+       TRI_STAT_WAVE_MAX_ENTRIES, TRI_STAT_WAVE_MAX_ROWS, TRI_STAT_RING2, TRI_STAT_RING3, TRI_STAT_UNSETTLED, TRI_STAT_OVER, TRI_STAT_SPHERE,
        TRI_STAT_WAVES, TRI_STAT_N };
 
 template <int L, bool STATS = false>
@@ -591,7 +592,8 @@ __global__ __launch_bounds__(256, 4) void k_tri_search_grid(const DevState *__re
         atomicAdd(&stats[TRI_STAT_QUERIES], 1ull);
         atomicAdd(&stats[TRI_STAT_ROWS], (unsigned long long)n_rows_loaded);
         atomicAdd(&stats[TRI_STAT_ENTRIES], (unsigned long long)n_entries);
-        atomicAdd(&stats[TRI_STAT_SURVIVORS], (unsigned long long)n_surv);
+        atomicAdd(&stats[TRI_STAT_SURVIVORS], (unsigned long long)(n_surv & 0xFFFF));
+        atomicAdd(&stats[TRI_STAT_SPHERE], (unsigned long long)((unsigned)n_surv >> 16));
         atomicAdd(&stats[TRI_STAT_EVALS], (unsigned long long)n_evals);
         if (max_ring >= 2) atomicAdd(&stats[TRI_STAT_RING2], 1ull);
         if (max_ring >= 3) atomicAdd(&stats[TRI_STAT_RING3], 1ull);
