@@ -127,9 +127,9 @@ def cpu_tiers(src, tgt, mxa, mxb):
     out = {}
     kd = orc.KDTree(tgt)
     n1 = 4000
-    t0 = time.perf_counter()
-    A, B, _ = orc.make_pairs_python_loop(src[:n1], tgt, mxa, mxb, 0.5, kd, calc_stats=True)
-    t1 = time.perf_counter() - t0
+    tm = {}
+    A, B, _ = orc.make_pairs_python_loop(src[:n1], tgt, mxa, mxb, 0.5, kd, calc_stats=True, timing=tm)
+    t1 = tm["loop_s"]              # the function body only: the duck-typed objects it is handed are built outside the clock
     A2, B2, _ = orc.make_pairs(src[:n1], tgt, mxa, mxb, 0.5, calc_stats=True, kd=kd)
     out["T1_reference_style_python_loop"] = {
         "us_per_vertex": 1e6 * t1 / n1, "cores": 1, "sample": "%d source vertices of the workload" % n1,
@@ -279,12 +279,15 @@ def main():
     if in_process:
         devices = [0] * n_gpus if same_device else list(range(n_gpus))
         eng = IcpEngine(devices=devices)
-        exchange = os.environ.get("OA_EXCHANGE", "mailbox")
+        xinfo = eng.exchange_info()                  # resolves AUTO: RCCL on distinct devices, else the mailbox
+        exchange, rccl_ranks, host_threads = xinfo["exchange"], xinfo["rccl_ranks"], xinfo["host_threads"]
     else:
         devices = [local_rank]
         eng = IcpEngine(local_rank)
         eng.set_stream(torch.cuda.current_stream().cuda_stream)
-        exchange = ("torch.distributed all_reduce (%s)" % backend) if world > 1 else None
+        exchange = ("torch.distributed all_reduce (%s)" % ("nccl = RCCL" if backend == "nccl" else backend)) if world > 1 else None
+        rccl_ranks = dist.get_world_size() if (world > 1 and backend == "nccl") else 0
+        host_threads = 1
     eng.set_search_mode("brute")          # the north-star kernel: LDS-tiled brute force (grid path measured below)
     t0 = time.perf_counter()
     eng.set_target(tgt)
@@ -305,8 +308,8 @@ def main():
             torch.cuda.synchronize(d)
 
     def loop(iters):
-        if in_process:
-            return eng.run(iters=iters, **kw)                    # the whole loop inside the library, all GPUs
+        if in_process or world == 1:
+            return eng.run(iters=iters, **kw)                    # the whole loop inside the library (oa_run): one GPU, or all of them
         return run_sharded(EngineShard(eng, iters=iters, **kw), iters, sums, world_size=world)
 
     def timed(steps, warmup):
@@ -395,7 +398,8 @@ def main():
             "config": {"workload": "1M<->1M uniform [-1,1]^3 clouds, sigma = 5%% of mean spacing, seed 1234, "
                                    "thresh 0.5, stride 1, %d iterations from a cold start (no seeds), early-exit off" % args.steps,
                        "n_source": args.n_source, "n_target": args.n_target, "search": "brute force (north-star kernel)",
-                       "parallelism": par},
+                       "parallelism": par, "exchange": exchange, "rccl_ranks": rccl_ranks, "host_threads_per_process": host_threads,
+                       "host_enqueue_us_per_iteration": (eng.stat("enqueue_us") if in_process else None)},
             "roofline": {"bound": "valu", "achieved": laneops, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s",
                          "frac": laneops / VALU_PEAK_TLANEOPS, "traffic": traffic,
                          "kernel": KERNELS["brute"], "valu_instructions_per_pair": per_pair,

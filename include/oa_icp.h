@@ -81,23 +81,32 @@ typedef struct oa_report {
 int         oa_device_count(void);
 int         oa_create(oa_ctx **out, int device);
 /* One context over n_dev GPUs of this process (1 <= n_dev <= 64; SURVEY.md 8b's oa_create(&ctx, devices, n_dev)).
- * Every upload goes to all of them (target replicated; source: device i keeps shard i of n_dev, see oa_set_source;
- * children on different GPUs upload and build their search structures concurrently, one host thread each),
- * oa_run / oa_iterate drive all devices from the calling thread -- one stream per device, no host round trip per
- * iteration -- and every iteration the devices exchange their OA_NSUMS partial sums and perform the identical solve
+ * Every upload goes to all of them (target replicated; source: the selection is Morton-sorted ONCE, on the first
+ * device, and device i receives range i of n_dev of it, see oa_set_source; the devices build their search structures
+ * concurrently, one persistent host thread per GPU), oa_run hands every GPU's host thread the whole loop of its
+ * device -- one stream per device, no host round trip per iteration, enqueue cost independent of n_dev -- and every
+ * iteration the devices exchange their OA_NSUMS partial sums and perform the identical solve
  * (operators/icp_align.py:96-151 is still ONE call).  A device may be listed more than once (its shards then share
- * one stream); that is how the path is tested on a single GPU.  oa_make_pairs and oa_nn_search work on such a context
- * too: every device answers for its shard and the library merges the answers back into the caller's (vlist) order.
- * Not available on it: oa_set_stream and the split-phase calls. */
+ * one stream and one host thread); that is how the path is tested on a single GPU.  oa_make_pairs and oa_nn_search
+ * work on such a context too: every device answers for its shard and the library merges the answers back into the
+ * caller's (vlist) order.  Device pointers (on_device != 0) may live on any GPU of the process: the library stages
+ * them to the device that needs them.  Not available on it: oa_set_stream and the split-phase calls. */
 int         oa_create_multi(oa_ctx **out, const int *devices, int n_dev);
 int         oa_num_devices(oa_ctx *ctx);
-/* How the devices of an oa_create_multi context join their sums (default: OA_EXCHANGE_MAILBOX; env OA_EXCHANGE=rccl):
- *   OA_EXCHANGE_MAILBOX  all-gather through a pinned host mailbox every device maps; the solve kernel of each device
- *                        waits for the world's posts and adds them in rank order (bitwise identical everywhere);
- *                        nothing is added to the streams: ~2 PCIe round trips per iteration
+/* How the devices of an oa_create_multi context join their sums (env OA_EXCHANGE=rccl / mailbox; default AUTO):
+ *   OA_EXCHANGE_AUTO     RCCL when the listed devices are distinct and librccl can be brought up, else the mailbox;
+ *                        decided before the first loop (OA_STAT_EXCHANGE reports the outcome)
  *   OA_EXCHANGE_RCCL     ncclAllReduce(OA_NSUMS doubles, sum) over xGMI on every device's stream, single-process
  *                        communicator (ncclCommInitAll); librccl.so.1 is loaded on first use; needs distinct devices
- * Returns OA_E_RCCL when RCCL cannot be brought up. */
+ *   OA_EXCHANGE_MAILBOX  all-gather through mailboxes: every device's post is written into every device's inbox --
+ *                        fine-grained device memory, peer-mapped, i.e. 200-byte remote writes over xGMI -- and the solve
+ *                        kernel of each device waits for the world's posts in its own inbox and adds them in rank order
+ *                        (bitwise identical everywhere); nothing is added to the streams.  Without peer access between
+ *                        the devices the inboxes collapse into one box in pinned host memory (PCIe; env OA_MAILBOX=host
+ *                        forces that, OA_MAILBOX=device refuses the fallback).  A device whose post does not arrive
+ *                        within OA_EXCHANGE_TIMEOUT_S (default 30 s) ends the loop with OA_E_RCCL on every device.
+ * Returns OA_E_RCCL when RCCL is asked for and cannot be brought up. */
+#define OA_EXCHANGE_AUTO   (-1)
 #define OA_EXCHANGE_MAILBOX 0
 #define OA_EXCHANGE_RCCL    1
 int         oa_set_exchange(oa_ctx *ctx, int mode);
@@ -182,6 +191,12 @@ int oa_reset_seeds(oa_ctx *ctx);
 #define OA_STAT_CACHE_BYTES       6   /* device bytes currently held by the process-wide allocation cache */
 #define OA_STAT_BRUTE_KERNEL      7   /* what OA_SEARCH_BRUTE launches for the current shard: 0 = k_nn_search (exact only), 1 =
                                        * k_nn_search_filtered (default), 2 = k_nn_search_mfma (experiment, env OA_NN_MFMA=1) */
+#define OA_STAT_EXCHANGE          8   /* multi-device context: what its loops exchange through (resolves AUTO): 0 = mailbox in pinned
+                                       * host memory, 1 = RCCL, 2 = mailboxes in peer-mapped device memory; -1 = not a multi context */
+#define OA_STAT_RCCL_RANKS        9   /* ranks of the RCCL communicator the loops use (0 = RCCL not in use) */
+#define OA_STAT_ENQUEUE_US       10   /* multi-device context: host time per iteration spent enqueuing ONE device's work in the
+                                       * last oa_run (mean over iterations, max over devices), microseconds */
+#define OA_STAT_HOST_THREADS     11   /* multi-device context: host threads that drive its devices (1 = the caller alone) */
 int oa_get_stat(oa_ctx *ctx, int what, double *value);
 int64_t oa_num_selected(oa_ctx *ctx);     /* selected source points held by this context (its shard) */
 

@@ -22,6 +22,7 @@ OA_E_STATE = -6
 OA_E_BAD_THRESH = -7
 OA_E_CAPACITY = -8
 OA_E_RCCL = -9
+OA_EXCHANGE_AUTO = -1
 OA_EXCHANGE_MAILBOX = 0
 OA_EXCHANGE_RCCL = 1
 OA_NSUMS = 24

@@ -5,8 +5,17 @@
 // compute entry point needs a usable HIP device and fails loudly otherwise.
 #include <cstring>
 #include <rocprim/rocprim.hpp>
-#include <rccl/rccl.h>
 #include <dlfcn.h>
+// librccl is loaded with dlopen on first use (liboa_icp.so has no link dependency on it); a ROCm install without the
+// RCCL development headers still builds this file from the handful of declarations the exchange needs
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#else
+typedef struct ncclComm *ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclFloat64 = 8, ncclDouble = 8 } ncclDataType_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+#endif
 
 #include "oa_kernels.hpp"
 #include "oa_grid.hpp"
@@ -18,6 +27,9 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <memory>
 #include <mutex>
 #include <unordered_map>
 #include <thread>
@@ -216,10 +228,95 @@ double env_double(const char *name, double dflt)
     return (v && *v) ? atof(v) : dflt;
 }
 
-// A multi-device parent's uploads (target: 20+ ms of copies, sorts and index builds per device at 1M) would take n_dev
-// times as long driven one child after the other; every child has its own device and stream, so each gets a host
-// thread.  Children that share a device also share a stream: they stay sequential (OA_MULTI_THREADS=1 forces threads --
-// how the path is tested on a one-GPU box --, 0 forbids them).  The first failing child's code and message win.
+// Host threads of a multi-device context.  One PERSISTENT worker per listed GPU (children that share a GPU share a
+// worker and stay sequential): uploads and index builds (20+ ms of copies, sorts and builds per device at 1M) run on all
+// GPUs at the same time, and oa_run hands every worker the whole loop of its device -- each GPU is fed by its own
+// thread, so the enqueue cost per iteration does not grow with the number of GPUs.  Round 2 spawned fresh std::threads
+// per upload call and enqueued every device's iteration from the calling thread (~50 runtime calls per iteration at 8
+// GPUs).  OA_MULTI_THREADS: -1 (default) as above, 0 = everything on the calling thread, 1 = one worker per CHILD even
+// when children share a GPU (test hook: the threaded paths on a one-GPU box).
+struct WorkerPool {
+    struct Worker {
+        std::thread th;
+        std::mutex mu;
+        std::condition_variable cv;
+        std::function<int()> job;
+        bool has_job = false, done = true, quit = false;
+        int rc = 0;
+        std::string err;
+    };
+    std::vector<std::unique_ptr<Worker>> workers;
+
+    static void loop(Worker *w)
+    {
+        for (;;) {
+            std::function<int()> job;
+            {
+                std::unique_lock<std::mutex> lk(w->mu);
+                w->cv.wait(lk, [w] { return w->has_job || w->quit; });
+                if (w->quit) return;
+                job = std::move(w->job);
+                w->has_job = false;
+            }
+            g_err.clear();
+            const int rc = job();
+            {
+                std::lock_guard<std::mutex> lk(w->mu);
+                w->rc = rc;
+                w->err = rc ? g_err : std::string();
+                w->done = true;
+            }
+            w->cv.notify_all();
+        }
+    }
+
+    void start(size_t n)
+    {
+        while (workers.size() < n) {
+            workers.emplace_back(new Worker());
+            Worker *w = workers.back().get();
+            w->th = std::thread(loop, w);
+        }
+    }
+
+    // f(k) for k = 0 .. n-1: k = 0 on the calling thread, the others on workers 0 .. n-2.  The first failure (lowest k)
+    // wins: its code is returned and its message becomes this thread's oa_last_error().
+    template <typename F> int run(size_t n, F f)
+    {
+        if (n == 0) return OA_OK;
+        start(n - 1);
+        for (size_t k = 1; k < n; ++k) {
+            Worker *w = workers[k - 1].get();
+            {
+                std::lock_guard<std::mutex> lk(w->mu);
+                w->job = [f, k]() -> int { return f(k); };
+                w->has_job = true;
+                w->done = false;
+            }
+            w->cv.notify_all();
+        }
+        int rc0 = f(0);
+        std::string err0 = rc0 ? g_err : std::string();
+        for (size_t k = 1; k < n; ++k) {
+            Worker *w = workers[k - 1].get();
+            std::unique_lock<std::mutex> lk(w->mu);
+            w->cv.wait(lk, [w] { return w->done; });
+            if (!rc0 && w->rc) { rc0 = w->rc; err0 = w->err; }
+        }
+        if (rc0) g_err = err0;
+        return rc0;
+    }
+
+    ~WorkerPool()
+    {
+        for (auto &w : workers) {
+            { std::lock_guard<std::mutex> lk(w->mu); w->quit = true; }
+            w->cv.notify_all();
+            if (w->th.joinable()) w->th.join();
+        }
+    }
+};
+
 template <typename F> int route_all_parallel(oa_ctx *c, F f);
 
 }  // namespace
@@ -328,6 +425,15 @@ struct oa_ctx {
     struct oa_exchange *xch = nullptr;  // parent: owns it; child: the parent's
     oa_ctx *parent = nullptr;
     int rank = 0, world = 1;            // child: its place in the device list
+    std::vector<std::vector<int>> groups;   // parent: children per host thread (one group per GPU, see WorkerPool)
+    WorkerPool *pool = nullptr;         // parent: the persistent host threads of groups 1 .. n-1 (group 0 = the caller)
+    double enq_ns = 0.0;                // child: host time spent enqueuing its iterations in the last loop
+    long long enq_iters = 0;
+    // parent: whole selection in slot (Morton) order, kept on the first child's device by oa_set_source so that
+    // per-vertex attributes uploaded later (oa_set_normals) are gathered once and dealt out by range
+    int *d_all_sel = nullptr;
+    long long all_n_sel = 0;
+    std::vector<long long> shard_off;   // parent: begin of every child's range of the selection (n_dev + 1 entries)
 };
 
 namespace {
@@ -339,30 +445,25 @@ int use_device(oa_ctx *c)
     return OA_OK;
 }
 
+// which GPU a device pointer lives on (-1: not a device pointer the runtime knows)
+int pointer_device(const void *ptr)
+{
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, ptr) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return at.type == hipMemoryTypeDevice ? at.device : -1;
+}
+
 template <typename F> int route_all_parallel(oa_ctx *c, F f)
 {
-    const size_t n = c->subs.size();
-    bool distinct = true;
-    for (size_t i = 0; i < n && distinct; ++i)
-        for (size_t j = i + 1; j < n; ++j)
-            if (c->subs[i]->device == c->subs[j]->device) { distinct = false; break; }
-    const int force = env_int("OA_MULTI_THREADS", -1);
-    if (n < 2 || force == 0 || (force < 0 && !distinct)) {
+    const size_t ng = c->groups.size();
+    if (ng <= 1 || !c->pool) {
         for (oa_ctx *sub : c->subs) { const int rc = f(sub); if (rc) return rc; }
         return OA_OK;
     }
-    std::vector<int> rcs(n, OA_OK);
-    std::vector<std::string> errs(n);
-    std::vector<std::thread> workers;
-    workers.reserve(n - 1);
-    for (size_t i = 1; i < n; ++i)
-        workers.emplace_back([&, i]() { rcs[i] = f(c->subs[i]); if (rcs[i]) errs[i] = g_err; });
-    rcs[0] = f(c->subs[0]);
-    if (rcs[0]) errs[0] = g_err;
-    for (std::thread &w : workers) w.join();
-    for (size_t i = 0; i < n; ++i)
-        if (rcs[i]) { g_err = errs[i]; return rcs[i]; }
-    return OA_OK;
+    return c->pool->run(ng, [c, f](size_t g) -> int {
+        for (int i : c->groups[g]) { const int rc = f(c->subs[(size_t)i]); if (rc) return rc; }
+        return OA_OK;
+    });
 }
 
 void plan_geometry(oa_ctx *c)
@@ -821,24 +922,39 @@ int fill_report(oa_ctx *c, oa_report *rep)
 // ------------------------------------------------------------------------------------------------
 // multi-device exchange: how the children of an oa_create_multi context join their sums
 // ------------------------------------------------------------------------------------------------
-//   OA_EXCHANGE_MAILBOX  one-shot all-gather through a mailbox in pinned, portable host memory every device maps:
-//                        k_reduce_post writes a rank's 24 sums + a sequence word, k_gather_solve_update waits for the
-//                        world's posts and adds them in rank order (bitwise identical on every device).  No host
-//                        involvement, no extra launches: an iteration stays search -> accumulate -> post -> solve.
-//   OA_EXCHANGE_RCCL     ncclAllReduce(24 doubles, sum) on every device's stream through a single-process
+//   OA_EXCHANGE_RCCL     ncclAllReduce(24 doubles, sum) over xGMI on every device's stream through a single-process
 //                        ncclCommInitAll communicator (librccl is loaded on first use: liboa_icp.so does not link it).
+//                        What BASELINE.json's north-star names; the DEFAULT whenever the listed devices are distinct and
+//                        librccl can be brought up (OA_EXCHANGE_AUTO).
+//   OA_EXCHANGE_MAILBOX  one-shot all-gather through mailboxes: k_reduce_post writes a rank's 24 sums + a sequence word
+//                        into every rank's inbox, k_gather_solve_update waits for the world's posts in its own inbox and
+//                        adds them in rank order (bitwise identical on every device).  No host involvement, no extra
+//                        launches: an iteration stays search -> accumulate -> post -> solve.  The inboxes live in device
+//                        memory (fine-grained, peer-mapped: the 200 B travel over xGMI and every rank polls its own HBM);
+//                        when peer access is not available, one box in pinned host memory every device maps (PCIe).
+//                        The fallback of AUTO: duplicate devices (one-GPU test boxes), no librccl.
 }  // namespace
 struct oa_exchange {
     int world = 0;
-    int mode = OA_EXCHANGE_MAILBOX;
-    oa::MailSlot *h_box = nullptr;                 // [2][world]
-    std::vector<oa::MailSlot *> d_box;             // the same memory as each child's device sees it
+    int requested = OA_EXCHANGE_AUTO;              // what the caller asked for (env OA_EXCHANGE / oa_set_exchange)
+    int mode = OA_EXCHANGE_MAILBOX;                // what the loops use once `resolved`
+    bool resolved = false;
+    std::string auto_note;                         // why AUTO did not take RCCL
+    // mailbox
+    bool device_box = false;                       // inboxes in device memory (peer-mapped) instead of the pinned host box
+    oa::MailSlot *h_box = nullptr;                 // host box [2][world]
+    std::vector<oa::MailSlot *> box;               // rank r's mailbox as rank r's device sees it (its inbox / the host box)
+    std::vector<oa::MailSlot **> d_dests;          // rank r: device array of the mailboxes r posts into
+    int n_dest = 1;
     unsigned long long timeout_ticks = 0;
+    unsigned long long seq_next = 0;               // DevState::seq_base of the next loop
+    int fault_skip_rank = -1;                      // OA_FAULT_SKIP_POST_RANK: that rank's posts never arrive (test hook)
     // RCCL
     void *lib = nullptr;
     std::vector<ncclComm_t> comms;
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
@@ -854,6 +970,14 @@ using Exchange = oa_exchange;
             return fail(OA_E_RCCL, "%s failed: %s", #expr, (x)->GetErrorString ? (x)->GetErrorString(r_) : "?"); \
     } while (0)
 
+bool devices_distinct(const oa_ctx *p)
+{
+    for (size_t i = 0; i < p->subs.size(); ++i)
+        for (size_t j = 0; j < i; ++j)
+            if (p->subs[i]->device == p->subs[j]->device) return false;
+    return true;
+}
+
 int exchange_init_rccl(oa_ctx *p)
 {
     Exchange *x = p->xch;
@@ -868,6 +992,7 @@ int exchange_init_rccl(oa_ctx *p)
         if (!x->lib) return fail(OA_E_RCCL, "librccl not found (%s)", dlerror());
         x->CommInitAll = (decltype(x->CommInitAll))dlsym(x->lib, "ncclCommInitAll");
         x->CommDestroy = (decltype(x->CommDestroy))dlsym(x->lib, "ncclCommDestroy");
+        x->CommCount = (decltype(x->CommCount))dlsym(x->lib, "ncclCommCount");
         x->AllReduce = (decltype(x->AllReduce))dlsym(x->lib, "ncclAllReduce");
         x->GroupStart = (decltype(x->GroupStart))dlsym(x->lib, "ncclGroupStart");
         x->GroupEnd = (decltype(x->GroupEnd))dlsym(x->lib, "ncclGroupEnd");
@@ -886,35 +1011,134 @@ int exchange_init_rccl(oa_ctx *p)
     return OA_OK;
 }
 
-void exchange_destroy(Exchange *x)
+// how many ranks RCCL's communicator spans (0 = RCCL is not what this context exchanges through)
+int exchange_rccl_ranks(const Exchange *x)
 {
-    if (!x) return;
-    for (ncclComm_t cm : x->comms) if (cm && x->CommDestroy) (void)x->CommDestroy(cm);
-    if (x->h_box) (void)hipHostFree(x->h_box);
-    // the library handle stays open: unloading RCCL under a live HIP runtime is not worth the risk
-    delete x;
+    if (!x || x->mode != OA_EXCHANGE_RCCL || x->comms.empty()) return 0;
+    int n = 0;
+    if (x->CommCount && x->CommCount(x->comms[0], &n) == ncclSuccess) return n;
+    return (int)x->comms.size();
 }
 
-// all children, all-reduce of their d_sums in place (RCCL mode); one group = one launch per device
-int exchange_allreduce_rccl(oa_ctx *p)
+// AUTO -> RCCL when the devices are distinct and RCCL comes up, else the mailbox.  Decided once, before the first loop
+// (ncclCommInitAll takes ~0.1-1 s: not something to pay inside oa_create_multi for contexts that only upload and pair).
+int exchange_resolve(oa_ctx *p)
 {
     Exchange *x = p->xch;
-    RCCLCHK(x, x->GroupStart());
-    for (size_t i = 0; i < p->subs.size(); ++i) {
-        oa_ctx *c = p->subs[i];
-        ncclResult_t r = x->AllReduce(c->d_sums, c->d_sums, oa::NSUMS, ncclDouble, ncclSum, x->comms[i], c->stream);
-        if (r != ncclSuccess) { (void)x->GroupEnd(); return fail(OA_E_RCCL, "ncclAllReduce failed: %s", x->GetErrorString ? x->GetErrorString(r) : "?"); }
+    if (x->resolved) return OA_OK;
+    if (x->requested == OA_EXCHANGE_RCCL) {
+        const int rc = exchange_init_rccl(p);
+        if (rc) return rc;
+        x->mode = OA_EXCHANGE_RCCL;
+    } else if (x->requested == OA_EXCHANGE_MAILBOX) {
+        x->mode = OA_EXCHANGE_MAILBOX;
+    } else {
+        x->mode = OA_EXCHANGE_MAILBOX;
+        if (p->subs.size() < 2) x->auto_note = "one device: nothing to exchange";
+        else if (!devices_distinct(p)) x->auto_note = "a device is listed more than once";
+        else {
+            const std::string keep = g_err;
+            if (exchange_init_rccl(p) == OA_OK) x->mode = OA_EXCHANGE_RCCL;
+            else { x->auto_note = g_err; g_err = keep; }
+        }
     }
-    RCCLCHK(x, x->GroupEnd());
+    x->resolved = true;
     return OA_OK;
 }
 
-// one iteration on every child: search + accumulate + post / reduce, [all-reduce], gather + solve
-int multi_iteration(oa_ctx *p, bool timed)
+void exchange_destroy(oa_ctx *p)
+{
+    Exchange *x = p->xch;
+    if (!x) return;
+    for (ncclComm_t cm : x->comms) if (cm && x->CommDestroy) (void)x->CommDestroy(cm);
+    for (size_t r = 0; r < p->subs.size(); ++r) {
+        if (hipSetDevice(p->subs[r]->device) != hipSuccess) { (void)hipGetLastError(); continue; }
+        if (r < x->d_dests.size() && x->d_dests[r]) (void)hipFree(x->d_dests[r]);
+        if (x->device_box && r < x->box.size() && x->box[r]) (void)hipFree(x->box[r]);
+    }
+    if (x->h_box) (void)hipHostFree(x->h_box);
+    // the library handle stays open: unloading RCCL under a live HIP runtime is not worth the risk
+    delete x;
+    p->xch = nullptr;
+}
+
+// Mailboxes of a new multi-device context.  Device placement needs every pair of distinct devices to map each other's
+// memory (hipDeviceEnablePeerAccess) and a fine-grained allocation per rank; anything less falls back to the pinned host
+// box.  OA_MAILBOX=host / device forces one (device: fails instead of falling back).
+int exchange_setup_mailboxes(oa_ctx *p)
+{
+    Exchange *x = p->xch;
+    const int world = x->world;
+    const size_t bytes = sizeof(oa::MailSlot) * 2 * (size_t)world;
+    const char *want = getenv("OA_MAILBOX");
+    const bool force_host = want && !strcmp(want, "host"), force_dev = want && !strcmp(want, "device");
+    bool dev_ok = !force_host;
+    std::string why;
+    if (dev_ok) {
+        for (int i = 0; i < world && dev_ok; ++i)
+            for (int j = 0; j < world && dev_ok; ++j) {
+                const int di = p->subs[(size_t)i]->device, dj = p->subs[(size_t)j]->device;
+                if (di == dj) continue;
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, di, dj) != hipSuccess || !can) { (void)hipGetLastError(); dev_ok = false; why = "no peer access between the listed devices"; break; }
+                if (hipSetDevice(di) != hipSuccess) { (void)hipGetLastError(); dev_ok = false; why = "hipSetDevice failed"; break; }
+                const hipError_t e = hipDeviceEnablePeerAccess(dj, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { dev_ok = false; why = std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e); }
+                (void)hipGetLastError();
+            }
+    }
+    x->box.assign((size_t)world, nullptr);
+    x->d_dests.assign((size_t)world, nullptr);
+    if (dev_ok) {
+        for (int r = 0; r < world && dev_ok; ++r) {
+            void *ptr = nullptr;
+            hipError_t e = hipSetDevice(p->subs[(size_t)r]->device);
+            if (e == hipSuccess) e = hipExtMallocWithFlags(&ptr, bytes, hipDeviceMallocFinegrained);
+            if (e == hipSuccess) e = hipMemset(ptr, 0, bytes);
+            if (e != hipSuccess) { (void)hipGetLastError(); dev_ok = false; why = std::string("fine-grained device allocation: ") + hipGetErrorString(e); if (ptr) (void)hipFree(ptr); break; }
+            x->box[(size_t)r] = (oa::MailSlot *)ptr;
+        }
+        if (!dev_ok) for (int r = 0; r < world; ++r) if (x->box[(size_t)r]) { (void)hipSetDevice(p->subs[(size_t)r]->device); (void)hipFree(x->box[(size_t)r]); x->box[(size_t)r] = nullptr; }
+    }
+    if (!dev_ok && force_dev) return fail(OA_E_HIP, "OA_MAILBOX=device: %s", why.c_str());
+    x->device_box = dev_ok;
+    if (!dev_ok) {
+        hipError_t e = hipHostMalloc((void **)&x->h_box, bytes, hipHostMallocPortable | hipHostMallocMapped);
+        if (e != hipSuccess) return fail(OA_E_HIP, "oa_create_multi: mailbox allocation failed: %s", hipGetErrorString(e));
+        memset(x->h_box, 0, bytes);
+        for (int r = 0; r < world; ++r) {
+            void *dp = nullptr;
+            e = hipSetDevice(p->subs[(size_t)r]->device);
+            if (e == hipSuccess) e = hipHostGetDevicePointer(&dp, x->h_box, 0);
+            if (e != hipSuccess) return fail(OA_E_HIP, "oa_create_multi: device %d cannot map the mailbox: %s", p->subs[(size_t)r]->device, hipGetErrorString(e));
+            x->box[(size_t)r] = (oa::MailSlot *)dp;
+        }
+    }
+    // where rank r posts: every rank's inbox (device placement) or the one host box as r's device sees it
+    x->n_dest = dev_ok ? world : 1;
+    for (int r = 0; r < world; ++r) {
+        std::vector<oa::MailSlot *> dst;
+        if (dev_ok) dst = x->box; else dst.push_back(x->box[(size_t)r]);
+        void *dp = nullptr;
+        hipError_t e = hipSetDevice(p->subs[(size_t)r]->device);
+        if (e == hipSuccess) e = hipMalloc(&dp, sizeof(oa::MailSlot *) * dst.size());
+        if (e == hipSuccess) e = hipMemcpy(dp, dst.data(), sizeof(oa::MailSlot *) * dst.size(), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return fail(OA_E_HIP, "oa_create_multi: mailbox table: %s", hipGetErrorString(e));
+        x->d_dests[(size_t)r] = (oa::MailSlot **)dp;
+    }
+    return OA_OK;
+}
+
+// One iteration on the children of one host thread's group: pass 1 search + accumulate + post / reduce on each child,
+// [all-reduce], pass 2 gather + solve on each.  (Two passes, not child by child: children that share a GPU may share a
+// hardware queue, and every post of an iteration has to be submitted ahead of the gathers that wait for it.)
+int multi_iteration_group(oa_ctx *p, const std::vector<int> &group, bool timed)
 {
     Exchange *x = p->xch;
     int rc;
-    for (oa_ctx *c : p->subs) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i : group) {
+        oa_ctx *c = p->subs[(size_t)i];
         if ((rc = use_device(c))) return rc;
         const bool t = timed && c->time_events;
         if (t) {
@@ -927,23 +1151,49 @@ int multi_iteration(oa_ctx *p, bool timed)
         if (x->mode == OA_EXCHANGE_RCCL) rc = launch_reduce(c, c->d_sums);
         else {
             hipLaunchKernelGGL(oa::k_reduce_post, dim3(1), dim3(1024), 0, c->stream, (const oa::DevState *)c->d_state,
-                               (const double *)c->d_partials, c->acc_blocks, x->d_box[(size_t)c->rank], c->rank, x->world);
+                               (const double *)c->d_partials, c->acc_blocks, (oa::MailSlot *const *)x->d_dests[(size_t)c->rank],
+                               x->n_dest, c->rank, x->world, x->fault_skip_rank == c->rank ? 1 : 0);
             HIPCHK(hipGetLastError());
         }
         if (rc) return rc;
     }
-    if (x->mode == OA_EXCHANGE_RCCL && (rc = exchange_allreduce_rccl(p))) return rc;
-    for (oa_ctx *c : p->subs) {
+    if (x->mode == OA_EXCHANGE_RCCL) {
+        // one thread, several devices: group semantics; one thread per device: plain calls (each rank's kernel waits
+        // for its peers on the device, the host call only enqueues)
+        const bool grouped = group.size() > 1;
+        if (grouped) RCCLCHK(x, x->GroupStart());
+        for (int i : group) {
+            oa_ctx *c = p->subs[(size_t)i];
+            if ((rc = use_device(c))) { if (grouped) (void)x->GroupEnd(); return rc; }
+            ncclResult_t r = x->AllReduce(c->d_sums, c->d_sums, oa::NSUMS, ncclDouble, ncclSum, x->comms[(size_t)i], c->stream);
+            if (r != ncclSuccess) { if (grouped) (void)x->GroupEnd(); return fail(OA_E_RCCL, "ncclAllReduce failed: %s", x->GetErrorString ? x->GetErrorString(r) : "?"); }
+        }
+        if (grouped) RCCLCHK(x, x->GroupEnd());
+    }
+    for (int i : group) {
+        oa_ctx *c = p->subs[(size_t)i];
         if ((rc = use_device(c))) return rc;
         if (x->mode == OA_EXCHANGE_RCCL) rc = iter_finish(c, c->d_sums);
         else {
-            hipLaunchKernelGGL(oa::k_gather_solve_update, dim3(1), dim3(64), 0, c->stream, c->d_state, x->d_box[(size_t)c->rank],
+            hipLaunchKernelGGL(oa::k_gather_solve_update, dim3(1), dim3(64), 0, c->stream, c->d_state, x->box[(size_t)c->rank],
                                x->world, c->d_sums, c->d_hist, c->d_todo_count, x->timeout_ticks);
             HIPCHK(hipGetLastError());
         }
         if (rc) return rc;
     }
+    const double ns = (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    for (int i : group) { p->subs[(size_t)i]->enq_ns += ns / (double)group.size(); p->subs[(size_t)i]->enq_iters++; }
     return OA_OK;
+}
+
+// f(group index) on every host thread of the context (group 0 on the caller's)
+template <typename F> int multi_for_groups(oa_ctx *p, F f)
+{
+    if (p->groups.size() <= 1 || !p->pool) {
+        for (size_t g = 0; g < p->groups.size(); ++g) { const int rc = f(g); if (rc) return rc; }
+        return OA_OK;
+    }
+    return p->pool->run(p->groups.size(), f);
 }
 
 void multi_abort(oa_ctx *p)
@@ -956,13 +1206,16 @@ int multi_begin(oa_ctx *p, const oa_settings *st, int iters)
 {
     Exchange *x = p->xch;
     int rc;
-    if (x->mode == OA_EXCHANGE_RCCL && (rc = exchange_init_rccl(p))) return rc;
+    if ((rc = exchange_resolve(p))) return rc;
+    // sequence numbers of this loop's posts: above everything an earlier loop left in the mailboxes
+    const unsigned long long seq_base = x->seq_next;
+    x->seq_next += (iters == ITERATE_OPEN || iters < 0) ? (1ull << 32) : (unsigned long long)iters + 2ull;
     for (oa_ctx *c : p->subs) {
+        c->h_state.seq_base = seq_base;
         if ((rc = begin_loop(c, st, iters))) { multi_abort(p); return rc; }     // synchronises the child's stream first
         if ((rc = ensure_events(c, (c->time_events && iters != ITERATE_OPEN) ? std::max(1, std::min(iters, 1 << 16)) : 1))) { multi_abort(p); return rc; }
+        c->enq_ns = 0.0; c->enq_iters = 0;
     }
-    // every stream was idle when its begin_loop started and nothing enqueued since touches the mailbox
-    memset(x->h_box, 0, sizeof(oa::MailSlot) * 2 * (size_t)x->world);
     for (oa_ctx *c : p->subs) {
         if ((rc = use_device(c))) { multi_abort(p); return rc; }
         HIPCHK(hipEventRecord(c->ev_loop0, c->stream));
@@ -1007,11 +1260,13 @@ int multi_end(oa_ctx *p, oa_report *rep)
     return status_error(agg.status);
 }
 
-int multi_run(oa_ctx *p, const oa_settings *st, oa_report *rep)
+// the loop of one host thread's group: enqueue its children's iterations, at most `lag` ahead of the GPU, until the
+// budget is spent or the devices report the halt (every device takes the same decision from the same sums)
+int multi_group_loop(oa_ctx *p, size_t g, const oa_settings *st)
 {
-    int rc = multi_begin(p, st, st->iters);
-    if (rc) return rc;
-    oa_ctx *c0 = p->subs[0];
+    const std::vector<int> &group = p->groups[g];
+    if (group.empty()) return OA_OK;
+    oa_ctx *c0 = p->subs[(size_t)group[0]];
     const bool poll = c0->h_poll && st->early_exit && env_int("OA_RUN_POLL", 1);
     const int lag = 2;
     volatile int32_t *progress = c0->h_poll;
@@ -1024,8 +1279,18 @@ int multi_run(oa_ctx *p, const oa_settings *st, oa_report *rep)
             }
             if (progress[0]) break;
         }
-        if ((rc = multi_iteration(p, true))) { multi_abort(p); return rc; }
+        const int rc = multi_iteration_group(p, group, true);
+        if (rc) return rc;
     }
+    return OA_OK;
+}
+
+int multi_run(oa_ctx *p, const oa_settings *st, oa_report *rep)
+{
+    int rc = multi_begin(p, st, st->iters);
+    if (rc) return rc;
+    rc = multi_for_groups(p, [p, st](size_t g) -> int { return multi_group_loop(p, g, st); });
+    if (rc) { const std::string keep = g_err; multi_abort(p); g_err = keep; return rc; }
     return multi_end(p, rep);
 }
 }  // namespace
@@ -1086,8 +1351,10 @@ OA_EXPORT int oa_create(oa_ctx **out, int device)
 }
 
 // oa_create(&ctx, devices, n_dev).  One process, one child context (and stream) per listed device; the
-// same device may be listed more than once (its children then share one stream, so that the exchange's waits can
-// never starve each other on one hardware queue) -- that is how the multi-device path is tested on a single GPU.
+// same device may be listed more than once -- that is how the multi-device path is tested on a single GPU.  Children
+// that share a device share one stream by default (the exchange's waits then can never sit in front of the post they
+// wait for); OA_MULTI_OWN_STREAMS=1 gives each its own, so that k_gather_solve_update really spins against concurrent
+// producers on a one-GPU box (the two-pass enqueue order of multi_iteration_group keeps that deadlock-free).
 OA_EXPORT int oa_create_multi(oa_ctx **out, const int *devices, int n_dev)
 {
     if (!out) return fail(OA_E_BAD_ARG, "oa_create_multi: null out pointer");
@@ -1103,32 +1370,42 @@ OA_EXPORT int oa_create_multi(oa_ctx **out, const int *devices, int n_dev)
     if (!x) { delete p; return fail(OA_E_HIP, "out of host memory"); }
     p->xch = x;
     x->world = n_dev;
+    const bool own_streams = env_int("OA_MULTI_OWN_STREAMS", 0) != 0;
     int rc = OA_OK;
     for (int i = 0; i < n_dev && !rc; ++i) {
         oa_ctx *c = nullptr;
         rc = oa_create(&c, devices[i]);
         if (rc) break;
         c->parent = p; c->rank = i; c->world = n_dev; c->xch = x;
-        for (oa_ctx *e : p->subs) if (e->device == c->device) { c->stream = e->stream; break; }   // one stream per device
+        if (!own_streams)
+            for (oa_ctx *e : p->subs) if (e->device == c->device) { c->stream = e->stream; break; }   // one stream per device
         p->subs.push_back(c);
     }
-    if (!rc) {
-        hipError_t e = hipHostMalloc((void **)&x->h_box, sizeof(oa::MailSlot) * 2 * (size_t)n_dev, hipHostMallocPortable | hipHostMallocMapped);
-        if (e != hipSuccess) rc = fail(OA_E_HIP, "oa_create_multi: mailbox allocation failed: %s", hipGetErrorString(e));
-        else memset(x->h_box, 0, sizeof(oa::MailSlot) * 2 * (size_t)n_dev);
-    }
-    for (int i = 0; i < n_dev && !rc; ++i) {
-        void *dp = nullptr;
-        hipError_t e = hipSetDevice(devices[i]);
-        if (e == hipSuccess) e = hipHostGetDevicePointer(&dp, x->h_box, 0);
-        if (e != hipSuccess) rc = fail(OA_E_HIP, "oa_create_multi: device %d cannot map the mailbox: %s", devices[i], hipGetErrorString(e));
-        x->d_box.push_back((oa::MailSlot *)dp);
-    }
+    if (!rc) rc = exchange_setup_mailboxes(p);
     if (!rc) {
         const double secs = std::max(0.05, env_double("OA_EXCHANGE_TIMEOUT_S", 30.0));
         x->timeout_ticks = (unsigned long long)(secs * p->subs[0]->wall_clock_khz * 1e3);
+        x->seq_next = 0;
+        x->fault_skip_rank = env_int("OA_FAULT_SKIP_POST_RANK", -1);
         const char *m = getenv("OA_EXCHANGE");
-        if (m && (!strcmp(m, "rccl") || !strcmp(m, "RCCL") || !strcmp(m, "1"))) x->mode = OA_EXCHANGE_RCCL;
+        if (m && (!strcmp(m, "rccl") || !strcmp(m, "RCCL") || !strcmp(m, "1"))) x->requested = OA_EXCHANGE_RCCL;
+        else if (m && (!strcmp(m, "mailbox") || !strcmp(m, "MAILBOX") || !strcmp(m, "0"))) x->requested = OA_EXCHANGE_MAILBOX;
+        // host threads: one group of children per GPU (OA_MULTI_THREADS=1: per child, 0: a single group)
+        const int threads = env_int("OA_MULTI_THREADS", -1);
+        for (int i = 0; i < n_dev; ++i) {
+            size_t g = p->groups.size();
+            if (threads == 0) g = 0;
+            else if (threads < 0)
+                for (size_t k = 0; k < p->groups.size(); ++k)
+                    if (p->subs[(size_t)p->groups[k][0]]->device == devices[i]) { g = k; break; }
+            if (g == p->groups.size()) p->groups.emplace_back();
+            p->groups[g].push_back(i);
+        }
+        if (p->groups.size() > 1) {
+            p->pool = new (std::nothrow) WorkerPool();
+            if (!p->pool) rc = fail(OA_E_HIP, "out of host memory");
+            else p->pool->start(p->groups.size() - 1);
+        }
     }
     if (rc) { const std::string keep = g_err; oa_destroy(p); g_err = keep; return rc; }
     *out = p;
@@ -1139,11 +1416,11 @@ OA_EXPORT int oa_set_exchange(oa_ctx *c, int mode)
 {
     if (!c) return fail(OA_E_BAD_ARG, "null context");
     if (c->subs.empty()) return fail(OA_E_STATE, "oa_set_exchange: not a multi-device context (oa_create_multi)");
-    if (mode != OA_EXCHANGE_MAILBOX && mode != OA_EXCHANGE_RCCL) return fail(OA_E_BAD_ARG, "exchange mode %d", mode);
-    if (c->loop_active) return fail(OA_E_STATE, "oa_set_exchange inside a loop");
-    c->xch->mode = mode;
-    if (mode == OA_EXCHANGE_RCCL) return exchange_init_rccl(c);       // fails now rather than in the first iteration
-    return OA_OK;
+    if (mode != OA_EXCHANGE_AUTO && mode != OA_EXCHANGE_MAILBOX && mode != OA_EXCHANGE_RCCL) return fail(OA_E_BAD_ARG, "exchange mode %d", mode);
+    if (c->loop_active) multi_abort(c);                                 // an open oa_iterate sequence ends here
+    c->xch->requested = mode;
+    c->xch->resolved = false;
+    return exchange_resolve(c);                                         // RCCL fails now rather than in the first iteration
 }
 
 OA_EXPORT int oa_num_devices(oa_ctx *c) { return !c ? 0 : (c->subs.empty() ? 1 : (int)c->subs.size()); }
@@ -1154,9 +1431,13 @@ OA_EXPORT void oa_destroy(oa_ctx *c)
 {
     if (!c) return;
     if (!c->subs.empty() || c->xch) {
-        if (!c->parent) {                                           // a multi-device parent: children first, then the exchange
+        if (!c->parent) {                                           // a multi-device parent: workers, exchange, then the children
+            for (oa_ctx *sub : c->subs) { if (hipSetDevice(sub->device) == hipSuccess) (void)hipStreamSynchronize(sub->stream); }
+            delete c->pool;
+            c->pool = nullptr;
+            if (c->d_all_sel && !c->subs.empty() && hipSetDevice(c->subs[0]->device) == hipSuccess) { tl_stream_known = false; dev_free(c->d_all_sel, true); }
+            exchange_destroy(c);
             for (oa_ctx *sub : c->subs) { sub->xch = nullptr; sub->parent = nullptr; oa_destroy(sub); }
-            exchange_destroy(c->xch);
             delete c;
             return;
         }
@@ -1360,6 +1641,7 @@ int set_target_common(oa_ctx *c, const float *xyz, int64_t n, int on_device, boo
     int rc = use_device(c);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
+    c->loop_active = false;                                         // an open oa_iterate sequence ends with the old target
     dev_free(c->d_tgt_xyz); dev_free(c->d_tg); dev_free(c->d_tf); dev_free(c->d_tf3); dev_free(c->d_tfm);
     dev_free(c->d_tri9); dev_free(c->d_tcell_start); dev_free(c->d_tcell_rec);
     dev_free(c->d_bvh_box); dev_free(c->d_bvh_prims); dev_free(c->d_tbvh_box); dev_free(c->d_tbvh_prims);
@@ -1377,8 +1659,15 @@ int set_target_common(oa_ctx *c, const float *xyz, int64_t n, int on_device, boo
     }
     if (n == 0) return OA_OK;
     HIPCHK(dev_malloc(&c->d_tgt_xyz, sizeof(float) * 3 * (size_t)n));
-    HIPCHK(hipMemcpyAsync(c->d_tgt_xyz, xyz, sizeof(float) * 3 * (size_t)n,
-                          on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+    {
+        // a device pointer may live on another GPU of the process (multi-device contexts replicate the target)
+        const int src_dev = on_device ? pointer_device(xyz) : -1;
+        if (on_device && src_dev >= 0 && src_dev != c->device)
+            HIPCHK(hipMemcpyPeerAsync(c->d_tgt_xyz, c->device, xyz, src_dev, sizeof(float) * 3 * (size_t)n, c->stream));
+        else
+            HIPCHK(hipMemcpyAsync(c->d_tgt_xyz, xyz, sizeof(float) * 3 * (size_t)n,
+                                  on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+    }
     const long long groups = (n + 3) / 4;
     const long long tiles = (groups + oa::TILE_GROUPS - 1) / oa::TILE_GROUPS;
     c->n_groups_pad = (int)(tiles * oa::TILE_GROUPS);
@@ -1399,6 +1688,7 @@ int set_target_common(oa_ctx *c, const float *xyz, int64_t n, int on_device, boo
 }  // namespace
 OA_EXPORT int oa_set_target(oa_ctx *c, const float *xyz, int64_t n, int on_device)
 {
+    if (c && !c->subs.empty() && c->loop_active) multi_abort(c);            // a new target ends an open oa_iterate sequence
     OA_ROUTE_ALL_PAR(c, oa_set_target(sub, xyz, n, on_device));             // replicated on every device
     return set_target_common(c, xyz, n, on_device, true);
 }
@@ -1729,6 +2019,7 @@ OA_EXPORT int oa_set_target_mesh(oa_ctx *c, const float *xyz, int64_t n_verts, i
                                  int64_t n_tris)
 {
     if (!c) return fail(OA_E_BAD_ARG, "null context");
+    if (!c->subs.empty() && c->loop_active) multi_abort(c);
     OA_ROUTE_ALL_PAR(c, oa_set_target_mesh(sub, xyz, n_verts, on_device, tris, n_tris));
     if (n_tris < 1 || !tris) return fail(OA_E_BAD_ARG, "oa_set_target_mesh: no triangles");
     if (n_tris > 0x2AAAAAA0ll) return fail(OA_E_BAD_ARG, "too many triangles");
@@ -1753,33 +2044,33 @@ OA_EXPORT int oa_set_target_mesh(oa_ctx *c, const float *xyz, int64_t n_verts, i
     return build_tri_grid(c);
 }
 
-OA_EXPORT int oa_set_source(oa_ctx *c, const float *xyz, int64_t n_verts, int on_device, const int64_t *vlist,
-                            int64_t n_vlist, int32_t stride, int32_t shard_index, int32_t shard_count)
+namespace {
+// n floats of caller data, readable by c's device on c's stream: host data and pointers that live on ANOTHER GPU are
+// copied into `tmp` (a kernel of device i must not dereference device j's memory: nothing enables peer access for
+// caller buffers); a pointer on c's own device is used as it is
+int stage_floats(oa_ctx *c, const float *src, size_t n, int on_device, DevTmp<float> &tmp, const float *&local)
 {
-    if (!c) return fail(OA_E_BAD_ARG, "null context");
-    if (n_verts < 0 || (n_verts > 0 && !xyz)) return fail(OA_E_BAD_ARG, "bad source array");
-    if (vlist && n_vlist < 0) return fail(OA_E_BAD_ARG, "negative vlist length");
-    if (shard_count < 1 || shard_index < 0 || shard_index >= shard_count)
-        return fail(OA_E_BAD_ARG, "bad shard %d of %d", shard_index, shard_count);
-    if (!c->subs.empty()) {                                         // multi-device: child i keeps shard i of n_dev
-        if (shard_count != 1) return fail(OA_E_BAD_ARG, "oa_set_source: a multi-device context shards the source itself (pass shard 0 of 1)");
-        const int n_dev = (int)c->subs.size();
-        OA_ROUTE_ALL_PAR(c, oa_set_source(sub, xyz, n_verts, on_device, vlist, n_vlist, stride, sub->rank, n_dev));
+    local = src;
+    if (n == 0) return OA_OK;
+    if (!on_device) {
+        HIPCHK(tmp.alloc(n));
+        HIPCHK(hipMemcpyAsync(tmp, src, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+        local = tmp;
+        return OA_OK;
     }
-    const long long step = stride > 1 ? stride : 1;                 // sample > 1 -> vlist[0::sample] (general.py:274)
-    const long long n_all = vlist ? n_vlist : n_verts;
-    const long long n_sel = (n_all + step - 1) / step;
-    if (vlist)
-        for (long long i = 0; i < n_vlist; ++i)
-            if (vlist[i] < 0 || vlist[i] >= n_verts)
-                return fail(OA_E_BAD_ARG, "vlist[%lld] = %lld outside 0..%lld", i, (long long)vlist[i], (long long)n_verts - 1);
-    const long long per = (n_sel + shard_count - 1) / shard_count;
-    const long long begin = std::min(n_sel, per * shard_index);
-    const long long count = std::max(0ll, std::min(per, n_sel - begin));
-    if (count > 0x7FF00000ll) return fail(OA_E_BAD_ARG, "shard too large");
-    int rc = use_device(c);
-    if (rc) return rc;
+    const int dev = pointer_device(src);
+    if (dev < 0 || dev == c->device) return OA_OK;
+    HIPCHK(tmp.alloc(n));
+    HIPCHK(hipMemcpyPeerAsync(tmp, c->device, src, dev, sizeof(float) * n, c->stream));
+    local = tmp;
+    return OA_OK;
+}
+
+// release the old shard and allocate everything a shard of `count` selected points needs (seeds cleared, keys empty)
+int source_reset(oa_ctx *c, long long count, long long begin, long long n_verts)
+{
     HIPCHK(hipStreamSynchronize(c->stream));
+    c->loop_active = false;                                         // an open oa_iterate sequence ends with the old source
     dev_free(c->d_src4); dev_free(c->d_keys); dev_free(c->d_prev); dev_free(c->d_win); dev_free(c->d_sel); dev_free(c->d_src_n);
     dev_free(c->d_src4o); dev_free(c->d_perm); dev_free(c->d_members); dev_free(c->d_pos);
     c->h_members.clear();
@@ -1808,16 +2099,29 @@ OA_EXPORT int oa_set_source(oa_ctx *c, const float *xyz, int64_t n_verts, int on
     HIPCHK(dev_malloc(&c->d_todo_count, sizeof(int)));
     HIPCHK(hipMemsetAsync(c->d_todo_count, 0, sizeof(int), c->stream));
     hipLaunchKernelGGL(oa::k_fill_int, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, c->d_prev, c->ns_pad, -1);
+    hipLaunchKernelGGL(oa::k_fill_keys, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, c->d_keys, c->ns_pad);
+    HIPCHK(hipGetLastError());
     c->pivot[0] = c->pivot[1] = c->pivot[2] = 0.0;
+    return OA_OK;
+}
+
+// one context takes shard shard_index of shard_count: packs (and, for several shards, first Morton-sorts) the
+// selection by itself.  The one-process-per-GPU path, single-device contexts, and the fallback of multi-device ones.
+int set_source_single(oa_ctx *c, const float *xyz, int64_t n_verts, int on_device, const int64_t *vlist, int64_t n_vlist,
+                      long long step, long long n_sel, int32_t shard_index, int32_t shard_count)
+{
+    const long long per = (n_sel + shard_count - 1) / shard_count;
+    const long long begin = std::min(n_sel, per * shard_index);
+    const long long count = std::max(0ll, std::min(per, n_sel - begin));
+    if (count > 0x7FF00000ll) return fail(OA_E_BAD_ARG, "shard too large");
+    int rc = use_device(c);
+    if (rc) return rc;
+    if ((rc = source_reset(c, count, begin, n_verts))) return rc;
     if (n_sel > 0) {
         const float *d_xyz = xyz;
         DevTmp<float> tmp_xyz;
         DevTmp<long long> d_vlist;
-        if (!on_device) {
-            HIPCHK(tmp_xyz.alloc(3 * (size_t)n_verts));
-            HIPCHK(hipMemcpyAsync(tmp_xyz, xyz, sizeof(float) * 3 * (size_t)n_verts, hipMemcpyHostToDevice, c->stream));
-            d_xyz = tmp_xyz;
-        }
+        if ((rc = stage_floats(c, xyz, 3 * (size_t)n_verts, on_device, tmp_xyz, d_xyz))) return rc;
         if (vlist) {
             HIPCHK(d_vlist.alloc((size_t)n_vlist));
             HIPCHK(hipMemcpyAsync(d_vlist, vlist, sizeof(long long) * (size_t)n_vlist, hipMemcpyHostToDevice, c->stream));
@@ -1825,7 +2129,7 @@ OA_EXPORT int oa_set_source(oa_ctx *c, const float *xyz, int64_t n_verts, int on
         // pivot = first selected vertex of the WHOLE selection (identical on every shard)
         const long long v0 = vlist ? vlist[0] : 0;
         float p0[3];
-        if (on_device) HIPCHK(hipMemcpyAsync(p0, xyz + 3 * v0, sizeof p0, hipMemcpyDeviceToHost, c->stream));
+        if (on_device) HIPCHK(hipMemcpyAsync(p0, d_xyz + 3 * v0, sizeof p0, hipMemcpyDeviceToHost, c->stream));
         else memcpy(p0, xyz + 3 * v0, sizeof p0);
         // Which points of the selection this shard holds.  One shard: all of them.  Several shards: the
         // shard_index-th of shard_count equal ranges of the selection IN MORTON ORDER (every rank sorts the whole
@@ -1846,10 +2150,11 @@ OA_EXPORT int oa_set_source(oa_ctx *c, const float *xyz, int64_t n_verts, int on
                 }
             }
         }
-        hipLaunchKernelGGL(oa::k_pack_source, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, d_xyz,
-                           (const long long *)d_vlist.p, step, begin, (const int *)d_members.p, c->ns, c->ns_pad, c->d_src4, c->d_sel);
-        hipLaunchKernelGGL(oa::k_fill_keys, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, c->d_keys, c->ns_pad);
-        HIPCHK(hipGetLastError());
+        if (c->ns > 0) {
+            hipLaunchKernelGGL(oa::k_pack_source, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, d_xyz,
+                               (const long long *)d_vlist.p, step, begin, (const int *)d_members.p, c->ns, c->ns_pad, c->d_src4, c->d_sel);
+            HIPCHK(hipGetLastError());
+        } else HIPCHK(hipMemsetAsync(c->d_src4, 0, sizeof(float4) * (size_t)c->ns_pad, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         for (int k = 0; k < 3; ++k) c->pivot[k] = (double)p0[k];
         if (c->ns > 1 && env_int("OA_SORT_SOURCE", 1)) {
@@ -1858,10 +2163,158 @@ OA_EXPORT int oa_set_source(oa_ctx *c, const float *xyz, int64_t n_verts, int on
         }
     } else {
         HIPCHK(hipMemsetAsync(c->d_src4, 0, sizeof(float4) * (size_t)c->ns_pad, c->stream));
-        hipLaunchKernelGGL(oa::k_fill_keys, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, c->d_keys, c->ns_pad);
         HIPCHK(hipStreamSynchronize(c->stream));
     }
     plan_geometry(c);
+    return OA_OK;
+}
+
+// The whole selection packed and Morton-sorted ONCE, on one device of a multi-device context (round 2: every device
+// sorted the whole selection to find its range -- at 10M points, 8 sorts of 10M keys).  Slot j of the order holds the
+// point at selection position pos[j]; shard g of n is the range [g per, g per + count_g) of it -- exactly the slots the
+// per-context path (spatial_shard_members + sort_source_slots) ends up with, in the same order: both sort by the same
+// 30-bit key with ties in selection order.
+struct SelectionOrder {
+    DevTmp<float4> pts;
+    DevTmp<int> sel, pos;
+    float p0[3] = { 0.f, 0.f, 0.f };
+    bool ok = false;
+};
+
+int build_selection_order(oa_ctx *c, const float *xyz, int64_t n_verts, int on_device, const int64_t *vlist, int64_t n_vlist,
+                          long long step, long long n_sel, SelectionOrder &o)
+{
+    o.ok = false;
+    int rc = use_device(c);
+    if (rc) return rc;
+    const float *d_xyz = xyz;
+    DevTmp<float> tmp_xyz;
+    DevTmp<long long> d_vlist;
+    if ((rc = stage_floats(c, xyz, 3 * (size_t)n_verts, on_device, tmp_xyz, d_xyz))) return rc;
+    if (vlist) {
+        HIPCHK(d_vlist.alloc((size_t)n_vlist));
+        HIPCHK(hipMemcpyAsync(d_vlist, vlist, sizeof(long long) * (size_t)n_vlist, hipMemcpyHostToDevice, c->stream));
+    }
+    const long long v0 = vlist ? vlist[0] : 0;
+    if (on_device) HIPCHK(hipMemcpyAsync(o.p0, d_xyz + 3 * v0, sizeof o.p0, hipMemcpyDeviceToHost, c->stream));
+    else memcpy(o.p0, xyz + 3 * v0, sizeof o.p0);
+    float lo[3], sc[3];
+    bool finite = false;
+    if ((rc = morton_frame(c, d_xyz, n_verts, lo, sc, finite))) return rc;   // synchronises the stream
+    if (!finite) return OA_OK;                                     // caller falls back to contiguous ranges
+    const int n = (int)n_sel;
+    DevTmp<float4> all4;
+    DevTmp<int> all_sel, v_in;
+    DevTmp<unsigned> k_in, k_out;
+    HIPCHK(all4.alloc((size_t)n)); HIPCHK(all_sel.alloc((size_t)n)); HIPCHK(v_in.alloc((size_t)n));
+    HIPCHK(k_in.alloc((size_t)n)); HIPCHK(k_out.alloc((size_t)n));
+    HIPCHK(o.pts.alloc((size_t)n)); HIPCHK(o.sel.alloc((size_t)n)); HIPCHK(o.pos.alloc((size_t)n));
+    hipLaunchKernelGGL(oa::k_pack_source, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_xyz, (const long long *)d_vlist.p, step, 0ll,
+                       (const int *)nullptr, n, n, all4.p, all_sel.p);
+    hipLaunchKernelGGL(oa::k_morton_keys, dim3((n + 255) / 256), dim3(256), 0, c->stream, (const float4 *)all4.p, n,
+                       lo[0], lo[1], lo[2], sc[0], sc[1], sc[2], k_in.p, v_in.p);
+    HIPCHK(hipGetLastError());
+    size_t bytes = 0;
+    HIPCHK(rocprim::radix_sort_pairs(nullptr, bytes, k_in.p, k_out.p, v_in.p, o.pos.p, (size_t)n, 0, 30, c->stream));
+    DevTmp<char> tmp;
+    HIPCHK(tmp.alloc(bytes));
+    HIPCHK(rocprim::radix_sort_pairs((void *)tmp.p, bytes, k_in.p, k_out.p, v_in.p, o.pos.p, (size_t)n, 0, 30, c->stream));
+    hipLaunchKernelGGL(oa::k_apply_perm, dim3((n + 255) / 256), dim3(256), 0, c->stream, (const float4 *)all4.p, (const int *)all_sel.p,
+                       (const int *)o.pos.p, n, n, o.pts.p, o.sel.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));                      // temporaries are released on return; other devices read the order next
+    o.ok = true;
+    return OA_OK;
+}
+
+// device c takes the range [begin, begin + count) of the order built on `stage`'s device: three range copies over xGMI
+// (24 B per point), then a sort of ITS points' selection positions to get back to the caller's order for per-point outputs
+int adopt_shard(oa_ctx *c, const oa_ctx *stage, const SelectionOrder &o, long long begin, long long count, long long n_verts)
+{
+    int rc = use_device(c);
+    if (rc) return rc;
+    if ((rc = source_reset(c, count, begin, n_verts))) return rc;
+    for (int k = 0; k < 3; ++k) c->pivot[k] = (double)o.p0[k];
+    if (count == 0) {
+        HIPCHK(hipMemsetAsync(c->d_src4, 0, sizeof(float4) * (size_t)c->ns_pad, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        plan_geometry(c);
+        return OA_OK;
+    }
+    const int n = (int)count;
+    DevTmp<int> pos, inv, slots;
+    HIPCHK(pos.alloc((size_t)n)); HIPCHK(inv.alloc((size_t)n)); HIPCHK(slots.alloc((size_t)n));
+    const bool local = stage->device == c->device;
+#define OA_RANGE_COPY(dst, src, bytes)                                                                                   \
+    HIPCHK(local ? hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToDevice, c->stream)                             \
+                 : hipMemcpyPeerAsync((dst), c->device, (src), stage->device, (bytes), c->stream))
+    OA_RANGE_COPY(c->d_src4, o.pts.p + begin, sizeof(float4) * (size_t)n);
+    OA_RANGE_COPY(c->d_sel, o.sel.p + begin, sizeof(int) * (size_t)n);
+    OA_RANGE_COPY(pos.p, o.pos.p + begin, sizeof(int) * (size_t)n);
+#undef OA_RANGE_COPY
+    // caller order inside the shard = ascending selection position
+    HIPCHK(dev_malloc(&c->d_members, sizeof(int) * (size_t)n));
+    HIPCHK(dev_malloc(&c->d_perm, sizeof(int) * (size_t)n));
+    HIPCHK(dev_malloc(&c->d_src4o, sizeof(float4) * (size_t)c->ns_pad));
+    hipLaunchKernelGGL(oa::k_iota, dim3((n + 255) / 256), dim3(256), 0, c->stream, slots.p, n);
+    HIPCHK(hipGetLastError());
+    size_t bytes = 0;
+    HIPCHK(rocprim::radix_sort_pairs(nullptr, bytes, pos.p, c->d_members, slots.p, inv.p, (size_t)n, 0, 32, c->stream));
+    DevTmp<char> tmp;
+    HIPCHK(tmp.alloc(bytes));
+    HIPCHK(rocprim::radix_sort_pairs((void *)tmp.p, bytes, pos.p, c->d_members, slots.p, inv.p, (size_t)n, 0, 32, c->stream));
+    hipLaunchKernelGGL(oa::k_finish_shard, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, (const int *)inv.p, n, c->ns_pad,
+                       c->d_src4, c->d_sel, c->d_src4o, c->d_perm);
+    HIPCHK(hipGetLastError());
+    c->h_members.resize((size_t)n);
+    HIPCHK(hipMemcpyAsync(c->h_members.data(), c->d_members, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    plan_geometry(c);
+    return OA_OK;
+}
+}  // namespace
+
+OA_EXPORT int oa_set_source(oa_ctx *c, const float *xyz, int64_t n_verts, int on_device, const int64_t *vlist,
+                            int64_t n_vlist, int32_t stride, int32_t shard_index, int32_t shard_count)
+{
+    if (!c) return fail(OA_E_BAD_ARG, "null context");
+    if (n_verts < 0 || (n_verts > 0 && !xyz)) return fail(OA_E_BAD_ARG, "bad source array");
+    if (vlist && n_vlist < 0) return fail(OA_E_BAD_ARG, "negative vlist length");
+    if (shard_count < 1 || shard_index < 0 || shard_index >= shard_count)
+        return fail(OA_E_BAD_ARG, "bad shard %d of %d", shard_index, shard_count);
+    const long long step = stride > 1 ? stride : 1;                 // sample > 1 -> vlist[0::sample] (general.py:274)
+    const long long n_all = vlist ? n_vlist : n_verts;
+    const long long n_sel = (n_all + step - 1) / step;
+    if (vlist)
+        for (long long i = 0; i < n_vlist; ++i)
+            if (vlist[i] < 0 || vlist[i] >= n_verts)
+                return fail(OA_E_BAD_ARG, "vlist[%lld] = %lld outside 0..%lld", i, (long long)vlist[i], (long long)n_verts - 1);
+    if (c->subs.empty()) return set_source_single(c, xyz, n_verts, on_device, vlist, n_vlist, step, n_sel, shard_index, shard_count);
+
+    // multi-device: child i keeps shard i of n_dev
+    if (shard_count != 1) return fail(OA_E_BAD_ARG, "oa_set_source: a multi-device context shards the source itself (pass shard 0 of 1)");
+    if (c->loop_active) multi_abort(c);
+    c->loop_active = false;
+    const int n_dev = (int)c->subs.size();
+    const long long per = (n_sel + n_dev - 1) / n_dev;
+    if (n_dev > 1 && n_sel > 1 && n_sel < 0x7FF00000ll && env_int("OA_SORT_SOURCE", 1) && env_int("OA_SHARD_SPATIAL", 1) &&
+        env_int("OA_PARTITION_ONCE", 1)) {
+        // one Morton sort of the selection on the first device, then every device adopts its range of it
+        oa_ctx *stage = c->subs[0];
+        SelectionOrder order;
+        int rc = build_selection_order(stage, xyz, n_verts, on_device, vlist, n_vlist, step, n_sel, order);
+        if (rc) return rc;
+        if (order.ok) {
+            const SelectionOrder *po = &order;
+            return route_all_parallel(c, [=](oa_ctx *sub) -> int {
+                const long long begin = std::min(n_sel, per * sub->rank);
+                const long long count = std::max(0ll, std::min(per, n_sel - begin));
+                return adopt_shard(sub, stage, *po, begin, count, n_verts);
+            });
+        }
+    }
+    // fallback (non-finite coordinates, a single device, sorting switched off): every child finds its shard itself
+    OA_ROUTE_ALL_PAR(c, set_source_single(sub, xyz, n_verts, on_device, vlist, n_vlist, step, n_sel, sub->rank, n_dev));
     return OA_OK;
 }
 
@@ -1869,7 +2322,9 @@ OA_EXPORT int oa_set_normals(oa_ctx *c, const float *src_normals, int64_t n_vert
                              double max_angle_deg)
 {
     if (!c) return fail(OA_E_BAD_ARG, "null context");
+    if (!c->subs.empty() && c->loop_active) multi_abort(c);
     OA_ROUTE_ALL_PAR(c, oa_set_normals(sub, src_normals, n_verts, tgt_normals, nt, max_angle_deg));
+    if (c->loop_active) { HIPCHK(hipSetDevice(c->device)); HIPCHK(hipStreamSynchronize(c->stream)); c->loop_active = false; }
     c->normals_on = false;
     if (!src_normals || !(max_angle_deg > 0.0) || !(max_angle_deg < 180.0)) return OA_OK;       // switched off
     if (!c->d_src4 || !c->d_sel) return fail(OA_E_STATE, "oa_set_normals: call oa_set_source first");
@@ -1917,6 +2372,7 @@ OA_EXPORT int oa_set_matrices(oa_ctx *c, const float mx_align[16], const float m
 OA_EXPORT int oa_reset_seeds(oa_ctx *c)
 {
     if (!c) return fail(OA_E_BAD_ARG, "null context");
+    if (!c->subs.empty()) { if (c->loop_active) multi_abort(c); c->loop_active = false; }
     OA_ROUTE_ALL(c, oa_reset_seeds(sub));
     c->seeded = false;
     c->loop_active = false;
@@ -1933,6 +2389,20 @@ OA_EXPORT int oa_get_stat(oa_ctx *c, int what, double *value)
 {
     if (!c || !value) return fail(OA_E_BAD_ARG, "oa_get_stat: null argument");
     if (what == OA_STAT_CACHE_BYTES) { *value = (double)dev_cache().cached_bytes; return OA_OK; }
+    if (what == OA_STAT_EXCHANGE || what == OA_STAT_RCCL_RANKS || what == OA_STAT_ENQUEUE_US || what == OA_STAT_HOST_THREADS) {
+        if (c->subs.empty()) { *value = what == OA_STAT_EXCHANGE ? -1.0 : (what == OA_STAT_HOST_THREADS ? 1.0 : 0.0); return OA_OK; }
+        if (what == OA_STAT_HOST_THREADS) { *value = (double)std::max<size_t>(1, c->groups.size()); return OA_OK; }
+        if (what == OA_STAT_ENQUEUE_US) {
+            double us = 0.0;
+            for (oa_ctx *sub : c->subs) if (sub->enq_iters > 0) us = std::max(us, sub->enq_ns / (double)sub->enq_iters * 1e-3);
+            *value = us;
+            return OA_OK;
+        }
+        if (!c->loop_active) { const int rcx = exchange_resolve(c); if (rcx) return rcx; }
+        if (what == OA_STAT_EXCHANGE) *value = c->xch->mode == OA_EXCHANGE_RCCL ? 1.0 : (c->xch->device_box ? 2.0 : 0.0);
+        else *value = (double)exchange_rccl_ranks(c->xch);
+        return OA_OK;
+    }
     OA_ROUTE_FIRST(c, oa_get_stat(sub, what, value));
     switch (what) {
     case OA_STAT_GRID_CELLS: *value = c->grid_ok ? (double)c->n_cells : 0.0; return OA_OK;
@@ -1998,6 +2468,8 @@ OA_EXPORT int oa_nn_search(oa_ctx *c, int64_t *idx, float *d2, double *kernel_ms
         // multi-device: every child searches its shard; the answers go back to the caller's (vlist) order through the
         // shard membership each child kept.  kernel_ms = the slowest child (the children run one after the other here:
         // this entry point returns host arrays, it is not the loop).
+        if (c->loop_active) multi_abort(c);                          // re-stages every child's device state: the sequence ends
+        c->loop_active = false;
         if (kernel_ms) *kernel_ms = 0.0;
         std::vector<int64_t> ic;
         std::vector<float> dc;
@@ -2058,6 +2530,8 @@ OA_EXPORT int oa_make_pairs(oa_ctx *c, double thresh, int calc_stats, double *A,
         // means and population deviations combine exactly (K-weighted mean; variance = within + between).
         if (!K || cap < 0 || (cap > 0 && (!A || !B))) return fail(OA_E_BAD_ARG, "oa_make_pairs: bad output arguments");
         if (!(thresh > 0.0)) return fail(OA_E_BAD_THRESH, "thresh must be > 0 (the reference's make_pairs returns None)");
+        if (c->loop_active) multi_abort(c);                          // re-stages every child's device state: the sequence ends
+        c->loop_active = false;
         *K = 0;
         if (dstats) { dstats[0] = NAN; dstats[1] = NAN; }
         const size_t n_dev = c->subs.size();
@@ -2380,12 +2854,17 @@ OA_EXPORT int oa_iterate(oa_ctx *c, const oa_settings *st, double M_step[16], do
     if (!c->loop_active) {
         if ((rc = multi ? multi_begin(c, st, ITERATE_OPEN) : begin_loop(c, st, ITERATE_OPEN))) return rc;
         c->iterate_mode = true;
+        for (oa_ctx *sub : c->subs) sub->iterate_mode = true;       // oa_get_history reads the first child's ring
     }
     oa_ctx *c0 = multi ? c->subs[0] : c;
     if (multi) {
         for (oa_ctx *sub : c->subs) sub->ev_used = 0;
-        if ((rc = multi_iteration(c, false))) { multi_abort(c); return rc; }
-        for (oa_ctx *sub : c->subs) { if ((rc = use_device(sub))) return rc; if ((rc = fetch_state(sub))) { multi_abort(c); return rc; } }
+        rc = multi_for_groups(c, [c](size_t g) -> int {                  // every GPU's host thread: one iteration, then the state
+            int rg = multi_iteration_group(c, c->groups[g], false);
+            for (int i : c->groups[g]) { if (rg) break; oa_ctx *sub = c->subs[(size_t)i]; if (!(rg = use_device(sub))) rg = fetch_state(sub); }
+            return rg;
+        });
+        if (rc) { const std::string keep = g_err; multi_abort(c); g_err = keep; return rc; }
     } else {
         if ((rc = use_device(c))) return rc;
         c->ev_used = 0;
@@ -2427,7 +2906,7 @@ OA_EXPORT int oa_get_history(oa_ctx *c, int32_t max_n, double *step_M, float *st
     }
     const std::vector<oa::StepRecord> &h = h_local.empty() ? c->h_hist : h_local;
     // a loop that fits the history: its first n iterations; a ring that wrapped (oa_iterate): the last n, oldest first
-    const int first = total > cap ? total - n : 0;
+    const int first = (total > cap || c->iterate_mode) ? total - n : 0;
     for (int i = 0; i < n; ++i) {
         const oa::StepRecord &r = h[(size_t)((first + i) % cap)];
         if (step_M) memcpy(step_M + 16 * i, r.M, sizeof r.M);

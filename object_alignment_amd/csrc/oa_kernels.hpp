@@ -67,6 +67,10 @@ struct DevState {
     // kernels double their budget on: last step's translation + rotation x object size against a fraction of a cell.
     double turn_limit, turn_scale;   // OA_TURN_FRAC (0.1) x cell edge and largest |coordinate| of the grid in use
     int32_t tree_turn, pad3;
+    // multi-device mailbox exchange: sequence number of this loop's iteration 0 minus one.  It grows from loop to loop
+    // (the host adds iters + 2 per loop), so a slot left over from an earlier loop can never be mistaken for a post of
+    // this one and the mailboxes never have to be cleared (clearing them would need a cross-device ordering of its own)
+    unsigned long long seq_base;
 };
 
 // Squared local search radius for the query p (rounded up to float).  Derivation: the pair test measures
@@ -405,6 +409,28 @@ __global__ void k_apply_perm(const float4 *__restrict__ src4o, const int *__rest
     const int o = perm[i < ns ? i : (ns > 0 ? ns - 1 : 0)];
     src4[i] = src4o[o];
     sel[i] = selo[o];
+}
+
+__global__ void k_iota(int *__restrict__ a, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = i;
+}
+
+// A shard adopted from the whole-selection order (oa_icp.hip: adopt_shard): src4 / sel hold its n points in slot
+// (Morton) order; inv[m] = the slot of the shard's m-th point in the caller's order.  Fills the caller-order copy and the
+// slot -> caller-order permutation, and pads both images to ns_pad by repeating their last point -- the layout
+// k_pack_source + k_apply_perm leave behind.
+__global__ void k_finish_shard(const int *__restrict__ inv, int n, int ns_pad, float4 *__restrict__ src4, int *__restrict__ sel,
+                               float4 *__restrict__ src4o, int *__restrict__ perm)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ns_pad) return;
+    const int m = i < n ? i : n - 1;
+    const int s = inv[m];
+    src4o[i] = src4[s];
+    if (i < n) perm[s] = i;
+    else { src4[i] = src4[n - 1]; sel[i] = sel[n - 1]; }
 }
 
 // target: groups of 4 vertices as [x0..x3][y0..y3][z0..z3]; vertices past nt are +INF (never selected)
@@ -1210,40 +1236,51 @@ __global__ __launch_bounds__(512) void k_reduce_solve_update(DevState *__restric
 }
 
 // ------------------------------------------------------------------------------------------------
-// multi-device exchange (oa_create_multi): the per-iteration all-gather of the OA_NSUMS partial sums through a
-// mailbox in pinned, portable, device-mapped host memory.  box[parity][rank] holds rank's sums of iteration
-// `seq - 1` (parity = seq & 1); every device adds the world's posts in RANK ORDER, so all devices solve from
-// bitwise identical sums and end with identical matrices -- no broadcast.  Two parities suffice: rank A can post
-// iteration k + 2 only after its own solve of iteration k + 1, which needed rank B's post of k + 1, which B enqueued
-// after its solve of iteration k had read A's post of k.
+// multi-device exchange (oa_create_multi): the per-iteration all-gather of the OA_NSUMS partial sums through
+// mailboxes.  Two placements (oa_icp.hip picks): DEVICE -- every rank owns an inbox in its own HBM (fine-grained,
+// peer-mapped); a post is a remote write into every rank's inbox over xGMI and every rank polls local memory -- or
+// HOST -- one box in pinned, portable, device-mapped host memory (fallback when peer access is not available).
+// box[parity][rank] holds rank's sums of sequence number `seq` (parity = seq & 1, seq = DevState::seq_base + n + 1);
+// every device adds the world's posts in RANK ORDER, so all devices solve from bitwise identical sums and end with
+// identical matrices -- no broadcast.  Two parities suffice: rank A can post iteration k + 2 only after its own solve
+// of iteration k + 1, which needed rank B's post of k + 1, which B enqueued after its solve of iteration k had read
+// A's post of k (from B's own inbox, in the device placement).
 // ------------------------------------------------------------------------------------------------
 struct MailSlot {
     double sums[NSUMS];
-    unsigned long long seq;          // iteration number + 1 of the sums above (0 = nothing posted since the loop began)
+    unsigned long long seq;          // sequence number of the sums above (0 = never written)
     unsigned long long pad[7];       // 256 B per slot: a slot never shares a line with another rank's
 };
 constexpr int STATUS_EXCHANGE = -9;  // OA_E_RCCL: a rank's post did not arrive in time
 
-// step 1 on every device: fixed-order reduction of its per-workgroup partials, posted to the mailbox
+// step 1 on every device: fixed-order reduction of its per-workgroup partials, posted to the mailbox(es).
+// dests[0..n_dest): the mailboxes this rank writes its slot of.  Host mailbox: one (the shared pinned box).  Device
+// mailboxes: one inbox per rank, each in that rank's own HBM and peer-mapped -- a post is `world` remote writes of
+// 200 B that travel over xGMI (PUSH model: every rank later polls its OWN memory).  skip != 0: fault injection
+// (OA_FAULT_SKIP_POST_RANK), this rank's sums never arrive and the world's gather kernels run into their time limit.
 __global__ __launch_bounds__(1024) void k_reduce_post(const DevState *__restrict__ st, const double *__restrict__ partials,
-                                                      int n_blocks, MailSlot *box, int rank, int world)
+                                                      int n_blocks, MailSlot *const *__restrict__ dests, int n_dest, int rank,
+                                                      int world, int skip)
 {
-    if (st->halt) return;
+    if (st->halt || skip) return;
     __shared__ double sums[NSUMS];
     reduce_partials_block<1024>(partials, n_blocks, sums);
     __syncthreads();
-    const unsigned long long seq = (unsigned long long)st->n + 1ull;
-    MailSlot *slot = box + (size_t)(seq & 1ull) * world + rank;
-    if (threadIdx.x < NSUMS)
-        __hip_atomic_store(&slot->sums[threadIdx.x], sums[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long seq = st->seq_base + (unsigned long long)st->n + 1ull;
+    const size_t slot_ix = (size_t)(seq & 1ull) * world + rank;
+    for (int e = threadIdx.x; e < n_dest * 32; e += 1024) {          // 32 threads per destination, all destinations in flight
+        const int d = e >> 5, k = e & 31;
+        if (k < NSUMS) __hip_atomic_store(&dests[d][slot_ix].sums[k], sums[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     __threadfence_system();
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(&slot->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (int d = threadIdx.x; d < n_dest; d += 1024)
+        __hip_atomic_store(&dests[d][slot_ix].seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// step 2 on every device: wait for the world's posts of this iteration, add them in rank order, solve + update.
-// Lane r waits for rank r (world <= 64).  The wait is bounded (timeout_ticks of wall_clock64): a rank that never
-// posts -- its device faulted -- ends the loop with STATUS_EXCHANGE instead of hanging this one.
+// step 2 on every device: wait for the world's posts of this iteration (in this rank's mailbox), add them in rank
+// order, solve + update.  Lane r waits for rank r (world <= 64).  The wait is bounded (timeout_ticks of wall_clock64):
+// a rank that never posts -- its device faulted -- ends the loop with STATUS_EXCHANGE instead of hanging this one.
 __global__ __launch_bounds__(64) void k_gather_solve_update(DevState *__restrict__ st, MailSlot *box, int world,
                                                             double *__restrict__ sums_out, StepRecord *__restrict__ hist,
                                                             int *__restrict__ todo_count, unsigned long long timeout_ticks)
@@ -1252,7 +1289,7 @@ __global__ __launch_bounds__(64) void k_gather_solve_update(DevState *__restrict
     __shared__ int arrived;
     const bool live = st->halt == 0;
     if (live) {
-        const unsigned long long seq = (unsigned long long)st->n + 1ull;
+        const unsigned long long seq = st->seq_base + (unsigned long long)st->n + 1ull;
         MailSlot *row = box + (size_t)(seq & 1ull) * world;
         if (threadIdx.x == 0) arrived = 1;
         __syncthreads();

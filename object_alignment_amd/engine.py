@@ -65,8 +65,9 @@ def resolve_devices(spec):
 class IcpEngine:
     """One context: one GPU (`device`, the HIP ordinal -- LOCAL_RANK in one-process-per-GPU runs), or several GPUs of
     this process (`devices=[0, 1, ...]`, oa_create_multi): the source is sharded over them, the target replicated,
-    and run() / iterate() join the devices' sums inside the library every iteration.  `exchange`: "mailbox"
-    (default) or "rccl"."""
+    and run() / iterate() join the devices' sums inside the library every iteration.  `exchange`: "auto" (default:
+    RCCL's all-reduce over xGMI when the devices are distinct and librccl loads, else the mailbox), "rccl" or
+    "mailbox"."""
 
     def __init__(self, device: int = 0, devices=None, exchange=None):
         self._L = capi.load()
@@ -92,8 +93,10 @@ class IcpEngine:
             self.set_exchange(exchange)
 
     def set_exchange(self, mode):
-        """'mailbox' (all-gather through a pinned host mailbox, rank-ordered sum) or 'rccl' (ncclAllReduce over xGMI)."""
-        code = {"mailbox": capi.OA_EXCHANGE_MAILBOX, "rccl": capi.OA_EXCHANGE_RCCL}[mode] if isinstance(mode, str) else int(mode)
+        """'auto', 'rccl' (ncclAllReduce over xGMI) or 'mailbox' (all-gather through peer-mapped device mailboxes --
+        pinned host memory without peer access --, rank-ordered sum)."""
+        code = ({"auto": capi.OA_EXCHANGE_AUTO, "mailbox": capi.OA_EXCHANGE_MAILBOX, "rccl": capi.OA_EXCHANGE_RCCL}[mode]
+                if isinstance(mode, str) else int(mode))
         capi.check(self._L.oa_set_exchange(self._h, code))
 
     # ---- lifetime
@@ -177,7 +180,13 @@ class IcpEngine:
         capi.check(self._L.oa_reset_seeds(self._h))
 
     STATS = {"grid_cells": 1, "tri_grid_cells": 2, "tri_grid_entries": 3, "n_tris": 4, "surface": 5, "cache_bytes": 6,
-             "brute_kernel": 7}
+             "brute_kernel": 7, "exchange": 8, "rccl_ranks": 9, "enqueue_us": 10, "host_threads": 11}
+    EXCHANGE_NAMES = {-1: None, 0: "mailbox (pinned host memory)", 1: "rccl", 2: "mailbox (peer-mapped device memory)"}
+
+    def exchange_info(self):
+        """What a multi-device engine's loops exchange their sums through: {"exchange": name, "rccl_ranks": n}."""
+        return {"exchange": self.EXCHANGE_NAMES.get(int(self.stat("exchange"))), "rccl_ranks": int(self.stat("rccl_ranks")),
+                "host_threads": int(self.stat("host_threads"))}
 
     def stat(self, name) -> float:
         v = C.c_double(0.0)

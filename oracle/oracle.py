@@ -455,14 +455,19 @@ class NearestVertexBVH:
 
 # ---------------------------------------------------------------- reference-style cost structure (bench tier T1)
 
-def make_pairs_python_loop(src, target, mx_align, mx_base, thresh, kd: KDTree, vlist=None, calc_stats=False):
+def make_pairs_python_loop(src, target, mx_align, mx_base, thresh, kd: KDTree, vlist=None, calc_stats=False, timing=None):
     """The reference's make_pairs COST STRUCTURE (functions/general.py:280-321): an interpreter-level loop with
     float32 4x4 transforms on Python objects and one tree query per vertex (stdout writes omitted).  Same results as
-    :func:`make_pairs`; used only to time what a per-vertex Python loop costs (tier T1)."""
-    align, base = MeshObject(src, mx_align), MeshObject(target, mx_base)
-    mx1, mx2 = align.matrix_world, base.matrix_world
-    imx1, imx2 = mx1.inverted(), mx2.inverted()
+    :func:`make_pairs`; used only to time what a per-vertex Python loop costs (tier T1).
+    timing (a dict): receives 'loop_s', the seconds spent in the function body the reference times -- the objects the
+    reference is HANDED (the align object's vertices, the matrices) are built before the clock starts, and the base
+    object's vertices, which make_pairs never touches, are not built at all."""
+    import time as _time
+    align = MeshObject(src, mx_align)
+    mx1, mx2 = align.matrix_world, Matrix(mx_base)
     tgt = _f32(target).reshape(-1, 3)
+    _t0 = _time.perf_counter()
+    imx1, imx2 = mx1.inverted(), mx2.inverted()
     verts1, verts2, dists = [], [], []
     for vert_ind in (range(len(align.data.vertices)) if vlist is None else vlist):
         vert = align.data.vertices[vert_ind]
@@ -480,4 +485,7 @@ def make_pairs_python_loop(src, target, mx_align, mx_base, thresh, kd: KDTree, v
     for i in range(len(verts1)):
         A[0][i], A[1][i], A[2][i] = verts1[i][0], verts1[i][1], verts1[i][2]
         B[0][i], B[1][i], B[2][i] = verts2[i][0], verts2[i][1], verts2[i][2]
-    return A, B, ([float(np.mean(dists)), float(np.std(dists))] if calc_stats else None)
+    stats = [float(np.mean(dists)), float(np.std(dists))] if calc_stats else None
+    if timing is not None:
+        timing["loop_s"] = _time.perf_counter() - _t0
+    return A, B, stats

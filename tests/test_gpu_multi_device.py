@@ -369,3 +369,231 @@ def test_bench_self_launches_multi_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["unit"] == "iterations/s" and d["value"] > 0
     assert "in-library" in d["config"]["parallelism"]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 3: the exchange protocol under real concurrency, fault injection, host threads, the partition-once upload
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("box", ["device", "host"])
+@pytest.mark.parametrize("n_dev", [2, 8])
+@pytest.mark.parametrize("name", LOOPS)
+def test_mailbox_protocol_with_concurrent_producers(golden_dir, monkeypatch, name, n_dev, box):
+    """OA_MULTI_OWN_STREAMS=1: children that share the GPU get their own streams, so every k_gather_solve_update really
+    spins on its mailbox while the other children's searches and k_reduce_post launches run beside it -- the sequence
+    words, the system-scope release / acquire and the two-parity reuse of the slots execute against concurrent producers
+    (round 2 only ever ran them in stream order).  Both placements of the mailboxes: peer-mapped device memory (what
+    distinct GPUs use: remote writes over xGMI) and the pinned host box (the fallback).  Same bar as the single-device
+    loop: K per iteration exact, M to 1e-9, final float32 matrix within 1 ulp."""
+    from object_alignment_amd.engine import IcpEngine
+    monkeypatch.setenv("OA_MULTI_OWN_STREAMS", "1")
+    monkeypatch.setenv("OA_MAILBOX", box)
+    monkeypatch.setenv("OA_EXCHANGE_TIMEOUT_S", "20")
+    g = _load(golden_dir, name)
+    with IcpEngine(devices=[0] * n_dev) as eng:
+        info = eng.exchange_info()
+        assert info["exchange"].startswith("mailbox") and ("device" in info["exchange"]) == (box == "device")
+        assert info["rccl_ranks"] == 0
+        res = _run_fixture(g, eng)
+        again = _run_fixture(g, eng)                                # a second loop on the same mailboxes: nothing is cleared
+    assert res.iters_done == int(g["iters_done"]) and res.converged == bool(g["converged"])
+    assert np.array_equal(res.step_K, g["step_K"])
+    assert np.abs(res.step_M - g["step_M"]).max() < 1e-9
+    assert np.abs(res.matrix_world - g["final_world"]).max() <= F32_ULP
+    assert np.array_equal(again.step_M, res.step_M) and np.array_equal(again.matrix_world, res.matrix_world)
+
+
+def test_own_streams_match_shared_stream_bitwise(golden_dir, monkeypatch):
+    """The rank-ordered sum does not depend on who arrives first: concurrent children give the bits of sequential ones."""
+    from object_alignment_amd.engine import IcpEngine
+    g = _load(golden_dir, "icp_loop_bumpy_converge")
+    out = []
+    for own in ("0", "1"):
+        monkeypatch.setenv("OA_MULTI_OWN_STREAMS", own)
+        with IcpEngine(devices=[0] * 5) as eng:
+            out.append(_run_fixture(g, eng))
+    assert np.array_equal(out[0].step_M, out[1].step_M) and np.array_equal(out[0].matrix_world, out[1].matrix_world)
+
+
+@pytest.mark.parametrize("box", ["device", "host"])
+def test_a_rank_that_never_posts_ends_the_loop_with_an_error(golden_dir, monkeypatch, box):
+    """Fault injection (OA_FAULT_SKIP_POST_RANK): rank 1's sums never reach the mailboxes.  Every device's gather kernel
+    gives up after OA_EXCHANGE_TIMEOUT_S, the loop ends with OA_E_RCCL -- it does not hang -- and the process can go on
+    using the GPU afterwards."""
+    import time
+    from object_alignment_amd import _capi
+    from object_alignment_amd.engine import IcpEngine
+    g = _load(golden_dir, "icp_loop_bumpy_converge")
+    monkeypatch.setenv("OA_MULTI_OWN_STREAMS", "1")
+    monkeypatch.setenv("OA_MAILBOX", box)
+    monkeypatch.setenv("OA_EXCHANGE_TIMEOUT_S", "1.5")
+    monkeypatch.setenv("OA_FAULT_SKIP_POST_RANK", "1")
+    with IcpEngine(devices=[0, 0, 0]) as eng:
+        eng.set_target(g["tgt"])
+        eng.set_source(g["src"], stride=1)
+        eng.set_matrices(g["mx_align"], g["mx_base"])
+        t0 = time.perf_counter()
+        with pytest.raises(_capi.OaError) as ei:
+            eng.run(iters=20, thresh=0.5, early_exit=True)
+        dt = time.perf_counter() - t0
+        assert ei.value.code == _capi.OA_E_RCCL
+        assert 1.0 < dt < 15.0, dt
+        with pytest.raises(_capi.OaError):                          # the modal step reports it too
+            eng.iterate(thresh=0.5)
+    monkeypatch.delenv("OA_FAULT_SKIP_POST_RANK")
+    with IcpEngine(devices=[0, 0, 0]) as eng:                       # a healthy context right after
+        res = _run_fixture(g, eng)
+    assert res.iters_done == int(g["iters_done"]) and np.array_equal(res.step_K, g["step_K"])
+
+
+def test_one_host_thread_per_child(golden_dir, monkeypatch):
+    """OA_MULTI_THREADS=1 on the one-GPU box: every child is driven by its own persistent host thread, as children on
+    distinct GPUs are -- uploads, the whole oa_run loop and the modal step.  Two children on their own streams; the
+    result is the sequential one, bit for bit."""
+    from object_alignment_amd.engine import IcpEngine
+    g = _load(golden_dir, "icp_loop_bumpy_converge")
+    monkeypatch.setenv("OA_EXCHANGE_TIMEOUT_S", "10")
+    out = []
+    for threads, own in (("0", "0"), ("1", "1")):
+        monkeypatch.setenv("OA_MULTI_THREADS", threads)
+        monkeypatch.setenv("OA_MULTI_OWN_STREAMS", own)
+        with IcpEngine(devices=[0, 0]) as eng:
+            assert eng.exchange_info()["host_threads"] == (2 if threads == "1" else 1)
+            res = _run_fixture(g, eng)
+            eng.set_matrices(g["mx_align"], g["mx_base"])
+            steps = np.stack([eng.iterate(thresh=0.5)[0] for _ in range(4)])
+            out.append((res, steps, eng.stat("enqueue_us")))
+    assert np.array_equal(out[0][0].step_M, out[1][0].step_M) and np.array_equal(out[0][0].matrix_world, out[1][0].matrix_world)
+    assert np.array_equal(out[0][1], out[1][1])
+    assert np.array_equal(out[0][1], out[0][0].step_M[:4])
+    assert out[0][2] > 0 and out[1][2] > 0
+
+
+def test_partition_once_equals_per_device_partition(monkeypatch):
+    """oa_set_source on a multi-device context sorts the selection once and deals out ranges (round 2: every device
+    sorted the whole selection).  The children end up exactly as the per-device path leaves them: same loop, bit for
+    bit, same pairs in the same order, same nearest neighbours -- with an unsorted, duplicated vlist and a stride."""
+    from object_alignment_amd import synth
+    from object_alignment_amd.engine import IcpEngine
+    rng = np.random.default_rng(7)
+    v, t = synth.bumpy_icosphere_mesh(5)
+    src = (synth.bumpy_icosphere(5) * np.float32(1.02)).astype(np.float32)
+    vlist = rng.permutation(len(src))[: len(src) * 2 // 3]
+    vlist = np.concatenate([vlist, vlist[:50]])
+    mxa = synth.rigid4(synth.rotation_from_rotvec([0.03, -0.02, 0.04]), [0.02, -0.01, 0.015])
+    eye = np.identity(4, dtype=np.float32)
+    out = []
+    for once in ("1", "0"):
+        monkeypatch.setenv("OA_PARTITION_ONCE", once)
+        with IcpEngine(devices=[0] * 7) as e:
+            e.set_target(v)
+            e.set_source(src, vlist=vlist, stride=2)
+            e.set_matrices(mxa, eye)
+            r = e.run(iters=6, thresh=0.5, early_exit=False)
+            e.set_matrices(mxa, eye)
+            A, B, st = e.make_pairs(0.1, calc_stats=True)
+            idx, d2, _ = e.nn_search()
+            out.append((r.step_M, r.step_K, r.matrix_world, A, B, np.array(st), idx, d2))
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)
+
+
+def test_device_tensors_as_uploads_on_a_multi_device_context():
+    """on_device uploads through oa_create_multi: the library stages a device pointer to the device that needs it
+    (here all children sit on GPU 0, the pointer is local; on distinct GPUs it is a peer copy)."""
+    import torch
+    from object_alignment_amd import synth
+    from object_alignment_amd.engine import IcpEngine
+    v = synth.bumpy_icosphere(4)
+    src = (v[::2] * np.float32(1.01)).astype(np.float32)
+    mxa = synth.rigid4(synth.rotation_from_rotvec([0.03, -0.02, 0.04]), [0.02, -0.01, 0.015])
+    eye = np.identity(4, dtype=np.float32)
+    out = []
+    for dev_arrays in (False, True):
+        with IcpEngine(devices=[0, 0, 0]) as e:
+            e.set_target(torch.from_numpy(v).cuda() if dev_arrays else v)
+            e.set_source(torch.from_numpy(src).cuda() if dev_arrays else src)
+            e.set_matrices(mxa, eye)
+            out.append(e.run(iters=5, thresh=0.5, early_exit=False))
+    assert np.array_equal(out[0].step_M, out[1].step_M)
+
+
+@pytest.mark.parametrize("devices", [None, [0, 0, 0]])
+def test_calls_between_modal_steps_end_the_sequence(devices):
+    """oa_iterate's sequence ends with every call that re-stages the device state (include/oa_icp.h): a search, a
+    make_pairs, a new target or source in between.  The next oa_iterate starts a new sequence from the current pose --
+    it must neither continue on the one-shot's device state nor on the old target's filter constants."""
+    from object_alignment_amd import synth
+    from object_alignment_amd.engine import IcpEngine
+    v = synth.bumpy_icosphere(4)
+    v2 = (synth.bumpy_icosphere(4) * np.float32(1.7) + np.float32(0.3)).astype(np.float32)
+    src = (v[::2] * np.float32(1.01)).astype(np.float32)
+    mxa = synth.rigid4(synth.rotation_from_rotvec([0.03, -0.02, 0.04]), [0.02, -0.01, 0.015])
+    eye = np.identity(4, dtype=np.float32)
+
+    def fresh(target):
+        e = IcpEngine(0) if devices is None else IcpEngine(devices=devices)
+        e.set_target(target); e.set_source(src); e.set_matrices(mxa, eye)
+        return e
+
+    # reference: three plain steps; then, from the pose they reach, two more as a NEW sequence
+    with fresh(v) as e:
+        first = [e.iterate(thresh=0.5)[0] for _ in range(3)]
+        pose = e.matrix_world()
+    with fresh(v) as e:
+        e.set_matrices(pose, eye)
+        restart = [e.iterate(thresh=0.5) for _ in range(2)]
+    with fresh(v2) as e:
+        e.set_matrices(pose, eye)
+        other = [e.iterate(thresh=0.5)[0] for _ in range(2)]
+
+    for between in ("nn_search", "make_pairs", "reset_seeds", "set_source", "set_target"):
+        with fresh(v) as e:
+            got = [e.iterate(thresh=0.5)[0] for _ in range(3)]
+            assert np.array_equal(np.stack(got), np.stack(first)), between
+            if between == "nn_search":
+                e.nn_search()
+            elif between == "make_pairs":
+                e.make_pairs(0.3, calc_stats=True)
+            elif between == "reset_seeds":
+                e.reset_seeds()
+            elif between == "set_source":
+                e.set_source(src)
+            else:
+                e.set_target(v2)
+            nxt = [e.iterate(thresh=0.5) for _ in range(2)]
+            want = other if between == "set_target" else [m for m, _ in restart]
+            assert np.array_equal(np.stack([m for m, _ in nxt]), np.stack(want)), between
+            if between != "set_target":
+                assert [s["K"] for _, s in nxt] == [s["K"] for _, s in restart], between
+
+
+def test_history_of_a_modal_sequence_is_its_last_steps():
+    """oa_get_history after oa_iterate: the LAST max_n iterations, oldest first -- also before the 64-entry ring wraps."""
+    import ctypes as C
+    from object_alignment_amd import synth, _capi as capi
+    from object_alignment_amd.engine import IcpEngine
+    v = synth.bumpy_icosphere(4)
+    src = (v[::2] * np.float32(1.01)).astype(np.float32)
+    mxa = synth.rigid4(synth.rotation_from_rotvec([0.03, -0.02, 0.04]), [0.02, -0.01, 0.015])
+    for devs in (None, [0, 0]):
+        with (IcpEngine(0) if devs is None else IcpEngine(devices=devs)) as e:
+            e.set_target(v); e.set_source(src); e.set_matrices(mxa, np.identity(4, dtype=np.float32))
+            steps = [e.iterate(thresh=0.5)[0] for _ in range(7)]
+            sM = np.zeros((3, 4, 4))
+            got = e._L.oa_get_history(e._h, 3, capi.dptr(sM), None, None, None, None)
+            assert got == 3 and np.array_equal(sM, np.stack(steps[-3:]))
+
+
+def test_bench_two_shards_reports_its_exchange(monkeypatch):
+    """`python bench.py --gpus 2` on the one-GPU box with the shards on their own streams: the line names the exchange
+    that ran, how many ranks RCCL saw (none here: the device is listed twice, so AUTO takes the mailbox), and the measured
+    host enqueue time per iteration."""
+    env = dict(os.environ, OA_BENCH_SAME_DEVICE="1", OA_MULTI_OWN_STREAMS="1")
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--n-source", "120000",
+           "--n-target", "100000", "--no-cpu-baseline", "--no-surface"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, text=True)
+    assert p.returncode == 0, p.stdout[-3000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    cfg = d["config"]
+    assert cfg["exchange"].startswith("mailbox") and cfg["rccl_ranks"] == 0
+    assert cfg["host_enqueue_us_per_iteration"] > 0
