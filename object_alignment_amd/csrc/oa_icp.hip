@@ -425,7 +425,8 @@ struct oa_ctx {
     struct oa_exchange *xch = nullptr;  // parent: owns it; child: the parent's
     oa_ctx *parent = nullptr;
     int rank = 0, world = 1;            // child: its place in the device list
-    std::vector<std::vector<int>> groups;   // parent: children per host thread (one group per GPU, see WorkerPool)
+    std::vector<std::vector<int>> groups;   // parent: children per host thread in the LOOP (one group per GPU, see WorkerPool)
+    std::vector<std::vector<int>> upload_groups;   // ... and in uploads / index builds (OA_MULTI_THREADS=1: one per child)
     WorkerPool *pool = nullptr;         // parent: the persistent host threads of groups 1 .. n-1 (group 0 = the caller)
     double enq_ns = 0.0;                // child: host time spent enqueuing its iterations in the last loop
     long long enq_iters = 0;
@@ -455,13 +456,13 @@ int pointer_device(const void *ptr)
 
 template <typename F> int route_all_parallel(oa_ctx *c, F f)
 {
-    const size_t ng = c->groups.size();
+    const size_t ng = c->upload_groups.size();
     if (ng <= 1 || !c->pool) {
         for (oa_ctx *sub : c->subs) { const int rc = f(sub); if (rc) return rc; }
         return OA_OK;
     }
     return c->pool->run(ng, [c, f](size_t g) -> int {
-        for (int i : c->groups[g]) { const int rc = f(c->subs[(size_t)i]); if (rc) return rc; }
+        for (int i : c->upload_groups[g]) { const int rc = f(c->subs[(size_t)i]); if (rc) return rc; }
         return OA_OK;
     });
 }
@@ -1390,21 +1391,28 @@ OA_EXPORT int oa_create_multi(oa_ctx **out, const int *devices, int n_dev)
         const char *m = getenv("OA_EXCHANGE");
         if (m && (!strcmp(m, "rccl") || !strcmp(m, "RCCL") || !strcmp(m, "1"))) x->requested = OA_EXCHANGE_RCCL;
         else if (m && (!strcmp(m, "mailbox") || !strcmp(m, "MAILBOX") || !strcmp(m, "0"))) x->requested = OA_EXCHANGE_MAILBOX;
-        // host threads: one group of children per GPU (OA_MULTI_THREADS=1: per child, 0: a single group)
+        // host threads: one group of children per GPU (OA_MULTI_THREADS=1: per child, 0: a single group).  In the loop
+        // children that share a STREAM always share a thread: enqueued from two threads, one child's gather could land
+        // in front of the post it waits for.
         const int threads = env_int("OA_MULTI_THREADS", -1);
-        for (int i = 0; i < n_dev; ++i) {
-            size_t g = p->groups.size();
-            if (threads == 0) g = 0;
-            else if (threads < 0)
-                for (size_t k = 0; k < p->groups.size(); ++k)
-                    if (p->subs[(size_t)p->groups[k][0]]->device == devices[i]) { g = k; break; }
-            if (g == p->groups.size()) p->groups.emplace_back();
-            p->groups[g].push_back(i);
-        }
-        if (p->groups.size() > 1) {
+        auto deal = [&](std::vector<std::vector<int>> &groups, bool per_child) {
+            for (int i = 0; i < n_dev; ++i) {
+                size_t g = groups.size();
+                if (threads == 0) g = 0;
+                else if (!per_child)
+                    for (size_t k = 0; k < groups.size(); ++k)
+                        if (p->subs[(size_t)groups[k][0]]->device == devices[i]) { g = k; break; }
+                if (g == groups.size()) groups.emplace_back();
+                groups[g].push_back(i);
+            }
+        };
+        deal(p->upload_groups, threads > 0);
+        deal(p->groups, threads > 0 && own_streams);
+        const size_t n_threads = std::max(p->groups.size(), p->upload_groups.size());
+        if (n_threads > 1) {
             p->pool = new (std::nothrow) WorkerPool();
             if (!p->pool) rc = fail(OA_E_HIP, "out of host memory");
-            else p->pool->start(p->groups.size() - 1);
+            else p->pool->start(n_threads - 1);
         }
     }
     if (rc) { const std::string keep = g_err; oa_destroy(p); g_err = keep; return rc; }
