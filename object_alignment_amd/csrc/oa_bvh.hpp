@@ -22,16 +22,8 @@
 
 namespace oa {
 
-constexpr int BVH_W = 64;
-constexpr int BVH_MAX_LEVELS = 6;
-
-struct BvhParams {
-    int n_prims;                          // real primitives
-    int levels;                           // box levels L >= 1: level 1 = leaf boxes ... level L = top (<= 64 boxes)
-    int cnt[BVH_MAX_LEVELS + 1];          // boxes at level l (1..L)
-    int off[BVH_MAX_LEVELS + 1];          // offset of level l in the box array, in boxes (each level padded to 64)
-    double scale, slack;                  // largest |coordinate| and absolute slack (triangle mode's delta)
-};
+// (BVH_W, BVH_MAX_LEVELS, BvhParams, BvhLds and the declaration of bvh_wave_query live in oa_grid.hpp: the grid search
+//  finishes the queries it cannot settle through this tree, in the same launch)
 
 #if defined(__HIPCC__)
 
@@ -191,29 +183,140 @@ __device__ __forceinline__ bool bvh_prune(float lb, float best)
     return lb * 0.99999f - 1e-30f > best;                          // cannot beat or tie
 }
 
+// The descent for ONE query by ONE wave (all 64 lanes call it together; p, cutf and the running best are wave-uniform).
+// In: the seed (best, bidx; vertex mode: its coordinates in bx, by, bz).  Out: the exact nearest primitive -- the same
+// (d2, index) every other search returns.  lds: this wave's scratch (per level 64 bounds, a mask, a node).
+template <bool TRI>
+__device__ __forceinline__ void bvh_wave_query(const BvhParams &bp, const float4 *__restrict__ boxes,
+                                               const float4 *__restrict__ prims, const float *p, float cutf, float &best,
+                                               uint32_t &bidx, float &bx, float &by, float &bz, const BvhLds &lds, int lane)
+{
+    const int top = bp.levels;
+    // `lim`: the best so far or the search radius (search_cutoff2), whichever is smaller -- see k_nn_search_grid
+    float lim = fminf(best, cutf);
+    const bool finite = fabsf(p[0]) < INFINITY && fabsf(p[1]) < INFINITY && fabsf(p[2]) < INFINITY;
+    if (!finite) return;                                            // a non-finite query has no finite distance: stays as seeded
+    const double delta = TRI ? 64.0 * 5.9604644775390625e-08 * (bp.scale + fabs((double)p[0]) + fabs((double)p[1]) + fabs((double)p[2])) + bp.slack : 0.0;
+    float thr = TRI ? tri_skip_threshold(lim, delta) : 0.f;         // squared bounding-box gap beyond which a triangle is out
+    int level = top;
+    int node = 0;
+    bool fresh = true;                                              // `level` holds a node whose children are not tested yet
+    while (true) {
+        if (fresh) {
+            const long long ch = (long long)node * BVH_W + lane;
+            float lb = INFINITY;
+            bool pass = false;
+            if (ch < bp.cnt[level]) {
+                const float4 lo = boxes[2 * ((long long)bp.off[level] + ch)], hi = boxes[2 * ((long long)bp.off[level] + ch) + 1];
+                lb = bvh_box_bound<TRI>(p, lo, hi, delta);
+                pass = lb < INFINITY && !bvh_prune(lb, lim);
+            }
+            lds.lb(level)[lane] = lb;
+            const unsigned long long m = __ballot(pass);
+            if (lane == 0) { *lds.mask(level) = m; *lds.node(level) = node; }
+            fresh = false;
+        }
+        const unsigned long long m = *lds.mask(level);
+        if (m == 0ull) {
+            if (level == top) break;
+            ++level;
+            continue;
+        }
+        const bool member = (m >> lane) & 1ull;
+        const uint32_t lbits = member ? __float_as_uint(lds.lb(level)[lane]) : 0xFFFFFFFFu;   // bounds are >= +0
+        const uint32_t mb = wave_min_u32(lbits);
+        if (bvh_prune(__uint_as_float(mb), lim)) {                  // the nearest candidate is out: so are the others
+            if (lane == 0) *lds.mask(level) = 0ull;
+            continue;
+        }
+        const unsigned long long eq = __ballot(member && lbits == mb);
+        const int pick = __ffsll((long long)eq) - 1;
+        if (lane == 0) *lds.mask(level) = m & ~(1ull << pick);
+        const long long child = (long long)*lds.node(level) * BVH_W + pick;
+        if (level > 1) {
+            --level;
+            node = (int)child;
+            fresh = true;
+            continue;
+        }
+        // leaf: 64 primitives, one per lane
+        const long long j = child * BVH_W + lane;
+        float d;
+        uint32_t qi;
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (TRI) {
+            float a[3], b[3], c[3], r[3];
+            load_tri(prims, j, a, b, c);
+            qi = __float_as_uint(prims[3 * j + 2].y);
+            // the leaf's box passed, but it bounds 64 triangles: when no single triangle's own box can matter
+            // the ~300-instruction closest-point evaluation of the whole wave is skipped
+            float lb = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float lo = fminf(fminf(a[k], b[k]), c[k]), hi = fmaxf(fmaxf(a[k], b[k]), c[k]);
+                const float g = fmaxf(fmaxf(lo - p[k], p[k] - hi), 0.f);
+                lb += g * g;
+            }
+            if (!__any(!(lb > thr))) continue;
+            closest_on_tri(p, a, b, c, r);
+            d = tri_dist2(p, r);
+        } else {
+            q = prims[j];
+            qi = __float_as_uint(q.w);
+            d = d2_metric(p[0], p[1], p[2], q.x, q.y, q.z);
+        }
+        const uint32_t dbits = (d < INFINITY) ? __float_as_uint(d) : 0xFFFFFFFFu;   // d >= +0 here; NaN / inf never win
+        const uint32_t md = wave_min_u32(dbits);
+        if (md <= __float_as_uint(best) && md != 0xFFFFFFFFu) {
+            const uint32_t mi = wave_min_u32(dbits == md ? qi : IDX_NONE);
+            if (md < __float_as_uint(best) || mi < bidx) {
+                best = __uint_as_float(md); bidx = mi; lim = fminf(best, cutf);
+                if (TRI) thr = tri_skip_threshold(lim, delta);
+                else {
+                    const int wl = __ffsll((long long)__ballot(dbits == md && qi == mi)) - 1;   // the winner's lane
+                    bx = __shfl(q.x, wl, 64); by = __shfl(q.y, wl, 64); bz = __shfl(q.z, wl, 64);
+                }
+            }
+        }
+    }
+}
+
 // One wave per query.  list == nullptr: every source point, seeded with last iteration's primitive (vertex mode: the
 // winner record win[i]; triangles: `prev`, original index, evaluated through tri9); else the points the grid search
 // could not settle, seeded with keys[i].
-template <bool TRI>
-__global__ __launch_bounds__(256) void k_bvh_search(const DevState *__restrict__ st, const float4 *__restrict__ src4,
+// ACC (loop iterations, whole-shard searches only): the pair test and the fp64 sums of the iteration are taken in the
+// same launch -- the wave holds its query, the winner and d2 already; every wave keeps running sums over its queries
+// (wave-uniform, so no cross-lane reduction), the workgroup's four waves are added in order into one row of `partials`.
+// keys[] / prev[] are not written then: nothing reads them inside the loop.
+// ACC launches workgroups of 16 waves (one row of partials per 16 queries in flight, not per 4: the single-workgroup
+// reduction behind it is a chain of row loads).
+template <bool TRI, bool ACC = false>
+__global__ __launch_bounds__(ACC ? 1024 : 256) void k_bvh_search(const DevState *__restrict__ st, const float4 *__restrict__ src4,
                                                     int ns, BvhParams bp, const float4 *__restrict__ boxes,
                                                     const float4 *__restrict__ prims,
                                                     const float4 *__restrict__ tri9,
-                                                    const int *__restrict__ prev, float4 *__restrict__ win,
+                                                    int *__restrict__ prev, float4 *__restrict__ win,
                                                     unsigned long long *__restrict__ keys,
-                                                    const int *__restrict__ list, const int *__restrict__ list_count, int turn)
+                                                    const int *__restrict__ list, const int *__restrict__ list_count, int turn,
+                                                    NormalTest nrm = NormalTest{}, double *__restrict__ partials = nullptr)
 {
     if (st->halt) return;
     if (turn >= 0 && (st->tree_turn != 0) != (turn != 0)) return;  // not this kernel's turn (DevState::tree_turn)
-    __shared__ float s_lb[4][BVH_MAX_LEVELS + 1][BVH_W];
-    __shared__ unsigned long long s_mask[4][BVH_MAX_LEVELS + 1];
-    __shared__ int s_node[4][BVH_MAX_LEVELS + 1];
+    constexpr int WPB = ACC ? 16 : 4;                               // waves per workgroup
+    __shared__ float s_lb[WPB][BVH_MAX_LEVELS + 1][BVH_W];
+    __shared__ unsigned long long s_mask[WPB][BVH_MAX_LEVELS + 1];
+    __shared__ int s_node[WPB][BVH_MAX_LEVELS + 1];
+    __shared__ double red[WPB][NSUMS];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const BvhLds lds{ &s_lb[w][0][0], BVH_W, &s_mask[w][0], 1, &s_node[w][0], 1 };
     const int n_items = list ? *list_count : ns;
-    const int n_waves = gridDim.x * 4;
-    const int top = bp.levels;
+    const int n_waves = gridDim.x * WPB;
+    // ACC: the wave's running sums live in LDS, number k owned by lane k (in registers the 24 doubles would sit there
+    // through the whole descent and halve the kernel's occupancy)
+    if (ACC) { if (lane < NSUMS) red[w][lane] = 0.0; }
+    const double thresh = st->thresh, pvx = st->pivot[0], pvy = st->pivot[1], pvz = st->pivot[2], d_pivot = st->d_pivot;
 
-    for (int slot = blockIdx.x * 4 + w; slot < n_items; slot += n_waves) {
+    for (int slot = blockIdx.x * WPB + w; slot < n_items; slot += n_waves) {
         const int i = list ? list[slot] : slot;
         const float4 p4 = src4[i];
         float wx, wy, wz, p[3];
@@ -248,99 +351,62 @@ __global__ __launch_bounds__(256) void k_bvh_search(const DevState *__restrict__
                 if (d < INFINITY) { best = d; bidx = (uint32_t)__float_as_int(sw.w); bx = sw.x; by = sw.y; bz = sw.z; }
             }
         }
-        // `lim`: the best so far or the search radius (search_cutoff2), whichever is smaller -- see k_nn_search_grid
         const float cutf = search_cutoff2(st, p[0], p[1], p[2]);
-        float lim = fminf(best, cutf);
-        const bool finite = fabsf(p[0]) < INFINITY && fabsf(p[1]) < INFINITY && fabsf(p[2]) < INFINITY;
-        const double delta = TRI ? 64.0 * 5.9604644775390625e-08 * (bp.scale + fabs((double)p[0]) + fabs((double)p[1]) + fabs((double)p[2])) + bp.slack : 0.0;
-        float thr = TRI ? tri_skip_threshold(lim, delta) : 0.f;     // squared bounding-box gap beyond which a triangle is out
-
-        if (finite) {                                               // a non-finite query has no finite distance: stays (inf, none)
-            int level = top;
-            int node = 0;
-            bool fresh = true;                                      // `level` holds a node whose children are not tested yet
-            while (true) {
-                if (fresh) {
-                    const long long ch = (long long)node * BVH_W + lane;
-                    float lb = INFINITY;
-                    bool pass = false;
-                    if (ch < bp.cnt[level]) {
-                        const float4 lo = boxes[2 * ((long long)bp.off[level] + ch)], hi = boxes[2 * ((long long)bp.off[level] + ch) + 1];
-                        lb = bvh_box_bound<TRI>(p, lo, hi, delta);
-                        pass = lb < INFINITY && !bvh_prune(lb, lim);
-                    }
-                    s_lb[w][level][lane] = lb;
-                    const unsigned long long m = __ballot(pass);
-                    if (lane == 0) { s_mask[w][level] = m; s_node[w][level] = node; }
-                    fresh = false;
-                }
-                const unsigned long long m = s_mask[w][level];
-                if (m == 0ull) {
-                    if (level == top) break;
-                    ++level;
-                    continue;
-                }
-                const bool member = (m >> lane) & 1ull;
-                const uint32_t lbits = member ? __float_as_uint(s_lb[w][level][lane]) : 0xFFFFFFFFu;   // bounds are >= +0
-                const uint32_t mb = wave_min_u32(lbits);
-                if (bvh_prune(__uint_as_float(mb), lim)) {          // the nearest candidate is out: so are the others
-                    if (lane == 0) s_mask[w][level] = 0ull;
-                    continue;
-                }
-                const unsigned long long eq = __ballot(member && lbits == mb);
-                const int pick = __ffsll((long long)eq) - 1;
-                if (lane == 0) s_mask[w][level] = m & ~(1ull << pick);
-                const long long child = (long long)s_node[w][level] * BVH_W + pick;
-                if (level > 1) {
-                    --level;
-                    node = (int)child;
-                    fresh = true;
-                    continue;
-                }
-                // leaf: 64 primitives, one per lane
-                const long long j = child * BVH_W + lane;
-                float d;
-                uint32_t qi;
-                float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        bvh_wave_query<TRI>(bp, boxes, prims, p, cutf, best, bidx, bx, by, bz, lds, lane);
+        if (ACC) {
+            if (lane == 0) {
+                if (TRI) prev[i] = (bidx == IDX_NONE) ? -1 : (int)bidx;      // the next search's seed
+                else win[i] = make_float4(bx, by, bz, __int_as_float((int)bidx));
+            }
+            if (bidx != IDX_NONE) {                                 // wave-uniform: every lane adds the same terms to its copy
+                float qx = bx, qy = by, qz = bz;
+                float tn[3] = { 0.f, 0.f, 0.f };
                 if (TRI) {
-                    float a[3], b[3], c[3], r[3];
-                    load_tri(prims, j, a, b, c);
-                    qi = __float_as_uint(prims[3 * j + 2].y);
-                    // the leaf's box passed, but it bounds 64 triangles: when no single triangle's own box can matter
-                    // the ~300-instruction closest-point evaluation of the whole wave is skipped
-                    float lb = 0.f;
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        const float lo = fminf(fminf(a[k], b[k]), c[k]), hi = fmaxf(fmaxf(a[k], b[k]), c[k]);
-                        const float g = fmaxf(fmaxf(lo - p[k], p[k] - hi), 0.f);
-                        lb += g * g;
+                    float ta[3], tb[3], tc[3], rr[3];
+                    load_tri(tri9, bidx, ta, tb, tc);
+                    closest_on_tri(p, ta, tb, tc, rr);
+                    qx = rr[0]; qy = rr[1]; qz = rr[2];
+                    if (nrm.src_n) {                                 // geometric face normal (Blender normal_tri_v3 order)
+                        const float e1[3] = { ta[0] - tb[0], ta[1] - tb[1], ta[2] - tb[2] };
+                        const float e2[3] = { tb[0] - tc[0], tb[1] - tc[1], tb[2] - tc[2] };
+                        tn[0] = e1[1] * e2[2] - e1[2] * e2[1];
+                        tn[1] = e1[2] * e2[0] - e1[0] * e2[2];
+                        tn[2] = e1[0] * e2[1] - e1[1] * e2[0];
                     }
-                    if (!__any(!(lb > thr))) continue;
-                    closest_on_tri(p, a, b, c, r);
-                    d = tri_dist2(p, r);
-                } else {
-                    q = prims[j];
-                    qi = __float_as_uint(q.w);
-                    d = d2_metric(p[0], p[1], p[2], q.x, q.y, q.z);
-                }
-                const uint32_t dbits = (d < INFINITY) ? __float_as_uint(d) : 0xFFFFFFFFu;   // d >= +0 here; NaN / inf never win
-                const uint32_t md = wave_min_u32(dbits);
-                if (md <= __float_as_uint(best) && md != 0xFFFFFFFFu) {
-                    const uint32_t mi = wave_min_u32(dbits == md ? qi : IDX_NONE);
-                    if (md < __float_as_uint(best) || mi < bidx) {
-                        best = __uint_as_float(md); bidx = mi; lim = fminf(best, cutf);
-                        if (TRI) thr = tri_skip_threshold(lim, delta);
-                        else {
-                            const int wl = __ffsll((long long)__ballot(dbits == md && qi == mi)) - 1;   // the winner's lane
-                            bx = __shfl(q.x, wl, 64); by = __shfl(q.y, wl, 64); bz = __shfl(q.z, wl, 64);
-                        }
-                    }
+                } else if (nrm.src_n) { tn[0] = nrm.tgt_n[3ll * bidx]; tn[1] = nrm.tgt_n[3ll * bidx + 1]; tn[2] = nrm.tgt_n[3ll * bidx + 2]; }
+                float vbx, vby, vbz;
+                double dist;
+                if (pair_eval(st, p[0], p[1], p[2], qx, qy, qz, nrm, i, tn, thresh, vbx, vby, vbz, dist)) {
+                    const double a0 = (double)p4.x - pvx, a1 = (double)p4.y - pvy, a2 = (double)p4.z - pvz;
+                    const double b0 = (double)vbx - pvx, b1 = (double)vby - pvy, b2 = (double)vbz - pvz;
+                    const double dd = dist - d_pivot;
+                    double *row = red[w];
+#define OA_LANE_ADD(k, expr) if (lane == (k)) row[k] += (expr)
+                    OA_LANE_ADD(S_A, a0); OA_LANE_ADD(S_A + 1, a1); OA_LANE_ADD(S_A + 2, a2);
+                    OA_LANE_ADD(S_B, b0); OA_LANE_ADD(S_B + 1, b1); OA_LANE_ADD(S_B + 2, b2);
+                    OA_LANE_ADD(S_H + 0, b0 * a0); OA_LANE_ADD(S_H + 1, b0 * a1); OA_LANE_ADD(S_H + 2, b0 * a2);
+                    OA_LANE_ADD(S_H + 3, b1 * a0); OA_LANE_ADD(S_H + 4, b1 * a1); OA_LANE_ADD(S_H + 5, b1 * a2);
+                    OA_LANE_ADD(S_H + 6, b2 * a0); OA_LANE_ADD(S_H + 7, b2 * a1); OA_LANE_ADD(S_H + 8, b2 * a2);
+                    OA_LANE_ADD(S_AA, (a0 * a0 + a1 * a1) + a2 * a2);
+                    OA_LANE_ADD(S_BB, (b0 * b0 + b1 * b1) + b2 * b2);
+                    OA_LANE_ADD(S_K, 1.0);
+                    OA_LANE_ADD(S_D, dd);
+                    OA_LANE_ADD(S_DD, dd * dd);
+#undef OA_LANE_ADD
                 }
             }
-        }
-        if (lane == 0) {
+        } else if (lane == 0) {
             keys[i] = ((unsigned long long)__float_as_uint(best) << 32) | bidx;
             if (!TRI) win[i] = make_float4(bx, by, bz, __int_as_float((int)bidx));
+        }
+    }
+    if (ACC) {
+        // the waves' sums, added in order
+        __syncthreads();
+        if (threadIdx.x < NSUMS) {
+            double t = red[0][threadIdx.x];
+            for (int k = 1; k < WPB; ++k) t += red[k][threadIdx.x];
+            partials[(long long)blockIdx.x * NSUMS + threadIdx.x] = t;
         }
     }
 }

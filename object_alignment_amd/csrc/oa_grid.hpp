@@ -46,7 +46,36 @@ inline void grid_params_finish(GridParams &gp)
     if ((double)gp.slackf < s) gp.slackf = nextafterf(gp.slackf, INFINITY);
 }
 
+// ---- the 64-ary box tree (oa_bvh.hpp) as far as the grid search needs it: queries it cannot settle are finished through
+// the tree by the wave that owns them, in the same launch ---------------------------------------------------------------
+constexpr int BVH_W = 64;
+constexpr int BVH_MAX_LEVELS = 6;
+
+struct BvhParams {
+    int n_prims;                          // real primitives
+    int levels;                           // box levels L >= 1: level 1 = leaf boxes ... level L = top (<= 64 boxes)
+    int cnt[BVH_MAX_LEVELS + 1];          // boxes at level l (1..L)
+    int off[BVH_MAX_LEVELS + 1];          // offset of level l in the box array, in boxes (each level padded to 64)
+    double scale, slack;                  // largest |coordinate| and absolute slack (triangle mode's delta)
+};
+
 #if defined(__HIPCC__)
+
+// one wave's scratch for a descent: per level 64 lower bounds, the mask of children still to visit, the node.  Strides in
+// elements, so that the grid kernels can lay it over the LDS their (finished) scan no longer needs.
+struct BvhLds {
+    float *lb0; int lb_stride;
+    unsigned long long *mask0; int mask_stride;
+    int *node0; int node_stride;
+    __device__ __forceinline__ float *lb(int level) const { return lb0 + (long long)level * lb_stride; }
+    __device__ __forceinline__ unsigned long long *mask(int level) const { return mask0 + (long long)level * mask_stride; }
+    __device__ __forceinline__ int *node(int level) const { return node0 + (long long)level * node_stride; }
+};
+
+template <bool TRI>
+__device__ __forceinline__ void bvh_wave_query(const BvhParams &bp, const float4 *__restrict__ boxes,
+                                               const float4 *__restrict__ prims, const float *p, float cutf, float &best,
+                                               uint32_t &bidx, float &bx, float &by, float &bz, const BvhLds &lds, int lane);
 
 __device__ __forceinline__ int grid_cell_coord(double q, double lo, double inv_h, int n)
 {
@@ -205,14 +234,26 @@ __device__ __forceinline__ void grid_candidate(float px, float py, float pz, con
 // the longest range in each.
 constexpr int GRID_SEGS = 10;      // ranges of one batch: 9 rows of the first block (one each), or as many later rows (two each) as fit
 
-template <int L>
+//
+// ACC (the loop's iterations): ONE launch does what took three.  (i) A query the rings did not settle -- far from the
+// target, or in a crowded cell -- is finished through the box tree right here, by the wave that owns it (one wave per
+// query, one query after the other: bvh_wave_query; its scratch lies over the range lists, which are dead by then).
+// Round 2 appended such queries to a list with an atomic and launched k_bvh_search behind every grid search, on a list
+// that is empty most of the time.  (ii) The pair test and the iteration's fp64 sums are taken in the epilogue: the lane
+// holds the query, the winner's coordinates and nothing else is needed -- no second pass over src4 / keys / win
+// (k_pair_accumulate, 16 us at 1M points and its own launch).  One row of `partials` per workgroup, fixed order.
+// keys[] is not written then: nothing reads it inside the loop.
+template <int L, bool ACC = false>
 __global__ __launch_bounds__(256, 6) void k_nn_search_grid(const DevState *__restrict__ st,
                                                         const float4 *__restrict__ src4, int ns, GridParams gp,
                                                         const int *__restrict__ cell_start,
                                                         const float4 *__restrict__ sorted,
                                                         float4 *__restrict__ win,
                                                         unsigned long long *__restrict__ keys,
-                                                        int *__restrict__ todo_list, int *__restrict__ todo_count, int turn)
+                                                        int *__restrict__ todo_list, int *__restrict__ todo_count, int turn,
+                                                        BvhParams bp = BvhParams{}, const float4 *__restrict__ boxes = nullptr,
+                                                        const float4 *__restrict__ prims = nullptr, NormalTest nrm = NormalTest{},
+                                                        double *__restrict__ partials = nullptr)
 {
     constexpr int RPL = (9 + L - 1) / L;                            // rows per lane and batch
     static_assert(RPL <= GRID_SEGS && (L == 1 || 2 * RPL <= GRID_SEGS), "a batch of rows must fit the per-thread range list");
@@ -360,12 +401,66 @@ __global__ __launch_bounds__(256, 6) void k_nn_search_grid(const DevState *__res
             }
         }
     }
-    if (sub != 0 || !alive) return;
-    keys[i] = ((unsigned long long)__float_as_uint(best) << 32) | bidx;
-    // the winner record is read by k_pair_accumulate, the tree search and the next search; a winner that is still the
-    // seed (the usual case once the loop converges) is already there
-    if (bj >= 0) win[i] = sorted[bj];
-    if (!settled) todo_list[atomicAdd(todo_count, 1)] = i;      // finished exactly by the tree search (k_bvh_search)
+    if (!ACC) {
+        if (sub != 0 || !alive) return;
+        keys[i] = ((unsigned long long)__float_as_uint(best) << 32) | bidx;
+        // the winner record is read by k_pair_accumulate, the tree search and the next search; a winner that is still the
+        // seed (the usual case once the loop converges) is already there
+        if (bj >= 0) win[i] = sorted[bj];
+        if (!settled) {                                             // finished exactly by the tree search (k_bvh_search)
+            todo_list[atomicAdd(todo_count, 1)] = i;
+            // (how crowded the hand-over is per wave: what the host looks at before it lets a later search finish its own leftovers)
+            atomicMax(todo_count + 1, __popcll(__ballot(1)));
+        }
+        return;
+    }
+    // ---- ACC: finish, record, accumulate -- all 256 threads stay to the end (wave-wide descents, workgroup-wide reduction)
+    __shared__ double red[4][NSUMS];
+    const bool mine = sub == 0 && alive;
+    float4 wq = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));  // the winner's record: the seed's, or the scan's
+    if (mine && bidx != IDX_NONE) wq = bj >= 0 ? sorted[bj] : win[i];      // (bj < 0: still the seed, re-read rather than kept in registers through the scan)
+    bool changed = mine && bj >= 0;
+    {
+        // (a non-finite query has no finite distance: it stays as it is; recomputed here, not held through the scan)
+        const bool finite = fabsf(px) < INFINITY && fabsf(py) < INFINITY && fabsf(pz) < INFINITY;
+        unsigned long long todo = __ballot(mine && !settled && finite);
+        if (todo) {
+            if ((threadIdx.x & 63) == 0) { atomicAdd(todo_count, __popcll(todo)); atomicMax(todo_count + 1, __popcll(todo)); }
+            // this wave's columns of the range lists are free now: per level 256 B of bounds, then the mask and the node
+            const int lane = threadIdx.x & 63, col0 = threadIdx.x & ~63;
+            char *base = (char *)&seg[0][col0];
+            const int row_bytes = (int)sizeof(seg[0]);
+            const BvhLds lds{ (float *)base, row_bytes / 4, (unsigned long long *)(base + 256), row_bytes / 8, (int *)(base + 264), row_bytes / 4 };
+            while (todo) {
+                const int l = __ffsll((long long)todo) - 1;
+                todo &= todo - 1ull;
+                const float qp[3] = { __shfl(px, l, 64), __shfl(py, l, 64), __shfl(pz, l, 64) };
+                float b = __shfl(best, l, 64);
+                uint32_t bi = (uint32_t)__shfl((int)bidx, l, 64);
+                float tx = __shfl(wq.x, l, 64), ty = __shfl(wq.y, l, 64), tz = __shfl(wq.z, l, 64);
+                const uint32_t bi0 = bi;
+                bvh_wave_query<false>(bp, boxes, prims, qp, __shfl(cutf, l, 64), b, bi, tx, ty, tz, lds, lane);
+                if (lane == l && bi != bi0) { best = b; bidx = bi; wq = make_float4(tx, ty, tz, __int_as_float((int)bi)); changed = true; }
+            }
+        }
+    }
+    if (changed) win[i] = wq;                                     // the next search's seed (and what a one-shot call would read)
+    bool valid = false;
+    float vbx = 0.f, vby = 0.f, vbz = 0.f;
+    double dist = 0.0;
+    if (mine && bidx != IDX_NONE) {
+        float tn[3] = { 0.f, 0.f, 0.f };
+        if (nrm.src_n) { tn[0] = nrm.tgt_n[3ll * bidx]; tn[1] = nrm.tgt_n[3ll * bidx + 1]; tn[2] = nrm.tgt_n[3ll * bidx + 2]; }
+        valid = pair_eval(st, px, py, pz, wq.x, wq.y, wq.z, nrm, i, tn, st->thresh, vbx, vby, vbz, dist);
+    }
+    const double pvx = st->pivot[0], pvy = st->pivot[1], pvz = st->pivot[2];
+    // the source point again (a coalesced, cached 16-byte load) rather than three registers held through the whole scan:
+    // the pointer is laundered so that the compiler does not merge this load with the one at the top
+    const float4 *src_again = src4;
+    asm volatile("" : "+s"(src_again));
+    const float4 a4 = src_again[i];
+    block_store_pair(valid, (double)a4.x - pvx, (double)a4.y - pvy, (double)a4.z - pvz, (double)vbx - pvx, (double)vby - pvy,
+                     (double)vbz - pvz, dist - st->d_pivot, red, partials + (long long)blockIdx.x * NSUMS);
 }
 
 __global__ void k_count_nonzero(const int *__restrict__ a, int n, int *__restrict__ out)

@@ -402,6 +402,11 @@ struct oa_ctx {
     bool h_hist_valid = false;
     int max_records = 0;
     double *d_partials = nullptr, *d_sums = nullptr, *d_solve = nullptr;
+    int fused_acc = 1;                      // OA_FUSED_ACC: grid / tree searches of the loop accumulate in their epilogue
+    int grid_path = 0;                      // OA_GRID_PATH: 0 = adaptive (see grid_fast_now), 1 = always the fused path, 2 = never
+    int iter_enq = 0;                       // iterations enqueued since the loop began
+    bool fast_prev = false;                 // what the last iteration's grid search did
+    int last_todo_wave_max = -1;            // most queries one wave handed over in the last iteration the host heard of (-1: unknown)
     // make_pairs scratch (sized to ns)
     int emit_cap = 0;
     unsigned char *d_valid = nullptr;
@@ -414,7 +419,7 @@ struct oa_ctx {
     std::vector<hipEvent_t> ev;
     int ev_used = 0;
     hipEvent_t ev_loop0 = nullptr, ev_loop1 = nullptr;
-    int32_t *h_poll = nullptr;          // pinned, device-mapped {halt, n}: the solve kernel mirrors them here for oa_run
+    int32_t *h_poll = nullptr;          // pinned, device-mapped {halt, n, hand-over entries, most per wave}: the solve kernel mirrors them here for the enqueuing host
     bool time_events = true;            // hipEvent pair around every search (brute force); else GPU-side stamps (see iter_fused)
     double wall_clock_khz = 100000.0;   // rate of wall_clock64()
     oa_settings settings;
@@ -497,8 +502,8 @@ int ensure_common(oa_ctx *c)
     if (!c->d_sums) HIPCHK(dev_malloc(&c->d_sums, sizeof(double) * oa::NSUMS));
     if (!c->d_solve) HIPCHK(dev_malloc(&c->d_solve, sizeof(double) * 32));
     if (!c->h_poll) {
-        HIPCHK(hipHostMalloc((void **)&c->h_poll, 2 * sizeof(int32_t), hipHostMallocMapped));
-        c->h_poll[0] = 0; c->h_poll[1] = 0;
+        HIPCHK(hipHostMalloc((void **)&c->h_poll, 4 * sizeof(int32_t), hipHostMallocMapped));
+        for (int k = 0; k < 4; ++k) c->h_poll[k] = 0;
     }
     if (!c->h_state_pin) HIPCHK(hipHostMalloc((void **)&c->h_state_pin, sizeof(oa::DevState), hipHostMallocDefault));
     return OA_OK;
@@ -578,58 +583,139 @@ int build_grid(oa_ctx *c);
 int build_tri_grid(oa_ctx *c);
 int build_bvh(oa_ctx *c, bool tri);
 int scan_counts(oa_ctx *c, const int *d_counts, int n, long long *d_off);
-int launch_tri_search(oa_ctx *c);
+int launch_tri_search(oa_ctx *c, bool acc = false);
 
 // one wave per query: 4 queries per workgroup, workgroups loop when there are more queries than that
-template <bool TRI>
-int launch_bvh(oa_ctx *c, const int *list, const int *list_count, int turn = -1)
+inline unsigned bvh_blocks(const oa_ctx *c, bool listed, bool acc = false)
 {
-    const int items = list ? std::min(c->ns, 1 << 17) : c->ns;
-    const unsigned blocks = (unsigned)std::max(1, std::min((items + 3) / 4, c->n_cu * 16));   // 16 waves per SIMD: enough to fill the chip, cheap to dispatch when the list is empty
-    hipLaunchKernelGGL(oa::k_bvh_search<TRI>, dim3(blocks), dim3(256), 0, c->stream, c->d_state, c->d_src4, c->ns,
-                       TRI ? c->tbvh : c->bvh, TRI ? c->d_tbvh_box : c->d_bvh_box, TRI ? c->d_tbvh_prims : c->d_bvh_prims,
-                       c->d_tri9, c->d_prev, TRI ? (float4 *)nullptr : c->d_win, c->d_keys, list, list_count, turn);
+    const int items = listed ? std::min(c->ns, 1 << 17) : c->ns;
+    if (acc) return (unsigned)std::max(1, std::min((items + 15) / 16, c->n_cu * 4));   // workgroups of 16 waves
+    return (unsigned)std::max(1, std::min((items + 3) / 4, c->n_cu * 16));   // 16 waves per SIMD: enough to fill the chip, cheap to dispatch when the list is empty
+}
+
+oa::NormalTest normal_test(const oa_ctx *c)
+{
+    oa::NormalTest nrm{};
+    if (c->normals_on) { nrm.src_n = c->d_src_n; nrm.tgt_n = c->surface ? nullptr : c->d_tgt_n; nrm.cos_min = c->cos_min; }
+    return nrm;
+}
+
+// acc: a whole-shard search of the loop that also takes the pair test and the sums (k_bvh_search<TRI, true>)
+template <bool TRI>
+int launch_bvh(oa_ctx *c, const int *list, const int *list_count, int turn = -1, bool acc = false)
+{
+    const unsigned blocks = bvh_blocks(c, list != nullptr, acc);
+#define OA_BVH_ARGS c->d_state, c->d_src4, c->ns, TRI ? c->tbvh : c->bvh, TRI ? c->d_tbvh_box : c->d_bvh_box, TRI ? c->d_tbvh_prims : c->d_bvh_prims, \
+                    c->d_tri9, c->d_prev, TRI ? (float4 *)nullptr : c->d_win, c->d_keys, list, list_count, turn
+    if (acc) hipLaunchKernelGGL((oa::k_bvh_search<TRI, true>), dim3(blocks), dim3(1024), 0, c->stream, OA_BVH_ARGS, normal_test(c), c->d_partials);
+    else hipLaunchKernelGGL((oa::k_bvh_search<TRI, false>), dim3(blocks), dim3(256), 0, c->stream, OA_BVH_ARGS, oa::NormalTest{}, (double *)nullptr);
+#undef OA_BVH_ARGS
     HIPCHK(hipGetLastError());
     return OA_OK;
 }
 
-int launch_nn_impl(oa_ctx *c);
-int launch_nn(oa_ctx *c)
+// lanes per query of the vertex grid search: shards too small to fill the chip's wave slots split every query's rows
+// between 2 or 4 lanes.  Measured on 256 CUs with the round-2 kernel (profiles/r02n_grid_lanes_sweep.txt; round 1:
+// r01h_grid_lanes_sweep.txt): against a target that sits in cache 4 lanes win up to ~20k queries and 2 up to ~350k;
+// against >= 500k vertices every round trip is longer and the lanes pay for longer: 4 up to ~100k queries, 2 up to
+// ~700k; 1M queries lose 7 % with 2
+inline int grid_lanes_for(const oa_ctx *c)
 {
-    const int rc = launch_nn_impl(c);
+    int lanes = c->grid_lanes;
+    if (lanes != 1 && lanes != 2 && lanes != 4) {
+        const bool big = c->nt >= 500000;
+        lanes = (c->ns <= (big ? 400 : 80) * c->n_cu) ? 4 : ((c->ns <= (big ? 2800 : 1400) * c->n_cu) ? 2 : 1);
+    }
+    return lanes;
+}
+
+// Workgroups of the canonical accumulation (k_pair_accumulate_canon, and the epilogue of k_nn_search_grid<L, true>): one
+// thread per (slot, lane of the query).  0 = the shard is too large for it (> ACC_MAX_BLOCKS rows before combining) or the
+// target is a surface: the grid-stride k_pair_accumulate is used instead.
+inline int canon_blocks(const oa_ctx *c)
+{
+    if (c->surface || c->ns <= 0) return 0;
+    const long long b = ((long long)c->ns * grid_lanes_for(c) + 255) / 256;
+    return b <= oa::ACC_MAX_BLOCKS ? (int)b : 0;
+}
+
+// What the loop's next search launch looks like.
+//   TREE   every query through the tree, which also accumulates (k_bvh_search<.., true>)
+//   DUAL   tree and grid both enqueued, DevState::tree_turn picks on the device; both accumulate; the grid search finishes
+//          its leftovers itself (it only has the turn once the pose has settled)
+//   GRID   the grid search.  FAST: it finishes its leftovers itself and accumulates -- two launches per iteration.  SAFE:
+//          grid search -> tree search of the hand-over list -> k_pair_accumulate_canon -- four launches, and the right
+//          thing when many queries are handed over (one wave per query over the whole chip instead of the owner wave
+//          walking its own leftovers one after the other: a cold start far from the target is 3-4x slower the FAST way).
+//          Both leave bitwise the same rows, so the choice -- taken per iteration from what the host last heard about the
+//          hand-over list, i.e. timing dependent -- never shows in a result.
+//   PLAIN  search, then accumulate (brute force; surface grid; shards too large for the canonical rows)
+enum SearchPlan { PLAN_PLAIN, PLAN_TREE, PLAN_DUAL, PLAN_GRID };
+SearchPlan search_plan(const oa_ctx *c)
+{
+    if (!c->fused_acc || !c->loop_active || c->ns <= 0) return PLAN_PLAIN;
+    if (c->surface) return bvh_whole(c, c->tbvh_ok, tri_tree_max(c)) ? PLAN_TREE : PLAN_PLAIN;
+    if (bvh_whole(c, c->bvh_ok, vertex_tree_max(c))) return PLAN_TREE;
+    if (!grid_active(c) || canon_blocks(c) == 0) return PLAN_PLAIN;
+    return (c->grid_mode == -1 && c->turns_on && c->ns <= vertex_tree_early(c)) ? PLAN_DUAL : PLAN_GRID;
+}
+
+// PLAN_GRID: may this iteration's grid search finish its own leftovers?  Yes while the most any one wave handed over in
+// the last iteration the host heard of is small (a wave walks its leftovers one after the other, ~5-10 us each).  The
+// host stays within a few iterations of the device (oa_run throttles itself), so "last heard of" is recent; with no
+// news from this loop yet the previous decision stands, and a loop starts SAFE unless it continues on warm seeds.
+constexpr int FAST_WAVE_MAX = 3;
+bool grid_fast_now(oa_ctx *c)
+{
+    if (c->grid_path == 1) return true;
+    if (c->grid_path == 2) return false;
+    bool fast = c->fast_prev;
+    const volatile int32_t *poll = c->h_poll;
+    const int n_done = poll ? poll[1] : 0;
+    if (n_done > 0 && n_done >= c->iter_enq - 4) fast = poll[3] <= FAST_WAVE_MAX;
+    else if (c->iter_enq == 0) fast = c->seeded && c->last_todo_wave_max >= 0 && c->last_todo_wave_max <= FAST_WAVE_MAX;
+    else if (n_done <= 0 && c->iter_enq > 4) fast = false;          // the host ran far ahead of the device: no news, no risk
+    c->fast_prev = fast;
+    return fast;
+}
+
+int launch_nn_impl(oa_ctx *c, bool acc);
+// acc: the search also accumulates (launch_search_accumulate decided so: no accumulation launch follows)
+int launch_nn(oa_ctx *c, bool acc = false)
+{
+    const int rc = launch_nn_impl(c, acc);
     if (rc == OA_OK) c->seeded = true;
     return rc;
 }
-int launch_nn_impl(oa_ctx *c)
+int launch_nn_impl(oa_ctx *c, bool acc)
 {
     if (c->ns <= 0) return OA_OK;
-    if (c->surface) return launch_tri_search(c);
+    if (c->surface) return launch_tri_search(c, acc);
     dim3 grid(c->n_splits, c->ns_pad / (oa::NN_THREADS * c->R));
     dim3 block(oa::NN_THREADS);
-    if (bvh_whole(c, c->bvh_ok, vertex_tree_max(c))) return launch_bvh<false>(c, nullptr, nullptr);
+    if (bvh_whole(c, c->bvh_ok, vertex_tree_max(c))) return launch_bvh<false>(c, nullptr, nullptr, -1, acc);
     if (grid_active(c)) {
-        // the grid search settles the queries near the target; the rest (far away, or in crowded cells) are appended
-        // to a list that the tree search finishes.  Inside the loop k_solve_update leaves the list counter at zero;
-        // one-shot calls clear it here.
-        if (!c->loop_active) HIPCHK(hipMemsetAsync(c->d_todo_count, 0, sizeof(int), c->stream));
+        // the grid search settles the queries near the target; the rest (far away, or in crowded cells) go through the
+        // tree: in the loop by the wave that owns them (acc), in one-shot calls through a list that k_bvh_search finishes
+        if (!acc && !c->loop_active) HIPCHK(hipMemsetAsync(c->d_todo_count, 0, 2 * sizeof(int), c->stream));
         const bool dual = c->grid_mode == -1 && c->turns_on && c->ns <= vertex_tree_early(c);
-        if (dual) { int rcb = launch_bvh<false>(c, nullptr, nullptr, 1); if (rcb) return rcb; }   // runs when DevState::tree_turn
+        if (dual) { int rcb = launch_bvh<false>(c, nullptr, nullptr, 1, acc); if (rcb) return rcb; }   // runs when DevState::tree_turn
         const int turn = dual ? 0 : -1;
-        // lanes per query: shards too small to fill the chip's wave slots split every query's rows between 2 or 4
-        // lanes.  Measured on 256 CUs with the round-2 kernel (profiles/r02n_grid_lanes_sweep.txt; round 1:
-        // r01h_grid_lanes_sweep.txt): against a target that sits in cache 4 lanes win up to ~20k queries and 2 up to
-        // ~350k; against >= 500k vertices every round trip is longer and the lanes pay for longer: 4 up to ~100k
-        // queries, 2 up to ~700k; 1M queries lose 7 % with 2
-        int lanes = c->grid_lanes;
-        if (lanes != 1 && lanes != 2 && lanes != 4) {
-            const bool big = c->nt >= 500000;
-            lanes = (c->ns <= (big ? 400 : 80) * c->n_cu) ? 4 : ((c->ns <= (big ? 2800 : 1400) * c->n_cu) ? 2 : 1);
-        }
+        const int lanes = grid_lanes_for(c);
 #define OA_GRID_ARGS c->d_state, c->d_src4, c->ns, c->gp, c->d_cell_start, c->d_sorted, c->d_win, c->d_keys, c->d_todo_list, c->d_todo_count, turn
+#define OA_GRID_ACC_ARGS OA_GRID_ARGS, c->bvh, (const float4 *)c->d_bvh_box, (const float4 *)c->d_bvh_prims, normal_test(c), c->d_partials
         const dim3 gblocks((unsigned)(((long long)c->ns * lanes + 255) / 256));
-        if (lanes == 4) hipLaunchKernelGGL(oa::k_nn_search_grid<4>, gblocks, dim3(256), 0, c->stream, OA_GRID_ARGS);
-        else if (lanes == 2) hipLaunchKernelGGL(oa::k_nn_search_grid<2>, gblocks, dim3(256), 0, c->stream, OA_GRID_ARGS);
-        else hipLaunchKernelGGL(oa::k_nn_search_grid<1>, gblocks, dim3(256), 0, c->stream, OA_GRID_ARGS);
+        if (acc) {
+            if (lanes == 4) hipLaunchKernelGGL((oa::k_nn_search_grid<4, true>), gblocks, dim3(256), 0, c->stream, OA_GRID_ACC_ARGS);
+            else if (lanes == 2) hipLaunchKernelGGL((oa::k_nn_search_grid<2, true>), gblocks, dim3(256), 0, c->stream, OA_GRID_ACC_ARGS);
+            else hipLaunchKernelGGL((oa::k_nn_search_grid<1, true>), gblocks, dim3(256), 0, c->stream, OA_GRID_ACC_ARGS);
+            HIPCHK(hipGetLastError());
+            return OA_OK;
+        }
+        if (lanes == 4) hipLaunchKernelGGL((oa::k_nn_search_grid<4, false>), gblocks, dim3(256), 0, c->stream, OA_GRID_ARGS);
+        else if (lanes == 2) hipLaunchKernelGGL((oa::k_nn_search_grid<2, false>), gblocks, dim3(256), 0, c->stream, OA_GRID_ARGS);
+        else hipLaunchKernelGGL((oa::k_nn_search_grid<1, false>), gblocks, dim3(256), 0, c->stream, OA_GRID_ARGS);
+#undef OA_GRID_ACC_ARGS
 #undef OA_GRID_ARGS
         HIPCHK(hipGetLastError());
         return launch_bvh<false>(c, c->d_todo_list, c->d_todo_count);
@@ -672,14 +758,18 @@ int launch_nn_impl(oa_ctx *c)
 int launch_accumulate(oa_ctx *c, bool emit, int *nn_idx, float *nn_d2)
 {
     oa::PairOut po{};
-    oa::NormalTest nrm{};
-    if (c->normals_on) { nrm.src_n = c->d_src_n; nrm.tgt_n = c->surface ? nullptr : c->d_tgt_n; nrm.cos_min = c->cos_min; }
+    const oa::NormalTest nrm = normal_test(c);
     if (emit) {
         po.valid = c->d_valid; po.b = c->d_b; po.dist = c->d_dist; po.nn_idx = nn_idx; po.nn_d2 = nn_d2; po.perm = c->d_perm;
         hipLaunchKernelGGL(oa::k_pair_accumulate<true>, dim3(c->acc_blocks), dim3(oa::ACC_THREADS), 0, c->stream,
                            c->d_state, c->d_src4, c->ns, c->d_tgt_xyz, c->d_keys, c->d_prev, c->surface ? (float4 *)nullptr : c->d_win,
                            c->surface ? (const float4 *)c->d_tri9 : (const float4 *)nullptr, nrm, c->d_partials, po,
                            (unsigned long long *)nullptr);
+    } else if (canon_blocks(c) > 0) {
+        hipLaunchKernelGGL(oa::k_pair_accumulate_canon, dim3((unsigned)canon_blocks(c)), dim3(256), 0, c->stream, (const oa::DevState *)c->d_state,
+                           (const float4 *)c->d_src4, c->ns, grid_lanes_for(c), (const float *)c->d_tgt_xyz, c->d_keys, c->d_prev, c->d_win,
+                           (const float4 *)nullptr, nrm, c->d_partials,
+                           c->loop_active ? &c->d_state->t_acc_start : (unsigned long long *)nullptr);
     } else {
         hipLaunchKernelGGL(oa::k_pair_accumulate<false>, dim3(c->acc_blocks), dim3(oa::ACC_THREADS), 0, c->stream,
                            c->d_state, c->d_src4, c->ns, c->d_tgt_xyz, c->d_keys, c->d_prev, c->surface ? (float4 *)nullptr : c->d_win,
@@ -690,10 +780,51 @@ int launch_accumulate(oa_ctx *c, bool emit, int *nn_idx, float *nn_d2)
     return OA_OK;
 }
 
-int launch_reduce(oa_ctx *c, double *d_sums)
+// rows the (non-emitting) accumulation of this context leaves for the reduce launch when it is its own kernel
+inline oa::RowSel plain_rows(const oa_ctx *c)
 {
-    hipLaunchKernelGGL(oa::k_reduce_partials, dim3(1), dim3(1024), 0, c->stream, c->d_partials, c->acc_blocks, d_sums);
+    const int cb = canon_blocks(c);
+    return oa::RowSel{ cb > 0 ? cb : c->acc_blocks, 0, 0 };
+}
+
+// rows of partials -> d_sums.  stamp: the launch marks the end of the search + accumulate part (fused searches)
+int launch_reduce(oa_ctx *c, double *d_sums, const oa::RowSel &sel, bool stamp)
+{
+    hipLaunchKernelGGL(oa::k_reduce_partials, dim3(1), dim3(oa::RED_THREADS), 0, c->stream, (const oa::DevState *)c->d_state,
+                       (const double *)c->d_partials, sel, d_sums, stamp ? &c->d_state->t_acc_start : (unsigned long long *)nullptr);
     HIPCHK(hipGetLastError());
+    return OA_OK;
+}
+
+// search + accumulate of one iteration, by the plan above; sel = the rows the reduce launch finds; fused = no separate
+// accumulation launch ran (the reduce launch then stamps the end of the search part)
+int launch_search_accumulate(oa_ctx *c, bool timed, oa::RowSel &sel, bool &fused)
+{
+    int rc;
+    // hipEvent pairs around the search cost ~7 us of stream time per iteration (two barrier packets): fine for the
+    // brute-force kernel (50 ms per launch), not for the grid / tree searches, whose launches are that short
+    // themselves -- those are timed on the GPU instead (DevState::t_prev_end / t_acc_start, StepRecord::search_ticks)
+    timed = timed && c->time_events;
+    const SearchPlan plan = search_plan(c);
+    fused = plan == PLAN_TREE || plan == PLAN_DUAL || (plan == PLAN_GRID && grid_fast_now(c));
+    c->iter_enq++;
+    if (timed) {
+        if ((rc = ensure_events(c, c->ev_used + 1))) return rc;
+        HIPCHK(hipEventRecord(c->ev[2 * c->ev_used], c->stream));
+    }
+    if ((rc = launch_nn(c, fused))) return rc;
+    if (timed) {
+        HIPCHK(hipEventRecord(c->ev[2 * c->ev_used + 1], c->stream));
+        c->ev_used++;
+    }
+    if (!fused) {
+        if ((rc = launch_accumulate(c, false, nullptr, nullptr))) return rc;
+        sel = plain_rows(c);
+        return OA_OK;
+    }
+    const int tree_rows = (int)bvh_blocks(c, false, true);
+    if (plan == PLAN_TREE) sel = oa::RowSel{ tree_rows, 0, 0 };
+    else sel = oa::RowSel{ canon_blocks(c), plan == PLAN_DUAL ? tree_rows : 0, plan == PLAN_DUAL ? 1 : 0 };
     return OA_OK;
 }
 
@@ -775,6 +906,8 @@ void init_loop_state(oa_ctx *c, const oa_settings *st, int iters, bool cutoff = 
     s.pad1 = 0.f; s.pad2 = 0;
     s.qmax = c->qmax;
     s.d_pivot = c->d_pivot0;
+    s.jac_valid = 0; s.pad4 = 0;                                    // every loop starts its Jacobi from the identity
+    for (int k = 0; k < 9; ++k) s.jac_v[k] = 0.0;
 }
 
 // oa_iterate opens a loop without an end; its history is a ring of the last ITERATE_RING iterations
@@ -792,7 +925,7 @@ int begin_loop(oa_ctx *c, const oa_settings *st, int iters)
     c->settings = *st;
     c->iterate_mode = false;
     HIPCHK(hipStreamSynchronize(c->stream));                    // nothing of an earlier loop may still write the host flag
-    if (c->h_poll) { c->h_poll[0] = 0; c->h_poll[1] = 0; }
+    if (c->h_poll) { for (int k = 0; k < 4; ++k) c->h_poll[k] = 0; }
     init_loop_state(c, st, iters);
     *c->h_state_pin = c->h_state;                               // pinned staging copy (the stream is idle, see above)
     HIPCHK(hipMemcpyAsync(c->d_state, c->h_state_pin, sizeof(oa::DevState), hipMemcpyHostToDevice, c->stream));
@@ -800,6 +933,7 @@ int begin_loop(oa_ctx *c, const oa_settings *st, int iters)
     hipLaunchKernelGGL(oa::k_stamp_start, dim3(1), dim3(64), 0, c->stream, c->d_state);
     HIPCHK(hipGetLastError());
     c->ev_used = 0;
+    c->iter_enq = 0;
     c->h_hist_valid = false;
     {
         const bool brute = !c->surface ? !(bvh_whole(c, c->bvh_ok, vertex_tree_max(c)) || grid_active(c))
@@ -812,22 +946,11 @@ int begin_loop(oa_ctx *c, const oa_settings *st, int iters)
 
 int iter_partial(oa_ctx *c, double *d_sums, bool timed)
 {
-    int rc;
-    // hipEvent pairs around the search cost ~7 us of stream time per iteration (two barrier packets): fine for the
-    // brute-force kernel (50 ms per launch), not for the grid / tree searches, whose launches are that short
-    // themselves -- those are timed on the GPU instead (DevState::t_prev_end / t_acc_start, StepRecord::search_ticks)
-    timed = timed && c->time_events;
-    if (timed) {
-        if ((rc = ensure_events(c, c->ev_used + 1))) return rc;
-        HIPCHK(hipEventRecord(c->ev[2 * c->ev_used], c->stream));
-    }
-    if ((rc = launch_nn(c))) return rc;
-    if (timed) {
-        HIPCHK(hipEventRecord(c->ev[2 * c->ev_used + 1], c->stream));
-        c->ev_used++;
-    }
-    if ((rc = launch_accumulate(c, false, nullptr, nullptr))) return rc;
-    return launch_reduce(c, d_sums);
+    oa::RowSel sel;
+    bool fused;
+    const int rc = launch_search_accumulate(c, timed, sel, fused);
+    if (rc) return rc;
+    return launch_reduce(c, d_sums, sel, fused);
 }
 
 int iter_finish(oa_ctx *c, const double *d_sums)
@@ -837,26 +960,15 @@ int iter_finish(oa_ctx *c, const double *d_sums)
     return OA_OK;
 }
 
-// single-GPU iteration: search, accumulate, then reduce + solve in one launch
+// single-GPU iteration: search (+ accumulate), then reduce + solve in one launch
 int iter_fused(oa_ctx *c, bool timed)
 {
-    int rc;
-    // hipEvent pairs around the search cost ~7 us of stream time per iteration (two barrier packets): fine for the
-    // brute-force kernel (50 ms per launch), not for the grid / tree searches, whose launches are that short
-    // themselves -- those are timed on the GPU instead (DevState::t_prev_end / t_acc_start, StepRecord::search_ticks)
-    timed = timed && c->time_events;
-    if (timed) {
-        if ((rc = ensure_events(c, c->ev_used + 1))) return rc;
-        HIPCHK(hipEventRecord(c->ev[2 * c->ev_used], c->stream));
-    }
-    if ((rc = launch_nn(c))) return rc;
-    if (timed) {
-        HIPCHK(hipEventRecord(c->ev[2 * c->ev_used + 1], c->stream));
-        c->ev_used++;
-    }
-    if ((rc = launch_accumulate(c, false, nullptr, nullptr))) return rc;
-    hipLaunchKernelGGL(oa::k_reduce_solve_update, dim3(1), dim3(512), 0, c->stream, c->d_state, (const double *)c->d_partials,
-                       c->acc_blocks, c->d_sums, c->d_hist, c->d_todo_count);
+    oa::RowSel sel;
+    bool fused;
+    const int rc = launch_search_accumulate(c, timed, sel, fused);
+    if (rc) return rc;
+    hipLaunchKernelGGL(oa::k_reduce_solve_update, dim3(1), dim3(oa::RED_THREADS), 0, c->stream, c->d_state,
+                       (const double *)c->d_partials, sel, c->d_sums, c->d_hist, c->d_todo_count, fused ? 1 : 0);
     HIPCHK(hipGetLastError());
     return OA_OK;
 }
@@ -883,6 +995,7 @@ int fill_report(oa_ctx *c, oa_report *rep)
     if (rc) return rc;
     const oa::DevState &s = c->h_state;
     memset(rep, 0, sizeof *rep);
+    if (c->h_poll && s.n > 0) c->last_todo_wave_max = c->h_poll[3];   // where the next loop's first grid search starts from (grid_fast_now)
     rep->iters_done = s.n;
     rep->converged = s.converged;
     rep->status = s.status;
@@ -1141,19 +1254,15 @@ int multi_iteration_group(oa_ctx *p, const std::vector<int> &group, bool timed)
     for (int i : group) {
         oa_ctx *c = p->subs[(size_t)i];
         if ((rc = use_device(c))) return rc;
-        const bool t = timed && c->time_events;
-        if (t) {
-            if ((rc = ensure_events(c, c->ev_used + 1))) return rc;
-            HIPCHK(hipEventRecord(c->ev[2 * c->ev_used], c->stream));
-        }
-        if ((rc = launch_nn(c))) return rc;
-        if (t) { HIPCHK(hipEventRecord(c->ev[2 * c->ev_used + 1], c->stream)); c->ev_used++; }
-        if ((rc = launch_accumulate(c, false, nullptr, nullptr))) return rc;
-        if (x->mode == OA_EXCHANGE_RCCL) rc = launch_reduce(c, c->d_sums);
+        oa::RowSel sel;
+        bool fused;
+        if ((rc = launch_search_accumulate(c, timed, sel, fused))) return rc;
+        if (x->mode == OA_EXCHANGE_RCCL) rc = launch_reduce(c, c->d_sums, sel, fused);
         else {
-            hipLaunchKernelGGL(oa::k_reduce_post, dim3(1), dim3(1024), 0, c->stream, (const oa::DevState *)c->d_state,
-                               (const double *)c->d_partials, c->acc_blocks, (oa::MailSlot *const *)x->d_dests[(size_t)c->rank],
-                               x->n_dest, c->rank, x->world, x->fault_skip_rank == c->rank ? 1 : 0);
+            hipLaunchKernelGGL(oa::k_reduce_post, dim3(1), dim3(oa::RED_THREADS), 0, c->stream, (const oa::DevState *)c->d_state,
+                               (const double *)c->d_partials, sel,
+                               (oa::MailSlot *const *)x->d_dests[(size_t)c->rank], x->n_dest, c->rank, x->world,
+                               x->fault_skip_rank == c->rank ? 1 : 0, fused ? &c->d_state->t_acc_start : (unsigned long long *)nullptr);
             HIPCHK(hipGetLastError());
         }
         if (rc) return rc;
@@ -1268,7 +1377,8 @@ int multi_group_loop(oa_ctx *p, size_t g, const oa_settings *st)
     const std::vector<int> &group = p->groups[g];
     if (group.empty()) return OA_OK;
     oa_ctx *c0 = p->subs[(size_t)group[0]];
-    const bool poll = c0->h_poll && st->early_exit && env_int("OA_RUN_POLL", 1);
+    // (the adaptive grid path needs recent news from the device too: then the host stays close even without early exit)
+    const bool poll = c0->h_poll && env_int("OA_RUN_POLL", 1) && (st->early_exit || (search_plan(c0) == PLAN_GRID && c0->grid_path == 0));
     const int lag = 2;
     volatile int32_t *progress = c0->h_poll;
     for (int it = 0; it < st->iters; ++it) {
@@ -1346,6 +1456,11 @@ OA_EXPORT int oa_create(oa_ctx **out, int device)
     c->use_filter = env_int("OA_NN_FILTER", 1) != 0;
     c->nn_mfma = env_int("OA_NN_MFMA", 0);
     c->grid_mode = env_int("OA_NN_GRID", -1);
+    c->fused_acc = env_int("OA_FUSED_ACC", 1);
+    {
+        const char *gp = getenv("OA_GRID_PATH");
+        c->grid_path = (gp && !strcmp(gp, "fast")) ? 1 : ((gp && !strcmp(gp, "safe")) ? 2 : 0);
+    }
     dev_cache().context_created();
     *out = c;
     return OA_OK;
@@ -1964,16 +2079,16 @@ int build_tri_grid(oa_ctx *c)
     return OA_OK;
 }
 
-int launch_tri_search(oa_ctx *c)
+int launch_tri_search(oa_ctx *c, bool acc)
 {
-    if (bvh_whole(c, c->tbvh_ok, tri_tree_max(c))) return launch_bvh<true>(c, nullptr, nullptr);
+    if (bvh_whole(c, c->tbvh_ok, tri_tree_max(c))) return launch_bvh<true>(c, nullptr, nullptr, -1, acc);
     const bool use_grid = c->tri_grid_ok && c->tbvh_ok && c->grid_mode != 0;
     if (c->debug)
         fprintf(stderr, "[oa] tri search: grid=%d ns=%d n_tris=%d state=%p src4=%p tri9=%p prev=%p keys=%p todo=%p/%p cells=%p/%p\n",
                 (int)use_grid, c->ns, c->n_tris, (void *)c->d_state, (void *)c->d_src4, (void *)c->d_tri9, (void *)c->d_prev,
                 (void *)c->d_keys, (void *)c->d_todo_list, (void *)c->d_todo_count, (void *)c->d_tcell_start, (void *)c->d_tcell_rec);
     if (use_grid) {
-        if (!c->loop_active) HIPCHK(hipMemsetAsync(c->d_todo_count, 0, sizeof(int), c->stream));
+        if (!c->loop_active) HIPCHK(hipMemsetAsync(c->d_todo_count, 0, 2 * sizeof(int), c->stream));
         const bool dual = c->grid_mode == -1 && c->turns_on && c->ns <= tri_tree_early(c);
         if (dual) { int rcb = launch_bvh<true>(c, nullptr, nullptr, 1); if (rcb) return rcb; }    // runs when DevState::tree_turn
         const int turn = dual ? 0 : -1;
@@ -2104,8 +2219,8 @@ int source_reset(oa_ctx *c, long long count, long long begin, long long n_verts)
     HIPCHK(hipMemsetAsync(c->d_sel, 0, sizeof(int) * (size_t)c->ns_pad, c->stream));
     dev_free(c->d_todo_list); dev_free(c->d_todo_count);
     HIPCHK(dev_malloc(&c->d_todo_list, sizeof(int) * (size_t)c->ns_pad));
-    HIPCHK(dev_malloc(&c->d_todo_count, sizeof(int)));
-    HIPCHK(hipMemsetAsync(c->d_todo_count, 0, sizeof(int), c->stream));
+    HIPCHK(dev_malloc(&c->d_todo_count, 2 * sizeof(int)));      // {entries of the hand-over list, most handed over by one wave}
+    HIPCHK(hipMemsetAsync(c->d_todo_count, 0, 2 * sizeof(int), c->stream));
     hipLaunchKernelGGL(oa::k_fill_int, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, c->d_prev, c->ns_pad, -1);
     hipLaunchKernelGGL(oa::k_fill_keys, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, c->d_keys, c->ns_pad);
     HIPCHK(hipGetLastError());
@@ -2374,6 +2489,7 @@ OA_EXPORT int oa_set_matrices(oa_ctx *c, const float mx_align[16], const float m
     memcpy(c->h_state.imx2, i2, sizeof i2);
     c->have_mats = true;
     c->loop_active = false;
+    c->last_todo_wave_max = -1;                                     // a new pose: what the last loop handed over says nothing about the next one
     return OA_OK;
 }
 
@@ -2617,7 +2733,7 @@ OA_EXPORT int oa_make_pairs(oa_ctx *c, double thresh, int calc_stats, double *A,
     if ((rc = push_state_for_oneshot(c, thresh, true))) return rc;
     if ((rc = launch_nn(c))) return rc;
     if ((rc = launch_accumulate(c, true, nullptr, nullptr))) return rc;
-    if ((rc = launch_reduce(c, c->d_sums))) return rc;
+    if ((rc = launch_reduce(c, c->d_sums, oa::RowSel{ c->acc_blocks, 0, 0 }, false))) return rc;   // (emitting accumulation: k_pair_accumulate<true>)
     if (calc_stats) {
         // np.std is two-pass; redo the (cheap) accumulation around the mean of the first pass so that the
         // population std is accurate even when it is tiny compared with the mean
@@ -2628,7 +2744,7 @@ OA_EXPORT int oa_make_pairs(oa_ctx *c, double thresh, int calc_stats, double *A,
             if ((rc = push_state_for_oneshot(c, thresh, true))) { c->d_pivot0 = 0.0; return rc; }
             rc = launch_nn(c);
             if (!rc) rc = launch_accumulate(c, true, nullptr, nullptr);
-            if (!rc) rc = launch_reduce(c, c->d_sums);
+            if (!rc) rc = launch_reduce(c, c->d_sums, oa::RowSel{ c->acc_blocks, 0, 0 }, false);
             if (rc) { c->d_pivot0 = 0.0; return rc; }
         }
     }
@@ -2698,7 +2814,8 @@ OA_EXPORT int oa_kabsch(oa_ctx *c, const double *A, const double *B, int64_t K, 
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(oa::ACC_MAX_BLOCKS, (K + oa::ACC_THREADS - 1) / oa::ACC_THREADS));
     hipLaunchKernelGGL(oa::k_accumulate_pairs, dim3(blocks), dim3(oa::ACC_THREADS), 0, c->stream, (const double *)dA.p,
                        (const double *)dB.p, (long long)K, (long long)K, pv[0], pv[1], pv[2], c->d_partials);
-    hipLaunchKernelGGL(oa::k_reduce_partials, dim3(1), dim3(1024), 0, c->stream, c->d_partials, blocks, c->d_sums);
+    hipLaunchKernelGGL(oa::k_reduce_partials, dim3(1), dim3(oa::RED_THREADS), 0, c->stream, (const oa::DevState *)nullptr,
+                       (const double *)c->d_partials, oa::RowSel{ blocks, 0, 0 }, c->d_sums, (unsigned long long *)nullptr);
     HIPCHK(hipGetLastError());
     rc = solve_on_device(c, c->d_sums, pv, with_scale, M);      // synchronises the stream
     if (rc) (void)hipStreamSynchronize(c->stream);
@@ -2820,7 +2937,9 @@ OA_EXPORT int oa_run(oa_ctx *c, const oa_settings *st, oa_report *rep)
     // The host also stays at most `lag` iterations ahead of the GPU (the solve kernel mirrors its iteration counter
     // next to the halt flag): enqueuing is much faster than executing, and a host that is 40 iterations ahead learns
     // about the halt too late to save anything.  Two iterations are always queued, so the GPU never idles.
-    const bool poll = c->h_poll && st->early_exit && env_int("OA_RUN_POLL", 1);
+    // The adaptive grid path (grid_fast_now) needs recent news from the device as well: then the host stays close even
+    // when the loop cannot end early.
+    const bool poll = c->h_poll && env_int("OA_RUN_POLL", 1) && (st->early_exit || (search_plan(c) == PLAN_GRID && c->grid_path == 0) || env_int("OA_RUN_THROTTLE", 0));
     const int lag = 2;
     volatile int32_t *progress = c->h_poll;
     for (int it = 0; it < st->iters; ++it) {

@@ -71,6 +71,11 @@ struct DevState {
     // (the host adds iters + 2 per loop), so a slot left over from an earlier loop can never be mistaken for a post of
     // this one and the mailboxes never have to be cleared (clearing them would need a cross-device ordering of its own)
     unsigned long long seq_base;
+    // Jacobi warm start (rotation_from_covariance): the right singular vectors of the last iteration's covariance.
+    // H = sum b a^T ~ R (sum a a^T), so H^T H -- what V diagonalises -- hardly changes from one iteration to the next:
+    // started from the last V a solve takes one sweep of small rotations instead of three (8 rotations -> 3).
+    double jac_v[9];
+    int32_t jac_valid, pad4;
 };
 
 // Squared local search radius for the query p (rounded up to float).  Derivation: the pair test measures
@@ -173,8 +178,36 @@ __host__ __device__ inline bool jacobi_rotate(double g[3][3], double v[3][3])
     // t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)), zeta = (nqq - npp) / (2 dpq), written with one division:
     // t = 2 dpq sign(w) / (|w| + sqrt(w^2 + 4 dpq^2)), w = nqq - npp
     const double w = nqq - npp, d2 = 2.0 * dpq;
-    const double t = (w >= 0.0 ? d2 : -d2) / (fabs(w) + sqrt(w * w + d2 * d2));
-    const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+    double c, s;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // On the device a rotation is a chain of dependent fp64 operations on ONE lane, and the IEEE sqrt and division
+    // sequences were four fifths of it (~0.5 us per rotation, 8 rotations per solve: tools/solve_microbench.hip).  The
+    // ANGLE only steers the convergence -- any (c, s) with c^2 + s^2 = 1 is an exact orthogonal update of g and v -- so
+    // t comes from the hardware's reciprocal-square-root / reciprocal seeds plus one Newton step each (relative error
+    // ~1e-13: the off-diagonal term this rotation is meant to cancel survives at that level and the next sweep's test
+    // sees it far below its threshold), and c = (1 + t^2)^(-1/2) from the seed plus two Newton steps (full precision,
+    // so that c^2 + s^2 = 1 to the last bits).  Out-of-range magnitudes take the IEEE formulas below.
+    const double h2 = __builtin_fma(w, w, d2 * d2);
+    if (h2 > 1e-280 && h2 < 1e280) {
+        const double y = __builtin_amdgcn_rsq(h2);
+        double hyp = h2 * y;
+        hyp = __builtin_fma(0.5 * y, __builtin_fma(-hyp, hyp, h2), hyp);
+        const double den = fabs(w) + hyp;
+        double r = __builtin_amdgcn_rcp(den);
+        r = __builtin_fma(r, __builtin_fma(-den, r, 1.0), r);
+        const double t = (w >= 0.0 ? d2 : -d2) * r;
+        const double q = __builtin_fma(t, t, 1.0);
+        c = __builtin_amdgcn_rsq(q);
+        c = c * __builtin_fma(-0.5 * q * c, c, 1.5);
+        c = c * __builtin_fma(-0.5 * q * c, c, 1.5);
+        s = c * t;
+    } else
+#endif
+    {
+        const double t = (w >= 0.0 ? d2 : -d2) / (fabs(w) + sqrt(w * w + d2 * d2));
+        c = 1.0 / sqrt(1.0 + t * t);
+        s = c * t;
+    }
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -192,21 +225,34 @@ __host__ __device__ inline double col3(const double m[3][3], int r, int j)
     return j == 0 ? m[r][0] : (j == 1 ? m[r][1] : m[r][2]);
 }
 
-__host__ __device__ inline void rotation_from_covariance(const double H[9], double R[9])
+// v_io (optional, 9 doubles, row-major): in = an orthogonal matrix to start from (the V of a similar covariance: then
+// g = H V has nearly orthogonal columns already), out = the V this solve ends with.  Any orthogonal start gives the same
+// singular vectors up to rounding.
+__host__ __device__ inline void rotation_from_covariance(const double H[9], double R[9], double *v_io = nullptr, bool v_valid = false)
 {
     double g[3][3], v[3][3];
-    g[0][0] = H[0]; g[0][1] = H[1]; g[0][2] = H[2];
-    g[1][0] = H[3]; g[1][1] = H[4]; g[1][2] = H[5];
-    g[2][0] = H[6]; g[2][1] = H[7]; g[2][2] = H[8];
-    v[0][0] = 1.0; v[0][1] = 0.0; v[0][2] = 0.0;
-    v[1][0] = 0.0; v[1][1] = 1.0; v[1][2] = 0.0;
-    v[2][0] = 0.0; v[2][1] = 0.0; v[2][2] = 1.0;
+    if (v_io && v_valid) {
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) v[i][j] = v_io[3 * i + j];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) g[i][j] = (H[3 * i] * v[0][j] + H[3 * i + 1] * v[1][j]) + H[3 * i + 2] * v[2][j];
+    } else {
+        g[0][0] = H[0]; g[0][1] = H[1]; g[0][2] = H[2];
+        g[1][0] = H[3]; g[1][1] = H[4]; g[1][2] = H[5];
+        g[2][0] = H[6]; g[2][1] = H[7]; g[2][2] = H[8];
+        v[0][0] = 1.0; v[0][1] = 0.0; v[0][2] = 0.0;
+        v[1][0] = 0.0; v[1][1] = 1.0; v[1][2] = 0.0;
+        v[2][0] = 0.0; v[2][1] = 0.0; v[2][2] = 1.0;
+    }
     for (int sweep = 0; sweep < 64; ++sweep) {
         bool any = jacobi_rotate<0, 1>(g, v);
         any = jacobi_rotate<0, 2>(g, v) || any;
         any = jacobi_rotate<1, 2>(g, v) || any;
         if (!any) break;
     }
+    if (v_io)
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) v_io[3 * i + j] = v[i][j];
     const double sg0 = sqrt(g[0][0] * g[0][0] + g[1][0] * g[1][0] + g[2][0] * g[2][0]);
     const double sg1 = sqrt(g[0][1] * g[0][1] + g[1][1] * g[1][1] + g[2][1] * g[2][1]);
     const double sg2 = sqrt(g[0][2] * g[0][2] + g[1][2] * g[1][2] + g[2][2] * g[2][2]);
@@ -220,10 +266,11 @@ __host__ __device__ inline void rotation_from_covariance(const double H[9], doub
     }
     const double s_j1 = j1 == 0 ? sg0 : (j1 == 1 ? sg1 : sg2), s_j2 = j2 == 0 ? sg0 : (j2 == 1 ? sg1 : sg2);
     double u1[3], u2[3], v1[3], v2[3];
+    const double i_j1 = (s_j1 > 0.0) ? 1.0 / s_j1 : 0.0, i_j2 = (s_j2 > 0.0) ? 1.0 / s_j2 : 0.0;   // (side by side: independent)
     for (int r = 0; r < 3; ++r) {
         v1[r] = col3(v, r, j1); v2[r] = col3(v, r, j2);
-        u1[r] = (s_j1 > 0.0) ? col3(g, r, j1) / s_j1 : (r == 0 ? 1.0 : 0.0);
-        u2[r] = (s_j2 > 0.0) ? col3(g, r, j2) / s_j2 : 0.0;
+        u1[r] = (s_j1 > 0.0) ? col3(g, r, j1) * i_j1 : (r == 0 ? 1.0 : 0.0);
+        u2[r] = (s_j2 > 0.0) ? col3(g, r, j2) * i_j2 : 0.0;
     }
     if (!(s_j2 > 0.0)) {   // rank <= 1: the rotation is not unique; complete u2 deterministically
         int m = 0;
@@ -243,17 +290,19 @@ __host__ __device__ inline void rotation_from_covariance(const double H[9], doub
 }
 
 // Solve from the accumulated sums.  Returns false when K < 3 (the reference's ValueError).
-__host__ __device__ inline bool solve_from_sums(const double *s, const double pivot[3], bool with_scale, double M[16])
+__host__ __device__ inline bool solve_from_sums(const double *s, const double pivot[3], bool with_scale, double M[16],
+                                                double *v_io = nullptr, bool v_valid = false)
 {
     const double K = s[S_K];
     if (!(K >= 3.0)) return false;
     double ca[3], cb[3];
-    for (int i = 0; i < 3; ++i) { ca[i] = s[S_A + i] / K; cb[i] = s[S_B + i] / K; }     // centroids (:160,:164)
+    const double inv_K = 1.0 / K;
+    for (int i = 0; i < 3; ++i) { ca[i] = s[S_A + i] * inv_K; cb[i] = s[S_B + i] * inv_K; }     // centroids (:160,:164)
     double H[9];
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) H[3 * i + j] = s[S_H + 3 * i + j] - K * cb[i] * ca[j];  // dot(v1c, v0c.T) (:181)
     double R[9];
-    rotation_from_covariance(H, R);
+    rotation_from_covariance(H, R, v_io, v_valid);
     double sc = 1.0;
     if (with_scale) {                                                                    // :208-212
         const double n0 = s[S_AA] - K * (ca[0] * ca[0] + ca[1] * ca[1] + ca[2] * ca[2]);
@@ -947,6 +996,135 @@ struct PairOut {            // optional per-point outputs for the make_pairs con
     const int *perm;        // sorted slot -> caller-order slot (nullptr = identity); outputs are in caller order
 };
 
+// ---- the pair test and its contribution to the sums: shared by k_pair_accumulate and by the search kernels that
+// accumulate in their epilogue (same operations, same order, same bits) ------------------------------------------------
+// (cx, cy, cz) = co_find, the source point in base-local space; (qx, qy, qz) = co1, its correspondence there;
+// tn = the correspondence's normal (only read when the normal-angle extension is on); slot = the source slot (normals).
+// Returns the reference's `dist < thresh` (functions/general.py:299-302) and, for a pair that passes, b = imx1 @ (mx2 @ co1).
+__device__ __forceinline__ bool pair_eval(const DevState *__restrict__ st, float cx, float cy, float cz, float qx, float qy,
+                                          float qz, const NormalTest &nrm, long long slot, const float *tn, double thresh,
+                                          float &bx, float &by, float &bz, double &dist)
+{
+    float ax, ay, az, wbx, wby, wbz;
+    m4_mul_v3(st->mx2, cx, cy, cz, ax, ay, az);         // mx2 @ co_find             (general.py:299)
+    m4_mul_v3(st->mx2, qx, qy, qz, wbx, wby, wbz);      // mx2 @ co1                 (general.py:299)
+    dist = v3_length(ax - wbx, ay - wby, az - wbz);
+    bool valid = dist < thresh;                        // face_index != -1 always holds (general.py:302)
+    if (valid && nrm.src_n) {
+        const float sn[3] = { nrm.src_n[3ll * slot], nrm.src_n[3ll * slot + 1], nrm.src_n[3ll * slot + 2] };
+        valid = normal_angle_ok(st->imx1, st->imx2, sn, tn, nrm.cos_min);
+    }
+    bx = by = bz = 0.f;
+    if (valid) m4_mul_v3(st->imx1, wbx, wby, wbz, bx, by, bz);   // imx1 @ (mx2 @ co1)  (general.py:304)
+    return valid;
+}
+
+__device__ __forceinline__ void pair_add(double (&acc)[NSUMS], float p_x, float p_y, float p_z, float bx, float by, float bz,
+                                         double dist, double pvx, double pvy, double pvz, double d_pivot)
+{
+    const double a0 = (double)p_x - pvx, a1 = (double)p_y - pvy, a2 = (double)p_z - pvz;
+    const double b0 = (double)bx - pvx, b1 = (double)by - pvy, b2 = (double)bz - pvz;
+    acc[S_A] += a0; acc[S_A + 1] += a1; acc[S_A + 2] += a2;
+    acc[S_B] += b0; acc[S_B + 1] += b1; acc[S_B + 2] += b2;
+    acc[S_H + 0] += b0 * a0; acc[S_H + 1] += b0 * a1; acc[S_H + 2] += b0 * a2;
+    acc[S_H + 3] += b1 * a0; acc[S_H + 4] += b1 * a1; acc[S_H + 5] += b1 * a2;
+    acc[S_H + 6] += b2 * a0; acc[S_H + 7] += b2 * a1; acc[S_H + 8] += b2 * a2;
+    acc[S_AA] += (a0 * a0 + a1 * a1) + a2 * a2;
+    acc[S_BB] += (b0 * b0 + b1 * b1) + b2 * b2;
+    acc[S_K] += 1.0;
+    const double dd = dist - d_pivot;
+    acc[S_D] += dd;
+    acc[S_DD] += dd * dd;
+}
+
+// every lane's acc -> the workgroup's totals -> one row of per-workgroup partials (wave butterfly, then the waves in
+// order through LDS: a fixed pattern, bitwise reproducible).  red: __shared__ double[blockDim.x / 64][NSUMS].
+// Called by ALL threads of the workgroup.
+__device__ __forceinline__ void block_store_partial(const double (&acc)[NSUMS], double (*red)[NSUMS], double *__restrict__ row)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    {
+        double tot[3];
+        int first;
+        wave_reduce_sums(acc, lane, tot, first);
+        if ((lane & 7) == 0) { red[wave][first] = tot[0]; red[wave][first + 1] = tot[1]; red[wave][first + 2] = tot[2]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < NSUMS) {
+        double v = red[0][threadIdx.x];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) v += red[w][threadIdx.x];
+        row[threadIdx.x] = v;
+    }
+}
+
+// The same for search kernels whose lanes hold ONE pair each (k_nn_search_grid<L, true>): the 20 sums are formed and
+// reduced in two halves of 12 and 8, so that the epilogue of a kernel built for 6 waves per SIMD (80 VGPRs) never holds 24
+// doubles plus the butterfly's temporaries at once.  Reduce-scatter over lane bits 5, 4 (, 3), then a plain butterfly.
+// (a, b) = the pair relative to the pivot, dd = dist - d_pivot; lanes without a valid pair contribute zeros.
+template <int N>
+__device__ __forceinline__ void wave_reduce_scatter(double (&v)[N], int lane, double *red_row)
+{
+    static_assert(N == 12 || N == 8, "halves of the 24 sums");
+    const bool b5 = (lane & 32) != 0, b4 = (lane & 16) != 0, b3 = (lane & 8) != 0;
+    double u[N / 2], w[3];                                          // (w: N / 4 values; 3 slots so that the N == 12 branch indexes in bounds when N == 8 is compiled)
+#pragma unroll
+    for (int k = 0; k < N / 2; ++k) {
+        const double keep = b5 ? v[N / 2 + k] : v[k], send = b5 ? v[k] : v[N / 2 + k];
+        u[k] = keep + __shfl_xor(send, 32, 64);
+    }
+#pragma unroll
+    for (int k = 0; k < N / 4; ++k) {
+        const double keep = b4 ? u[N / 4 + k] : u[k], send = b4 ? u[k] : u[N / 4 + k];
+        w[k] = keep + __shfl_xor(send, 16, 64);
+    }
+    if (N == 12) {                                                   // 3 values left, 16 lanes share them
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            double t = w[k];
+            t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 1, 64);
+            w[k] = t;
+        }
+        if ((lane & 15) == 0) {
+            const int first = (b5 ? 6 : 0) + (b4 ? 3 : 0);
+            red_row[first] = w[0]; red_row[first + 1] = w[1]; red_row[first + 2] = w[2];
+        }
+    } else {                                                         // 2 values left: one more halving, then 8 lanes share one
+        const double keep = b3 ? w[1] : w[0], send = b3 ? w[0] : w[1];
+        double t = keep + __shfl_xor(send, 8, 64);
+        t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 1, 64);
+        if ((lane & 7) == 0) red_row[(b5 ? 4 : 0) + (b4 ? 2 : 0) + (b3 ? 1 : 0)] = t;
+    }
+}
+
+// red: __shared__ double[blockDim.x / 64][NSUMS].  Called by ALL threads of the workgroup.
+// (Combining the workgroups' rows any further inside the launch -- groups of 16 meeting at a counter, rows and counter in
+// agent-scope atomics -- was built and measured: the store -> acknowledge -> atomic -> load chain adds 4-5 us to the end
+// of every launch, more than the wider reduction it saves; a reduction over several workgroups meeting at ONE counter
+// costs +8 us with 16 of them and +16..23 us with 64, with or without fences.  So: one row per workgroup, one wide
+// single-workgroup reduction behind it.)
+__device__ __forceinline__ void block_store_pair(bool valid, double a0, double a1, double a2, double b0, double b1, double b2,
+                                                 double dd, double (*red)[NSUMS], double *__restrict__ row)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (!valid) { a0 = a1 = a2 = b0 = b1 = b2 = dd = 0.0; }
+    {
+        double h[12] = { a0, a1, a2, b0, b1, b2, b0 * a0, b0 * a1, b0 * a2, b1 * a0, b1 * a1, b1 * a2 };   // sums 0 .. 11
+        wave_reduce_scatter<12>(h, lane, &red[wave][0]);
+    }
+    {
+        double h[8] = { b2 * a0, b2 * a1, b2 * a2, (a0 * a0 + a1 * a1) + a2 * a2, (b0 * b0 + b1 * b1) + b2 * b2,
+                        valid ? 1.0 : 0.0, dd, dd * dd };                                                       // sums 12 .. 19
+        wave_reduce_scatter<8>(h, lane, &red[wave][12]);
+    }
+    if (lane < 4) red[wave][20 + lane] = 0.0;                                                                   // reserved
+    __syncthreads();
+    if (threadIdx.x < NSUMS) {
+        double v = red[0][threadIdx.x];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) v += red[w][threadIdx.x];
+        row[threadIdx.x] = v;
+    }
+}
+
 template <bool EMIT>
 __global__ __launch_bounds__(ACC_THREADS) void k_pair_accumulate(const DevState *__restrict__ st,
                                                                  const float4 *__restrict__ src4, int ns,
@@ -1009,16 +1187,7 @@ __global__ __launch_bounds__(ACC_THREADS) void k_pair_accumulate(const DevState 
                     }
                     if (nrm.src_n) { tn[0] = nrm.tgt_n[3ll * idx]; tn[1] = nrm.tgt_n[3ll * idx + 1]; tn[2] = nrm.tgt_n[3ll * idx + 2]; }
                 }
-                float ax, ay, az, wbx, wby, wbz;
-                m4_mul_v3(st->mx2, cx, cy, cz, ax, ay, az);         // mx2 @ co_find             (general.py:299)
-                m4_mul_v3(st->mx2, qx, qy, qz, wbx, wby, wbz);      // mx2 @ co1                 (general.py:299)
-                dist = v3_length(ax - wbx, ay - wby, az - wbz);
-                valid = dist < thresh;                             // face_index != -1 always holds (general.py:302)
-                if (valid && nrm.src_n) {
-                    const float sn[3] = { nrm.src_n[3ll * i], nrm.src_n[3ll * i + 1], nrm.src_n[3ll * i + 2] };
-                    valid = normal_angle_ok(st->imx1, st->imx2, sn, tn, nrm.cos_min);
-                }
-                if (valid) m4_mul_v3(st->imx1, wbx, wby, wbz, bx, by, bz);   // imx1 @ (mx2 @ co1)  (general.py:304)
+                valid = pair_eval(st, cx, cy, cz, qx, qy, qz, nrm, i, tn, thresh, bx, by, bz, dist);
             }
             if (EMIT) {
                 const long long o = out.perm ? out.perm[i] : i;
@@ -1027,75 +1196,140 @@ __global__ __launch_bounds__(ACC_THREADS) void k_pair_accumulate(const DevState 
                 out.dist[o] = dist;
                 if (out.nn_idx) { out.nn_idx[o] = (int)idx; out.nn_d2[o] = __uint_as_float((uint32_t)(key >> 32)); }
             }
-            if (valid) {
-                const double a0 = (double)p.x - pvx, a1 = (double)p.y - pvy, a2 = (double)p.z - pvz;
-                const double b0 = (double)bx - pvx, b1 = (double)by - pvy, b2 = (double)bz - pvz;
-                acc[S_A] += a0; acc[S_A + 1] += a1; acc[S_A + 2] += a2;
-                acc[S_B] += b0; acc[S_B + 1] += b1; acc[S_B + 2] += b2;
-                acc[S_H + 0] += b0 * a0; acc[S_H + 1] += b0 * a1; acc[S_H + 2] += b0 * a2;
-                acc[S_H + 3] += b1 * a0; acc[S_H + 4] += b1 * a1; acc[S_H + 5] += b1 * a2;
-                acc[S_H + 6] += b2 * a0; acc[S_H + 7] += b2 * a1; acc[S_H + 8] += b2 * a2;
-                acc[S_AA] += (a0 * a0 + a1 * a1) + a2 * a2;
-                acc[S_BB] += (b0 * b0 + b1 * b1) + b2 * b2;
-                acc[S_K] += 1.0;
-                const double dd = dist - d_pivot;
-                acc[S_D] += dd;
-                acc[S_DD] += dd * dd;
-            }
+            if (valid) pair_add(acc, p.x, p.y, p.z, bx, by, bz, dist, pvx, pvy, pvz, d_pivot);
         }
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    {
-        double tot[3];
-        int first;
-        wave_reduce_sums(acc, lane, tot, first);
-        if ((lane & 7) == 0) { red[wave][first] = tot[0]; red[wave][first + 1] = tot[1]; red[wave][first + 2] = tot[2]; }
-    }
-    __syncthreads();
-    if (threadIdx.x < NSUMS) {
-        double v = red[0][threadIdx.x];
-        for (int w = 1; w < ACC_THREADS / 64; ++w) v += red[w][threadIdx.x];
-        partials[(long long)blockIdx.x * NSUMS + threadIdx.x] = v;
-    }
+    block_store_partial(acc, red, partials + (long long)blockIdx.x * NSUMS);
 }
 
-// fixed-order reduction of the per-block partials: 32 interleaved slices, then slices 0..31 in order.
-// Called by all THREADS (1024 or 512) threads of a block -- with 512 every 32-thread group sums two slices, one after
-// the other: same arithmetic, same bits; the totals land in out[0..NSUMS) (shared or global memory).
-template <int THREADS>
-__device__ __forceinline__ void reduce_partials_block(const double *__restrict__ partials, int n_blocks, double *out)
+// The stand-alone form of what k_nn_search_grid<L, true> does in its epilogue: one thread per (source slot, lane of the
+// query), the same pair test, the same reduction tree, the same rows -- BIT FOR BIT.  The loop switches between "the grid
+// search finishes and accumulates everything itself" and "grid search -> tree search of the hand-over list -> this kernel"
+// from one iteration to the next on what the host last heard about the list (oa_icp.hip: adaptive path), and that choice
+// depends on timing: it must not show in the sums.  The brute-force searches use it too (for shards whose rows fit), so
+// every search mode still ends with bitwise the same matrices.
+__global__ __launch_bounds__(256) void k_pair_accumulate_canon(const DevState *__restrict__ st, const float4 *__restrict__ src4,
+                                                               int ns, int L, const float *__restrict__ tgt_xyz,
+                                                               unsigned long long *__restrict__ keys, int *__restrict__ prev,
+                                                               float4 *__restrict__ win, const float4 *__restrict__ tri9,
+                                                               NormalTest nrm, double *__restrict__ partials,
+                                                               unsigned long long *__restrict__ t_acc_start)
 {
-    __shared__ double red[32][32];
-    const int j = threadIdx.x & 31;
-    for (int s = threadIdx.x >> 5; s < 32; s += THREADS / 32) {
-        double v = 0.0;
-        if (j < NSUMS) {
-            // loads eight rows ahead of the (ordered) adds: a plain loop serialises on the memory latency of every row
-            const double *__restrict__ col = partials + j;
-            int b = s;
-            for (; b + 7 * 32 < n_blocks; b += 8 * 32) {
-                double p[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) p[u] = col[(long long)(b + 32 * u) * NSUMS];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v += p[u];
+    __shared__ double red[4][NSUMS];
+    if (t_acc_start && blockIdx.x == 0 && threadIdx.x == 0) *t_acc_start = wall_clock64();   // ~ the end of the search
+    if (st->halt) return;
+    const int gt = blockIdx.x * 256 + threadIdx.x;
+    const int i = gt / L;
+    const bool mine = (gt - i * L) == 0 && i < ns;
+    bool valid = false;
+    float bx = 0.f, by = 0.f, bz = 0.f;
+    double dist = 0.0;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (mine) {
+        const unsigned long long key = keys[i];
+        keys[i] = KEY_EMPTY;                                       // ready for the next iteration's atomicMin
+        const uint32_t idx = (uint32_t)key;
+        if (prev) prev[i] = (idx == IDX_NONE) ? -1 : (int)idx;
+        p = src4[i];
+        float4 wrec = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+        if (win) wrec = win[i];
+        if (idx != IDX_NONE) {
+            float wx, wy, wz, cx, cy, cz;
+            m4_mul_v3(st->mx1, p.x, p.y, p.z, wx, wy, wz);
+            m4_mul_v3(st->imx2, wx, wy, wz, cx, cy, cz);           // co_find                   (general.py:287)
+            float qx, qy, qz;
+            float tn[3] = { 0.f, 0.f, 0.f };
+            if (tri9) {
+                float ta[3], tb[3], tc[3], rr[3];
+                const float cf[3] = { cx, cy, cz };
+                load_tri(tri9, idx, ta, tb, tc);
+                closest_on_tri(cf, ta, tb, tc, rr);
+                qx = rr[0]; qy = rr[1]; qz = rr[2];
+                if (nrm.src_n) {
+                    const float e1[3] = { ta[0] - tb[0], ta[1] - tb[1], ta[2] - tb[2] };
+                    const float e2[3] = { tb[0] - tc[0], tb[1] - tc[1], tb[2] - tc[2] };
+                    tn[0] = e1[1] * e2[2] - e1[2] * e2[1];
+                    tn[1] = e1[2] * e2[0] - e1[0] * e2[2];
+                    tn[2] = e1[0] * e2[1] - e1[1] * e2[0];
+                }
+            } else {
+                if ((uint32_t)__float_as_int(wrec.w) == idx) { qx = wrec.x; qy = wrec.y; qz = wrec.z; }
+                else {
+                    qx = tgt_xyz[3ll * idx]; qy = tgt_xyz[3ll * idx + 1]; qz = tgt_xyz[3ll * idx + 2];
+                    if (win) win[i] = make_float4(qx, qy, qz, __int_as_float((int)idx));
+                }
+                if (nrm.src_n) { tn[0] = nrm.tgt_n[3ll * idx]; tn[1] = nrm.tgt_n[3ll * idx + 1]; tn[2] = nrm.tgt_n[3ll * idx + 2]; }
             }
-            for (; b < n_blocks; b += 32) v += col[(long long)b * NSUMS];
+            valid = pair_eval(st, cx, cy, cz, qx, qy, qz, nrm, i, tn, st->thresh, bx, by, bz, dist);
         }
-        red[s][j] = v;
+    }
+    const double pvx = st->pivot[0], pvy = st->pivot[1], pvz = st->pivot[2];
+    block_store_pair(valid, (double)p.x - pvx, (double)p.y - pvy, (double)p.z - pvz, (double)bx - pvx, (double)by - pvy,
+                     (double)bz - pvz, dist - st->d_pivot, red, partials + (long long)blockIdx.x * NSUMS);
+}
+
+// ---- fixed-order reduction of the rows of per-workgroup partials (bitwise reproducible, no float atomics) -------------
+// A row is NSUMS doubles = 12 x 16 bytes.  1024 threads = 85 slices of 12 threads: slice s adds rows s, s + 85, ... in
+// order (thread c of a slice owns columns 2c, 2c + 1 and loads them as one 16-byte word, 16 rows in flight per thread),
+// then the slices are added in order.  Round 2's version (32 slices of 32 threads, 8 rows in flight) was sized for the
+// <= 512 rows of k_pair_accumulate; the search kernels that accumulate in their epilogue write one row per workgroup,
+// up to 4096 of them, and a chain of 16 round trips per thread would cost more than the launch the fusion saves.
+constexpr int RED_THREADS = 1024;
+constexpr int RED_SLICES = RED_THREADS / 12;        // 85
+
+// rows [0, n_rows) of `rows` -> out[0 .. NSUMS) (shared or global).  Called by all RED_THREADS threads of a workgroup.
+__device__ __forceinline__ void reduce_rows_block(const double *__restrict__ rows, int n_rows, double *out)
+{
+    __shared__ double red[RED_SLICES][NSUMS];
+    const int s = threadIdx.x / 12, c = threadIdx.x - 12 * s;
+    if (s < RED_SLICES) {
+        double v0 = 0.0, v1 = 0.0;
+        const double2 *__restrict__ col = (const double2 *)rows + c;       // row r, columns 2c, 2c+1: col[12 r]
+        int r = s;
+        for (; r + 15 * RED_SLICES < n_rows; r += 16 * RED_SLICES) {
+            double2 p[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) p[u] = col[12ll * (r + RED_SLICES * u)];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { v0 += p[u].x; v1 += p[u].y; }
+        }
+        for (; r + 3 * RED_SLICES < n_rows; r += 4 * RED_SLICES) {
+            double2 p[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) p[u] = col[12ll * (r + RED_SLICES * u)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { v0 += p[u].x; v1 += p[u].y; }
+        }
+        for (; r < n_rows; r += RED_SLICES) { const double2 q = col[12ll * r]; v0 += q.x; v1 += q.y; }
+        red[s][2 * c] = v0; red[s][2 * c + 1] = v1;
     }
     __syncthreads();
     if (threadIdx.x < NSUMS) {
         double t = red[0][threadIdx.x];
-        for (int k = 1; k < 32; ++k) t += red[k][threadIdx.x];
+        for (int k = 1; k < RED_SLICES; ++k) t += red[k][threadIdx.x];
         out[threadIdx.x] = t;
     }
 }
 
-__global__ __launch_bounds__(1024) void k_reduce_partials(const double *__restrict__ partials, int n_blocks,
-                                                          double *__restrict__ sums)
+// How many rows a reduce launch has to add up.  Shards in the zone where the tree and the grid search take turns
+// (DevState::tree_turn) have both searches enqueued and only one of them writes rows: the count is picked on the device.
+struct RowSel {
+    int n, n_tree;      // rows (of the grid search / the only search); rows the whole-tree search writes
+    int by_turn;        // 1: n_tree when DevState::tree_turn, n otherwise
+};
+__device__ __forceinline__ int rows_of(const RowSel &sel, const DevState *st)
 {
-    reduce_partials_block<1024>(partials, n_blocks, sums);
+    return (sel.by_turn && st->tree_turn != 0) ? sel.n_tree : sel.n;
+}
+
+// stamp: where the launch leaves wall_clock64() at its start (the end of the search + accumulate part of the iteration,
+// DevState::t_acc_start), or nullptr
+__global__ __launch_bounds__(RED_THREADS) void k_reduce_partials(const DevState *__restrict__ st, const double *__restrict__ partials,
+                                                                 RowSel sel, double *__restrict__ sums_out,
+                                                                 unsigned long long *__restrict__ stamp)
+{
+    if (stamp && threadIdx.x == 0) *stamp = wall_clock64();
+    reduce_rows_block(partials, st ? rows_of(sel, st) : sel.n, sums_out);
 }
 
 // sums over explicit pairs (contract 2: oa_kabsch).  A, B: 3 x K row-major with leading dimension ld.
@@ -1120,19 +1354,7 @@ __global__ __launch_bounds__(ACC_THREADS) void k_accumulate_pairs(const double *
         acc[S_BB] += (b0 * b0 + b1 * b1) + b2 * b2;
         acc[S_K] += 1.0;
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    {
-        double tot[3];
-        int first;
-        wave_reduce_sums(acc, lane, tot, first);
-        if ((lane & 7) == 0) { red[wave][first] = tot[0]; red[wave][first + 1] = tot[1]; red[wave][first + 2] = tot[2]; }
-    }
-    __syncthreads();
-    if (threadIdx.x < NSUMS) {
-        double v = red[0][threadIdx.x];
-        for (int w = 1; w < ACC_THREADS / 64; ++w) v += red[w][threadIdx.x];
-        partials[(long long)blockIdx.x * NSUMS + threadIdx.x] = v;
-    }
+    block_store_partial(acc, red, partials + (long long)blockIdx.x * NSUMS);
 }
 
 // one thread: solve only (oa_kabsch / oa_kabsch_from_sums).  out[0..15] = M, out[16] = ok flag
@@ -1154,15 +1376,23 @@ __global__ void k_solve_only(const double *__restrict__ sums, double pvx, double
 __device__ __forceinline__ void solve_update_body(DevState *__restrict__ st, const double *sums, StepRecord *__restrict__ hist,
                                                   int *__restrict__ todo_count)
 {
-    if (todo_count) *todo_count = 0;                                // the grid search's unsettled list restarts empty
+    // the grid search's hand-over list restarts empty; what it held -- entries, and the most any one wave handed over --
+    // goes to the host, which decides from it whether the next grid search can finish its leftovers itself
+    const int todo_n = todo_count ? todo_count[0] : 0, todo_wave_max = todo_count ? todo_count[1] : 0;
+    if (todo_count) { todo_count[0] = 0; todo_count[1] = 0; }
     if (st->halt) return;
     double s[NSUMS], M[16];
     for (int k = 0; k < NSUMS; ++k) s[k] = sums[k];
-    if (!solve_from_sums(s, st->pivot, st->with_scale != 0, M)) {   // K < 3 -> ValueError in the reference
+    double jv[9];
+    const bool jv_valid = st->jac_valid != 0;
+    for (int k = 0; k < 9; ++k) jv[k] = jv_valid ? st->jac_v[k] : 0.0;
+    if (!solve_from_sums(s, st->pivot, st->with_scale != 0, M, jv, jv_valid)) {   // K < 3 -> ValueError in the reference
         st->status = -3;                                            // OA_E_TOO_FEW_PAIRS
         st->halt = 1;
         return;
     }
+    for (int k = 0; k < 9; ++k) st->jac_v[k] = jv[k];
+    st->jac_valid = 1;
     float new_mat[16];
     for (int k = 0; k < 16; ++k) new_mat[k] = (float)M[k];          // new_mat[y][z] = M[y][z]      (:116-119)
     float mw[16];
@@ -1202,6 +1432,8 @@ __device__ __forceinline__ void solve_update_body(DevState *__restrict__ st, con
     }
     st->t_prev_end = wall_clock64();                                // the next search starts (about) now
     if (st->host_halt) {                                            // progress and halt flag for the enqueuing host
+        st->host_halt[2] = todo_n;
+        st->host_halt[3] = todo_wave_max;
         st->host_halt[1] = st->n;
         if (st->halt) st->host_halt[0] = 1;
         __threadfence_system();
@@ -1223,13 +1455,13 @@ __global__ __launch_bounds__(64) void k_solve_update(DevState *__restrict__ st, 
 }
 
 // single-GPU form: the fixed-order reduction and the solve in one launch (same arithmetic, one boundary less)
-// (512 threads: the one-thread solve needs more than the 128 registers a 1024-thread workgroup leaves a lane)
-__global__ __launch_bounds__(512) void k_reduce_solve_update(DevState *__restrict__ st, const double *__restrict__ partials,
-                                                              int n_blocks, double *__restrict__ sums_out,
-                                                              StepRecord *__restrict__ hist, int *__restrict__ todo_count)
+__global__ __launch_bounds__(RED_THREADS) void k_reduce_solve_update(DevState *__restrict__ st, const double *__restrict__ partials,
+                                                                     RowSel sel, double *__restrict__ sums_out,
+                                                                     StepRecord *__restrict__ hist, int *__restrict__ todo_count, int stamp)
 {
     __shared__ double sums[NSUMS];
-    reduce_partials_block<512>(partials, n_blocks, sums);
+    if (stamp && threadIdx.x == 0) st->t_acc_start = wall_clock64();   // the search + accumulate part ends here
+    reduce_rows_block(partials, rows_of(sel, st), sums);
     __syncthreads();
     if (threadIdx.x < NSUMS && sums_out) sums_out[threadIdx.x] = sums[threadIdx.x];
     if (threadIdx.x == 0) solve_update_body(st, sums, hist, todo_count);
@@ -1258,23 +1490,24 @@ constexpr int STATUS_EXCHANGE = -9;  // OA_E_RCCL: a rank's post did not arrive 
 // mailboxes: one inbox per rank, each in that rank's own HBM and peer-mapped -- a post is `world` remote writes of
 // 200 B that travel over xGMI (PUSH model: every rank later polls its OWN memory).  skip != 0: fault injection
 // (OA_FAULT_SKIP_POST_RANK), this rank's sums never arrive and the world's gather kernels run into their time limit.
-__global__ __launch_bounds__(1024) void k_reduce_post(const DevState *__restrict__ st, const double *__restrict__ partials,
-                                                      int n_blocks, MailSlot *const *__restrict__ dests, int n_dest, int rank,
-                                                      int world, int skip)
+__global__ __launch_bounds__(RED_THREADS) void k_reduce_post(const DevState *__restrict__ st, const double *__restrict__ partials,
+                                                             RowSel sel, MailSlot *const *__restrict__ dests, int n_dest, int rank,
+                                                             int world, int skip, unsigned long long *__restrict__ stamp)
 {
+    if (stamp && threadIdx.x == 0) *stamp = wall_clock64();
     if (st->halt || skip) return;
     __shared__ double sums[NSUMS];
-    reduce_partials_block<1024>(partials, n_blocks, sums);
+    reduce_rows_block(partials, rows_of(sel, st), sums);
     __syncthreads();
     const unsigned long long seq = st->seq_base + (unsigned long long)st->n + 1ull;
     const size_t slot_ix = (size_t)(seq & 1ull) * world + rank;
-    for (int e = threadIdx.x; e < n_dest * 32; e += 1024) {          // 32 threads per destination, all destinations in flight
+    for (int e = threadIdx.x; e < n_dest * 32; e += RED_THREADS) {   // 32 threads per destination, all destinations in flight
         const int d = e >> 5, k = e & 31;
         if (k < NSUMS) __hip_atomic_store(&dests[d][slot_ix].sums[k], sums[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     __threadfence_system();
     __syncthreads();
-    for (int d = threadIdx.x; d < n_dest; d += 1024)
+    for (int d = threadIdx.x; d < n_dest; d += RED_THREADS)
         __hip_atomic_store(&dests[d][slot_ix].seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 

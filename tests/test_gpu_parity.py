@@ -1333,7 +1333,10 @@ def test_step_mode_equals_fused_loop_surface_and_shards(mode):
 def test_search_mode_changes_between_steps():
     """The per-slot winner records (vertex mode) are written by the grid / tree searches and by k_pair_accumulate
     after a brute-force search; whatever mode ran last, the next step must see a consistent seed.  Step-by-step
-    loops that switch the search mode every iteration give bitwise the same steps as one mode throughout."""
+    loops that switch the search mode every iteration give the same steps as one mode throughout: bitwise between the
+    brute-force and the grid search (both end in the canonical accumulation, k_pair_accumulate_canon or its fused twin in
+    the grid search's epilogue); K exact and M to 1e-12 once the whole-shard tree search takes a step (it keeps running
+    sums per wave, another summation order)."""
     from object_alignment_amd import synth
     from object_alignment_amd.engine import IcpEngine
     rng = np.random.default_rng(77)
@@ -1364,7 +1367,10 @@ def test_search_mode_changes_between_steps():
         got, idx, d2 = steps(modes)
         for k, (a, b) in enumerate(zip(ref, got)):
             assert a[1] == b[1], (modes, k)
-            assert np.array_equal(a[0], b[0]) and a[2] == b[2], (modes, k)
+            if "bvh" in modes:
+                assert np.abs(a[0] - b[0]).max() < 1e-12 and abs(a[2] - b[2]) <= 1e-12 * abs(a[2]), (modes, k)
+            else:
+                assert np.array_equal(a[0], b[0]) and a[2] == b[2], (modes, k)
         assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2)
 
 
@@ -1413,5 +1419,5 @@ def test_tree_then_grid_turns(surface):
     assert ref[0][1] > 0.9 * ns and ref[-1][2] < ref[0][2]              # a real, converging run
     for env in (None, {"OA_SEARCH_TURNS": "0"}, {"OA_TURN_FRAC": "0"}, {"OA_TURN_FRAC": "1e9"}):
         got = steps("auto", env)
-        for k, (a, b) in enumerate(zip(ref, got)):
-            assert a[1] == b[1] and a[2] == b[2] and np.array_equal(a[0], b[0]), (env, k)
+        for k, (a, b) in enumerate(zip(ref, got)):      # (the whole-shard tree search sums per wave: another order than the canonical rows)
+            assert a[1] == b[1] and abs(a[2] - b[2]) <= 1e-12 * abs(a[2]) and np.abs(a[0] - b[0]).max() < 1e-12, (env, k)
