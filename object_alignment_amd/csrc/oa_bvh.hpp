@@ -311,9 +311,9 @@ __global__ __launch_bounds__(ACC ? 1024 : 256) void k_bvh_search(const DevState 
     const BvhLds lds{ &s_lb[w][0][0], BVH_W, &s_mask[w][0], 1, &s_node[w][0], 1 };
     const int n_items = list ? *list_count : ns;
     const int n_waves = gridDim.x * WPB;
-    // ACC: the wave's running sums live in LDS, number k owned by lane k (in registers the 24 doubles would sit there
-    // through the whole descent and halve the kernel's occupancy)
-    if (ACC) { if (lane < NSUMS) red[w][lane] = 0.0; }
+    // ACC: the wave's running sums: lane k owns number k, ONE double per lane (all 24 in every lane would sit in registers
+    // through the whole descent and halve the kernel's occupancy; in LDS every query paid 20 read-modify-write round trips)
+    double lane_sum = 0.0;
     const double thresh = st->thresh, pvx = st->pivot[0], pvy = st->pivot[1], pvz = st->pivot[2], d_pivot = st->d_pivot;
 
     for (int slot = blockIdx.x * WPB + w; slot < n_items; slot += n_waves) {
@@ -380,8 +380,9 @@ __global__ __launch_bounds__(ACC ? 1024 : 256) void k_bvh_search(const DevState 
                     const double a0 = (double)p4.x - pvx, a1 = (double)p4.y - pvy, a2 = (double)p4.z - pvz;
                     const double b0 = (double)vbx - pvx, b1 = (double)vby - pvy, b2 = (double)vbz - pvz;
                     const double dd = dist - d_pivot;
-                    double *row = red[w];
-#define OA_LANE_ADD(k, expr) if (lane == (k)) row[k] += (expr)
+                    // the pair's terms are wave-uniform: every lane forms them, lane k keeps number k
+                    double mine = 0.0;
+#define OA_LANE_ADD(k, expr) mine = (lane == (k)) ? (expr) : mine
                     OA_LANE_ADD(S_A, a0); OA_LANE_ADD(S_A + 1, a1); OA_LANE_ADD(S_A + 2, a2);
                     OA_LANE_ADD(S_B, b0); OA_LANE_ADD(S_B + 1, b1); OA_LANE_ADD(S_B + 2, b2);
                     OA_LANE_ADD(S_H + 0, b0 * a0); OA_LANE_ADD(S_H + 1, b0 * a1); OA_LANE_ADD(S_H + 2, b0 * a2);
@@ -393,6 +394,7 @@ __global__ __launch_bounds__(ACC ? 1024 : 256) void k_bvh_search(const DevState 
                     OA_LANE_ADD(S_D, dd);
                     OA_LANE_ADD(S_DD, dd * dd);
 #undef OA_LANE_ADD
+                    lane_sum += mine;
                 }
             }
         } else if (lane == 0) {
@@ -402,6 +404,7 @@ __global__ __launch_bounds__(ACC ? 1024 : 256) void k_bvh_search(const DevState 
     }
     if (ACC) {
         // the waves' sums, added in order
+        if (lane < NSUMS) red[w][lane] = lane_sum;
         __syncthreads();
         if (threadIdx.x < NSUMS) {
             double t = red[0][threadIdx.x];

@@ -3,8 +3,8 @@
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/gpurun_out/prof_fused
-for fused in 1 0; do
-  for cfg in c1 c3; do
+for fused in 1; do
+  for cfg in c1 c2 c3; do
     OA_FUSED_ACC=$fused rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_fused/${cfg}_f${fused} -o out -- python $R/tools/run_cfg.py $cfg 200 > /dev/null 2>&1
     f=$(find $R/gpurun_out/prof_fused/${cfg}_f${fused} -name "*kernel_stats.csv" | head -1)
     echo "== $cfg fused=$fused"; python3 - "$f" <<'PY'

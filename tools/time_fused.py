@@ -53,6 +53,8 @@ run("C3  1M <-> 1M random", s, t, a, b, 200)
 run("C3  cold, 5 iterations", s, t, a, b, 5, cold=True)
 run("C3  cold, 50 iterations", s, t, a, b, 50, cold=True)
 run("C4  shard-size 125k <-> 1M", s[:125_000], t, a, b, 200)
+run("12k <-> 1M (whole-shard tree)", s[:12_000], t, a, b, 200)
+run("24k <-> 1M (tree / grid turns)", s[:24_000], t, a, b, 200)
 far = synth.rigid4(synth.rotation_from_rotvec([0.2, -0.1, 0.15]), [0.3, -0.2, 0.25])
 s2, t2, a2, _ = synth.c2_bunny_pair(100_000)
 run("100k bunny, far start, cold 10 iterations", s2, t2, far, eye, 10, cold=True, thresh=1.0)
