@@ -37,6 +37,7 @@ class _Run:
     use_target: bool
     with_scale: bool
     drag_m_objects: bool
+    stride: int = 1
     done: int = 0
     converged: bool = False
     last_stats: dict | None = None
@@ -73,8 +74,9 @@ class OBJECT_OT_icp_align_feedback(_OperatorBase):
                    with_scale=(prefs.align_meth == '1'), drag_m_objects=bool(prefs.take_m_with))
         run.ring_t = [run.target_d * 2.0] * RING
         run.ring_r = [None] * RING
+        run.stride = round(1 / prefs.sample_fraction)
         self._run = run
-        self._upload(run, stride=round(1 / prefs.sample_fraction), context=context)
+        self._upload(run, stride=run.stride, context=context)
         try:
             align.rotation_mode = 'QUATERNION'
         except Exception:
@@ -113,6 +115,11 @@ class OBJECT_OT_icp_align_feedback(_OperatorBase):
     # ------------------------------------------------------------------ one device iteration
     def iterate(self, context):
         run = self._run
+        # the engine is the process-wide one: a plain ICP call or a make_pairs between two timer ticks may have replaced
+        # its geometry and matrices -- then this run's state goes up again (from the pose reached so far) before it steps
+        eng = self.engine
+        if eng.target_owner is not self or eng.source_owner is not self:
+            self._upload(run, stride=run.stride, context=context)
         M, stats = self.engine.iterate(thresh=run.thresh, target_d=run.target_d, use_target=run.use_target,
                                        with_scale=run.with_scale)
         _assign_matrix(run.align_obj, self.engine.matrix_world())
@@ -138,6 +145,7 @@ class OBJECT_OT_icp_align_feedback(_OperatorBase):
             eng.set_target_mesh(_coords_of(base_geo), tris)
         eng.set_source(_coords_of(run.align_obj), vlist=vlist_for_engine(run.align_obj), stride=stride)
         eng.set_matrices(_matrix_to_np(run.align_obj.matrix_world), _matrix_to_np(run.base_obj.matrix_world))
+        eng.target_owner = eng.source_owner = self                  # GpuBVH and this operator check these before they trust the engine
 
     @staticmethod
     def _apply_to_m_objects(context, new_mat):
