@@ -360,6 +360,7 @@ struct oa_ctx {
     long long shard_begin = 0;
     int *d_pos = nullptr;            // oa_make_pairs on a shard: whole-selection position of every pair
     std::vector<int> h_members;      // host copy of d_members (children of a multi-device context)
+    int mfma_wps = 4;                // OA_MFMA_WPS: waves per SIMD k_nn_search_mfma is built for (4: 128 registers, 3: 168, 2: 256)
     int nn_mfma = 0;                 // OA_NN_MFMA=1 (experiment): first filter level of the brute-force search on the matrix cores (oa_mfma.hpp)
     oa::half8 *d_tfm = nullptr;      // its image of the target
     double mfma_sigma = 1.0;
@@ -729,8 +730,11 @@ int launch_nn_impl(oa_ctx *c, bool acc)
 #define OA_NN_ARGS c->d_state, c->d_src4, c->d_tg, c->groups_per_split, c->n_groups_pad, c->d_keys
 #define OA_NNF_ARGS c->d_state, c->d_src4, c->d_tg, c->d_tf, c->d_tf3, (const float4 *)c->d_win, c->groups_per_split, c->n_groups_pad, c->d_keys
     if (c->filter_ok && c->use_filter && c->nn_mfma && c->d_tfm && c->R == 4 && c->tile_groups == oa::FTILE_GROUPS) {
-        hipLaunchKernelGGL(oa::k_nn_search_mfma, grid, block, 0, c->stream, c->d_state, c->d_src4, c->d_tg,
-                           (const oa::half8 *)c->d_tfm, (const float4 *)c->d_win, c->groups_per_split, c->n_groups_pad, c->mfma_sigma, c->d_keys);
+#define OA_MFMA_ARGS c->d_state, c->d_src4, c->d_tg, (const oa::half8 *)c->d_tfm, (const float4 *)c->d_win, c->groups_per_split, c->n_groups_pad, c->mfma_sigma, c->d_keys
+        if (c->mfma_wps == 2) hipLaunchKernelGGL(oa::k_nn_search_mfma<2>, grid, block, 0, c->stream, OA_MFMA_ARGS);
+        else if (c->mfma_wps == 3) hipLaunchKernelGGL(oa::k_nn_search_mfma<3>, grid, block, 0, c->stream, OA_MFMA_ARGS);
+        else hipLaunchKernelGGL(oa::k_nn_search_mfma<4>, grid, block, 0, c->stream, OA_MFMA_ARGS);
+#undef OA_MFMA_ARGS
     } else if (c->filter_ok && c->use_filter) {
         const bool small = (c->tile_groups == 64);
 #define OA_LAUNCH_F(RR)                                                                                              \
@@ -1459,6 +1463,7 @@ OA_EXPORT int oa_create(oa_ctx **out, int device)
     c->turn_frac = env_double("OA_TURN_FRAC", 0.1);
     c->use_filter = env_int("OA_NN_FILTER", 1) != 0;
     c->nn_mfma = env_int("OA_NN_MFMA", 0);
+    c->mfma_wps = env_int("OA_MFMA_WPS", 4);
     c->grid_mode = env_int("OA_NN_GRID", -1);
     c->fused_acc = env_int("OA_FUSED_ACC", 1);
     c->tree_acc_max = env_int("OA_TREE_ACC_MAX", 4096);

@@ -137,7 +137,8 @@ __device__ __forceinline__ half8 shfl_xor32_half8(half8 v)
 // Same launch geometry and the same reporting as k_nn_search_filtered<4, 256>; `tfm` is the MFMA image (through LDS),
 // `tg` the exact target image (read from global memory by the slow path).  A wave's 256 points form 8 blocks of 32 columns: block
 // (r, h) = register r of lanes 32 h .. 32 h + 31.
-__global__ __launch_bounds__(NN_THREADS, 4) void k_nn_search_mfma(const DevState *__restrict__ st,
+template <int WPS>
+__global__ __launch_bounds__(NN_THREADS, WPS) void k_nn_search_mfma(const DevState *__restrict__ st,
                                                                 const float4 *__restrict__ src4,
                                                                 const float4 *__restrict__ tg,
                                                                 const half8 *__restrict__ tfm,
