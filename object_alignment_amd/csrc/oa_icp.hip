@@ -1531,8 +1531,17 @@ OA_EXPORT int oa_create_multi(oa_ctx **out, const int *devices, int n_dev)
                 groups[g].push_back(i);
             }
         };
+        // (per-child loop threads only while the children of a GPU fit its hardware queues -- HIP multiplexes streams
+        //  over 4 of them -- or two children's packets can end up in one queue in the wrong order; a test-box matter:
+        //  on distinct GPUs every child has a device of its own)
+        int max_on_one = 0;
+        for (int i = 0; i < n_dev; ++i) {
+            int same = 0;
+            for (int j = 0; j < n_dev; ++j) same += devices[j] == devices[i] ? 1 : 0;
+            max_on_one = std::max(max_on_one, same);
+        }
         deal(p->upload_groups, threads > 0);
-        deal(p->groups, threads > 0 && own_streams);
+        deal(p->groups, threads > 0 && own_streams && max_on_one <= 4);
         const size_t n_threads = std::max(p->groups.size(), p->upload_groups.size());
         if (n_threads > 1) {
             p->pool = new (std::nothrow) WorkerPool();
@@ -2949,7 +2958,7 @@ OA_EXPORT int oa_run(oa_ctx *c, const oa_settings *st, oa_report *rep)
     // about the halt too late to save anything.  Two iterations are always queued, so the GPU never idles.
     // The adaptive grid path (grid_fast_now) needs recent news from the device as well: then the host stays close even
     // when the loop cannot end early.
-    const bool poll = c->h_poll && env_int("OA_RUN_POLL", 1) && (st->early_exit || (search_plan(c) == PLAN_GRID && c->grid_path == 0) || env_int("OA_RUN_THROTTLE", 0));
+    const bool poll = c->h_poll && env_int("OA_RUN_POLL", 1) && (st->early_exit || (search_plan(c) == PLAN_GRID && c->grid_path == 0));
     const int lag = 2;
     volatile int32_t *progress = c->h_poll;
     for (int it = 0; it < st->iters; ++it) {
