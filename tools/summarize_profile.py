@@ -107,9 +107,25 @@ def main():
                                         write_size_kb=mean[(k, "WRITE_SIZE")], source=rel)
         if per_pair is not None:
             tr["1000000x1000000_n1"]["valu_instructions_per_pair"] = per_pair
-    gk = [k for k in traffic if k.startswith("k_nn_search_grid")]          # k_nn_search_grid<1> at this size
+    gk = sorted((k for k in traffic if k.startswith("k_nn_search_grid")), key=lambda k: "true" not in k)   # the loop's kernel first: k_nn_search_grid<1, true>
     if gk:
         tr["grid_1000000x1000000_n1"] = dict(stamp, kernel=gk[0], bytes_per_launch=traffic[gk[0]], source=rel)
+    # ---- two shards on this GPU (python bench.py --gpus 2 with OA_BENCH_SAME_DEVICE=1): the figures an N = 2 line reports
+    agg2 = collect(("prof_n2_FETCH_SIZE", "prof_n2_WRITE_SIZE", "prof_n2_SQ"), lambda k: k.startswith("k_nn_search_filtered"))
+    if agg2:
+        lines.append("")
+        lines.append("# two shards of 500k points on this GPU (OA_BENCH_SAME_DEVICE=1 python bench.py --gpus 2 ...): per-dispatch means")
+        mean2, traffic2 = table(agg2, lines)
+        b2 = [k for k in traffic2 if k.startswith("k_nn_search_filtered")]
+        if b2:
+            e2 = dict(stamp, kernel=b2[0], bytes_per_launch=traffic2[b2[0]], fetch_size_kb=mean2[(b2[0], "FETCH_SIZE")],
+                      write_size_kb=mean2[(b2[0], "WRITE_SIZE")], source=rel,
+                      note="measured with both shards on ONE GPU (OA_BENCH_SAME_DEVICE=1); per launch of one 500k-point shard")
+            if (b2[0], "SQ_INSTS_VALU") in mean2:
+                e2["valu_instructions_per_pair"] = mean2[(b2[0], "SQ_INSTS_VALU")] * 64.0 / 0.5e12
+                lines.append("%s (500k-point shard): SQ_INSTS_VALU*64/0.5e12 pairs = %.4g VALU instructions per pair" % (b2[0], e2["valu_instructions_per_pair"]))
+            tr["1000000x1000000_n2"] = e2
+        open(summ, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
     # ---- the surface loop
