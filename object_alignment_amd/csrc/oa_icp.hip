@@ -937,7 +937,7 @@ int begin_loop(oa_ctx *c, const oa_settings *st, int iters)
     init_loop_state(c, st, iters);
     *c->h_state_pin = c->h_state;                               // pinned staging copy (the stream is idle, see above)
     HIPCHK(hipMemcpyAsync(c->d_state, c->h_state_pin, sizeof(oa::DevState), hipMemcpyHostToDevice, c->stream));
-    if (c->d_todo_count) HIPCHK(hipMemsetAsync(c->d_todo_count, 0, sizeof(int), c->stream));   // kept at zero by k_solve_update
+    if (c->d_todo_count) HIPCHK(hipMemsetAsync(c->d_todo_count, 0, 2 * sizeof(int), c->stream));   // kept at zero by k_solve_update
     hipLaunchKernelGGL(oa::k_stamp_start, dim3(1), dim3(64), 0, c->stream, c->d_state);
     HIPCHK(hipGetLastError());
     c->ev_used = 0;
@@ -963,7 +963,7 @@ int iter_partial(oa_ctx *c, double *d_sums, bool timed)
 
 int iter_finish(oa_ctx *c, const double *d_sums)
 {
-    hipLaunchKernelGGL(oa::k_solve_update, dim3(1), dim3(64), 0, c->stream, c->d_state, d_sums, c->d_hist, c->d_todo_count);
+    hipLaunchKernelGGL(oa::k_solve_update, dim3(1), dim3(128), 0, c->stream, c->d_state, d_sums, c->d_hist, c->d_todo_count);
     HIPCHK(hipGetLastError());
     return OA_OK;
 }
@@ -1293,7 +1293,7 @@ int multi_iteration_group(oa_ctx *p, const std::vector<int> &group, bool timed)
         if ((rc = use_device(c))) return rc;
         if (x->mode == OA_EXCHANGE_RCCL) rc = iter_finish(c, c->d_sums);
         else {
-            hipLaunchKernelGGL(oa::k_gather_solve_update, dim3(1), dim3(64), 0, c->stream, c->d_state, x->box[(size_t)c->rank],
+            hipLaunchKernelGGL(oa::k_gather_solve_update, dim3(1), dim3(128), 0, c->stream, c->d_state, x->box[(size_t)c->rank],
                                x->world, c->d_sums, c->d_hist, c->d_todo_count, x->timeout_ticks);
             HIPCHK(hipGetLastError());
         }

@@ -1371,72 +1371,147 @@ __global__ void k_solve_only(const double *__restrict__ sums, double pvx, double
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_solve_update : operators/icp_align.py:106-149, one thread
+// k_solve_update : operators/icp_align.py:106-149 (solve_update_block: two waves)
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void solve_update_body(DevState *__restrict__ st, const double *sums, StepRecord *__restrict__ hist,
-                                                  int *__restrict__ todo_count)
+// element `lane` (0..15) of m4_inverted(Af): the same sub-determinants, the same numerators, the same IEEE division as
+// m4_inverted -- hence the same float -- but ONE division per lane instead of sixteen on one lane (they were a third of the
+// post-solve chain).  Called by (at least) 16 lanes with the same Af; false if singular.
+__device__ __forceinline__ bool m4_inverted_lane(const float *Af, int lane, float &out)
 {
-    // the grid search's hand-over list restarts empty; what it held -- entries, and the most any one wave handed over --
-    // goes to the host, which decides from it whether the next grid search can finish its leftovers itself
-    const int todo_n = todo_count ? todo_count[0] : 0, todo_wave_max = todo_count ? todo_count[1] : 0;
-    if (todo_count) { todo_count[0] = 0; todo_count[1] = 0; }
-    if (st->halt) return;
-    double s[NSUMS], M[16];
-    for (int k = 0; k < NSUMS; ++k) s[k] = sums[k];
-    double jv[9];
-    const bool jv_valid = st->jac_valid != 0;
-    for (int k = 0; k < 9; ++k) jv[k] = jv_valid ? st->jac_v[k] : 0.0;
-    if (!solve_from_sums(s, st->pivot, st->with_scale != 0, M, jv, jv_valid)) {   // K < 3 -> ValueError in the reference
-        st->status = -3;                                            // OA_E_TOO_FEW_PAIRS
-        st->halt = 1;
-        return;
+    double a[16];
+    for (int i = 0; i < 16; ++i) a[i] = (double)Af[i];
+    const double s0 = a[0] * a[5] - a[4] * a[1], s1 = a[0] * a[6] - a[4] * a[2], s2 = a[0] * a[7] - a[4] * a[3];
+    const double s3 = a[1] * a[6] - a[5] * a[2], s4 = a[1] * a[7] - a[5] * a[3], s5 = a[2] * a[7] - a[6] * a[3];
+    const double c5 = a[10] * a[15] - a[14] * a[11], c4 = a[9] * a[15] - a[13] * a[11], c3 = a[9] * a[14] - a[13] * a[10];
+    const double c2 = a[8] * a[15] - a[12] * a[11], c1 = a[8] * a[14] - a[12] * a[10], c0 = a[8] * a[13] - a[12] * a[9];
+    const double det = ((((s0 * c5 - s1 * c4) + s2 * c3) + s3 * c2) - s4 * c1) + s5 * c0;
+    if (det == 0.0) return false;
+    double nk = (( a[5] * c5 - a[6] * c4) + a[7] * c3);
+#define OA_INV_PICK(k, expr) nk = (lane == (k)) ? (expr) : nk
+    OA_INV_PICK(1,  ((-a[1] * c5 + a[2] * c4) - a[3] * c3));
+    OA_INV_PICK(2,  (( a[13] * s5 - a[14] * s4) + a[15] * s3));
+    OA_INV_PICK(3,  ((-a[9] * s5 + a[10] * s4) - a[11] * s3));
+    OA_INV_PICK(4,  ((-a[4] * c5 + a[6] * c2) - a[7] * c1));
+    OA_INV_PICK(5,  (( a[0] * c5 - a[2] * c2) + a[3] * c1));
+    OA_INV_PICK(6,  ((-a[12] * s5 + a[14] * s2) - a[15] * s1));
+    OA_INV_PICK(7,  (( a[8] * s5 - a[10] * s2) + a[11] * s1));
+    OA_INV_PICK(8,  (( a[4] * c4 - a[5] * c2) + a[7] * c0));
+    OA_INV_PICK(9,  ((-a[0] * c4 + a[1] * c2) - a[3] * c0));
+    OA_INV_PICK(10, (( a[12] * s4 - a[13] * s2) + a[15] * s0));
+    OA_INV_PICK(11, ((-a[8] * s4 + a[9] * s2) - a[11] * s0));
+    OA_INV_PICK(12, ((-a[4] * c3 + a[5] * c1) - a[6] * c0));
+    OA_INV_PICK(13, (( a[0] * c3 - a[1] * c1) + a[2] * c0));
+    OA_INV_PICK(14, ((-a[12] * s3 + a[13] * s1) - a[14] * s0));
+    OA_INV_PICK(15, (( a[8] * s3 - a[9] * s1) + a[10] * s0));
+#undef OA_INV_PICK
+    out = (float)(nk / det);
+    return true;
+}
+
+// What follows the sums of an iteration (operators/icp_align.py:106-149), by a WORKGROUP of at least two waves; `sums`
+// readable by all of them.  Called by ALL threads of the workgroup (it contains workgroup barriers); waves 2.. only pass.
+//   wave 0, every lane redundantly (one lane's latency): the Kabsch solve (Jacobi, warm-started)           -> M, new_mat
+//   then wave 0: matrix_world @ new_mat (lane k = element k), its inverse (lane k = element k: one division per lane),
+//                |translation|, the convergence ring, n, halt, the report for the host
+//        wave 1, at the same time: rotation angle (acos), d_stats (sqrt), the step record (lane k = element k of M and
+//                new_mat), the angle ring, whose turn the next search is, d_pivot
+// Round 2 ran all of it on one lane, one after the other: the part after the solve -- 64 products accumulated in double,
+// 16 divisions, an acos, 40 stores -- took as long as the solve.
+__device__ __forceinline__ void solve_update_block(DevState *__restrict__ st, const double *sums, StepRecord *__restrict__ hist,
+                                                   int *__restrict__ todo_count)
+{
+    __shared__ double sh_M[16];
+    __shared__ float sh_new[16], sh_mw[16];
+    __shared__ int sh_go, sh_n;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (threadIdx.x == 0) {
+        // the grid search's hand-over list restarts empty; what it held -- entries, and the most any one wave handed over --
+        // goes to the host, which decides from it whether the next grid search can finish its leftovers itself
+        const int todo_n = todo_count ? todo_count[0] : 0, todo_wave_max = todo_count ? todo_count[1] : 0;
+        if (todo_count) { todo_count[0] = 0; todo_count[1] = 0; }
+        if (st->host_halt) { st->host_halt[2] = todo_n; st->host_halt[3] = todo_wave_max; }
+        sh_go = st->halt ? 0 : 1;
+        sh_n = st->n;
     }
-    for (int k = 0; k < 9; ++k) st->jac_v[k] = jv[k];
-    st->jac_valid = 1;
-    float new_mat[16];
-    for (int k = 0; k < 16; ++k) new_mat[k] = (float)M[k];          // new_mat[y][z] = M[y][z]      (:116-119)
-    float mw[16];
-    m4_mul_m4(st->mx1, new_mat, mw);                                // matrix_world @ new_mat       (:121)
-    for (int k = 0; k < 16; ++k) st->mx1[k] = mw[k];
-    float inv[16];
-    if (!m4_inverted(mw, inv)) { st->status = -4; st->halt = 1; }   // next make_pairs would raise   (general.py:265)
-    else for (int k = 0; k < 16; ++k) st->imx1[k] = inv[k];
-    const double trans = v3_length(new_mat[3], new_mat[7], new_mat[11]);   // new_mat.to_translation().length (:129,:138)
-    const double angle = rotation_angle_3x3(M);
-    const double K = s[S_K];
-    const double mean_dd = s[S_D] / K;                               // mean of (d - d_pivot)
-    const double mean_d = mean_dd + st->d_pivot;
-    double var = s[S_DD] / K - mean_dd * mean_dd;
-    if (var < 0.0) var = 0.0;
-    const int n = st->n;
-    if (hist && st->max_records > 0) {
-        StepRecord &r = hist[n % st->max_records];
-        for (int k = 0; k < 16; ++k) { r.M[k] = M[k]; r.new_mat[k] = new_mat[k]; }
-        r.K = K; r.mean_d = mean_d; r.std_d = sqrt(var); r.trans = trans; r.angle = angle;
-        r.search_ticks = (st->t_acc_start > st->t_prev_end) ? (double)(st->t_acc_start - st->t_prev_end) : 0.0;
+    __syncthreads();
+    if (!sh_go) return;                                             // (uniform)
+    if (wave == 0) {
+        double s[NSUMS], M[16];
+        for (int k = 0; k < NSUMS; ++k) s[k] = sums[k];
+        double jv[9];
+        const bool jv_valid = st->jac_valid != 0;
+        for (int k = 0; k < 9; ++k) jv[k] = jv_valid ? st->jac_v[k] : 0.0;
+        const bool ok = solve_from_sums(s, st->pivot, st->with_scale != 0, M, jv, jv_valid);
+        if (lane == 0) {
+            if (!ok) { st->status = -3; st->halt = 1; sh_go = 0; }  // K < 3 -> ValueError in the reference: OA_E_TOO_FEW_PAIRS
+            else {
+                for (int k = 0; k < 9; ++k) st->jac_v[k] = jv[k];
+                st->jac_valid = 1;
+                for (int k = 0; k < 16; ++k) { sh_M[k] = M[k]; sh_new[k] = (float)M[k]; }   // new_mat[y][z] = M[y][z]  (:116-119)
+            }
+        }
     }
-    if (st->use_target) {                                           // if d_stats:                  (:136)
-        st->ring_t[n % 5] = trans;                                  // conv_t_list[i] = trans.length (:137-138)
-        st->ring_r[n % 5] = angle;
-        bool all = true;
-        for (int k = 0; k < 5; ++k) all = all && (st->ring_t[k] < st->target_d);   // (:141)
-        if (all) st->converged = 1;
-    }
-    st->d_pivot = mean_d;                                           // next iteration sums d relative to this mean
-    st->n = n + 1;                                                  // n += 1                        (:151)
-    if ((st->converged && st->early_exit) || st->n >= st->iters) st->halt = 1;
-    {   // whose turn is the next search (DevState::tree_turn)
-        const int last = n % 5;
-        const double moved = st->use_target ? (st->ring_t[last] + st->ring_r[last] * st->turn_scale) * st->local_per_world : 0.0;
-        st->tree_turn = (moved > st->turn_limit) ? 1 : 0;
-    }
-    st->t_prev_end = wall_clock64();                                // the next search starts (about) now
-    if (st->host_halt) {                                            // progress and halt flag for the enqueuing host
-        st->host_halt[2] = todo_n;
-        st->host_halt[3] = todo_wave_max;
-        st->host_halt[1] = st->n;
-        if (st->halt) st->host_halt[0] = 1;
-        __threadfence_system();
+    __syncthreads();
+    if (!sh_go) return;
+    const int n = sh_n;
+    if (wave == 0) {
+        // matrix_world @ new_mat (:121): element `lane`, the operation order of m4_mul_m4
+        if (lane < 16) {
+            const int i = lane >> 2, j = lane & 3;
+            double acc = 0.0;
+            for (int k = 0; k < 4; ++k) { const float p = st->mx1[4 * i + k] * sh_new[4 * k + j]; acc += (double)p; }
+            sh_mw[lane] = (float)acc;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // this wave's LDS writes above, its LDS reads below
+        float mw[16];
+        for (int k = 0; k < 16; ++k) mw[k] = sh_mw[k];
+        if (lane < 16) st->mx1[lane] = mw[lane & 15];
+        float inv_k = 0.f;
+        const bool nonsingular = m4_inverted_lane(mw, lane & 15, inv_k);
+        if (nonsingular && lane < 16) st->imx1[lane] = inv_k;
+        if (lane == 0) {
+            if (!nonsingular) { st->status = -4; st->halt = 1; }    // next make_pairs would raise   (general.py:265)
+            const double trans = v3_length(sh_new[3], sh_new[7], sh_new[11]);   // new_mat.to_translation().length (:129,:138)
+            if (st->use_target) {                                   // if d_stats:                  (:136)
+                st->ring_t[n % 5] = trans;                          // conv_t_list[i] = trans.length (:137-138)
+                bool all = true;
+                for (int k = 0; k < 5; ++k) all = all && (st->ring_t[k] < st->target_d);   // (:141)
+                if (all) st->converged = 1;
+            }
+            st->n = n + 1;                                          // n += 1                        (:151)
+            if ((st->converged && st->early_exit) || st->n >= st->iters) st->halt = 1;
+            st->t_prev_end = wall_clock64();                        // the next search starts (about) now
+            if (st->host_halt) {                                    // progress and halt flag for the enqueuing host
+                st->host_halt[1] = st->n;
+                if (st->halt) st->host_halt[0] = 1;
+                __threadfence_system();
+            }
+        }
+    } else if (wave == 1) {
+        double M[16];
+        for (int k = 0; k < 16; ++k) M[k] = sh_M[k];
+        const double trans = v3_length(sh_new[3], sh_new[7], sh_new[11]);
+        const double angle = rotation_angle_3x3(M);
+        const double K = sums[S_K];
+        const double mean_dd = sums[S_D] / K;                       // mean of (d - d_pivot)
+        const double mean_d = mean_dd + st->d_pivot;
+        double var = sums[S_DD] / K - mean_dd * mean_dd;
+        if (var < 0.0) var = 0.0;
+        if (hist && st->max_records > 0) {
+            StepRecord &r = hist[n % st->max_records];
+            if (lane < 16) { r.M[lane] = sh_M[lane]; r.new_mat[lane] = sh_new[lane]; }
+            if (lane == 0) {
+                r.K = K; r.mean_d = mean_d; r.std_d = sqrt(var); r.trans = trans; r.angle = angle;
+                r.search_ticks = (st->t_acc_start > st->t_prev_end) ? (double)(st->t_acc_start - st->t_prev_end) : 0.0;
+            }
+        }
+        if (lane == 0) {
+            if (st->use_target) st->ring_r[n % 5] = angle;
+            st->d_pivot = mean_d;                                   // next iteration sums d relative to this mean
+            // whose turn is the next search (DevState::tree_turn)
+            const double moved = st->use_target ? (trans + angle * st->turn_scale) * st->local_per_world : 0.0;
+            st->tree_turn = (moved > st->turn_limit) ? 1 : 0;
+        }
     }
 }
 
@@ -1447,11 +1522,10 @@ __global__ void k_stamp_start(DevState *__restrict__ st)
 }
 
 // split-phase form (one process per GPU): the sums come back from the all-reduce
-__global__ __launch_bounds__(64) void k_solve_update(DevState *__restrict__ st, const double *__restrict__ sums, StepRecord *__restrict__ hist,
+__global__ __launch_bounds__(128) void k_solve_update(DevState *__restrict__ st, const double *__restrict__ sums, StepRecord *__restrict__ hist,
                                int *__restrict__ todo_count)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    solve_update_body(st, sums, hist, todo_count);
+    solve_update_block(st, sums, hist, todo_count);
 }
 
 // single-GPU form: the fixed-order reduction and the solve in one launch (same arithmetic, one boundary less)
@@ -1464,7 +1538,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce_solve_update(DevState *_
     reduce_rows_block(partials, rows_of(sel, st), sums);
     __syncthreads();
     if (threadIdx.x < NSUMS && sums_out) sums_out[threadIdx.x] = sums[threadIdx.x];
-    if (threadIdx.x == 0) solve_update_body(st, sums, hist, todo_count);
+    solve_update_block(st, sums, hist, todo_count);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1514,7 +1588,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce_post(const DevState *__r
 // step 2 on every device: wait for the world's posts of this iteration (in this rank's mailbox), add them in rank
 // order, solve + update.  Lane r waits for rank r (world <= 64).  The wait is bounded (timeout_ticks of wall_clock64):
 // a rank that never posts -- its device faulted -- ends the loop with STATUS_EXCHANGE instead of hanging this one.
-__global__ __launch_bounds__(64) void k_gather_solve_update(DevState *__restrict__ st, MailSlot *box, int world,
+__global__ __launch_bounds__(128) void k_gather_solve_update(DevState *__restrict__ st, MailSlot *box, int world,
                                                             double *__restrict__ sums_out, StepRecord *__restrict__ hist,
                                                             int *__restrict__ todo_count, unsigned long long timeout_ticks)
 {
@@ -1543,15 +1617,16 @@ __global__ __launch_bounds__(64) void k_gather_solve_update(DevState *__restrict
         }
         __syncthreads();
     }
-    if (threadIdx.x != 0) return;
-    if (live && !arrived) {
-        if (todo_count) *todo_count = 0;
-        st->status = STATUS_EXCHANGE;
-        st->halt = 1;
-        if (st->host_halt) { st->host_halt[0] = 1; __threadfence_system(); }
+    if (live && !arrived) {                                         // (uniform: `arrived` is shared, read after the barrier)
+        if (threadIdx.x == 0) {
+            if (todo_count) { todo_count[0] = 0; todo_count[1] = 0; }
+            st->status = STATUS_EXCHANGE;
+            st->halt = 1;
+            if (st->host_halt) { st->host_halt[0] = 1; __threadfence_system(); }
+        }
         return;
     }
-    solve_update_body(st, sums, hist, todo_count);
+    solve_update_block(st, sums, hist, todo_count);
 }
 
 // ------------------------------------------------------------------------------------------------
