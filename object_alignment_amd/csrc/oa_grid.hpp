@@ -243,8 +243,11 @@ constexpr int GRID_SEGS = 10;      // ranges of one batch: 9 rows of the first b
 // holds the query, the winner's coordinates and nothing else is needed -- no second pass over src4 / keys / win
 // (k_pair_accumulate, 16 us at 1M points and its own launch).  One row of `partials` per workgroup, fixed order.
 // keys[] is not written then: nothing reads it inside the loop.
-template <int L, bool ACC = false>
-__global__ __launch_bounds__(256, 6) void k_nn_search_grid(const DevState *__restrict__ st,
+// BT = threads per workgroup: 256, or 512 for the accumulating variant on large shards -- half as many rows of partials for
+// the reduction behind it (1M points 63.6 -> 60.3 us per iteration), the same six waves per SIMD (three
+// workgroups of eight waves per CU instead of six of four); small shards lose with the coarser workgroups (100k: +1.5 us).
+template <int L, bool ACC = false, int BT = 256>
+__global__ __launch_bounds__(BT, 6) void k_nn_search_grid(const DevState *__restrict__ st,
                                                         const float4 *__restrict__ src4, int ns, GridParams gp,
                                                         const int *__restrict__ cell_start,
                                                         const float4 *__restrict__ sorted,
@@ -259,7 +262,7 @@ __global__ __launch_bounds__(256, 6) void k_nn_search_grid(const DevState *__res
     static_assert(RPL <= GRID_SEGS && (L == 1 || 2 * RPL <= GRID_SEGS), "a batch of rows must fit the per-thread range list");
     if (st->halt) return;
     if (turn >= 0 && (st->tree_turn != 0) != (turn != 0)) return;  // not this kernel's turn (DevState::tree_turn)
-    __shared__ int2 seg[GRID_SEGS][256];
+    __shared__ int2 seg[GRID_SEGS][BT];
     const int gt = blockIdx.x * blockDim.x + threadIdx.x;
     int i = gt / L;
     const int sub = gt % L;                                         // the L lanes of a query are neighbours in a wave
@@ -414,8 +417,8 @@ __global__ __launch_bounds__(256, 6) void k_nn_search_grid(const DevState *__res
         }
         return;
     }
-    // ---- ACC: finish, record, accumulate -- all 256 threads stay to the end (wave-wide descents, workgroup-wide reduction)
-    __shared__ double red[4][NSUMS];
+    // ---- ACC: finish, record, accumulate -- all threads stay to the end (wave-wide descents, workgroup-wide reduction)
+    __shared__ double red[BT / 64][NSUMS];
     const bool mine = sub == 0 && alive;
     float4 wq = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));  // the winner's record: the seed's, or the scan's
     if (mine && bidx != IDX_NONE) wq = bj >= 0 ? sorted[bj] : win[i];      // (bj < 0: still the seed, re-read rather than kept in registers through the scan)

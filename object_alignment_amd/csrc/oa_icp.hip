@@ -634,10 +634,14 @@ inline int grid_lanes_for(const oa_ctx *c)
 // Workgroups of the canonical accumulation (k_pair_accumulate_canon, and the epilogue of k_nn_search_grid<L, true>): one
 // thread per (slot, lane of the query).  0 = the shard is too large for it (> ACC_MAX_BLOCKS rows before combining) or the
 // target is a surface: the grid-stride k_pair_accumulate is used instead.
+// (512 threads per workgroup from 262k (query, lane) pairs on: half the rows for the reduction behind it; below that the
+//  finer workgroups balance better)
+inline int canon_threads(const oa_ctx *c) { return (long long)c->ns * grid_lanes_for(c) >= 262144 ? 512 : 256; }
 inline int canon_blocks(const oa_ctx *c)
 {
     if (c->surface || c->ns <= 0) return 0;
-    const long long b = ((long long)c->ns * grid_lanes_for(c) + 255) / 256;
+    const int t = canon_threads(c);
+    const long long b = ((long long)c->ns * grid_lanes_for(c) + t - 1) / t;
     return b <= oa::ACC_MAX_BLOCKS ? (int)b : 0;
 }
 
@@ -711,9 +715,16 @@ int launch_nn_impl(oa_ctx *c, bool acc)
 #define OA_GRID_ACC_ARGS OA_GRID_ARGS, c->bvh, (const float4 *)c->d_bvh_box, (const float4 *)c->d_bvh_prims, normal_test(c), c->d_partials
         const dim3 gblocks((unsigned)(((long long)c->ns * lanes + 255) / 256));
         if (acc) {
-            if (lanes == 4) hipLaunchKernelGGL((oa::k_nn_search_grid<4, true>), gblocks, dim3(256), 0, c->stream, OA_GRID_ACC_ARGS);
-            else if (lanes == 2) hipLaunchKernelGGL((oa::k_nn_search_grid<2, true>), gblocks, dim3(256), 0, c->stream, OA_GRID_ACC_ARGS);
-            else hipLaunchKernelGGL((oa::k_nn_search_grid<1, true>), gblocks, dim3(256), 0, c->stream, OA_GRID_ACC_ARGS);
+            const dim3 ablocks((unsigned)canon_blocks(c));
+            if (canon_threads(c) == 512) {
+                if (lanes == 4) hipLaunchKernelGGL((oa::k_nn_search_grid<4, true, 512>), ablocks, dim3(512), 0, c->stream, OA_GRID_ACC_ARGS);
+                else if (lanes == 2) hipLaunchKernelGGL((oa::k_nn_search_grid<2, true, 512>), ablocks, dim3(512), 0, c->stream, OA_GRID_ACC_ARGS);
+                else hipLaunchKernelGGL((oa::k_nn_search_grid<1, true, 512>), ablocks, dim3(512), 0, c->stream, OA_GRID_ACC_ARGS);
+            } else {
+                if (lanes == 4) hipLaunchKernelGGL((oa::k_nn_search_grid<4, true, 256>), ablocks, dim3(256), 0, c->stream, OA_GRID_ACC_ARGS);
+                else if (lanes == 2) hipLaunchKernelGGL((oa::k_nn_search_grid<2, true, 256>), ablocks, dim3(256), 0, c->stream, OA_GRID_ACC_ARGS);
+                else hipLaunchKernelGGL((oa::k_nn_search_grid<1, true, 256>), ablocks, dim3(256), 0, c->stream, OA_GRID_ACC_ARGS);
+            }
             HIPCHK(hipGetLastError());
             return OA_OK;
         }
@@ -774,7 +785,7 @@ int launch_accumulate(oa_ctx *c, bool emit, int *nn_idx, float *nn_d2)
                            c->surface ? (const float4 *)c->d_tri9 : (const float4 *)nullptr, nrm, c->d_partials, po,
                            (unsigned long long *)nullptr);
     } else if (canon_blocks(c) > 0) {
-        hipLaunchKernelGGL(oa::k_pair_accumulate_canon, dim3((unsigned)canon_blocks(c)), dim3(256), 0, c->stream, (const oa::DevState *)c->d_state,
+        hipLaunchKernelGGL(oa::k_pair_accumulate_canon, dim3((unsigned)canon_blocks(c)), dim3((unsigned)canon_threads(c)), 0, c->stream, (const oa::DevState *)c->d_state,
                            (const float4 *)c->d_src4, c->ns, grid_lanes_for(c), (const float *)c->d_tgt_xyz, c->d_keys, c->d_prev, c->d_win,
                            (const float4 *)nullptr, nrm, c->d_partials,
                            c->loop_active ? &c->d_state->t_acc_start : (unsigned long long *)nullptr);

@@ -1208,17 +1208,20 @@ __global__ __launch_bounds__(ACC_THREADS) void k_pair_accumulate(const DevState 
 // from one iteration to the next on what the host last heard about the list (oa_icp.hip: adaptive path), and that choice
 // depends on timing: it must not show in the sums.  The brute-force searches use it too (for shards whose rows fit), so
 // every search mode still ends with bitwise the same matrices.
-__global__ __launch_bounds__(256) void k_pair_accumulate_canon(const DevState *__restrict__ st, const float4 *__restrict__ src4,
+// Launched with the workgroup size the accumulating grid search of this shard uses (256 or 512 threads, oa_icp.hip:
+// canon_threads): the same workgroups, hence the same rows.
+constexpr int CANON_THREADS = 512;
+__global__ __launch_bounds__(CANON_THREADS) void k_pair_accumulate_canon(const DevState *__restrict__ st, const float4 *__restrict__ src4,
                                                                int ns, int L, const float *__restrict__ tgt_xyz,
                                                                unsigned long long *__restrict__ keys, int *__restrict__ prev,
                                                                float4 *__restrict__ win, const float4 *__restrict__ tri9,
                                                                NormalTest nrm, double *__restrict__ partials,
                                                                unsigned long long *__restrict__ t_acc_start)
 {
-    __shared__ double red[4][NSUMS];
+    __shared__ double red[CANON_THREADS / 64][NSUMS];
     if (t_acc_start && blockIdx.x == 0 && threadIdx.x == 0) *t_acc_start = wall_clock64();   // ~ the end of the search
     if (st->halt) return;
-    const int gt = blockIdx.x * 256 + threadIdx.x;
+    const int gt = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = gt / L;
     const bool mine = (gt - i * L) == 0 && i < ns;
     bool valid = false;

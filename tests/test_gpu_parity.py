@@ -1528,3 +1528,46 @@ def test_make_pairs_sees_in_place_edits_of_the_source():
     A3, _, _ = make_pairs(fresh, base, bvh, vl, 0.5)
     A4, _, _ = make_pairs(fresh, base, bvh, vl2, 0.5)
     assert np.array_equal(A3, A2) and not np.array_equal(A4, A3) and np.array_equal(np.sort(A4, axis=1), np.sort(A3, axis=1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["settled", "far_start", "half_target", "lanes4"])
+def test_grid_paths_give_the_same_bits(orc, case, monkeypatch):
+    """The loop's grid search has two forms: FAST -- it finishes the queries its rings did not settle through
+    the tree itself and accumulates in its epilogue -- and SAFE -- grid search, tree search of the hand-over list,
+    k_pair_accumulate_canon.  The host picks per iteration from what the device last reported, i.e. timing dependent, so
+    the two must leave the same bits: forced fast, forced safe and adaptive runs are compared bitwise, and against the
+    oracle's loop (K exact, M to 1e-9) -- settled poses, a start far from the target (most queries leave the rings), a
+    target cut in half (half the queries have no partner in range), and a shard small enough for four lanes per query."""
+    from object_alignment_amd import synth
+    from object_alignment_amd.engine import IcpEngine
+    n = 60_000 if case != "lanes4" else 9_000
+    src, tgt, mxa, mxb = synth.c2_bunny_pair(n)
+    thresh, iters = 0.5, 6
+    if case == "far_start":
+        mxa = synth.rigid4(synth.rotation_from_rotvec([0.2, -0.1, 0.15]), [0.3, -0.2, 0.25])
+        thresh = 1.0
+    if case == "half_target":
+        tgt = np.ascontiguousarray(tgt[tgt[:, 0] > 0.0])
+    out = {}
+    for tag, env in (("safe", {"OA_GRID_PATH": "safe"}), ("fast", {"OA_GRID_PATH": "fast"}), ("adaptive", {}),
+                     ("plain", {"OA_FUSED_ACC": "0"})):
+        monkeypatch.delenv("OA_GRID_PATH", raising=False)
+        monkeypatch.delenv("OA_FUSED_ACC", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with IcpEngine(0) as e:
+            e.set_search_mode("grid")
+            e.set_target(tgt)
+            e.set_source(src, stride=1)
+            e.set_matrices(mxa, mxb)
+            r1 = e.run(iters=iters, thresh=thresh, early_exit=False)
+            r2 = e.run(iters=3, thresh=thresh, early_exit=False)          # a second loop continues on warm seeds
+            out[tag] = (r1, r2)
+    ref = orc.icp_run(src, tgt, mxa, mxb, iters=iters, sample=1, thresh=thresh, target_d=1e-300, use_target=True, kd=orc.KDTree(tgt))
+    for tag in ("fast", "adaptive", "plain"):
+        for a, b in zip(out["safe"], out[tag]):
+            assert np.array_equal(a.step_K, b.step_K), (case, tag)
+            assert np.array_equal(a.step_M, b.step_M) and np.array_equal(a.matrix_world, b.matrix_world), (case, tag)
+    assert np.array_equal(out["safe"][0].step_K, ref["step_K"])
+    assert np.abs(out["safe"][0].step_M - ref["step_M"]).max() < 1e-9

@@ -229,3 +229,68 @@ def test_header_is_plain_c_and_library_links(built, tmp_path):
     p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert p.returncode == 0, p.stdout
     assert "ABI_SMOKE_OK" in p.stdout
+
+
+def test_content_hash_sees_permutations_and_nans():
+    """GpuBVH decides from this hash whether the source has to go up again (the reference re-reads every vertex on every
+    call, functions/general.py:284): order-sensitive, NaN-stable, independent of the array object."""
+    from object_alignment_amd.functions.general import _content_hash
+    rng = np.random.default_rng(0)
+    a = rng.normal(size=(5000, 3)).astype(np.float32)
+    h = _content_hash(a)
+    assert _content_hash(a.copy()) == h
+    b = a.copy()
+    b[[10, 20]] = b[[20, 10]]                                       # every sum unchanged
+    assert _content_hash(b) != h
+    c = a.copy()
+    c[7, 1] = np.nan
+    assert _content_hash(c) == _content_hash(c.copy()) != h
+    v = np.arange(100, dtype=np.int64)
+    assert _content_hash(v) != _content_hash(v[::-1].copy())
+
+
+def test_modal_operator_reuploads_when_the_engine_changed_hands():
+    """The modal operator shares the process-wide engine with every other entry point; a make_pairs or a plain ICP call
+    between two timer ticks replaces the engine's geometry.  iterate() must notice -- the engine records who
+    uploaded last -- and put its own run back before it steps."""
+    from object_alignment_amd.operators import icp_align_feedback as fb
+
+    class FakeEngine:
+        def __init__(self):
+            self.target_owner = self.source_owner = None
+            self.calls = []
+
+        def set_target(self, xyz): self.calls.append("target")
+        def set_target_mesh(self, xyz, tris): self.calls.append("mesh")
+        def set_source(self, xyz, vlist=None, stride=0): self.calls.append("source")
+        def set_matrices(self, a, b): self.calls.append("matrices")
+        def matrix_world(self): return np.identity(4, dtype=np.float32)
+
+        def iterate(self, **kw):
+            self.calls.append("iterate")
+            return np.identity(4), dict(K=10, mean_dist=0.1, std_dist=0.0, translation=1.0, rot_angle=0.0, converged=False)
+
+    eng = FakeEngine()
+    old = fb.default_engine
+    fb.default_engine = lambda devices=None: eng
+    try:
+        from object_alignment_amd.functions import AlignObject
+        op = fb.OBJECT_OT_icp_align_feedback()
+        xyz = np.random.default_rng(1).normal(size=(50, 3)).astype(np.float32)
+        run = fb._Run(align_obj=AlignObject(xyz), base_obj=AlignObject(xyz), thresh=0.5, target_d=0.01, budget=5, burst=1,
+                      use_target=True, with_scale=False, drag_m_objects=False)
+        run.ring_t = [0.02] * fb.RING
+        run.ring_r = [None] * fb.RING
+        op._run = run
+        op._upload(run, stride=1)
+        assert eng.target_owner is op and eng.source_owner is op
+        n0 = len(eng.calls)
+        op.iterate(None)
+        assert eng.calls[n0:] == ["iterate"]                         # still the owner: no upload
+        eng.target_owner = object()                                  # somebody else uploaded a target in between
+        n1 = len(eng.calls)
+        op.iterate(None)
+        assert eng.calls[n1:n1 + 3] == ["target", "source", "matrices"] and eng.calls[-1] == "iterate"
+        assert eng.target_owner is op
+    finally:
+        fb.default_engine = old
