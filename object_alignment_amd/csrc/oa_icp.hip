@@ -386,7 +386,7 @@ struct oa_ctx {
     bool normals_on = false;
     double pivot[3] = { 0, 0, 0 };
     // launch geometry for k_nn_search
-    int n_splits = 1, groups_per_split = 0, acc_blocks = 1;
+    int n_splits = 1, acc_blocks = 1;
     int tile_groups = oa::FTILE_GROUPS;   // LDS tile of k_nn_search_filtered: 256 groups, 64 for small targets
     int R_env = 0;                      // OA_NN_R override (0 = choose from the shard size)
     bool use_filter = true;
@@ -490,9 +490,7 @@ void plan_geometry(oa_ctx *c)
     if (splits > 8) splits = std::min(tiles_total, ((splits + 7) / 8) * 8);   // multiple of 8: one XCD per split residue
     const int forced = env_int("OA_NN_SPLITS", 0);
     if (forced > 0) splits = std::min(forced, tiles_total);
-    const int tiles_per_split = (tiles_total + splits - 1) / splits;
-    c->groups_per_split = tiles_per_split * c->tile_groups;
-    c->n_splits = (tiles_total + tiles_per_split - 1) / tiles_per_split;
+    c->n_splits = splits;                                          // the kernels cut the tiles into exactly this many ranges (split_range)
     const int acc_cap = std::max(1, std::min(oa::ACC_MAX_BLOCKS, env_int("OA_ACC_BLOCKS", 512)));
     c->acc_blocks = std::max(1, std::min(acc_cap, (c->ns + oa::ACC_THREADS - 1) / oa::ACC_THREADS));
 }
@@ -738,10 +736,10 @@ int launch_nn_impl(oa_ctx *c, bool acc)
     }
     if (c->ns_pad / (oa::NN_THREADS * c->R) > 65535)               // only the brute-force launch has this limit (grid.y)
         return fail(OA_E_BAD_ARG, "shard of %d points exceeds the brute-force launch grid (use more shards or OA_NN_R=8)", c->ns);
-#define OA_NN_ARGS c->d_state, c->d_src4, c->d_tg, c->groups_per_split, c->n_groups_pad, c->d_keys
-#define OA_NNF_ARGS c->d_state, c->d_src4, c->d_tg, c->d_tf, c->d_tf3, (const float4 *)c->d_win, c->groups_per_split, c->n_groups_pad, c->d_keys
+#define OA_NN_ARGS c->d_state, c->d_src4, c->d_tg, c->n_groups_pad, c->d_keys
+#define OA_NNF_ARGS c->d_state, c->d_src4, c->d_tg, c->d_tf, c->d_tf3, (const float4 *)c->d_win, c->n_groups_pad, c->d_keys
     if (c->filter_ok && c->use_filter && c->nn_mfma && c->d_tfm && c->R == 4 && c->tile_groups == oa::FTILE_GROUPS) {
-#define OA_MFMA_ARGS c->d_state, c->d_src4, c->d_tg, (const oa::half8 *)c->d_tfm, (const float4 *)c->d_win, c->groups_per_split, c->n_groups_pad, c->mfma_sigma, c->d_keys
+#define OA_MFMA_ARGS c->d_state, c->d_src4, c->d_tg, (const oa::half8 *)c->d_tfm, (const float4 *)c->d_win, c->n_groups_pad, c->mfma_sigma, c->d_keys
         if (c->mfma_wps == 2) hipLaunchKernelGGL(oa::k_nn_search_mfma<2>, grid, block, 0, c->stream, OA_MFMA_ARGS);
         else if (c->mfma_wps == 3) hipLaunchKernelGGL(oa::k_nn_search_mfma<3>, grid, block, 0, c->stream, OA_MFMA_ARGS);
         else hipLaunchKernelGGL(oa::k_nn_search_mfma<4>, grid, block, 0, c->stream, OA_MFMA_ARGS);

@@ -543,10 +543,24 @@ __device__ __forceinline__ float d2_metric(float px, float py, float pz, float q
     return t;
 }
 
+// Target split of workgroup blockIdx.x: tiles [x T / n, (x + 1) T / n) of the T tiles (of `tile_groups` groups each), n =
+// gridDim.x.  Split sizes differ by at most one tile, every split is non-empty (n <= T), and n stays what the host chose -- a
+// multiple of 8 above 8, so that the dispatcher's round-robin (workgroup b on XCD b % 8) pins every split to ONE XCD, whose
+// L2 then keeps its part of the image for the whole launch.  (Round 2 cut equal splits of ceil(T / n) tiles and launched
+// ceil(T / that) of them: 70 instead of 72 for a 250k-point shard, 123 instead of 136 for 125k -- every XCD then saw every
+// split, the 12 MB image no longer stayed in the L2s and the HBM-side traffic of a launch rose from 0.3 to 3.4 GB;
+// profiles/r03c_bench_1Mx1M_pmc_summary.txt, the 4- and 8-shard passes.)
+__device__ __forceinline__ void split_range(int n_groups_pad, int tile_groups, int &g_begin, int &g_end)
+{
+    const long long tiles = n_groups_pad / tile_groups;
+    g_begin = (int)((long long)blockIdx.x * tiles / gridDim.x) * tile_groups;
+    g_end = (int)((long long)(blockIdx.x + 1) * tiles / gridDim.x) * tile_groups;
+}
+
 template <int R>
 __global__ __launch_bounds__(NN_THREADS) void k_nn_search(const DevState *__restrict__ st,
                                                           const float4 *__restrict__ src4,
-                                                          const float4 *__restrict__ tg, int groups_per_split,
+                                                          const float4 *__restrict__ tg,
                                                           int n_groups_pad, unsigned long long *__restrict__ keys)
 {
     if (st->halt) return;
@@ -566,9 +580,8 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_search(const DevState *__rest
         bidx[r] = IDX_NONE;
     }
 
-    const int g_begin = blockIdx.x * groups_per_split;
-    int g_end = g_begin + groups_per_split;
-    if (g_end > n_groups_pad) g_end = n_groups_pad;
+    int g_begin, g_end;
+    split_range(n_groups_pad, TILE_GROUPS, g_begin, g_end);
     const int n_tiles = (g_end - g_begin) / TILE_GROUPS;           // splits are whole tiles by construction
     const float4 *tsrc = tg + 3ll * g_begin;
 
@@ -758,7 +771,7 @@ __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_filt
                                                                    const float4 *__restrict__ tg,
                                                                    const float4 *__restrict__ tf2,
                                                                    const float4 *__restrict__ tf3,
-                                                                   const float4 *__restrict__ win, int groups_per_split,
+                                                                   const float4 *__restrict__ win,
                                                                    int n_groups_pad,
                                                                    unsigned long long *__restrict__ keys)
 {
@@ -804,9 +817,8 @@ __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_filt
         filter_thresholds(best[r], hu[r], hv[r], hd[r], qmax, thr2[r], thr3[r]);
     }
 
-    const int g_begin = blockIdx.x * groups_per_split;
-    int g_end = g_begin + groups_per_split;
-    if (g_end > n_groups_pad) g_end = n_groups_pad;
+    int g_begin, g_end;
+    split_range(n_groups_pad, TG, g_begin, g_end);
     const int n_tiles = (g_end - g_begin) / TG;
     const float4 *tsrc = tf2 + 3ll * g_begin;
 

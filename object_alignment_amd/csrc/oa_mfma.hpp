@@ -142,7 +142,7 @@ __global__ __launch_bounds__(NN_THREADS, WPS) void k_nn_search_mfma(const DevSta
                                                                 const float4 *__restrict__ src4,
                                                                 const float4 *__restrict__ tg,
                                                                 const half8 *__restrict__ tfm,
-                                                                const float4 *__restrict__ win, int groups_per_split,
+                                                                const float4 *__restrict__ win,
                                                                 int n_groups_pad, double sigma,
                                                                 unsigned long long *__restrict__ keys)
 {
@@ -203,10 +203,9 @@ __global__ __launch_bounds__(NN_THREADS, WPS) void k_nn_search_mfma(const DevSta
 #pragma unroll
     for (int r = 0; r < R; ++r) OA_MF_REBUILD(r);
 
-    const int g_begin = blockIdx.x * groups_per_split;
-    int g_end = g_begin + groups_per_split;
-    if (g_end > n_groups_pad) g_end = n_groups_pad;
-    const int n_bufs = (g_end - g_begin) / MF_GROUPS;              // groups_per_split is a multiple of 256
+    int g_begin, g_end;
+    split_range(n_groups_pad, FTILE_GROUPS, g_begin, g_end);      // whole tiles of 256 groups, as k_nn_search_filtered<4, 256>
+    const int n_bufs = (g_end - g_begin) / MF_GROUPS;
     const half8 *tsrc = tfm + (long long)(g_begin / 8) * 64;       // 8 groups per MFMA tile
     // Tiles go global -> LDS directly (LDS-DMA, 16 B per lane: the destination is the wave's base + lane x 16, which is
     // exactly this image's layout).  Staging them through registers cost 16 VGPRs the hot loop does not have: the

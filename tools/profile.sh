@@ -18,13 +18,15 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU --output-format csv -d "$OUT/prof_pmc_SQ" -- $BENCH > "$OUT/prof_pmc_SQ.log" 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VMEM SQ_WAIT_ANY SQ_WAVE_CYCLES --output-format csv -d "$OUT/prof_pmc_SQ2" -- $BENCH > "$OUT/prof_pmc_SQ2.log" 2>&1
-# two shards (both on this GPU: OA_BENCH_SAME_DEVICE=1), so that an N = 2 bench line has PMC figures of its own shard size
-B2="env OA_BENCH_SAME_DEVICE=1 python $REPO/bench.py --gpus 2 --steps $STEPS --warmup 1 --no-cpu-baseline --no-surface --no-grid --no-mfma"
-rm -rf "$OUT"/prof_n2_*
-for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d "$OUT/prof_n2_$c" -- $B2 > "$OUT/prof_n2_$c.log" 2>&1
+# N = 2 / 4 / 8 shards, all on this GPU (OA_BENCH_SAME_DEVICE=1), so that an N > 1 bench line has PMC figures of its own shard size
+rm -rf "$OUT"/prof_n[248]_*
+for n in 2 4 8; do
+  BN="env OA_BENCH_SAME_DEVICE=1 python $REPO/bench.py --gpus $n --steps $STEPS --warmup 1 --no-cpu-baseline --no-surface --no-grid --no-mfma"
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $c --output-format csv -d "$OUT/prof_n${n}_$c" -- $BN > "$OUT/prof_n${n}_$c.log" 2>&1
+  done
+  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d "$OUT/prof_n${n}_SQ" -- $BN > "$OUT/prof_n${n}_SQ.log" 2>&1
 done
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d "$OUT/prof_n2_SQ" -- $B2 > "$OUT/prof_n2_SQ.log" 2>&1
 SURF="env ONLY=surface:auto python $REPO/tools/time_surface.py"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_surf_stats" -- $SURF > "$OUT/prof_surf_stats.log" 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do

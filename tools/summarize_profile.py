@@ -110,22 +110,25 @@ def main():
     gk = sorted((k for k in traffic if k.startswith("k_nn_search_grid")), key=lambda k: "true" not in k)   # the loop's kernel first: k_nn_search_grid<1, true>
     if gk:
         tr["grid_1000000x1000000_n1"] = dict(stamp, kernel=gk[0], bytes_per_launch=traffic[gk[0]], source=rel)
-    # ---- two shards on this GPU (python bench.py --gpus 2 with OA_BENCH_SAME_DEVICE=1): the figures an N = 2 line reports
-    agg2 = collect(("prof_n2_FETCH_SIZE", "prof_n2_WRITE_SIZE", "prof_n2_SQ"), lambda k: k.startswith("k_nn_search_filtered"))
-    if agg2:
+    # ---- N shards on this GPU (python bench.py --gpus N with OA_BENCH_SAME_DEVICE=1): the figures an N > 1 line reports
+    for n in (2, 4, 8):
+        aggn = collect(("prof_n%d_FETCH_SIZE" % n, "prof_n%d_WRITE_SIZE" % n, "prof_n%d_SQ" % n), lambda k: k.startswith("k_nn_search_filtered"))
+        if not aggn:
+            continue
+        shard = -(-1000000 // n)
         lines.append("")
-        lines.append("# two shards of 500k points on this GPU (OA_BENCH_SAME_DEVICE=1 python bench.py --gpus 2 ...): per-dispatch means")
-        mean2, traffic2 = table(agg2, lines)
-        b2 = [k for k in traffic2 if k.startswith("k_nn_search_filtered")]
-        if b2:
-            e2 = dict(stamp, kernel=b2[0], bytes_per_launch=traffic2[b2[0]], fetch_size_kb=mean2[(b2[0], "FETCH_SIZE")],
-                      write_size_kb=mean2[(b2[0], "WRITE_SIZE")], source=rel,
-                      note="measured with both shards on ONE GPU (OA_BENCH_SAME_DEVICE=1); per launch of one 500k-point shard")
-            if (b2[0], "SQ_INSTS_VALU") in mean2:
-                e2["valu_instructions_per_pair"] = mean2[(b2[0], "SQ_INSTS_VALU")] * 64.0 / 0.5e12
-                lines.append("%s (500k-point shard): SQ_INSTS_VALU*64/0.5e12 pairs = %.4g VALU instructions per pair" % (b2[0], e2["valu_instructions_per_pair"]))
-            tr["1000000x1000000_n2"] = e2
-        open(summ, "w").write("\n".join(lines) + "\n")
+        lines.append("# %d shards of %d points on this GPU (OA_BENCH_SAME_DEVICE=1 python bench.py --gpus %d ...): per-dispatch means" % (n, shard, n))
+        meann, trafficn = table(aggn, lines)
+        bn = [k for k in trafficn if k.startswith("k_nn_search_filtered")]
+        if bn:
+            en = dict(stamp, kernel=bn[0], bytes_per_launch=trafficn[bn[0]], fetch_size_kb=meann[(bn[0], "FETCH_SIZE")],
+                      write_size_kb=meann[(bn[0], "WRITE_SIZE")], source=rel,
+                      note="measured with all %d shards on ONE GPU (OA_BENCH_SAME_DEVICE=1); per launch of one %d-point shard" % (n, shard))
+            if (bn[0], "SQ_INSTS_VALU") in meann:
+                en["valu_instructions_per_pair"] = meann[(bn[0], "SQ_INSTS_VALU")] * 64.0 / (shard * 1e6)
+                lines.append("%s (%d-point shard): SQ_INSTS_VALU*64 / pairs = %.4g VALU instructions per pair" % (bn[0], shard, en["valu_instructions_per_pair"]))
+            tr["1000000x1000000_n%d" % n] = en
+    open(summ, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
     # ---- the surface loop
