@@ -263,7 +263,8 @@ __global__ __launch_bounds__(BT, 6) void k_nn_search_grid(const DevState *__rest
     if (st->halt) return;
     if (turn >= 0 && (st->tree_turn != 0) != (turn != 0)) return;  // not this kernel's turn (DevState::tree_turn)
     __shared__ int2 seg[GRID_SEGS][BT];
-    const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const int vb = xcd_block_index();                               // workgroup order: one contiguous part of the queries per XCD
+    const int gt = vb * (int)blockDim.x + threadIdx.x;
     int i = gt / L;
     const int sub = gt % L;                                         // the L lanes of a query are neighbours in a wave
     const bool alive = i < ns;                                      // (lanes past the last query repeat it, silently)
@@ -463,7 +464,7 @@ __global__ __launch_bounds__(BT, 6) void k_nn_search_grid(const DevState *__rest
     asm volatile("" : "+s"(src_again));
     const float4 a4 = src_again[i];
     block_store_pair(valid, (double)a4.x - pvx, (double)a4.y - pvy, (double)a4.z - pvz, (double)vbx - pvx, (double)vby - pvy,
-                     (double)vbz - pvz, dist - st->d_pivot, red, partials + (long long)blockIdx.x * NSUMS);
+                     (double)vbz - pvz, dist - st->d_pivot, red, partials + (long long)vb * NSUMS);
 }
 
 __global__ void k_count_nonzero(const int *__restrict__ a, int n, int *__restrict__ out)

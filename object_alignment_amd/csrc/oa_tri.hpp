@@ -448,7 +448,7 @@ __global__ __launch_bounds__(256, 4) void k_tri_search_grid(const DevState *__re
         pool.n = 0; pool.kslot = -1; pool.gmin = INFINITY;
     }
     int n_rows_loaded = 0, n_entries = 0, n_surv = 0, n_evals = 0, n_trips = 0, max_ring = 0;
-    const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const int gt = xcd_block_index() * (int)blockDim.x + threadIdx.x;      // one contiguous part of the queries per XCD
     int i = gt / L;
     const int sub = gt % L;                                         // the L lanes of a query are neighbours in a wave
     // Lanes past the last query stay: phase 2 deals pool entries to ALL 64 lanes of the wave (entry e to lane e mod 64),
