@@ -1448,21 +1448,31 @@ __device__ __forceinline__ bool m4_inverted_lane(const float *Af, int lane, floa
 //                new_mat), the angle ring, whose turn the next search is, d_pivot
 // Round 2 ran all of it on one lane, one after the other: the part after the solve -- 64 products accumulated in double,
 // 16 divisions, an acos, 40 stores -- took as long as the solve.
-__device__ __forceinline__ void solve_update_block(DevState *__restrict__ st, const double *sums, StepRecord *__restrict__ hist,
-                                                   int *__restrict__ todo_count)
+// snapshot of the loop state in LDS: every kernel that ends in solve_update_block takes it with one coalesced copy at its
+// very start (the row reduction, or the wait for the mailboxes, runs meanwhile), so that the solve's reads of the state --
+// three dependent global round trips on its critical path before -- are LDS reads.  Called by ALL threads; the caller's next
+// __syncthreads() makes it visible.
+__device__ __forceinline__ void snapshot_state(const DevState *__restrict__ st, DevState *sh)
 {
+    static_assert(sizeof(DevState) % 4 == 0, "DevState is copied word by word");
+    for (int t = threadIdx.x; t < (int)(sizeof(DevState) / 4); t += blockDim.x) ((uint32_t *)sh)[t] = ((const uint32_t *)st)[t];
+}
+
+__device__ __forceinline__ void solve_update_block(DevState *__restrict__ st, const DevState *cs, const double *sums,
+                                                   StepRecord *__restrict__ hist, int *__restrict__ todo_count)
+{
+    // st: the loop state in global memory (written); cs: its snapshot from the start of this launch (read)
     __shared__ double sh_M[16];
     __shared__ float sh_new[16], sh_mw[16];
-    __shared__ int sh_go, sh_n;
+    __shared__ int sh_go;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (threadIdx.x == 0) {
         // the grid search's hand-over list restarts empty; what it held -- entries, and the most any one wave handed over --
         // goes to the host, which decides from it whether the next grid search can finish its leftovers itself
         const int todo_n = todo_count ? todo_count[0] : 0, todo_wave_max = todo_count ? todo_count[1] : 0;
         if (todo_count) { todo_count[0] = 0; todo_count[1] = 0; }
-        if (st->host_halt) { st->host_halt[2] = todo_n; st->host_halt[3] = todo_wave_max; }
-        sh_go = st->halt ? 0 : 1;
-        sh_n = st->n;
+        if (cs->host_halt) { cs->host_halt[2] = todo_n; cs->host_halt[3] = todo_wave_max; }
+        sh_go = cs->halt ? 0 : 1;
     }
     __syncthreads();
     if (!sh_go) return;                                             // (uniform)
@@ -1470,9 +1480,9 @@ __device__ __forceinline__ void solve_update_block(DevState *__restrict__ st, co
         double s[NSUMS], M[16];
         for (int k = 0; k < NSUMS; ++k) s[k] = sums[k];
         double jv[9];
-        const bool jv_valid = st->jac_valid != 0;
-        for (int k = 0; k < 9; ++k) jv[k] = jv_valid ? st->jac_v[k] : 0.0;
-        const bool ok = solve_from_sums(s, st->pivot, st->with_scale != 0, M, jv, jv_valid);
+        const bool jv_valid = cs->jac_valid != 0;
+        for (int k = 0; k < 9; ++k) jv[k] = jv_valid ? cs->jac_v[k] : 0.0;
+        const bool ok = solve_from_sums(s, cs->pivot, cs->with_scale != 0, M, jv, jv_valid);
         if (lane == 0) {
             if (!ok) { st->status = -3; st->halt = 1; sh_go = 0; }  // K < 3 -> ValueError in the reference: OA_E_TOO_FEW_PAIRS
             else {
@@ -1484,13 +1494,13 @@ __device__ __forceinline__ void solve_update_block(DevState *__restrict__ st, co
     }
     __syncthreads();
     if (!sh_go) return;
-    const int n = sh_n;
+    const int n = cs->n;
     if (wave == 0) {
         // matrix_world @ new_mat (:121): element `lane`, the operation order of m4_mul_m4
         if (lane < 16) {
             const int i = lane >> 2, j = lane & 3;
             double acc = 0.0;
-            for (int k = 0; k < 4; ++k) { const float p = st->mx1[4 * i + k] * sh_new[4 * k + j]; acc += (double)p; }
+            for (int k = 0; k < 4; ++k) { const float p = cs->mx1[4 * i + k] * sh_new[4 * k + j]; acc += (double)p; }
             sh_mw[lane] = (float)acc;
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // this wave's LDS writes above, its LDS reads below
@@ -1501,20 +1511,23 @@ __device__ __forceinline__ void solve_update_block(DevState *__restrict__ st, co
         const bool nonsingular = m4_inverted_lane(mw, lane & 15, inv_k);
         if (nonsingular && lane < 16) st->imx1[lane] = inv_k;
         if (lane == 0) {
-            if (!nonsingular) { st->status = -4; st->halt = 1; }    // next make_pairs would raise   (general.py:265)
+            bool halt = false;
+            if (!nonsingular) { st->status = -4; halt = true; }     // next make_pairs would raise   (general.py:265)
             const double trans = v3_length(sh_new[3], sh_new[7], sh_new[11]);   // new_mat.to_translation().length (:129,:138)
-            if (st->use_target) {                                   // if d_stats:                  (:136)
+            bool converged = cs->converged != 0;
+            if (cs->use_target) {                                   // if d_stats:                  (:136)
                 st->ring_t[n % 5] = trans;                          // conv_t_list[i] = trans.length (:137-138)
                 bool all = true;
-                for (int k = 0; k < 5; ++k) all = all && (st->ring_t[k] < st->target_d);   // (:141)
-                if (all) st->converged = 1;
+                for (int k = 0; k < 5; ++k) all = all && ((k == n % 5 ? trans : cs->ring_t[k]) < cs->target_d);   // (:141)
+                if (all) { converged = true; st->converged = 1; }
             }
             st->n = n + 1;                                          // n += 1                        (:151)
-            if ((st->converged && st->early_exit) || st->n >= st->iters) st->halt = 1;
+            if ((converged && cs->early_exit) || n + 1 >= cs->iters) halt = true;
+            if (halt) st->halt = 1;
             st->t_prev_end = wall_clock64();                        // the next search starts (about) now
-            if (st->host_halt) {                                    // progress and halt flag for the enqueuing host
-                st->host_halt[1] = st->n;
-                if (st->halt) st->host_halt[0] = 1;
+            if (cs->host_halt) {                                    // progress and halt flag for the enqueuing host
+                cs->host_halt[1] = n + 1;
+                if (halt) cs->host_halt[0] = 1;
                 __threadfence_system();
             }
         }
@@ -1525,23 +1538,23 @@ __device__ __forceinline__ void solve_update_block(DevState *__restrict__ st, co
         const double angle = rotation_angle_3x3(M);
         const double K = sums[S_K];
         const double mean_dd = sums[S_D] / K;                       // mean of (d - d_pivot)
-        const double mean_d = mean_dd + st->d_pivot;
+        const double mean_d = mean_dd + cs->d_pivot;
         double var = sums[S_DD] / K - mean_dd * mean_dd;
         if (var < 0.0) var = 0.0;
-        if (hist && st->max_records > 0) {
-            StepRecord &r = hist[n % st->max_records];
+        if (hist && cs->max_records > 0) {
+            StepRecord &r = hist[n % cs->max_records];
             if (lane < 16) { r.M[lane] = sh_M[lane]; r.new_mat[lane] = sh_new[lane]; }
             if (lane == 0) {
                 r.K = K; r.mean_d = mean_d; r.std_d = sqrt(var); r.trans = trans; r.angle = angle;
-                r.search_ticks = (st->t_acc_start > st->t_prev_end) ? (double)(st->t_acc_start - st->t_prev_end) : 0.0;
+                r.search_ticks = (cs->t_acc_start > cs->t_prev_end) ? (double)(cs->t_acc_start - cs->t_prev_end) : 0.0;
             }
         }
         if (lane == 0) {
-            if (st->use_target) st->ring_r[n % 5] = angle;
+            if (cs->use_target) st->ring_r[n % 5] = angle;
             st->d_pivot = mean_d;                                   // next iteration sums d relative to this mean
             // whose turn is the next search (DevState::tree_turn)
-            const double moved = st->use_target ? (trans + angle * st->turn_scale) * st->local_per_world : 0.0;
-            st->tree_turn = (moved > st->turn_limit) ? 1 : 0;
+            const double moved = cs->use_target ? (trans + angle * cs->turn_scale) * cs->local_per_world : 0.0;
+            st->tree_turn = (moved > cs->turn_limit) ? 1 : 0;
         }
     }
 }
@@ -1556,7 +1569,10 @@ __global__ void k_stamp_start(DevState *__restrict__ st)
 __global__ __launch_bounds__(128) void k_solve_update(DevState *__restrict__ st, const double *__restrict__ sums, StepRecord *__restrict__ hist,
                                int *__restrict__ todo_count)
 {
-    solve_update_block(st, sums, hist, todo_count);
+    __shared__ DevState cs;
+    snapshot_state(st, &cs);
+    __syncthreads();
+    solve_update_block(st, &cs, sums, hist, todo_count);
 }
 
 // single-GPU form: the fixed-order reduction and the solve in one launch (same arithmetic, one boundary less)
@@ -1565,11 +1581,14 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce_solve_update(DevState *_
                                                                      StepRecord *__restrict__ hist, int *__restrict__ todo_count, int stamp)
 {
     __shared__ double sums[NSUMS];
-    if (stamp && threadIdx.x == 0) st->t_acc_start = wall_clock64();   // the search + accumulate part ends here
-    reduce_rows_block(partials, rows_of(sel, st), sums);
+    __shared__ DevState cs;
+    const unsigned long long t_start = wall_clock64();
+    snapshot_state(st, &cs);
+    reduce_rows_block(partials, rows_of(sel, st), sums);           // (its barrier also publishes the snapshot)
     __syncthreads();
+    if (stamp && threadIdx.x == 0) cs.t_acc_start = t_start;       // the search + accumulate part ended where this launch began
     if (threadIdx.x < NSUMS && sums_out) sums_out[threadIdx.x] = sums[threadIdx.x];
-    solve_update_block(st, sums, hist, todo_count);
+    solve_update_block(st, &cs, sums, hist, todo_count);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1625,9 +1644,12 @@ __global__ __launch_bounds__(128) void k_gather_solve_update(DevState *__restric
 {
     __shared__ double sums[NSUMS];
     __shared__ int arrived;
-    const bool live = st->halt == 0;
+    __shared__ DevState cs;
+    snapshot_state(st, &cs);
+    __syncthreads();
+    const bool live = cs.halt == 0;
     if (live) {
-        const unsigned long long seq = st->seq_base + (unsigned long long)st->n + 1ull;
+        const unsigned long long seq = cs.seq_base + (unsigned long long)cs.n + 1ull;
         MailSlot *row = box + (size_t)(seq & 1ull) * world;
         if (threadIdx.x == 0) arrived = 1;
         __syncthreads();
@@ -1657,7 +1679,7 @@ __global__ __launch_bounds__(128) void k_gather_solve_update(DevState *__restric
         }
         return;
     }
-    solve_update_block(st, sums, hist, todo_count);
+    solve_update_block(st, &cs, sums, hist, todo_count);
 }
 
 // ------------------------------------------------------------------------------------------------
