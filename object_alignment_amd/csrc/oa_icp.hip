@@ -887,7 +887,8 @@ void init_loop_state(oa_ctx *c, const oa_settings *st, int iters, bool cutoff = 
         s.turn_limit = grid_up ? c->turn_frac * g.h : 0.0;
         s.turn_scale = grid_up ? g.scale : 0.0;
         s.tree_turn = (iters > 1 || !c->seeded) ? 1 : 0;
-        s.pad3 = 0;
+        static const float eye16[16] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1 };
+        s.mx2_identity = (memcmp(s.mx2, eye16, sizeof eye16) == 0 && !env_int("OA_NO_IDENTITY_PATH", 0)) ? 1 : 0;
     }
     if (c->h_poll) {
         void *dp = nullptr;

@@ -66,7 +66,8 @@ struct DevState {
     // host for the first search (no seeds: tree) and by the solve kernel afterwards, from the same quantity the grid
     // kernels double their budget on: last step's translation + rotation x object size against a fraction of a cell.
     double turn_limit, turn_scale;   // OA_TURN_FRAC (0.1) x cell edge and largest |coordinate| of the grid in use
-    int32_t tree_turn, pad3;
+    int32_t tree_turn;
+    int32_t mx2_identity;     // base matrix_world is exactly the identity: mx2 @ v == v bit for bit for finite v (pair_eval)
     // multi-device mailbox exchange: sequence number of this loop's iteration 0 minus one.  It grows from loop to loop
     // (the host adds iters + 2 per loop), so a slot left over from an earlier loop can never be mistaken for a post of
     // this one and the mailboxes never have to be cleared (clearing them would need a cross-device ordering of its own)
@@ -1033,9 +1034,13 @@ __device__ __forceinline__ bool pair_eval(const DevState *__restrict__ st, float
                                           float qz, const NormalTest &nrm, long long slot, const float *tn, double thresh,
                                           float &bx, float &by, float &bz, double &dist)
 {
-    float ax, ay, az, wbx, wby, wbz;
-    m4_mul_v3(st->mx2, cx, cy, cz, ax, ay, az);         // mx2 @ co_find             (general.py:299)
-    m4_mul_v3(st->mx2, qx, qy, qz, wbx, wby, wbz);      // mx2 @ co1                 (general.py:299)
+    float ax = cx, ay = cy, az = cz, wbx = qx, wby = qy, wbz = qz;
+    if (!st->mx2_identity) {
+        // (with the identity the products below return their argument bit for bit -- up to the sign of a zero, which neither
+        //  the distance nor b can see -- and the two of them are a fifth of this function's fp64 work)
+        m4_mul_v3(st->mx2, cx, cy, cz, ax, ay, az);     // mx2 @ co_find             (general.py:299)
+        m4_mul_v3(st->mx2, qx, qy, qz, wbx, wby, wbz);  // mx2 @ co1                 (general.py:299)
+    }
     dist = v3_length(ax - wbx, ay - wby, az - wbz);
     bool valid = dist < thresh;                        // face_index != -1 always holds (general.py:302)
     if (valid && nrm.src_n) {

@@ -1571,3 +1571,35 @@ def test_grid_paths_give_the_same_bits(orc, case, monkeypatch):
             assert np.array_equal(a.step_M, b.step_M) and np.array_equal(a.matrix_world, b.matrix_world), (case, tag)
     assert np.array_equal(out["safe"][0].step_K, ref["step_K"])
     assert np.abs(out["safe"][0].step_M - ref["step_M"]).max() < 1e-9
+
+
+@pytest.mark.gpu
+def test_identity_base_matrix_shortcut_is_bit_exact(monkeypatch):
+    """pair_eval skips `mx2 @ v` when the base object's matrix_world is exactly the identity (for finite v the product
+    returns v bit for bit, up to the sign of a zero that neither the distance nor b can see).  With and without the
+    shortcut (OA_NO_IDENTITY_PATH=1): the same pairs, bit for bit -- including coordinates that are exactly +-0 -- and
+    the same loop."""
+    from object_alignment_amd import synth
+    from object_alignment_amd.engine import IcpEngine
+    rng = np.random.default_rng(9)
+    tgt = rng.uniform(-1, 1, size=(20000, 3)).astype(np.float32)
+    tgt[:300, 0] = 0.0
+    tgt[300:600, 1] = -0.0
+    src = (tgt[rng.permutation(20000)[:15000]] + rng.normal(size=(15000, 3)).astype(np.float32) * np.float32(1e-3)).astype(np.float32)
+    src[:200] = tgt[:200]                                           # exact hits, zeros included
+    mxa = synth.rigid4(synth.rotation_from_rotvec([0.01, -0.02, 0.015]), [0.004, -0.003, 0.002])
+    eye = np.identity(4, dtype=np.float32)
+    out = []
+    for off in ("0", "1"):
+        monkeypatch.setenv("OA_NO_IDENTITY_PATH", off)
+        for mode in ("grid", "brute"):
+            with IcpEngine(0) as e:
+                e.set_search_mode(mode)
+                e.set_target(tgt); e.set_source(src); e.set_matrices(mxa, eye)
+                A, B, st = e.make_pairs(0.05, calc_stats=True)
+                e.set_matrices(mxa, eye)
+                r = e.run(iters=5, thresh=0.05, early_exit=False)
+                out.append((A, B, np.array(st), r.step_M, r.step_K, r.matrix_world))
+    for o in out[1:]:
+        for a, b in zip(out[0], o):
+            assert np.array_equal(a, b)
