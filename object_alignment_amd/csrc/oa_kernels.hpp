@@ -566,7 +566,7 @@ __device__ __forceinline__ int xcd_block_index()
 // L2 then keeps its part of the image for the whole launch.  (Round 2 cut equal splits of ceil(T / n) tiles and launched
 // ceil(T / that) of them: 70 instead of 72 for a 250k-point shard, 123 instead of 136 for 125k -- every XCD then saw every
 // split, the 12 MB image no longer stayed in the L2s and the HBM-side traffic of a launch rose from 0.3 to 3.4 GB;
-// profiles/r03c_bench_1Mx1M_pmc_summary.txt, the 4- and 8-shard passes.)
+// profiles/r03d_bench_1Mx1M_pmc_summary.txt, the 4- and 8-shard passes.)
 __device__ __forceinline__ void split_range(int n_groups_pad, int tile_groups, int &g_begin, int &g_end)
 {
     const long long tiles = n_groups_pad / tile_groups;
