@@ -1396,14 +1396,14 @@ int multi_group_loop(oa_ctx *p, size_t g, const oa_settings *st)
     if (group.empty()) return OA_OK;
     oa_ctx *c0 = p->subs[(size_t)group[0]];
     // (the adaptive grid path needs recent news from the device too: then the host stays close even without early exit)
-    const bool poll = c0->h_poll && env_int("OA_RUN_POLL", 1) && (st->early_exit || (search_plan(c0) == PLAN_GRID && c0->grid_path == 0));
+    bool poll = c0->h_poll && env_int("OA_RUN_POLL", 1) && (st->early_exit || (search_plan(c0) == PLAN_GRID && c0->grid_path == 0));
     const int lag = 2;
     volatile int32_t *progress = c0->h_poll;
     for (int it = 0; it < st->iters; ++it) {
         if (poll) {                                                     // see oa_run
             const auto t_wait = std::chrono::steady_clock::now();
             while (!progress[0] && progress[1] < it - lag) {
-                if (std::chrono::steady_clock::now() - t_wait > std::chrono::seconds(5)) break;
+                if (std::chrono::steady_clock::now() - t_wait > std::chrono::seconds(5)) { poll = false; break; }   // once is enough: enqueue the rest blindly
                 std::this_thread::yield();
             }
             if (progress[0]) break;
@@ -2968,14 +2968,14 @@ OA_EXPORT int oa_run(oa_ctx *c, const oa_settings *st, oa_report *rep)
     // about the halt too late to save anything.  Two iterations are always queued, so the GPU never idles.
     // The adaptive grid path (grid_fast_now) needs recent news from the device as well: then the host stays close even
     // when the loop cannot end early.
-    const bool poll = c->h_poll && env_int("OA_RUN_POLL", 1) && (st->early_exit || (search_plan(c) == PLAN_GRID && c->grid_path == 0));
+    bool poll = c->h_poll && env_int("OA_RUN_POLL", 1) && (st->early_exit || (search_plan(c) == PLAN_GRID && c->grid_path == 0));
     const int lag = 2;
     volatile int32_t *progress = c->h_poll;
     for (int it = 0; it < st->iters; ++it) {
         if (poll) {
             const auto t_wait = std::chrono::steady_clock::now();
             while (!progress[0] && progress[1] < it - lag) {
-                if (std::chrono::steady_clock::now() - t_wait > std::chrono::seconds(5)) break;   // never hang on a sick GPU
+                if (std::chrono::steady_clock::now() - t_wait > std::chrono::seconds(5)) { poll = false; break; }   // never hang on a sick GPU; once is enough
                 std::this_thread::yield();
             }
             if (progress[0]) break;
