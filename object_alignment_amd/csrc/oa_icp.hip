@@ -437,11 +437,6 @@ struct oa_ctx {
     WorkerPool *pool = nullptr;         // parent: the persistent host threads of groups 1 .. n-1 (group 0 = the caller)
     double enq_ns = 0.0;                // child: host time spent enqueuing its iterations in the last loop
     long long enq_iters = 0;
-    // parent: whole selection in slot (Morton) order, kept on the first child's device by oa_set_source so that
-    // per-vertex attributes uploaded later (oa_set_normals) are gathered once and dealt out by range
-    int *d_all_sel = nullptr;
-    long long all_n_sel = 0;
-    std::vector<long long> shard_off;   // parent: begin of every child's range of the selection (n_dev + 1 entries)
 };
 
 namespace {
@@ -1587,7 +1582,6 @@ OA_EXPORT void oa_destroy(oa_ctx *c)
             for (oa_ctx *sub : c->subs) { if (hipSetDevice(sub->device) == hipSuccess) (void)hipStreamSynchronize(sub->stream); }
             delete c->pool;
             c->pool = nullptr;
-            if (c->d_all_sel && !c->subs.empty() && hipSetDevice(c->subs[0]->device) == hipSuccess) { tl_stream_known = false; dev_free(c->d_all_sel, true); }
             exchange_destroy(c);
             for (oa_ctx *sub : c->subs) { sub->xch = nullptr; sub->parent = nullptr; oa_destroy(sub); }
             delete c;
