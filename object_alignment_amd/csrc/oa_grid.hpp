@@ -96,7 +96,8 @@ __device__ __forceinline__ double grid_axis_gap(double v, double lo, double h, i
 // float square root that never underestimates (hardware sqrt is within 1 ulp; the factor covers it and the cast)
 __device__ __forceinline__ float grid_sqrt_up(float x)
 {
-    return __builtin_sqrtf(x) * 1.000001f + 1e-18f;                 // + 1e-18: x below the float normal range (sqrt < 1.1e-19)
+    // v_sqrt_f32 itself (1 ulp), not the correctly rounded sequence around it (19 instructions per row of cells)
+    return __builtin_amdgcn_sqrtf(x) * 1.000001f + 1e-18f;         // + 1e-18: x below the float normal range (sqrt < 1.1e-19)
 }
 
 __global__ void k_grid_count(const float *__restrict__ xyz, int nt, GridParams gp, int *__restrict__ cell_of,
@@ -212,6 +213,19 @@ __device__ __forceinline__ float grid_cube_bound2(const GridParams &gp, const Gr
     return __builtin_fmaf(m, m, q.off2);
 }
 
+// Loads through a 32-bit byte offset from a wave-uniform base (global_load ... v_off, s[base]): one VGPR and one shift per
+// address where the sign-extended 64-bit form costs two of each -- eighteen addresses are in flight per batch of rows.
+// The host builds a grid only for targets whose images stay below 4 GiB (build_grid: GRID_MAX_TARGETS, GRID_MAX_CELLS).
+constexpr long long GRID_MAX_TARGETS = (1ll << 28) - 1, GRID_MAX_CELLS = (1ll << 30) - 2;
+__device__ __forceinline__ int grid_ld_cell(const int *__restrict__ base, int idx)
+{
+    return *(const int *)((const char *)base + (unsigned)idx * 4u);
+}
+__device__ __forceinline__ float4 grid_ld_vertex(const float4 *__restrict__ base, int idx)
+{
+    return *(const float4 *)((const char *)base + (unsigned)idx * 16u);
+}
+
 // `bj` follows the winner's position in `sorted` (-1: still the seed)
 __device__ __forceinline__ void grid_candidate(float px, float py, float pz, const float4 q, int j, float &best,
                                                uint32_t &bidx, int &bj)
@@ -247,7 +261,10 @@ constexpr int GRID_SEGS = 10;      // ranges of one batch: 9 rows of the first b
 // the reduction behind it (1M points 63.6 -> 60.3 us per iteration), the same six waves per SIMD (three
 // workgroups of eight waves per CU instead of six of four); small shards lose with the coarser workgroups (100k: +1.5 us).
 template <int L, bool ACC = false, int BT = 256>
-__global__ __launch_bounds__(BT, 6) void k_nn_search_grid(const DevState *__restrict__ st,
+#ifndef OA_GRID_MIN_WAVES
+#define OA_GRID_MIN_WAVES 6
+#endif
+__global__ __launch_bounds__(BT, OA_GRID_MIN_WAVES) void k_nn_search_grid(const DevState *__restrict__ st,
                                                         const float4 *__restrict__ src4, int ns, GridParams gp,
                                                         const int *__restrict__ cell_start,
                                                         const float4 *__restrict__ sorted,
@@ -311,15 +328,86 @@ __global__ __launch_bounds__(BT, 6) void k_nn_search_grid(const DevState *__rest
     bool busy = q.finite && alive;
     while (__any(busy)) {
         bool ring_done = false;
-        if (busy) {
-            // The (2r+1)^2 rows (y, z) of the ring, RPL per lane at a time: first the cell ranges of the rows are
+        if (busy && r == 1) {
+            // The 3 x 3 rows around the own cell -- where a seeded query starts and, once the pose has settled, ends: ONE batch
+            // for every L (9 rows, at most 10 ranges), so the row offsets are compile-time constants for L = 1 and everything
+            // that depends on one axis only is computed once: four gaps, the two squared x-gaps of the row spans, the row
+            // stride.  Same bounds as the general code below (the same expressions in the same order) at a third of its
+            // instructions -- and that code was half of the kernel's VALU work at 1M points.
+            const bool first = (r_start == 1);
+            const float gzm = grid_gap(q.f[2], h, slack, -1), gzp = grid_gap(q.f[2], h, slack, 1);
+            const float gym = grid_gap(q.f[1], h, slack, -1), gyp = grid_gap(q.f[1], h, slack, 1);
+            const float z2m = __builtin_fmaf(gzm, gzm, q.off2), z2p = __builtin_fmaf(gzp, gzp, q.off2);
+            const float gl = fmaxf(q.f[0] - slack, 0.f), gr = fmaxf((h - q.f[0]) - slack, 0.f);
+            const float gl2 = gl * gl, gr2 = gr * gr;
+            const float reach = lim * 1.00001f + 1e-30f;
+            const int sy = gp.n[0], sz = gp.n[1] * gp.n[0];
+            const int row0 = (q.c[2] * gp.n[1] + q.c[1]) * gp.n[0];
+            // pass 1, no loads: which rows survive (bits 0..8 of `rows`; 9 / 10: the left / right neighbour of the own cell, for
+            // the own row of a second ring -- the own cell was ring 0) and which of their end cells (`ends`: bit k left, 9 + k right)
+            unsigned rows = 0u, ends = 0u;
+#pragma unroll
+            for (int m = 0; m < RPL; ++m) {
+                const int kk = sub + L * m;
+                if (kk >= 9) continue;
+                const int qz = (kk >= 3) + (kk >= 6);
+                const int dzi = qz - 1, dyi = kk - 3 * qz - 1;
+                const int z = q.c[2] + dzi, y = q.c[1] + dyi;
+                if (z < 0 || z >= gp.n[2] || y < 0 || y >= gp.n[1]) continue;
+                const float zz = dzi < 0 ? z2m : (dzi > 0 ? z2p : q.off2);
+                const float gy = dyi < 0 ? gym : (dyi > 0 ? gyp : 0.f);
+                const float row2 = __builtin_fmaf(gy, gy, zz);
+                if (row2 * 0.99999f - 1e-30f > lim) continue;                   // cannot beat or tie
+                float w2 = reach - row2 * 0.99999f;
+                bool dl = true, dr = true;                                      // (no reach known: the whole row)
+                if (w2 < 3.0e38f) { w2 = fmaxf(w2, 0.f); dl = gl2 <= w2; dr = gr2 <= w2; }
+                if (first || kk != 4) {
+                    rows |= 1u << kk;
+                    ends |= ((unsigned)dl << kk) | ((unsigned)dr << (9 + kk));
+                } else {
+                    if (dl && q.c[0] > 0) rows |= 1u << 9;
+                    if (dr && q.c[0] + 1 < gp.n[0]) rows |= 1u << 10;
+                }
+            }
+            // pass 2: the cell ranges of the survivors, UR rows (2 UR loads) in flight at a time -- one or two rows survive once
+            // the pose has settled; holding all nine rows' ranges in registers cost the kernel its sixth wave per SIMD
+            constexpr int UR = L == 1 ? 4 : (L == 2 ? 3 : 2);
+            while (rows) {
+                int ja[UR], jb[UR];
+#pragma unroll
+                for (int u = 0; u < UR; ++u) {
+                    ja[u] = jb[u] = 0;
+                    if (!rows) continue;
+                    const int k = __ffs((int)rows) - 1;
+                    rows &= rows - 1u;
+                    int row = row0, xa, xb;
+                    if (k < 9) {
+                        const int qz = (k >= 3) + (k >= 6);
+                        row += (qz - 1) * sz + (k - 3 * qz - 1) * sy;
+                        xa = max(q.c[0] - (int)((ends >> k) & 1u), 0);
+                        xb = min(q.c[0] + (int)((ends >> (9 + k)) & 1u), gp.n[0] - 1);
+                    } else { xa = xb = q.c[0] + (k == 9 ? -1 : 1); }
+                    ja[u] = grid_ld_cell(cell_start, row + xa); jb[u] = grid_ld_cell(cell_start, row + xb + 1);
+                }
+#pragma unroll
+                for (int u = 0; u < UR; ++u) {
+                    if (jb[u] > ja[u] && budget >= 0) {
+                        budget -= jb[u] - ja[u];                         // crowded cells: one wave of the tree search is faster
+                        if (budget >= 0) { seg[n_seg][threadIdx.x] = make_int2(ja[u], jb[u]); ++n_seg; }
+                    }
+                }
+            }
+            ring_done = true;
+        } else if (busy) {
+            // The (2r+1)^2 rows (y, z) of the ring (r = 0: the own cell; r >= 2), GR per lane at a time: first the cell ranges of the rows are
             // fetched (independent loads, all in flight together), then their vertices are scanned four per trip.
+            constexpr int GR = L == 1 ? 5 : RPL;                    // rows per lane and batch here: five rows' ranges in registers, not nine
             const bool first = (r == r_start);
             const int side = 2 * r + 1, n_rows = side * side;
             const unsigned div_mul = 65536u / (unsigned)side + 1u;  // k / side == (k * div_mul) >> 16 for k < 256, side <= 15
-            int ja[RPL], jb[RPL], jc[RPL], jd[RPL];                 // row m: vertices [ja, jb) and [jc, jd) of `sorted`
+            int ja[GR], jb[GR], jc[GR], jd[GR];                 // row m: vertices [ja, jb) and [jc, jd) of `sorted`
 #pragma unroll
-            for (int m = 0; m < RPL; ++m) {
+            for (int m = 0; m < GR; ++m) {
                 ja[m] = jb[m] = jc[m] = jd[m] = 0;
                 const int kk = b0 + sub + L * m;
                 if (kk >= n_rows) continue;
@@ -339,17 +427,17 @@ __global__ __launch_bounds__(BT, 6) void k_nn_search_grid(const DevState *__rest
                 // interior rows were fully covered by ring r-1: only their two end cells are new
                 const bool shell_row = first || dzi == -r || dzi == r || dyi == -r || dyi == r;
                 if (shell_row) {
-                    ja[m] = cell_start[row + xa]; jb[m] = cell_start[row + xb + 1];
+                    ja[m] = grid_ld_cell(cell_start, row + xa); jb[m] = grid_ld_cell(cell_start, row + xb + 1);
                 } else {
                     const int xl = q.c[0] - r, xr = q.c[0] + r;
-                    if (dl == r && xl >= 0) { ja[m] = cell_start[row + xl]; jb[m] = cell_start[row + xl + 1]; }
-                    if (dr == r && xr < gp.n[0]) { jc[m] = cell_start[row + xr]; jd[m] = cell_start[row + xr + 1]; }
+                    if (dl == r && xl >= 0) { ja[m] = grid_ld_cell(cell_start, row + xl); jb[m] = grid_ld_cell(cell_start, row + xl + 1); }
+                    if (dr == r && xr < gp.n[0]) { jc[m] = grid_ld_cell(cell_start, row + xr); jd[m] = grid_ld_cell(cell_start, row + xr + 1); }
                 }
             }
-            int consumed = RPL;                                    // rows of this batch that went on the list (L == 1: as many as fit)
+            int consumed = GR;                                    // rows of this batch that went on the list (L == 1: as many as fit)
             bool full = false;
 #pragma unroll
-            for (int m = 0; m < RPL; ++m) {
+            for (int m = 0; m < GR; ++m) {
                 if (L == 1 && !full && n_seg + 2 > GRID_SEGS) { full = true; consumed = m; }
                 if (full) continue;
 #pragma unroll
@@ -373,7 +461,7 @@ __global__ __launch_bounds__(BT, 6) void k_nn_search_grid(const DevState *__rest
                 if (active) {
                     const int last = end - 1;
                     const int e1 = min(j + 1, last), e2 = min(j + 2, last), e3 = min(j + 3, last);
-                    const float4 q0 = sorted[j], q1 = sorted[e1], q2 = sorted[e2], q3 = sorted[e3];
+                    const float4 q0 = grid_ld_vertex(sorted, j), q1 = grid_ld_vertex(sorted, e1), q2 = grid_ld_vertex(sorted, e2), q3 = grid_ld_vertex(sorted, e3);
                     grid_candidate(px, py, pz, q0, j, best, bidx, bj);
                     grid_candidate(px, py, pz, q1, e1, best, bidx, bj);
                     grid_candidate(px, py, pz, q2, e2, best, bidx, bj);

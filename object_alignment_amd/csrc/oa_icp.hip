@@ -1708,6 +1708,7 @@ int build_grid(oa_ctx *c)
     c->grid_ok = false;
     dev_free(c->d_cell_start); dev_free(c->d_sorted);
     if (!c->filter_ok || c->grid_mode == 0 || c->nt < 2) return OA_OK;
+    if ((long long)c->nt > oa::GRID_MAX_TARGETS) return OA_OK;       // k_nn_search_grid addresses `sorted` through 32-bit byte offsets; the tree takes over
     double ext[3], vol = 1.0, scale = 0.0;
     int nz = 0;
     for (int a = 0; a < 3; ++a) {
@@ -1719,6 +1720,7 @@ int build_grid(oa_ctx *c)
     double h = nz ? pow(vol * ppc / (double)c->nt, 1.0 / nz) : 1.0;
     if (!(h > 0.0) || !(h < INFINITY)) return OA_OK;
     const long long max_cells = 1ll << 24;
+    static_assert((1ll << 24) <= oa::GRID_MAX_CELLS, "cell_start is addressed through 32-bit byte offsets");
     DevTmp<int> d_cell_of, d_counts, d_nz;
     DevTmp<long long> d_off;
     HIPCHK(d_cell_of.alloc((size_t)c->nt));

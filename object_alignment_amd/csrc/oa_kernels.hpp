@@ -1,12 +1,18 @@
 // oa_kernels.hpp -- gfx950 (CDNA4, wave64) device code of the ICP hot path.
 //
-// Kernels (one ICP iteration = k_nn_search -> k_pair_accumulate -> k_reduce_partials -> [all-reduce] -> k_solve_update):
-//   k_nn_search        brute-force nearest target vertex per source point; target tiles staged through LDS and
-//                      read back as wave-uniform (broadcast) ds_read_b128; fp32 VALU bound
-//   k_pair_accumulate  world-space threshold test + fp64 sums (functions/general.py:299-306 fused with the
-//                      reductions affine_matrix_from_points needs, :160-167,:181,:208-212)
-//   k_reduce_partials  fixed-order reduction of the per-workgroup partials (bitwise reproducible, no float atomics)
-//   k_solve_update     3x3 Kabsch/SVD solve, matrix_world update, convergence ring (operators/icp_align.py:106-149)
+// One ICP iteration inside the loop (oa_run / oa_iterate) is two launches:
+//   search + accumulate   k_nn_search_grid<L, ACC> (oa_grid.hpp), k_bvh_search<TRI, ACC> (oa_bvh.hpp) or, for the modes whose
+//                         search has no accumulating form (brute force, triangle grid), the search followed by
+//                         k_pair_accumulate_canon: world-space threshold test + fp64 sums (functions/general.py:299-306 fused
+//                         with the reductions affine_matrix_from_points needs, :160-167,:181,:208-212), one row of NSUMS
+//                         doubles per workgroup, fixed order (bitwise reproducible, no float atomics)
+//   k_reduce_solve_update rows -> sums -> 3x3 Kabsch/SVD solve, matrix_world update, convergence ring
+//                         (operators/icp_align.py:106-149); across devices k_reduce_post -> k_gather_solve_update (mailboxes)
+//                         or k_reduce_partials -> ncclAllReduce -> k_solve_update
+// This file: the state (DevState), the float32 "mathutils" arithmetic, the brute-force searches
+//   k_nn_search / k_nn_search_filtered   nearest target vertex per source point; target tiles staged through LDS and read
+//                         back as wave-uniform (broadcast) ds_read_b128; fp32 VALU bound
+// the pair test and the accumulation helpers (pair_eval, block_store_pair), the row reduction and the solve.
 //
 // Arithmetic conventions are spelled out in DESIGN.md ("float32 semantics") and are shared bit-for-bit with the
 // CPU oracle.  This translation unit is compiled with -ffp-contract=off: every fma below is written explicitly.
