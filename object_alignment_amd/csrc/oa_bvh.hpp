@@ -319,9 +319,8 @@ __global__ __launch_bounds__(ACC ? 1024 : 256) void k_bvh_search(const DevState 
     for (int slot = blockIdx.x * WPB + w; slot < n_items; slot += n_waves) {
         const int i = list ? list[slot] : slot;
         const float4 p4 = src4[i];
-        float wx, wy, wz, p[3];
-        m4_mul_v3(st->mx1, p4.x, p4.y, p4.z, wx, wy, wz);
-        m4_mul_v3(st->imx2, wx, wy, wz, p[0], p[1], p[2]);          // co_find (general.py:287)
+        float p[3];
+        co_find(st, p4.x, p4.y, p4.z, p[0], p[1], p[2]);          // co_find (general.py:287)
 
         float best = INFINITY;
         uint32_t bidx = IDX_NONE;

@@ -288,9 +288,8 @@ __global__ __launch_bounds__(BT, OA_GRID_MIN_WAVES) void k_nn_search_grid(const 
     if (!alive) i = ns - 1;
     const float4 p4 = src4[i];
     const float4 sw = win[i];                                       // seed: this slot's winner record, see below
-    float wx, wy, wz, px, py, pz;
-    m4_mul_v3(st->mx1, p4.x, p4.y, p4.z, wx, wy, wz);
-    m4_mul_v3(st->imx2, wx, wy, wz, px, py, pz);                // co_find (general.py:287)
+    float px, py, pz;
+    co_find(st, p4.x, p4.y, p4.z, px, py, pz);                // co_find (general.py:287)
 
     // seed: this slot's winner record (coordinates + index) of the previous search -- one coalesced load where an
     // index would cost a dependent gather from the caller-ordered target array

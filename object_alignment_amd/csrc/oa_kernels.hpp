@@ -115,6 +115,18 @@ __host__ __device__ inline void m4_mul_v3(const float *M, float x, float y, floa
     ox = r[0]; oy = r[1]; oz = r[2];
 }
 
+// co_find = imx2 @ (mx1 @ p)  (functions/general.py:287), the query of every search.  With the identity as the base object's
+// matrix (DevState::mx2_identity; its inverse is then the identity too) the second product returns its argument bit for bit
+// -- up to the sign of a zero, which no distance, cell or pair can see; a non-finite coordinate fails the searches' finiteness
+// tests either way -- and is skipped: 39 fp32/fp64 instructions per query.
+__host__ __device__ inline void co_find(const DevState *__restrict__ st, float x, float y, float z, float &px, float &py, float &pz)
+{
+    float wx, wy, wz;
+    m4_mul_v3(st->mx1, x, y, z, wx, wy, wz);                       // mx1 @ p
+    if (st->mx2_identity) { px = wx; py = wy; pz = wz; return; }
+    m4_mul_v3(st->imx2, wx, wy, wz, px, py, pz);
+}
+
 __host__ __device__ inline void m4_mul_m4(const float *A, const float *B, float *out)
 {
     float r[16];
@@ -596,9 +608,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_search(const DevState *__rest
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const float4 p = src4[base + r * NN_THREADS + tid];
-        float wx, wy, wz;
-        m4_mul_v3(st->mx1, p.x, p.y, p.z, wx, wy, wz);           // mx1 @ vert.co          (general.py:287)
-        m4_mul_v3(st->imx2, wx, wy, wz, px[r], py[r], pz[r]);    // imx2 @ (...) = co_find (general.py:287)
+        co_find(st, p.x, p.y, p.z, px[r], py[r], pz[r]);    // imx2 @ (...) = co_find (general.py:287)
         best[r] = INFINITY;
         bidx[r] = IDX_NONE;
     }
@@ -817,9 +827,7 @@ __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_filt
     for (int r = 0; r < R; ++r) {
         const int i = base + r * NN_THREADS + tid;
         const float4 p = src4[i];
-        float wx, wy, wz;
-        m4_mul_v3(st->mx1, p.x, p.y, p.z, wx, wy, wz);
-        m4_mul_v3(st->imx2, wx, wy, wz, px[r], py[r], pz[r]);    // co_find (general.py:287)
+        co_find(st, p.x, p.y, p.z, px[r], py[r], pz[r]);    // co_find (general.py:287)
         const float h0 = (float)((double)px[r] - (double)cx);
         const float h1 = (float)((double)py[r] - (double)cy);
         const float h2 = (float)((double)pz[r] - (double)cz);
@@ -1100,6 +1108,50 @@ __device__ __forceinline__ void block_store_partial(const double (&acc)[NSUMS], 
 // reduced in two halves of 12 and 8, so that the epilogue of a kernel built for 6 waves per SIMD (80 VGPRs) never holds 24
 // doubles plus the butterfly's temporaries at once.  Reduce-scatter over lane bits 5, 4 (, 3), then a plain butterfly.
 // (a, b) = the pair relative to the pivot, dd = dist - d_pivot; lanes without a valid pair contribute zeros.
+// The exchanges stay in the VALU (round 3; they were ds_bpermute pairs with a select on either side -- 62 LDS operations and
+// as many selects per wave): gfx950's v_permlane32_swap / v_permlane16_swap ARE the halving step (the upper half of one
+// register against the lower half of the other: each half keeps its value and receives the other half's copy of it), and the
+// butterflies inside a row of 16 lanes are DPP moves.  Same additions between the same values as before (operands swapped in
+// half of the lanes; IEEE addition commutes), so the rows keep their bits: tools/reduce_check.hip holds the old form.
+__device__ __forceinline__ double f64_from(unsigned lo, unsigned hi) { return __hiloint2double((int)hi, (int)lo); }
+
+// lanes 0..31: a[l] + a[l + 32]     lanes 32..63: b[l - 32] + b[l]
+__device__ __forceinline__ double halve_add32(double a, double b)
+{
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return f64_from(lo[0], hi[0]) + f64_from(lo[1], hi[1]);
+}
+
+// even rows of 16 lanes: a[l] + a[l + 16]     odd rows: b[l - 16] + b[l]
+__device__ __forceinline__ double halve_add16(double a, double b)
+{
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return f64_from(lo[0], hi[0]) + f64_from(lo[1], hi[1]);
+}
+
+// t[l ^ X] inside a row of 16 lanes: X = 8 is a rotation by 8, X = 2 and 1 are quad permutations; X = 4 takes lane l + 4 in
+// the banks {0..3, 8..11} and lane l - 4 in the others (two DPP moves into one register)
+template <int X>
+__device__ __forceinline__ double row_xor(double t)
+{
+    static_assert(X == 8 || X == 4 || X == 2 || X == 1, "");
+    const int lo = __double2loint(t), hi = __double2hiint(t);
+    int rl, rh;
+    if (X == 4) {
+        rl = __builtin_amdgcn_update_dpp(lo, lo, 0x104, 0xf, 0x5, false);      // row_shl:4 -> banks 0, 2
+        rl = __builtin_amdgcn_update_dpp(rl, lo, 0x114, 0xf, 0xa, false);      // row_shr:4 -> banks 1, 3
+        rh = __builtin_amdgcn_update_dpp(hi, hi, 0x104, 0xf, 0x5, false);
+        rh = __builtin_amdgcn_update_dpp(rh, hi, 0x114, 0xf, 0xa, false);
+    } else {
+        constexpr int ctrl = X == 8 ? 0x128 : (X == 2 ? 0x4e : 0xb1);           // row_ror:8, quad_perm [2,3,0,1], [1,0,3,2]
+        rl = __builtin_amdgcn_update_dpp(lo, lo, ctrl, 0xf, 0xf, false);
+        rh = __builtin_amdgcn_update_dpp(hi, hi, ctrl, 0xf, 0xf, false);
+    }
+    return __hiloint2double(rh, rl);
+}
+
 template <int N>
 __device__ __forceinline__ void wave_reduce_scatter(double (&v)[N], int lane, double *red_row)
 {
@@ -1107,20 +1159,14 @@ __device__ __forceinline__ void wave_reduce_scatter(double (&v)[N], int lane, do
     const bool b5 = (lane & 32) != 0, b4 = (lane & 16) != 0, b3 = (lane & 8) != 0;
     double u[N / 2], w[3];                                          // (w: N / 4 values; 3 slots so that the N == 12 branch indexes in bounds when N == 8 is compiled)
 #pragma unroll
-    for (int k = 0; k < N / 2; ++k) {
-        const double keep = b5 ? v[N / 2 + k] : v[k], send = b5 ? v[k] : v[N / 2 + k];
-        u[k] = keep + __shfl_xor(send, 32, 64);
-    }
+    for (int k = 0; k < N / 2; ++k) u[k] = halve_add32(v[k], v[N / 2 + k]);     // lower half of the wave: v[k], upper: v[N/2 + k]
 #pragma unroll
-    for (int k = 0; k < N / 4; ++k) {
-        const double keep = b4 ? u[N / 4 + k] : u[k], send = b4 ? u[k] : u[N / 4 + k];
-        w[k] = keep + __shfl_xor(send, 16, 64);
-    }
+    for (int k = 0; k < N / 4; ++k) w[k] = halve_add16(u[k], u[N / 4 + k]);
     if (N == 12) {                                                   // 3 values left, 16 lanes share them
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             double t = w[k];
-            t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 1, 64);
+            t += row_xor<8>(t); t += row_xor<4>(t); t += row_xor<2>(t); t += row_xor<1>(t);
             w[k] = t;
         }
         if ((lane & 15) == 0) {
@@ -1129,8 +1175,8 @@ __device__ __forceinline__ void wave_reduce_scatter(double (&v)[N], int lane, do
         }
     } else {                                                         // 2 values left: one more halving, then 8 lanes share one
         const double keep = b3 ? w[1] : w[0], send = b3 ? w[0] : w[1];
-        double t = keep + __shfl_xor(send, 8, 64);
-        t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 1, 64);
+        double t = keep + row_xor<8>(send);
+        t += row_xor<4>(t); t += row_xor<2>(t); t += row_xor<1>(t);
         if ((lane & 7) == 0) red_row[(b5 ? 4 : 0) + (b4 ? 2 : 0) + (b3 ? 1 : 0)] = t;
     }
 }
@@ -1200,9 +1246,8 @@ __global__ __launch_bounds__(ACC_THREADS) void k_pair_accumulate(const DevState 
             float4 wrec = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
             if (win) wrec = win[i];
             if (idx != IDX_NONE) {
-                float wx, wy, wz, cx, cy, cz;
-                m4_mul_v3(st->mx1, p.x, p.y, p.z, wx, wy, wz);
-                m4_mul_v3(st->imx2, wx, wy, wz, cx, cy, cz);       // co_find                   (general.py:287)
+                float cx, cy, cz;
+                co_find(st, p.x, p.y, p.z, cx, cy, cz);       // co_find                   (general.py:287)
                 float qx, qy, qz;                                    // co1 (general.py:297)
                 float tn[3] = { 0.f, 0.f, 0.f };                     // correspondence normal (only for the extension)
                 if (tri9) {                                          // surface mode: closest point on triangle `idx`
@@ -1276,9 +1321,8 @@ __global__ __launch_bounds__(CANON_THREADS) void k_pair_accumulate_canon(const D
         float4 wrec = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
         if (win) wrec = win[i];
         if (idx != IDX_NONE) {
-            float wx, wy, wz, cx, cy, cz;
-            m4_mul_v3(st->mx1, p.x, p.y, p.z, wx, wy, wz);
-            m4_mul_v3(st->imx2, wx, wy, wz, cx, cy, cz);           // co_find                   (general.py:287)
+            float cx, cy, cz;
+            co_find(st, p.x, p.y, p.z, cx, cy, cz);           // co_find                   (general.py:287)
             float qx, qy, qz;
             float tn[3] = { 0.f, 0.f, 0.f };
             if (tri9) {

@@ -163,9 +163,7 @@ __global__ __launch_bounds__(NN_THREADS, WPS) void k_nn_search_mfma(const DevSta
     float X, Y, Z;                                                                                                   \
     {                                                                                                                \
         const float4 p_ = src4[base + (r) * NN_THREADS + tid];                                                       \
-        float wx_, wy_, wz_;                                                                                         \
-        m4_mul_v3(st->mx1, p_.x, p_.y, p_.z, wx_, wy_, wz_);                                                         \
-        m4_mul_v3(st->imx2, wx_, wy_, wz_, X, Y, Z);                /* co_find (general.py:287) */                   \
+        co_find(st, p_.x, p_.y, p_.z, X, Y, Z);                /* co_find (general.py:287) */                   \
     }
 #define OA_MF_SEED(r, X, Y, Z, SD, SI)                                                                              \
     float SD = INFINITY;                                                                                             \

@@ -456,9 +456,8 @@ __global__ __launch_bounds__(256, 4) void k_tri_search_grid(const DevState *__re
     const bool alive = i < ns;
     if (!alive) i = ns - 1;
     const float4 p4 = src4[i];
-    float wx, wy, wz, pf[3];
-    m4_mul_v3(st->mx1, p4.x, p4.y, p4.z, wx, wy, wz);
-    m4_mul_v3(st->imx2, wx, wy, wz, pf[0], pf[1], pf[2]);          // co_find (general.py:287)
+    float pf[3];
+    co_find(st, p4.x, p4.y, p4.z, pf[0], pf[1], pf[2]);          // co_find (general.py:287)
 
     float best = INFINITY;
     uint32_t bidx = IDX_NONE;
@@ -624,9 +623,8 @@ __global__ __launch_bounds__(256) void k_tri_search_all(const DevState *__restri
     if (st->halt) return;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) {
         const float4 p4 = src4[i];
-        float wx, wy, wz, pf[3];
-        m4_mul_v3(st->mx1, p4.x, p4.y, p4.z, wx, wy, wz);
-        m4_mul_v3(st->imx2, wx, wy, wz, pf[0], pf[1], pf[2]);
+        float pf[3];
+        co_find(st, p4.x, p4.y, p4.z, pf[0], pf[1], pf[2]);
         float best = INFINITY;
         uint32_t bidx = IDX_NONE;
         if (prev && prev[i] >= 0) tri_eval(pf, tri9, (uint32_t)prev[i], best, bidx);
