@@ -226,6 +226,82 @@ __device__ __forceinline__ float4 grid_ld_vertex(const float4 *__restrict__ base
     return *(const float4 *)((const char *)base + (unsigned)idx * 16u);
 }
 
+// ---- the 3 x 3 rows around the own cell (ring 1) -- where a seeded query starts and, once the pose has settled, ends ---------
+// ONE batch for every L (9 rows, at most 10 ranges), so the row offsets are compile-time constants for L = 1, and everything
+// that depends on one axis only is computed once: four gaps, the two squared x-gaps of the row spans, the row strides.  The
+// bounds are those of the general row code (the same expressions in the same order) at a third of its instructions -- and
+// that code was half of k_nn_search_grid's VALU work at 1M points.  Two passes, so that no more than UR rows' ranges sit in
+// registers: holding nine rows' ranges cost the kernel its sixth wave per SIMD, or spills.
+struct GridBlock3 {
+    unsigned rows;     // bits 0..8: rows (dz + 1) * 3 + (dy + 1) that can matter; 9 / 10: the left / right neighbour of the own
+                       // cell, for the own row of a SECOND ring (the own cell was ring 0)
+    unsigned ends;     // bit k: row k needs the cell left of the own column, bit 9 + k: the cell right of it
+    int row0, sy, sz;  // index of the own row's first cell; cells per step in y, in z
+};
+
+// pass 1, no loads.  A row at squared distance row2 is skipped when row2 * kf - prune_abs > prune_lim; its span along x is
+// what lies within w2 = reach - row2 * kf (reach = +inf: the whole row).  `first`: ring 1 is where this search started.
+template <int L>
+__device__ __forceinline__ GridBlock3 grid_block3_select(const GridParams &gp, const GridQuery &q, int sub, bool first,
+                                                         float prune_lim, float prune_abs, float reach, float kf)
+{
+    constexpr int RPL = (9 + L - 1) / L;
+    const float h = gp.hf, slack = gp.slackf;
+    const float gzm = grid_gap(q.f[2], h, slack, -1), gzp = grid_gap(q.f[2], h, slack, 1);
+    const float gym = grid_gap(q.f[1], h, slack, -1), gyp = grid_gap(q.f[1], h, slack, 1);
+    const float z2m = __builtin_fmaf(gzm, gzm, q.off2), z2p = __builtin_fmaf(gzp, gzp, q.off2);
+    const float gl = fmaxf(q.f[0] - slack, 0.f), gr = fmaxf((h - q.f[0]) - slack, 0.f);     // grid_row_span, r == 1
+    const float gl2 = gl * gl, gr2 = gr * gr;
+    GridBlock3 b;
+    b.rows = 0u; b.ends = 0u;
+    b.sy = gp.n[0]; b.sz = gp.n[1] * gp.n[0];
+    b.row0 = (q.c[2] * gp.n[1] + q.c[1]) * gp.n[0];
+#pragma unroll
+    for (int m = 0; m < RPL; ++m) {
+        const int kk = sub + L * m;
+        if (kk >= 9) continue;
+        const int qz = (kk >= 3) + (kk >= 6);
+        const int dzi = qz - 1, dyi = kk - 3 * qz - 1;
+        const int z = q.c[2] + dzi, y = q.c[1] + dyi;
+        if (z < 0 || z >= gp.n[2] || y < 0 || y >= gp.n[1]) continue;
+        // every primitive of this row of cells is at real distance^2 >= off2 + gy^2 + gz^2 from the query
+        const float zz = dzi < 0 ? z2m : (dzi > 0 ? z2p : q.off2);
+        const float gy = dyi < 0 ? gym : (dyi > 0 ? gyp : 0.f);
+        const float row2 = __builtin_fmaf(gy, gy, zz);
+        if (row2 * kf - prune_abs > prune_lim) continue;
+        float w2 = reach - row2 * kf;
+        bool dl = true, dr = true;
+        if (w2 < 3.0e38f) { w2 = fmaxf(w2, 0.f); dl = gl2 <= w2; dr = gr2 <= w2; }
+        if (first || kk != 4) {
+            b.rows |= 1u << kk;
+            b.ends |= ((unsigned)dl << kk) | ((unsigned)dr << (9 + kk));
+        } else {
+            if (dl && q.c[0] > 0) b.rows |= 1u << 9;
+            if (dr && q.c[0] + 1 < gp.n[0]) b.rows |= 1u << 10;
+        }
+    }
+    return b;
+}
+
+// pass 2: takes the next row off b.rows and loads its range [ja, jb) of the cell lists (both 0 when none is left)
+__device__ __forceinline__ void grid_block3_next(const GridParams &gp, const GridQuery &q, const int *__restrict__ cell_start,
+                                                 GridBlock3 &b, int &ja, int &jb)
+{
+    ja = jb = 0;
+    if (!b.rows) return;
+    const int k = __ffs((int)b.rows) - 1;
+    b.rows &= b.rows - 1u;
+    int row = b.row0, xa, xb;
+    if (k < 9) {
+        const int qz = (k >= 3) + (k >= 6);
+        row += (qz - 1) * b.sz + (k - 3 * qz - 1) * b.sy;
+        xa = max(q.c[0] - (int)((b.ends >> k) & 1u), 0);
+        xb = min(q.c[0] + (int)((b.ends >> (9 + k)) & 1u), gp.n[0] - 1);
+    } else { xa = xb = q.c[0] + (k == 9 ? -1 : 1); }
+    ja = grid_ld_cell(cell_start, row + xa); jb = grid_ld_cell(cell_start, row + xb + 1);
+}
+constexpr int grid_block3_unroll(int L) { return L == 1 ? 4 : (L == 2 ? 3 : 2); }      // rows in flight per lane
+
 // `bj` follows the winner's position in `sorted` (-1: still the seed)
 __device__ __forceinline__ void grid_candidate(float px, float py, float pz, const float4 q, int j, float &best,
                                                uint32_t &bidx, int &bj)
@@ -328,66 +404,14 @@ __global__ __launch_bounds__(BT, OA_GRID_MIN_WAVES) void k_nn_search_grid(const 
     while (__any(busy)) {
         bool ring_done = false;
         if (busy && r == 1) {
-            // The 3 x 3 rows around the own cell -- where a seeded query starts and, once the pose has settled, ends: ONE batch
-            // for every L (9 rows, at most 10 ranges), so the row offsets are compile-time constants for L = 1 and everything
-            // that depends on one axis only is computed once: four gaps, the two squared x-gaps of the row spans, the row
-            // stride.  Same bounds as the general code below (the same expressions in the same order) at a third of its
-            // instructions -- and that code was half of the kernel's VALU work at 1M points.
-            const bool first = (r_start == 1);
-            const float gzm = grid_gap(q.f[2], h, slack, -1), gzp = grid_gap(q.f[2], h, slack, 1);
-            const float gym = grid_gap(q.f[1], h, slack, -1), gyp = grid_gap(q.f[1], h, slack, 1);
-            const float z2m = __builtin_fmaf(gzm, gzm, q.off2), z2p = __builtin_fmaf(gzp, gzp, q.off2);
-            const float gl = fmaxf(q.f[0] - slack, 0.f), gr = fmaxf((h - q.f[0]) - slack, 0.f);
-            const float gl2 = gl * gl, gr2 = gr * gr;
-            const float reach = lim * 1.00001f + 1e-30f;
-            const int sy = gp.n[0], sz = gp.n[1] * gp.n[0];
-            const int row0 = (q.c[2] * gp.n[1] + q.c[1]) * gp.n[0];
-            // pass 1, no loads: which rows survive (bits 0..8 of `rows`; 9 / 10: the left / right neighbour of the own cell, for
-            // the own row of a second ring -- the own cell was ring 0) and which of their end cells (`ends`: bit k left, 9 + k right)
-            unsigned rows = 0u, ends = 0u;
-#pragma unroll
-            for (int m = 0; m < RPL; ++m) {
-                const int kk = sub + L * m;
-                if (kk >= 9) continue;
-                const int qz = (kk >= 3) + (kk >= 6);
-                const int dzi = qz - 1, dyi = kk - 3 * qz - 1;
-                const int z = q.c[2] + dzi, y = q.c[1] + dyi;
-                if (z < 0 || z >= gp.n[2] || y < 0 || y >= gp.n[1]) continue;
-                const float zz = dzi < 0 ? z2m : (dzi > 0 ? z2p : q.off2);
-                const float gy = dyi < 0 ? gym : (dyi > 0 ? gyp : 0.f);
-                const float row2 = __builtin_fmaf(gy, gy, zz);
-                if (row2 * 0.99999f - 1e-30f > lim) continue;                   // cannot beat or tie
-                float w2 = reach - row2 * 0.99999f;
-                bool dl = true, dr = true;                                      // (no reach known: the whole row)
-                if (w2 < 3.0e38f) { w2 = fmaxf(w2, 0.f); dl = gl2 <= w2; dr = gr2 <= w2; }
-                if (first || kk != 4) {
-                    rows |= 1u << kk;
-                    ends |= ((unsigned)dl << kk) | ((unsigned)dr << (9 + kk));
-                } else {
-                    if (dl && q.c[0] > 0) rows |= 1u << 9;
-                    if (dr && q.c[0] + 1 < gp.n[0]) rows |= 1u << 10;
-                }
-            }
-            // pass 2: the cell ranges of the survivors, UR rows (2 UR loads) in flight at a time -- one or two rows survive once
-            // the pose has settled; holding all nine rows' ranges in registers cost the kernel its sixth wave per SIMD
-            constexpr int UR = L == 1 ? 4 : (L == 2 ? 3 : 2);
-            while (rows) {
+            // the 3 x 3 block (GridBlock3): which rows can matter, then their ranges, UR rows in flight at a time -- one or two
+            // rows survive once the pose has settled
+            GridBlock3 blk = grid_block3_select<L>(gp, q, sub, r_start == 1, lim, 1e-30f, lim * 1.00001f + 1e-30f, 0.99999f);
+            constexpr int UR = grid_block3_unroll(L);
+            while (blk.rows) {
                 int ja[UR], jb[UR];
 #pragma unroll
-                for (int u = 0; u < UR; ++u) {
-                    ja[u] = jb[u] = 0;
-                    if (!rows) continue;
-                    const int k = __ffs((int)rows) - 1;
-                    rows &= rows - 1u;
-                    int row = row0, xa, xb;
-                    if (k < 9) {
-                        const int qz = (k >= 3) + (k >= 6);
-                        row += (qz - 1) * sz + (k - 3 * qz - 1) * sy;
-                        xa = max(q.c[0] - (int)((ends >> k) & 1u), 0);
-                        xb = min(q.c[0] + (int)((ends >> (9 + k)) & 1u), gp.n[0] - 1);
-                    } else { xa = xb = q.c[0] + (k == 9 ? -1 : 1); }
-                    ja[u] = grid_ld_cell(cell_start, row + xa); jb[u] = grid_ld_cell(cell_start, row + xb + 1);
-                }
+                for (int u = 0; u < UR; ++u) grid_block3_next(gp, q, cell_start, blk, ja[u], jb[u]);
 #pragma unroll
                 for (int u = 0; u < UR; ++u) {
                     if (jb[u] > ja[u] && budget >= 0) {

@@ -365,40 +365,60 @@ __host__ __device__ inline float dot3f(const float *a, const float *b)
     return s;
 }
 
-// Blender math_geom.c closest_on_tri_to_point_v3, float32, same operation order as the oracle
+// Blender math_geom.c closest_on_tri_to_point_v3, float32: the oracle's operations on the oracle's operands, but WITHOUT its
+// early returns.  A wavefront takes every branch some lane takes, and with seven ways out (three vertices, three edges, the
+// inside) the branchy form cost 370 instructions per call, the tail behind each return included.  Here everything the regions
+// need is computed once (six dot products, the three cross terms), the region is the first of the oracle's tests that holds,
+// ONE division serves whichever region it is (its numerator and denominator are selected first: the same IEEE quotient of
+// the same two floats), and the point is put together from selected operands: ~150 instructions, the same bits.
+// (A region's own expressions are evaluated for lanes outside it too; what they produce there -- a 0 / 0, say -- is dropped.)
 __host__ __device__ inline void closest_on_tri(const float *p, const float *a, const float *b, const float *c, float *r)
 {
-    float ab[3], ac[3], ap[3], bp[3], cp[3];
-    for (int i = 0; i < 3; ++i) { ab[i] = b[i] - a[i]; ac[i] = c[i] - a[i]; ap[i] = p[i] - a[i]; }
-    const float d1 = dot3f(ab, ap), d2 = dot3f(ac, ap);
-    if (d1 <= 0.0f && d2 <= 0.0f) { r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; return; }
-    for (int i = 0; i < 3; ++i) bp[i] = p[i] - b[i];
-    const float d3 = dot3f(ab, bp), d4 = dot3f(ac, bp);
-    if (d3 >= 0.0f && d4 <= d3) { r[0] = b[0]; r[1] = b[1]; r[2] = b[2]; return; }
-    const float vc = d1 * d4 - d3 * d2;
-    if (vc <= 0.0f && d1 >= 0.0f && d3 <= 0.0f) {
-        const float v = d1 / (d1 - d3);
-        for (int i = 0; i < 3; ++i) r[i] = a[i] + ab[i] * v;
-        return;
+    // (scalars, not arrays: selects between array elements keep the arrays in scratch memory)
+    const float ax = a[0], ay = a[1], az = a[2], bx = b[0], by = b[1], bz = b[2], cx = c[0], cy = c[1], cz = c[2];
+    const float px = p[0], py = p[1], pz = p[2];
+    const float abx = bx - ax, aby = by - ay, abz = bz - az, acx = cx - ax, acy = cy - ay, acz = cz - az;
+    const float apx = px - ax, apy = py - ay, apz = pz - az, bpx = px - bx, bpy = py - by, bpz = pz - bz;
+    const float cpx = px - cx, cpy = py - cy, cpz = pz - cz, cbx = cx - bx, cby = cy - by, cbz = cz - bz;
+#define OA_DOT3(ux, uy, uz, vx, vy, vz) (((ux) * (vx) + (uy) * (vy)) + (uz) * (vz))          /* dot3f's order */
+    const float d1 = OA_DOT3(abx, aby, abz, apx, apy, apz), d2 = OA_DOT3(acx, acy, acz, apx, apy, apz);
+    const float d3 = OA_DOT3(abx, aby, abz, bpx, bpy, bpz), d4 = OA_DOT3(acx, acy, acz, bpx, bpy, bpz);
+    const float d5 = OA_DOT3(abx, aby, abz, cpx, cpy, cpz), d6 = OA_DOT3(acx, acy, acz, cpx, cpy, cpz);
+#undef OA_DOT3
+    const float vc = d1 * d4 - d3 * d2, vb = d5 * d2 - d1 * d6, va = d3 * d6 - d5 * d4;
+    const float d43 = d4 - d3, d56 = d5 - d6;
+    // the oracle's tests, in the oracle's order: the first that holds names the region
+    const bool at_a = d1 <= 0.0f && d2 <= 0.0f;
+    const bool at_b = d3 >= 0.0f && d4 <= d3;
+    const bool on_ab = vc <= 0.0f && d1 >= 0.0f && d3 <= 0.0f;
+    const bool at_c = d6 >= 0.0f && d5 <= d6;
+    const bool on_ac = vb <= 0.0f && d2 >= 0.0f && d6 <= 0.0f;
+    const bool on_bc = va <= 0.0f && d43 >= 0.0f && d56 >= 0.0f;
+    enum { AT_A, AT_B, ON_AB, AT_C, ON_AC, ON_BC, INSIDE };
+    const int region = at_a ? AT_A : at_b ? AT_B : on_ab ? ON_AB : at_c ? AT_C : on_ac ? ON_AC : on_bc ? ON_BC : INSIDE;
+    // the one quotient: d1 / (d1 - d3) on ab, d2 / (d2 - d6) on ac, (d4 - d3) / ((d4 - d3) + (d5 - d6)) on bc,
+    // 1 / ((va + vb) + vc) inside
+    const float num = region == ON_AB ? d1 : region == ON_AC ? d2 : region == ON_BC ? d43 : 1.0f;
+    const float den = region == ON_AB ? d1 - d3 : region == ON_AC ? d2 - d6 : region == ON_BC ? d43 + d56 : (va + vb) + vc;
+    const float q = num / den;
+    const float s1 = region == INSIDE ? vb * q : q;                // inside: v = vb * denom
+    const float s2 = vc * q;                                       //         w = vc * denom
+    const bool from_b = region == ON_BC || region == AT_B, from_c = region == AT_C;
+    const bool vertex = region == AT_A || region == AT_B || region == AT_C, inside = region == INSIDE;
+    const bool along_ac = region == ON_AC, along_cb = region == ON_BC;
+    // t: a + ab v | a + ac w | (c - b) w + b | a + ab v;   inside: t + ac w
+#define OA_TRI_POINT(k, av, bv, cv, abv, acv, cbv)                                                       \
+    {                                                                                                    \
+        const float base = from_b ? (bv) : (from_c ? (cv) : (av));                                       \
+        const float e1 = along_ac ? (acv) : (along_cb ? (cbv) : (abv));                                  \
+        const float t = base + e1 * s1;                                                                  \
+        const float in = t + (acv) * s2;                                                                 \
+        r[k] = vertex ? base : (inside ? in : t);                                                        \
     }
-    for (int i = 0; i < 3; ++i) cp[i] = p[i] - c[i];
-    const float d5 = dot3f(ab, cp), d6 = dot3f(ac, cp);
-    if (d6 >= 0.0f && d5 <= d6) { r[0] = c[0]; r[1] = c[1]; r[2] = c[2]; return; }
-    const float vb = d5 * d2 - d1 * d6;
-    if (vb <= 0.0f && d2 >= 0.0f && d6 <= 0.0f) {
-        const float w = d2 / (d2 - d6);
-        for (int i = 0; i < 3; ++i) r[i] = a[i] + ac[i] * w;
-        return;
-    }
-    const float va = d3 * d6 - d5 * d4;
-    if (va <= 0.0f && (d4 - d3) >= 0.0f && (d5 - d6) >= 0.0f) {
-        const float w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
-        for (int i = 0; i < 3; ++i) { float t = c[i] - b[i]; t = t * w; r[i] = t + b[i]; }
-        return;
-    }
-    const float denom = 1.0f / ((va + vb) + vc);
-    const float v = vb * denom, w = vc * denom;
-    for (int i = 0; i < 3; ++i) { const float acw = ac[i] * w; const float t = a[i] + ab[i] * v; r[i] = t + acw; }
+    OA_TRI_POINT(0, ax, bx, cx, abx, acx, cbx)
+    OA_TRI_POINT(1, ay, by, cy, aby, acy, cby)
+    OA_TRI_POINT(2, az, bz, cz, abz, acz, cbz)
+#undef OA_TRI_POINT
 }
 
 __host__ __device__ inline float tri_dist2(const float *p, const float *r)

@@ -177,43 +177,46 @@ __device__ __forceinline__ void tri_eval(const float *p, const float4 *__restric
     if (d < best || (d == best && t < bidx && d < INFINITY)) { best = d; bidx = t; }
 }
 
-// Squared-gap threshold above which a triangle's bounding box proves it can neither beat nor tie `best`: the float32
-// closest-point evaluation is >= (D - delta)^2 (1 - 1e-5) for real distance D, so a box at squared gap
-// > (delta + sqrt((best + 1e-30) / (1 - 1e-5)))^2 is out.  The extra 3e-6 covers the float rounding of the gap (6u) and
-// of the threshold itself.
+// How far from the query anything that can still beat or tie `lim` may lie, as a real distance: the float32 closest-point
+// evaluation is >= (D - delta)^2 (1 - 1e-5) for real distance D, so whatever is farther than
+//     s = delta + sqrt((lim + 1e-30) / (1 - 1e-5))
+// is out.  An UPPER bound of s: the searches call this whenever a lane's best improves -- the whole wave walks through it --
+// and in double (a division and a square root, three times over for the three thresholds derived from it) it was 190
+// instructions, a fifth of k_tri_search_grid's VALU work.  Now: the quotient as a float product rounded up (1.0000102f covers
+// 1 / (1 - 1e-5) and the product's rounding; 1.1e-30f the same for the absolute term), v_sqrt_f32 (1 ulp) with 3e-7 on top.
+__device__ __forceinline__ double tri_reach_bound(float lim, double delta)
+{
+    const float x = lim * 1.0000102f + 1.1e-30f;
+    return delta + (double)__builtin_amdgcn_sqrtf(x) * (1.0 + 3e-7);
+}
+
+// Squared-gap threshold above which a triangle's bounding box proves it can neither beat nor tie `best`: s^2; the extra
+// 3e-6 covers the float rounding of the gap (6u) and of the threshold itself.
 __device__ __forceinline__ float tri_skip_threshold(float best, double delta)
 {
     if (!(best < INFINITY)) return INFINITY;
-    const double s = delta + sqrt(((double)best + 1e-30) / (1.0 - 1e-5));
+    const double s = tri_reach_bound(best, delta);
     return (float)(s * s * (1.0 + 3e-6));
-}
-
-// sqrt of the threshold, rounded up: how far from the query a triangle may be and still matter (sphere test)
-__device__ __forceinline__ float tri_reach(float thr)
-{
-    if (!(thr < INFINITY)) return INFINITY;
-    const double r = sqrt((double)thr) * (1.0 + 1e-6) + 1e-37;
-    return r < 3.0e38 ? (float)r : INFINITY;
 }
 
 struct TriSearchState {
     float best; uint32_t bidx;
-    float lim, thr, reach;    // lim = min(best, search radius^2); thr = squared-gap threshold; reach = sqrt(thr), rounded up
-    double reach2;            // (delta + sqrt((lim + 1e-30) / (1 - 1e-5)))^2: rows / rings whose squared gap exceeds it are out
-    float reach2f;            // the same as a float, rounded up (the per-row arithmetic is float, GridQuery)
+    float lim, thr, reach;    // lim = min(best, search radius^2); thr = squared-gap threshold; reach >= sqrt(thr)
+    float reach2f;            // s^2, rounded up: rows / rings whose squared gap exceeds it are out (the per-row arithmetic is float, GridQuery)
 };
 
-// everything derived from `lim` (called when the best improves: rare)
+// everything derived from `lim` (called when the best improves)
 __device__ __forceinline__ void tri_state_refresh(TriSearchState &s, double delta)
 {
-    s.thr = tri_skip_threshold(s.lim, delta);
-    s.reach = tri_reach(s.thr);
     if (s.lim < INFINITY) {
-        const double r = (delta + sqrt(((double)s.lim + 1e-30) / (1.0 - 1e-5))) * (1.0 + 1e-9);
-        s.reach2 = r * r;
-        const double rf = s.reach2 * (1.0 + 1e-6);
-        s.reach2f = rf < 3.0e38 ? (float)rf : INFINITY;
-    } else { s.reach2 = INFINITY; s.reach2f = INFINITY; }
+        const double r = tri_reach_bound(s.lim, delta);
+        s.thr = (float)(r * r * (1.0 + 3e-6));
+        // sqrt(thr) <= r sqrt(1 + 3e-6) (1 + u) < r (1 + 1.6e-6); rounded to float and up: the sphere test's reach
+        const double rr = r * (1.0 + 3e-6) + 1e-37;
+        s.reach = rr < 3.0e38 ? (float)rr : INFINITY;
+        const double r2 = r * r * (1.0 + 1.1e-6);
+        s.reach2f = r2 < 3.0e38 ? (float)r2 : INFINITY;
+    } else { s.thr = INFINITY; s.reach = INFINITY; s.reach2f = INFINITY; }
 }
 
 // Cell-list candidates go through two phases so that divergence does not multiply the expensive part.
@@ -419,7 +422,10 @@ enum { TRI_STAT_QUERIES, TRI_STAT_ROWS, TRI_STAT_ENTRIES, TRI_STAT_SURVIVORS, TR
        TRI_STAT_WAVES, TRI_STAT_N };
 
 template <int L, bool STATS = false>
-__global__ __launch_bounds__(256, 4) void k_tri_search_grid(const DevState *__restrict__ st,
+#ifndef OA_TRI_MIN_WAVES
+#define OA_TRI_MIN_WAVES 4
+#endif
+__global__ __launch_bounds__(256, OA_TRI_MIN_WAVES) void k_tri_search_grid(const DevState *__restrict__ st,
                                                          const float4 *__restrict__ src4, int ns, GridParams gp,
                                                          const int *__restrict__ cell_start,
                                                          const float4 *__restrict__ cell_rec,
@@ -496,16 +502,36 @@ __global__ __launch_bounds__(256, 4) void k_tri_search_grid(const DevState *__re
     bool busy = q.finite && alive;
     while (__any(busy)) {
         bool ring_done = false;
-        if (busy) {
+        if (busy && r == 1) {
+            // the 3 x 3 block, as in k_nn_search_grid (GridBlock3): which rows can matter -- the row test of the general code
+            // below -- then their ranges, UR rows in flight at a time
+            GridBlock3 blk = grid_block3_select<L>(gp, q, sub, r_start == 1, S.reach2f, 0.f, S.reach2f, 0.999998f);
+            if (STATS) n_rows_loaded += __popc(blk.rows);
+            constexpr int UR = grid_block3_unroll(L);
+            while (blk.rows) {
+                int ja[UR], jb[UR];
+#pragma unroll
+                for (int u = 0; u < UR; ++u) grid_block3_next(gp, q, cell_start, blk, ja[u], jb[u]);
+#pragma unroll
+                for (int u = 0; u < UR; ++u) {
+                    if (jb[u] > ja[u] && budget >= 0) {
+                        budget -= jb[u] - ja[u];                         // crowded cells: one wave of the tree search is faster
+                        if (budget >= 0) { seg[n_seg][threadIdx.x] = make_int2(ja[u], jb[u]); ++n_seg; if (STATS) n_entries += jb[u] - ja[u]; }
+                    }
+                }
+            }
+            ring_done = true;
+        } else if (busy) {
+            constexpr int GR = RPL;                                 // rows per lane and batch here (r = 0, r >= 2)
             const bool first = (r == r_start);
             const int side = 2 * r + 1, n_rows = side * side;
             const unsigned div_mul = 65536u / (unsigned)side + 1u;  // k / side == (k * div_mul) >> 16 for k < 256, side <= 15
-            const int rpl = RPL;
+            const int rpl = GR;
             // rows of the ring: cell ranges first (independent loads), then the candidates -- as in k_nn_search_grid;
             // per-row arithmetic in float on the query's frame (GridQuery)
-            int ja[RPL], jb[RPL], jc[RPL], jd[RPL];
+            int ja[GR], jb[GR], jc[GR], jd[GR];
 #pragma unroll
-            for (int k = 0; k < RPL; ++k) {
+            for (int k = 0; k < GR; ++k) {
                 ja[k] = jb[k] = 0;
                 jc[k] = jd[k] = 0;
                 const int kk = b0 + sub + L * k;
@@ -542,7 +568,7 @@ __global__ __launch_bounds__(256, 4) void k_tri_search_grid(const DevState *__re
             int consumed = rpl;                                   // rows of this batch that went on the list (L == 1: as many as fit)
             bool full = false;
 #pragma unroll
-            for (int k = 0; k < RPL; ++k) {
+            for (int k = 0; k < GR; ++k) {
                 if (L == 1 && !full && n_seg + 2 > TRI_SEGS) { full = true; consumed = k; }
                 if (full) continue;
 #pragma unroll
