@@ -155,13 +155,19 @@ __device__ __forceinline__ GridQuery grid_locate(const GridParams &gp, float px,
     q.finite = true;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        if (!(fabs(p[a]) < INFINITY)) q.finite = false;
-        pa += fabs(p[a]);
-        const double pc = p[a] < gp.lo[a] ? gp.lo[a] : (p[a] > gp.hi[a] ? gp.hi[a] : p[a]);
+        const double ab = fabs(p[a]);
+        if (!(ab < INFINITY)) q.finite = false;
+        pa += ab;
+        const double pc = fmin(fmax(p[a], gp.lo[a]), gp.hi[a]);    // (a NaN coordinate ends up at lo: the query is not searched anyway)
         const double d = p[a] - pc;
-        off2 += d * d;
-        q.c[a] = grid_cell_coord(pc, gp.lo[a], gp.inv_h, gp.n[a]);
-        q.f[a] = (float)(pc - (gp.lo[a] + (double)q.c[a] * gp.h));
+        off2 = fma(d, d, off2);
+        // cell = floor((pc - lo) / h), as the build's grid_cell_coord has it (t >= 0: the conversion truncates = floors); the
+        // position inside the cell from the same quotient: (t - c) h is pc - (lo + c h) up to 1e-13 h (inv_h h = 1 +- 2^-52
+        // on at most 1024 cells), far below what slackf covers
+        const double t = (pc - gp.lo[a]) * gp.inv_h;
+        const int c = min((int)t, gp.n[a] - 1);
+        q.c[a] = c;
+        q.f[a] = (float)((t - (double)c) * gp.h);
     }
     q.off2 = (float)off2;
     if (pabs) *pabs = pa;
