@@ -1603,3 +1603,19 @@ def test_identity_base_matrix_shortcut_is_bit_exact(monkeypatch):
     for o in out[1:]:
         for a, b in zip(out[0], o):
             assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_wave_reduction_keeps_the_bits_of_the_shuffle_form():
+    """The pair sums of every accumulating kernel go through wave_reduce_scatter (oa_kernels.hpp): v_permlane32_swap /
+    v_permlane16_swap halvings and DPP butterflies.  tools/reduce_check.hip holds the form it replaced (ds_bpermute shuffles
+    with selects) and compares the two bit for bit on random doubles of mixed magnitude, and the new form against a long
+    double host sum: the rows of partials -- and with them every loop fixture -- must not depend on which one is built."""
+    import subprocess
+    import __graft_entry__ as entry
+    exes = entry.build_tools()
+    exe = [e for e in exes if e.endswith("reduce_check.exe")]
+    assert exe, "tools/reduce_check.hip did not build"
+    out = subprocess.run([exe[0], "2048"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "identical" in out.stdout and "0 of" in out.stdout, out.stdout
