@@ -130,12 +130,12 @@ def main():
                 n_it = len(ref_loop["step_K"])
                 ok_l = len(sK) == n_it and np.array_equal(sK, ref_loop["step_K"])
                 dM = float("nan")
+                mag = float(np.abs(src).max()) + 1e-300
                 if ok_l and n_it:
                     # rotation part to 1e-7; translation relative to the coordinates' magnitude
                     # first iteration: same pairs in, so the transforms agree to solver precision.  Later iterations start
                     # from a float32 matrix_world that may differ in its last bit (a float64 entry of M on a rounding
                     # boundary), which an object far from the origin amplifies: looser there.
-                    mag = float(np.abs(src).max()) + 1e-300
                     dM = 0.0
                     for k in range(n_it):
                         dR = float(np.abs(sM[k, :3, :3] - ref_loop["step_M"][k, :3, :3]).max())
@@ -149,7 +149,8 @@ def main():
                     ok_l = np.array_equal(sM, brute_M)           # brute force and grid both end in the canonical accumulation: bit for bit
                 elif ok_l:
                     # the whole-shard tree search of a small shard accumulates per wave (another summation order): to rounding
-                    ok_l = bool(np.abs(sM - brute_M).max() <= 1e-12 * max(1.0, float(np.abs(brute_M).max())))
+                    # (relative to the coordinates' magnitude: a translation of 0.5 between clouds at 1e5 carries 1e-11 of noise)
+                    ok_l = bool(np.abs(sM - brute_M).max() <= 1e-12 * max(1.0, float(np.abs(brute_M).max()), mag))
                 detail_l = "" if ok_l else "loop K %s vs %s, dM %.3g" % ([int(k) for k in sK], [int(k) for k in ref_loop["step_K"]], dM)
                 if not ok_l and os.environ.get("FUZZ_DEBUG"):
                     np.set_printoptions(precision=9, linewidth=200)
