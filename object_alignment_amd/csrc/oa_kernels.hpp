@@ -1399,14 +1399,32 @@ __device__ __forceinline__ void reduce_rows_block(const double *__restrict__ row
 #pragma unroll
             for (int u = 0; u < 16; ++u) { v0 += p[u].x; v1 += p[u].y; }
         }
-        for (; r + 3 * RED_SLICES < n_rows; r += 4 * RED_SLICES) {
+        // the last (or only) batch, fewer than 16 rows: all loads at once, predicated -- ONE round trip where batches of four and
+        // single rows took up to five (1954 rows at 1M points: 23 per slice = 16 + 4 + 1 + 1 + 1); same additions, same order.
+        // (Four wide when that covers it: a few hundred rows are a 2562-point problem, where every instruction shows.)
+        if (r + 4 * RED_SLICES < n_rows) {
+            double2 p[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int rr = r + RED_SLICES * u;
+                p[u] = make_double2(0.0, 0.0);
+                if (rr < n_rows) p[u] = col[12ll * rr];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (r + RED_SLICES * u < n_rows) { v0 += p[u].x; v1 += p[u].y; }
+        } else if (r < n_rows) {
             double2 p[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) p[u] = col[12ll * (r + RED_SLICES * u)];
+            for (int u = 0; u < 4; ++u) {
+                const int rr = r + RED_SLICES * u;
+                p[u] = make_double2(0.0, 0.0);
+                if (rr < n_rows) p[u] = col[12ll * rr];
+            }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { v0 += p[u].x; v1 += p[u].y; }
+            for (int u = 0; u < 4; ++u)
+                if (r + RED_SLICES * u < n_rows) { v0 += p[u].x; v1 += p[u].y; }
         }
-        for (; r < n_rows; r += RED_SLICES) { const double2 q = col[12ll * r]; v0 += q.x; v1 += q.y; }
         red[s][2 * c] = v0; red[s][2 * c + 1] = v1;
     }
     __syncthreads();
@@ -1601,9 +1619,11 @@ __device__ __forceinline__ void solve_update_block(DevState *__restrict__ st, co
             if (halt) st->halt = 1;
             st->t_prev_end = wall_clock64();                        // the next search starts (about) now
             if (cs->host_halt) {                                    // progress and halt flag for the enqueuing host
+                // (no fence: the host only ever looks at these two words to decide whether to enqueue more; whichever arrives
+                //  first, it enqueues an iteration too many -- which returns at once -- or stops where it should.  A system-scope
+                //  fence here sat at the very end of every iteration's critical path.)
                 cs->host_halt[1] = n + 1;
                 if (halt) cs->host_halt[0] = 1;
-                __threadfence_system();
             }
         }
     } else if (wave == 1) {
