@@ -405,6 +405,7 @@ struct oa_ctx {
     double *d_partials = nullptr, *d_sums = nullptr, *d_solve = nullptr;
     int fused_acc = 1;                      // OA_FUSED_ACC: grid / tree searches of the loop accumulate in their epilogue
     int tree_acc_max = 4096;                // OA_TREE_ACC_MAX: largest shard whose whole-shard tree search also accumulates
+    int acc_threads = 0;                    // OA_ACC_THREADS: 256 / 512 threads per workgroup of the accumulating grid search and k_pair_accumulate_canon (0 = by shard size)
     int grid_path = 0;                      // OA_GRID_PATH: 0 = adaptive (see grid_fast_now), 1 = always the fused path, 2 = never
     int iter_enq = 0;                       // iterations enqueued since the loop began
     bool fast_prev = false;                 // what the last iteration's grid search did
@@ -629,7 +630,11 @@ inline int grid_lanes_for(const oa_ctx *c)
 // target is a surface: the grid-stride k_pair_accumulate is used instead.
 // (512 threads per workgroup from 262k (query, lane) pairs on: half the rows for the reduction behind it; below that the
 //  finer workgroups balance better)
-inline int canon_threads(const oa_ctx *c) { return (long long)c->ns * grid_lanes_for(c) >= 262144 ? 512 : 256; }
+inline int canon_threads(const oa_ctx *c)
+{
+    if (c->acc_threads == 256 || c->acc_threads == 512) return c->acc_threads;   // OA_ACC_THREADS (A/B)
+    return (long long)c->ns * grid_lanes_for(c) >= 262144 ? 512 : 256;
+}
 inline int canon_blocks(const oa_ctx *c)
 {
     if (c->surface || c->ns <= 0) return 0;
@@ -1462,6 +1467,7 @@ OA_EXPORT int oa_create(oa_ctx **out, int device)
     if (c->R_env != 1 && c->R_env != 2 && c->R_env != 4 && c->R_env != 8) c->R_env = 0;
     c->R = c->R_env ? c->R_env : 4;
     c->grid_lanes = env_int("OA_GRID_LANES", 0);
+    c->acc_threads = env_int("OA_ACC_THREADS", 0);
     c->turns_on = env_int("OA_SEARCH_TURNS", 1);
     c->debug = getenv("OA_DEBUG") != nullptr;
     c->grid_stats = env_int("OA_GRID_STATS", 0) != 0;
