@@ -197,6 +197,10 @@ int oa_reset_seeds(oa_ctx *ctx);
 #define OA_STAT_ENQUEUE_US       10   /* multi-device context: host time per iteration spent enqueuing ONE device's work in the
                                        * last oa_run (mean over iterations, max over devices), microseconds */
 #define OA_STAT_HOST_THREADS     11   /* multi-device context: host threads that drive its devices (1 = the caller alone) */
+#define OA_STAT_FAST_ITERATIONS  12   /* iterations of the last / current loop in which the grid search finished its own leftovers and
+                                       * accumulated in its epilogue (the adaptive choice of DESIGN.md 4.4; first device) */
+#define OA_STAT_HANDOVER_ENTRIES 13   /* what the last grid search handed to the tree: queries ... */
+#define OA_STAT_HANDOVER_WAVE_MAX 14  /* ... and the most any ONE wavefront handed over (what the adaptive choice looks at) */
 int oa_get_stat(oa_ctx *ctx, int what, double *value);
 int64_t oa_num_selected(oa_ctx *ctx);     /* selected source points held by this context (its shard) */
 

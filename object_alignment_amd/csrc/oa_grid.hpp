@@ -394,11 +394,13 @@ __global__ __launch_bounds__(BT, OA_GRID_MIN_WAVES) void k_nn_search_grid(const 
     // pose still moves by a good part of a cell per iteration (stale seeds: most queries need the second ring) -- see
     // k_tri_search_grid
     int budget = gp.budget;
+    int budget_extra = 0;                                            // what the doubling added (wave-uniform)
     {
         const int last = (st->n + 4) % 5;
         const double moved = st->use_target && st->n > 0 ? (st->ring_t[last] + st->ring_r[last] * gp.scale) * st->local_per_world : 0.0;
         if (st->n == 0 || moved > 0.25 * gp.h) budget *= 2;
         if (L > 1) budget = budget / L + 8;
+        budget_extra = budget - (L > 1 ? gp.budget / L + 8 : gp.budget);
     }
     // With a seed the search starts with the whole 3 x 3 x 3 block as its first "ring": the rows and cells the seed's
     // distance rules out are pruned exactly as they would be one ring later, a query far from its cell's faces still
@@ -522,17 +524,23 @@ __global__ __launch_bounds__(BT, OA_GRID_MIN_WAVES) void k_nn_search_grid(const 
             }
         }
     }
+    bool tight = budget < budget_extra;                             // used more than the base budget allows
+    if (L > 1) {
+#pragma unroll
+        for (int o = 1; o < L; o <<= 1) tight = (__shfl_xor((int)tight, o, 64) != 0) || tight;
+    }
     if (!ACC) {
         if (sub != 0 || !alive) return;
         keys[i] = ((unsigned long long)__float_as_uint(best) << 32) | bidx;
         // the winner record is read by k_pair_accumulate, the tree search and the next search; a winner that is still the
         // seed (the usual case once the loop converges) is already there
         if (bj >= 0) win[i] = sorted[bj];
-        if (!settled) {                                             // finished exactly by the tree search (k_bvh_search)
-            todo_list[atomicAdd(todo_count, 1)] = i;
-            // (how crowded the hand-over is per wave: what the host looks at before it lets a later search finish its own leftovers)
-            atomicMax(todo_count + 1, __popcll(__ballot(1)));
-        }
+        if (!settled) todo_list[atomicAdd(todo_count, 1)] = i;      // finished exactly by the tree search (k_bvh_search)
+        // How crowded the hand-over is per wave: what the host looks at before it lets a later search finish its own leftovers
+        // (grid_fast_now).  Counted against the BASE budget: a search that ran on the doubled one -- the first of a loop, or
+        // while the pose moves -- would otherwise report "nothing handed over" for queries the next search, on the base
+        // budget, hands over by the thousand (seen on C5's surface clouds: one 0.6 ms iteration per loop).
+        if (!settled || tight) atomicMax(todo_count + 1, __popcll(__ballot(1)));
         return;
     }
     // ---- ACC: finish, record, accumulate -- all threads stay to the end (wave-wide descents, workgroup-wide reduction)
@@ -545,8 +553,10 @@ __global__ __launch_bounds__(BT, OA_GRID_MIN_WAVES) void k_nn_search_grid(const 
         // (a non-finite query has no finite distance: it stays as it is; recomputed here, not held through the scan)
         const bool finite = fabsf(px) < INFINITY && fabsf(py) < INFINITY && fabsf(pz) < INFINITY;
         unsigned long long todo = __ballot(mine && !settled && finite);
+        const unsigned long long crowd = __ballot(mine && finite && (!settled || tight));   // (against the base budget, see above)
+        if (crowd && (threadIdx.x & 63) == 0) atomicMax(todo_count + 1, __popcll(crowd));
         if (todo) {
-            if ((threadIdx.x & 63) == 0) { atomicAdd(todo_count, __popcll(todo)); atomicMax(todo_count + 1, __popcll(todo)); }
+            if ((threadIdx.x & 63) == 0) atomicAdd(todo_count, __popcll(todo));
             // this wave's columns of the range lists are free now: per level 256 B of bounds, then the mask and the node
             const int lane = threadIdx.x & 63, col0 = threadIdx.x & ~63;
             char *base = (char *)&seg[0][col0];

@@ -408,6 +408,7 @@ struct oa_ctx {
     int acc_threads = 0;                    // OA_ACC_THREADS: 256 / 512 threads per workgroup of the accumulating grid search and k_pair_accumulate_canon (0 = by shard size)
     int grid_path = 0;                      // OA_GRID_PATH: 0 = adaptive (see grid_fast_now), 1 = always the fused path, 2 = never
     int iter_enq = 0;                       // iterations enqueued since the loop began
+    int fast_iters = 0;                     // ... of which the grid search finished its own leftovers and accumulated (OA_STAT_FAST_ITERATIONS)
     bool fast_prev = false;                 // what the last iteration's grid search did
     int last_todo_wave_max = -1;            // most queries one wave handed over in the last iteration the host heard of (-1: unknown)
     // make_pairs scratch (sized to ns)
@@ -682,6 +683,7 @@ bool grid_fast_now(oa_ctx *c)
     if (n_done > 0 && n_done >= c->iter_enq - 4) fast = poll[3] <= FAST_WAVE_MAX;
     else if (c->iter_enq == 0) fast = c->seeded && c->last_todo_wave_max >= 0 && c->last_todo_wave_max <= FAST_WAVE_MAX;
     else if (n_done <= 0 && c->iter_enq > 4) fast = false;          // the host ran far ahead of the device: no news, no risk
+    if (c->debug) fprintf(stderr, "[oa] grid path: iteration %d enqueued, device at %d, last hand-over %d entries / %d per wave (previous loop: %d) -> %s\n", c->iter_enq, n_done, poll ? poll[2] : -1, poll ? poll[3] : -1, c->last_todo_wave_max, fast ? "fast" : "safe");
     c->fast_prev = fast;
     return fast;
 }
@@ -825,6 +827,7 @@ int launch_search_accumulate(oa_ctx *c, bool timed, oa::RowSel &sel, bool &fused
     const SearchPlan plan = search_plan(c);
     fused = plan == PLAN_TREE || plan == PLAN_DUAL || (plan == PLAN_GRID && grid_fast_now(c));
     c->iter_enq++;
+    if (plan == PLAN_GRID && fused) c->fast_iters++;
     if (timed) {
         if ((rc = ensure_events(c, c->ev_used + 1))) return rc;
         HIPCHK(hipEventRecord(c->ev[2 * c->ev_used], c->stream));
@@ -952,6 +955,7 @@ int begin_loop(oa_ctx *c, const oa_settings *st, int iters)
     HIPCHK(hipGetLastError());
     c->ev_used = 0;
     c->iter_enq = 0;
+    c->fast_iters = 0;
     c->h_hist_valid = false;
     {
         const bool brute = !c->surface ? !(bvh_whole(c, c->bvh_ok, vertex_tree_max(c)) || grid_active(c))
@@ -1748,7 +1752,9 @@ int build_grid(oa_ctx *c)
         gp.h = h; gp.inv_h = 1.0 / h;
         gp.r_max = std::min(env_int("OA_GRID_RMAX", 3), 3);
         gp.seeded_start = env_int("OA_GRID_SEEDED_START", 1) ? 1 : 0;
-        gp.budget = env_int("OA_GRID_BUDGET", 128);
+        // (256: 128 was tuned in round 2, when a hand-over was a list entry; surface-like clouds -- C5 -- keep ~1000 queries per
+        //  search above 128 once the doubling for a moving pose ends, and every one of them costs the iteration its fast path)
+        gp.budget = env_int("OA_GRID_BUDGET", 256);
         gp.slack = 1e-10 * scale + 1e-300;
         gp.scale = scale;
         oa::grid_params_finish(gp);
@@ -2569,6 +2575,9 @@ OA_EXPORT int oa_get_stat(oa_ctx *c, int what, double *value)
         *value = !(c->filter_ok && c->use_filter) ? 0.0
                  : ((c->nn_mfma && c->d_tfm && c->R == 4 && c->tile_groups == oa::FTILE_GROUPS) ? 2.0 : 1.0);
         return OA_OK;
+    case OA_STAT_FAST_ITERATIONS: *value = (double)c->fast_iters; return OA_OK;
+    case OA_STAT_HANDOVER_ENTRIES: *value = c->h_poll ? (double)c->h_poll[2] : 0.0; return OA_OK;
+    case OA_STAT_HANDOVER_WAVE_MAX: *value = c->h_poll ? (double)c->h_poll[3] : 0.0; return OA_OK;
     default: return fail(OA_E_BAD_ARG, "oa_get_stat: unknown key %d", what);
     }
 }

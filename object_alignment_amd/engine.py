@@ -180,7 +180,8 @@ class IcpEngine:
         capi.check(self._L.oa_reset_seeds(self._h))
 
     STATS = {"grid_cells": 1, "tri_grid_cells": 2, "tri_grid_entries": 3, "n_tris": 4, "surface": 5, "cache_bytes": 6,
-             "brute_kernel": 7, "exchange": 8, "rccl_ranks": 9, "enqueue_us": 10, "host_threads": 11}
+             "brute_kernel": 7, "exchange": 8, "rccl_ranks": 9, "enqueue_us": 10, "host_threads": 11,
+             "fast_iterations": 12, "handover_entries": 13, "handover_wave_max": 14}
     EXCHANGE_NAMES = {-1: None, 0: "mailbox (pinned host memory)", 1: "rccl", 2: "mailbox (peer-mapped device memory)"}
 
     def exchange_info(self):
