@@ -28,6 +28,7 @@ struct GridParams {
     double slack;            // absolute slack subtracted from face distances (1e-10 x largest |coordinate|)
     double scale;            // largest |coordinate| of the box
     int    seeded_start;     // 1: a seeded query starts with the 3 x 3 x 3 block instead of its own cell (OA_GRID_SEEDED_START)
+    int    budget_moving;    // ... while the pose still moves by a good part of a cell per iteration, or in the first search of a loop
     int    budget;           // candidates one thread may look at before it hands the query to the tree search
                              // (crowded cells -- clusters, fans of thin triangles -- would otherwise stall its wave)
     // float images for the per-row arithmetic of the searches (GridQuery): cell edge, its inverse, and a slack that
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(BT, OA_GRID_MIN_WAVES) void k_nn_search_grid(const 
     {
         const int last = (st->n + 4) % 5;
         const double moved = st->use_target && st->n > 0 ? (st->ring_t[last] + st->ring_r[last] * gp.scale) * st->local_per_world : 0.0;
-        if (st->n == 0 || moved > 0.25 * gp.h) budget *= 2;
+        if (st->n == 0 || moved > 0.25 * gp.h) budget = gp.budget_moving;
         if (L > 1) budget = budget / L + 8;
         budget_extra = budget - (L > 1 ? gp.budget / L + 8 : gp.budget);
     }

@@ -1755,6 +1755,7 @@ int build_grid(oa_ctx *c)
         // (256: 128 was tuned in round 2, when a hand-over was a list entry; surface-like clouds -- C5 -- keep ~1000 queries per
         //  search above 128 once the doubling for a moving pose ends, and every one of them costs the iteration its fast path)
         gp.budget = env_int("OA_GRID_BUDGET", 256);
+        gp.budget_moving = (int)(gp.budget * env_double("OA_GRID_BUDGET_MOVING", 2.0));
         gp.slack = 1e-10 * scale + 1e-300;
         gp.scale = scale;
         oa::grid_params_finish(gp);
@@ -2081,6 +2082,7 @@ int build_tri_grid(oa_ctx *c)
         gp.r_max = std::min(env_int("OA_GRID_RMAX", 3), 3);
         gp.seeded_start = env_int("OA_TRI_SEEDED_START", 1) ? 1 : 0;
         gp.budget = env_int("OA_GRID_BUDGET", 192);
+        gp.budget_moving = (int)(gp.budget * env_double("OA_GRID_BUDGET_MOVING", 2.0));
         gp.scale = scale;
         gp.slack = 1e-10 * scale + 1e-300;
         oa::grid_params_finish(gp);

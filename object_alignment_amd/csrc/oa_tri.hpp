@@ -490,7 +490,7 @@ __global__ __launch_bounds__(256, OA_TRI_MIN_WAVES) void k_tri_search_grid(const
     {
         const int last = (st->n + 4) % 5;
         const double moved = st->use_target && st->n > 0 ? (st->ring_t[last] + st->ring_r[last] * gp.scale) * st->local_per_world : 0.0;
-        if (st->n == 0 || moved > 0.25 * gp.h) budget *= 2;
+        if (st->n == 0 || moved > 0.25 * gp.h) budget = gp.budget_moving;
         if (L > 1) budget = budget / L + 8;
     }
     const int r_start = (S.bidx != IDX_NONE && gp.seeded_start) ? 1 : 0;   // as in k_nn_search_grid
