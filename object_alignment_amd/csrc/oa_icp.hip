@@ -2096,7 +2096,7 @@ int build_tri_grid(oa_ctx *c)
         HIPCHK(hipGetLastError());
         { int rcr = read_small(c, &entries, d_total, sizeof(entries)); if (rcr) return rcr; }
         // triangles much larger than a cell explode the lists: coarsen
-        if (entries > 32ull * (unsigned long long)c->n_tris + (1ull << 20) || entries > 0x7FFFFFF0ull) { h *= 2.0; n_cells = 0; continue; }
+        if (entries > 32ull * (unsigned long long)c->n_tris + (1ull << 20) || entries > (unsigned long long)oa::TRI_REC_MAX_ENTRIES) { h *= 2.0; n_cells = 0; continue; }
         break;
     }
     if (n_cells <= 0 || entries == 0) return OA_OK;

@@ -250,19 +250,22 @@ struct TriPool {                   // this wave's part of the workgroup's LDS
 // Derivation in tri_record's comment; every rounding is covered: products and sums of floats are within 4u of their
 // operands' magnitudes (u = 2^-24), the margins below are 1e-6 relative plus eps_plane + 8u rs absolute, where
 // rs >= |p - c| (the caller passed the sphere test D2 <= rs^2 (1 + 3e-6)).
-__device__ __forceinline__ float tri_record_bound2(const float *p, const float4 rec0, const float4 rec1, float D2, float rs,
+// (dx, dy, dz) = c - p as the sphere test formed it: only |n . (p - c)| and its square are used, and negation is exact.
+__device__ __forceinline__ float tri_record_bound2(float dx, float dy, float dz, const float4 rec0, const float4 rec1, float D2, float rs,
                                                    float eps_plane)
 {
-    const float dx = p[0] - rec0.x, dy = p[1] - rec0.y, dz = p[2] - rec0.z;
-    const float pdc = dx * rec1.x + dy * rec1.y + dz * rec1.z;                   // n . (p - c), |n| <= 1
+    // (fma chains here and in the sphere test: these are bounds, not the oracle's arithmetic -- fewer roundings than the 4u the
+    //  margins allow for, and two instructions less each)
+    const float pdc = __builtin_fmaf(dz, rec1.z, __builtin_fmaf(dy, rec1.y, dx * rec1.x));   // -n . (p - c), |n| <= 1
     const float pd = fmaxf(fabsf(pdc) - (eps_plane + 4.8e-7f * rs), 0.f);         // >= 0, <= plane distance of every point
     // |perp(p - c)|^2 >= D2 - (n^ . (p - c))^2, and (n^ . v)^2 <= (n . v)^2 (1 + 5e-6) because |n| >= 1 - 2.5e-6
     // (the 2e-6 off D2: 4u for its own rounding, and 2 |pdc| e + e^2 <= 8e-7 D2 for the absolute error e <= 6u |p - c| of pdc)
-    const float t2 = D2 * 0.999998f - pdc * pdc * 1.000006f;
+    const float t2 = __builtin_fmaf(pdc * pdc, -1.000006f, D2 * 0.999998f);
     float lb = pd * pd;
     const float rr = rec0.w * rec0.w * 1.000001f;
     if (t2 > rr) {                                                                // the foot of p lies outside the disc
-        const float tg = __builtin_sqrtf(t2) * 0.9999998f - rec0.w;               // >= 0 here up to rounding
+        // v_sqrt_f32 itself (1 ulp; the correctly rounded sequence around it is 19 instructions, per record and for the whole wave)
+        const float tg = __builtin_amdgcn_sqrtf(t2) * 0.9999996f - rec0.w;        // >= 0 here up to rounding
         if (tg > 0.f) lb = __builtin_fmaf(tg, tg, lb);
     }
     return lb * 0.999999f;
@@ -276,11 +279,11 @@ __device__ __forceinline__ void tri_candidate(const float *p, const float4 rec0,
     float lb = 0.f;
     if (valid) {
         const float dx = rec0.x - p[0], dy = rec0.y - p[1], dz = rec0.z - p[2];
-        const float D2 = dx * dx + dy * dy + dz * dz;
+        const float D2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
         const float rs = rec0.w + s.reach;
         if (!(D2 > rs * rs * 1.000003f)) {                         // else: farther than radius + reach, cannot beat or tie
             if (surv) *surv += 1 << 16;                            // (instrumented build: sphere passes in the high half)
-            lb = tri_record_bound2(p, rec0, rec1, D2, rs, eps_plane);
+            lb = tri_record_bound2(dx, dy, dz, rec0, rec1, D2, rs, eps_plane);
             keep = !(lb > s.thr);                                  // else: the plane / disc bound rules it out
         }
     }
@@ -384,6 +387,12 @@ __device__ __forceinline__ void tri_pool_flush(const float *p, const float4 *__r
 
 // Phase 1 over the cell-list ranges a lane has collected (seg[0 .. n_seg), [first, last + 1) positions of cell_rec):
 // every lane walks ITS ranges, four records per trip; the wave leaves when every lane is through.
+constexpr long long TRI_REC_MAX_ENTRIES = (1ll << 27) - 16;        // 32 bytes each, addressed through 32-bit byte offsets
+__device__ __forceinline__ float4 tri_ld_rec(const float4 *__restrict__ base, int entry, int half)
+{
+    return *(const float4 *)((const char *)base + ((unsigned)entry * 32u + (unsigned)half * 16u));
+}
+
 __device__ __forceinline__ void tri_scan_segments(const float *p, const float4 *__restrict__ cell_rec,
                                                   const float4 *__restrict__ tri9, TriSearchState &s, float eps_plane,
                                                   int2 (*seg)[256], int &n_seg, TriPool &pool, double delta, float cutf,
@@ -399,9 +408,9 @@ __device__ __forceinline__ void tri_scan_segments(const float *p, const float4 *
         const int e1 = min(jj + 1, last), e2 = min(jj + 2, last), e3 = min(jj + 3, last);
         float4 a0, a1, b0, b1, c0, c1, d0, d1;
         a0 = a1 = b0 = b1 = c0 = c1 = d0 = d1 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (active) {
-            a0 = cell_rec[2ll * jj]; a1 = cell_rec[2ll * jj + 1]; b0 = cell_rec[2ll * e1]; b1 = cell_rec[2ll * e1 + 1];
-            c0 = cell_rec[2ll * e2]; c1 = cell_rec[2ll * e2 + 1]; d0 = cell_rec[2ll * e3]; d1 = cell_rec[2ll * e3 + 1];
+        if (active) {                                              // (32-bit byte offsets from the uniform base: TRI_REC_MAX_ENTRIES)
+            a0 = tri_ld_rec(cell_rec, jj, 0); a1 = tri_ld_rec(cell_rec, jj, 1); b0 = tri_ld_rec(cell_rec, e1, 0); b1 = tri_ld_rec(cell_rec, e1, 1);
+            c0 = tri_ld_rec(cell_rec, e2, 0); c1 = tri_ld_rec(cell_rec, e2, 1); d0 = tri_ld_rec(cell_rec, e3, 0); d1 = tri_ld_rec(cell_rec, e3, 1);
         }
         tri_candidate(p, a0, a1, active, s, eps_plane, pool, surv);
         tri_candidate(p, b0, b1, active && j + 1 < end, s, eps_plane, pool, surv);
