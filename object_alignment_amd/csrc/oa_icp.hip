@@ -2057,7 +2057,8 @@ int build_tri_grid(oa_ctx *c)
         max_ext = std::max(max_ext, ext[a]);
         scale = std::max(scale, std::max(fabs(c->bb_lo[a]), fabs(c->bb_hi[a])));
     }
-    double h = env_double("OA_TRI_CELL", 1.5) * diag_sum / (double)c->n_tris;   // ~1.5 mean triangle bbox diagonals per cell
+    double h = env_double("OA_TRI_CELL", 1.25) * diag_sum / (double)c->n_tris;  // mean triangle bbox diagonals per cell edge (1.5 until the scan
+                                                                                 // became VALU-bound at the end of round 3: fewer records per cell now pay)
     if (!(h > 0.0) || !(h < INFINITY)) h = max_ext > 0.0 ? max_ext / 64.0 : 1.0;
     h = std::max(h, max_ext / 1023.0);
     const long long max_cells = 1ll << std::max(16, std::min(29, env_int("OA_TRI_MAX_CELLS_LOG2", 24)));

@@ -30,7 +30,7 @@ tlo, thi = P.min(axis=1), P.max(axis=1)
 diag = np.sqrt(((thi - tlo) ** 2).sum(axis=1))
 lo, hi = tgt.min(axis=0).astype(np.float64), tgt.max(axis=0).astype(np.float64)
 ext = hi - lo
-h = float(os.environ.get("OA_TRI_CELL", 1.5)) * diag.sum() / len(tris)
+h = float(os.environ.get("OA_TRI_CELL", 1.25)) * diag.sum() / len(tris)
 h = max(h, ext.max() / 1023.0)
 while True:
     n = np.minimum(np.maximum(np.floor(ext / h).astype(np.int64) + 1, 1), 1024)
