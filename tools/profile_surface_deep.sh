@@ -1,6 +1,8 @@
 #!/bin/bash
 # GPU box: a wider set of counters for the surface-mode search (k_tri_search_grid) and, for comparison, the vertex grid search of
 # the bench: where the wave cycles go (VALU / LDS / VMEM issue, waits), how busy the texture path (TA / TD / TCP) and the L2 are.
+# NOTE: ten rocprofv3 passes; the TCP / TCC groups are slow (the whole script took > 25 min on the box): give gpurun --timeout 3000, or run
+# it for one group at a time.
 # One rocprofv3 --pmc pass per group (no tracing alongside).  Output: gpurun_out/prof_deep/<group>/, summarised to stdout.
 REPO="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 OUT="$REPO/gpurun_out/prof_deep"
