@@ -210,7 +210,7 @@ __device__ __forceinline__ void tri_state_refresh(TriSearchState &s, double delt
 {
     if (s.lim < INFINITY) {
         const double r = tri_reach_bound(s.lim, delta);
-        s.thr = (float)(r * r * (1.0 + 3e-6));
+        s.thr = (float)(r * r * (1.0 + 3e-6) * (1.0 + 1.1e-6));       // (x 1 / 0.999999: the records' bounds come unscaled)
         // sqrt(thr) <= r sqrt(1 + 3e-6) (1 + u) < r (1 + 1.6e-6); rounded to float and up: the sphere test's reach
         const double rr = r * (1.0 + 3e-6) + 1e-37;
         s.reach = rr < 3.0e38 ? (float)rr : INFINITY;
@@ -262,13 +262,11 @@ __device__ __forceinline__ float tri_record_bound2(float dx, float dy, float dz,
     // (the 2e-6 off D2: 4u for its own rounding, and 2 |pdc| e + e^2 <= 8e-7 D2 for the absolute error e <= 6u |p - c| of pdc)
     const float t2 = __builtin_fmaf(pdc * pdc, -1.000006f, D2 * 0.999998f);
     float lb = pd * pd;
-    const float rr = rec0.w * rec0.w * 1.000001f;
-    if (t2 > rr) {                                                                // the foot of p lies outside the disc
-        // v_sqrt_f32 itself (1 ulp; the correctly rounded sequence around it is 19 instructions, per record and for the whole wave)
-        const float tg = __builtin_amdgcn_sqrtf(t2) * 0.9999996f - rec0.w;        // >= 0 here up to rounding
-        if (tg > 0.f) lb = __builtin_fmaf(tg, tg, lb);
-    }
-    return lb * 0.999999f;
+    // the foot of p outside the disc: v_sqrt_f32 itself (1 ulp; the correctly rounded sequence around it is 19 instructions, per
+    // record and for the whole wave).  t2 <= r^2 gives tg <= 0, t2 < 0 a NaN: neither adds anything.
+    const float tg = __builtin_amdgcn_sqrtf(t2) * 0.9999996f - rec0.w;
+    if (tg > 0.f) lb = __builtin_fmaf(tg, tg, lb);
+    return lb;                                                                    // (its last 1e-6 is in TriSearchState::thr)
 }
 
 // phase 1 for one record per lane (valid = this lane has one); called by the whole wave
@@ -295,7 +293,7 @@ __device__ __forceinline__ void tri_candidate(const float *p, const float4 rec0,
         pool.tid[dst] = __float_as_int(rec1.w);
         pool.own[dst] = lane;
         pool.key[dst] = lb;
-        if (pool.kslot < 0 || lb < pool.gmin || pool.gmin != pool.gmin) { pool.gmin = lb; pool.kslot = dst; }
+        if (!(lb >= pool.gmin)) { pool.gmin = lb; pool.kslot = dst; }     // (gmin starts at +inf; a NaN bound -- never from a binned triangle -- goes first)
     }
     pool.n += __popcll(m);
 }
