@@ -48,7 +48,9 @@ extern "C" {
 #define OA_E_BAD_THRESH      -7   /* thresh <= 0: the reference returns None (functions/general.py:277) */
 #define OA_E_CAPACITY        -8
 #define OA_E_RCCL            -9   /* multi-device exchange failed: librccl missing / ncclCommInitAll / ncclAllReduce error,
-                                     or a device's sums did not arrive within OA_EXCHANGE_TIMEOUT_S (default 30 s) */
+                                     or a device's sums did not arrive within OA_EXCHANGE_TIMEOUT_S (default 30 s) -- mailbox:
+                                     the waiting kernels give up by themselves; RCCL: the host's watchdog sees no device
+                                     finish an iteration for that long and aborts the communicators (ncclCommAbort) */
 
 #define OA_NSUMS 24               /* doubles exchanged per iteration (see oa_iter_partial) */
 
@@ -97,7 +99,13 @@ int         oa_num_devices(oa_ctx *ctx);
  *   OA_EXCHANGE_AUTO     RCCL when the listed devices are distinct and librccl can be brought up, else the mailbox;
  *                        decided before the first loop (OA_STAT_EXCHANGE reports the outcome)
  *   OA_EXCHANGE_RCCL     ncclAllReduce(OA_NSUMS doubles, sum) over xGMI on every device's stream, single-process
- *                        communicator (ncclCommInitAll); librccl.so.1 is loaded on first use; needs distinct devices
+ *                        communicator (ncclCommInitAll); librccl.so.1 is loaded on first use; needs distinct devices.
+ *                        New communicators first pass one all-reduce of a known vector (bounded wait) or are given up.
+ *                        Every host thread enqueues the same number of collectives whatever its device reports when
+ *                        (OA_STAT_ENQUEUED_MIN == _MAX); no wait for the devices is unbounded: when no device finishes an
+ *                        iteration for OA_EXCHANGE_TIMEOUT_S, or RCCL reports an asynchronous error, the communicators
+ *                        are aborted and the call returns OA_E_RCCL.  After that AUTO stays on the mailbox;
+ *                        oa_set_exchange(OA_EXCHANGE_RCCL) builds new communicators.
  *   OA_EXCHANGE_MAILBOX  all-gather through mailboxes: every device's post is written into every device's inbox --
  *                        fine-grained device memory, peer-mapped, i.e. 200-byte remote writes over xGMI -- and the solve
  *                        kernel of each device waits for the world's posts in its own inbox and adds them in rank order
@@ -201,6 +209,11 @@ int oa_reset_seeds(oa_ctx *ctx);
                                        * accumulated in its epilogue (the adaptive choice of DESIGN.md 4.4; first device) */
 #define OA_STAT_HANDOVER_ENTRIES 13   /* what the last grid search handed to the tree: queries ... */
 #define OA_STAT_HANDOVER_WAVE_MAX 14  /* ... and the most any ONE wavefront handed over (what the adaptive choice looks at) */
+#define OA_STAT_ENQUEUED_MIN      15   /* multi-device context: iterations the host enqueued for its children in the last oa_run, the */
+#define OA_STAT_ENQUEUED_MAX      16   /* least and the most over the children.  Equal by construction ("the invariant"):
+                                       * in RCCL mode every enqueued iteration holds a collective every rank has to enter */
+#define OA_STAT_WATCHDOG_ABORTS   17   /* times this context's RCCL communicators were aborted (watchdog / asynchronous error) */
+#define OA_STAT_ENQUEUED_CHILD  1000   /* + i: the same count for child i alone */
 int oa_get_stat(oa_ctx *ctx, int what, double *value);
 int64_t oa_num_selected(oa_ctx *ctx);     /* selected source points held by this context (its shard) */
 

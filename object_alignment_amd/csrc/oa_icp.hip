@@ -12,7 +12,7 @@
 #include <rccl/rccl.h>
 #else
 typedef struct ncclComm *ncclComm_t;
-typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclSuccess = 0, ncclInProgress = 7 } ncclResult_t;
 typedef enum { ncclFloat64 = 8, ncclDouble = 8 } ncclDataType_t;
 typedef enum { ncclSum = 0 } ncclRedOp_t;
 #endif
@@ -26,6 +26,7 @@ typedef enum { ncclSum = 0 } ncclRedOp_t;
 #include "../../include/oa_icp.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <functional>
@@ -1085,9 +1086,30 @@ struct oa_exchange {
     unsigned long long timeout_ticks = 0;
     unsigned long long seq_next = 0;               // DevState::seq_base of the next loop
     int fault_skip_rank = -1;                      // OA_FAULT_SKIP_POST_RANK: that rank's posts never arrive (test hook)
+    double timeout_s = 30.0;                       // OA_EXCHANGE_TIMEOUT_S: the mailbox kernels' wait (timeout_ticks) and the host's watchdog in RCCL mode
+    // How many iterations the host threads of one oa_run enqueue: agreed, not observed.  Every thread stops on what ITS device
+    // reports (DevState::host_halt), and the threads hear of a halt at different times; an iteration enqueued in RCCL mode
+    // contains a collective, and a collective one rank enqueues and another does not never completes.  So: a thread COMMITS
+    // to iteration `it` under the lock before it enqueues it (agree_committed = most iterations any thread has committed to);
+    // the first thread that hears of the halt -- or fails -- freezes agree_stop_at = agree_committed; from then on every
+    // thread enqueues exactly agree_stop_at iterations, no more (it stops there) and no fewer (it tops up to it: iterations
+    // after the halt are empty but for the collective).  The count is a function of the lock order alone, never of what a
+    // thread happened to read from its device afterwards.  (multi_group_loop; DESIGN.md 4.7 "the invariant")
+    std::mutex agree_mu;
+    int agree_committed = 0;
+    std::atomic<int> agree_stop_at{ -1 };          // -1: not frozen yet
+    bool agree_on = true;                          // OA_MULTI_AGREE=0 (test hook, ignored in RCCL mode): round 3's every-thread-for-itself stop
+    int fault_lag_group = -1, fault_lag_us = 0;    // OA_FAULT_LAG_GROUP / OA_FAULT_LAG_US: that host thread sleeps before every look at its halt flag (test hook)
+    int fault_fail_group = -1, fault_fail_iter = -1;   // OA_FAULT_FAIL_GROUP / OA_FAULT_FAIL_ITER: that host thread's enqueue fails at that iteration (test hook)
+    int fault_stall_rank = -1, fault_stall_iter = 2;   // OA_FAULT_STALL_RANK / _ITER: that rank's stream stops ahead of its collective, as if its peers never arrived (test hook)
+    int32_t *h_release = nullptr;                  // pinned word the stalled stream watches: exchange_abort_rccl releases it
     // RCCL
     void *lib = nullptr;
     std::vector<ncclComm_t> comms;
+    bool rccl_aborted = false;                     // a loop ran into the watchdog and the communicators were aborted: AUTO stays on the mailbox from here on
+    long long watchdog_aborts = 0;                 // OA_STAT_WATCHDOG_ABORTS
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t *) = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
@@ -1114,6 +1136,134 @@ bool devices_distinct(const oa_ctx *p)
     return true;
 }
 
+// RCCL's communicators are given up: every collective kernel still waiting for a peer returns, the streams drain.
+// (ncclCommAbort frees the communicator; the next explicit oa_set_exchange(RCCL) builds new ones.)
+void exchange_abort_rccl(oa_ctx *p, const char *why)
+{
+    Exchange *x = p->xch;
+    if (x->h_release) { __atomic_store_n(x->h_release, 1, __ATOMIC_RELEASE); }   // (test hook: the stalled stream goes on)
+    if (x->comms.empty()) return;
+    if (p->subs.empty() ? false : p->subs[0]->debug) fprintf(stderr, "[oa] RCCL communicators aborted: %s\n", why);
+    for (size_t i = 0; i < x->comms.size(); ++i)
+        if (x->comms[i] && x->CommAbort) { if (i < p->subs.size()) (void)hipSetDevice(p->subs[i]->device); (void)x->CommAbort(x->comms[i]); }
+    x->comms.clear();
+    x->rccl_aborted = true;
+    x->watchdog_aborts++;
+    x->resolved = false;                             // AUTO resolves to the mailbox from here on (exchange_resolve)
+    x->auto_note = std::string("RCCL was aborted: ") + why;
+}
+
+// Wait for every child's stream, never for ever.  Mailbox: the gather kernels bound their own wait (timeout_ticks), so a
+// plain synchronise returns.  RCCL: a collective whose peers never enter it spins until its communicator is aborted, so
+// the host watches the streams (hipStreamQuery) and the devices' progress words; when no device has finished an
+// iteration for OA_EXCHANGE_TIMEOUT_S -- or RCCL reports an asynchronous error -- it aborts the communicators
+// (ncclCommAbort), gives the streams the same time again to drain, and the call fails with OA_E_RCCL.
+// abort_now: the caller knows the ranks' collective counts differ (a host thread failed mid-loop): no point in waiting.
+int multi_wait(oa_ctx *p, bool abort_now = false)
+{
+    Exchange *x = p->xch;
+    const size_t n = p->subs.size();
+    const bool rccl = x && x->mode == OA_EXCHANGE_RCCL && !x->comms.empty();
+    if (!rccl) {
+        int rc = OA_OK;
+        for (oa_ctx *c : p->subs) {
+            hipError_t e = hipSetDevice(c->device);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess && !rc) rc = fail(OA_E_HIP, "device %d: %s", c->device, hipGetErrorString(e));
+        }
+        return rc;
+    }
+    using clk = std::chrono::steady_clock;
+    const auto limit = std::chrono::duration<double>(x->timeout_s);
+    std::vector<char> done(n, 0);
+    std::vector<int> seen(n, -1);
+    bool aborted = false;
+    std::string why;
+    if (abort_now) { exchange_abort_rccl(p, "a host thread failed while the loop was being enqueued"); aborted = true; why = "a host thread failed mid-loop"; }
+    auto t_last = clk::now();
+    for (;;) {
+        bool all = true, moved = false;
+        for (size_t i = 0; i < n; ++i) {
+            if (done[i]) continue;
+            oa_ctx *c = p->subs[i];
+            hipError_t e = hipSetDevice(c->device);
+            if (e == hipSuccess) e = hipStreamQuery(c->stream);
+            if (e == hipSuccess) { done[i] = 1; moved = true; continue; }
+            if (e != hipErrorNotReady) { (void)hipGetLastError(); return fail(OA_E_HIP, "device %d: %s", c->device, hipGetErrorString(e)); }
+            (void)hipGetLastError();
+            all = false;
+            const int at = c->h_poll ? ((volatile int32_t *)c->h_poll)[1] : 0;
+            if (at != seen[i]) { seen[i] = at; moved = true; }
+            if (!aborted && x->CommGetAsyncError && i < x->comms.size() && x->comms[i]) {
+                ncclResult_t ar = ncclSuccess;
+                if (x->CommGetAsyncError(x->comms[i], &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress) {
+                    why = std::string("RCCL reported an asynchronous error on device ") + std::to_string(c->device) + ": " + (x->GetErrorString ? x->GetErrorString(ar) : "?");
+                    exchange_abort_rccl(p, why.c_str());
+                    aborted = true; t_last = clk::now();
+                }
+            }
+        }
+        if (all) break;
+        if (moved) t_last = clk::now();
+        else if (clk::now() - t_last > limit) {
+            if (aborted) return fail(OA_E_RCCL, "multi-device exchange: %s, and the streams did not drain within %.1f s of the abort", why.c_str(), x->timeout_s);
+            why = "no device finished an iteration for " + std::to_string(x->timeout_s) + " s (OA_EXCHANGE_TIMEOUT_S)";
+            exchange_abort_rccl(p, why.c_str());
+            aborted = true; t_last = clk::now();
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+    if (aborted) return fail(OA_E_RCCL, "multi-device exchange: %s; the RCCL communicators were aborted", why.c_str());
+    return OA_OK;
+}
+
+// first use of new communicators: one all-reduce of a known value on every device, waited for with the watchdog.  A
+// communicator that cannot do that (a link down, a peer mapping refused) is aborted here -- AUTO then takes the mailbox --
+// instead of in the middle of somebody's alignment.
+int exchange_handshake_rccl(oa_ctx *p)
+{
+    Exchange *x = p->xch;
+    const size_t n = p->subs.size();
+    std::vector<double *> bufs(n, nullptr);
+    int rc = OA_OK;
+    const int keep_mode = x->mode;
+    for (size_t i = 0; i < n && !rc; ++i) {
+        oa_ctx *c = p->subs[i];
+        if ((rc = use_device(c))) break;
+        double h[oa::NSUMS];
+        for (int k = 0; k < oa::NSUMS; ++k) h[k] = (double)(i + 1) * (k + 1);
+        hipError_t e = hipMalloc((void **)&bufs[i], sizeof h);
+        if (e == hipSuccess) e = hipMemcpy(bufs[i], h, sizeof h, hipMemcpyHostToDevice);
+        if (e != hipSuccess) rc = fail(OA_E_HIP, "RCCL handshake: %s", hipGetErrorString(e));
+    }
+    if (!rc) {
+        ncclResult_t r = x->GroupStart();
+        for (size_t i = 0; i < n && r == ncclSuccess; ++i) {
+            oa_ctx *c = p->subs[i];
+            if (hipSetDevice(c->device) != hipSuccess) { r = (ncclResult_t)1; break; }
+            r = x->AllReduce(bufs[i], bufs[i], oa::NSUMS, ncclDouble, ncclSum, x->comms[i], c->stream);
+        }
+        const ncclResult_t r2 = x->GroupEnd();
+        if (r == ncclSuccess) r = r2;
+        if (r != ncclSuccess) rc = fail(OA_E_RCCL, "RCCL handshake: ncclAllReduce failed: %s", x->GetErrorString ? x->GetErrorString(r) : "?");
+    }
+    if (!rc) {
+        x->mode = OA_EXCHANGE_RCCL;                                     // (multi_wait's watchdog is the RCCL one)
+        rc = multi_wait(p);
+        x->mode = keep_mode;
+    }
+    for (size_t i = 0; i < n && !rc; ++i) {
+        double h[oa::NSUMS];
+        if (hipSetDevice(p->subs[i]->device) != hipSuccess || hipMemcpy(h, bufs[i], sizeof h, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(OA_E_HIP, "RCCL handshake: read-back failed"); break; }
+        for (int k = 0; k < oa::NSUMS; ++k)
+            if (h[k] != (double)(n * (n + 1) / 2) * (k + 1)) { rc = fail(OA_E_RCCL, "RCCL handshake: device %d holds a wrong sum", p->subs[i]->device); break; }
+    }
+    for (size_t i = 0; i < n; ++i) if (bufs[i]) { (void)hipSetDevice(p->subs[i]->device); (void)hipFree(bufs[i]); }
+    if (rc && !x->comms.empty()) { const std::string keep = g_err; exchange_abort_rccl(p, "handshake failed"); g_err = keep; }
+    if (!rc) x->rccl_aborted = false;
+    return rc;
+}
+
 int exchange_init_rccl(oa_ctx *p)
 {
     Exchange *x = p->xch;
@@ -1133,7 +1283,9 @@ int exchange_init_rccl(oa_ctx *p)
         x->GroupStart = (decltype(x->GroupStart))dlsym(x->lib, "ncclGroupStart");
         x->GroupEnd = (decltype(x->GroupEnd))dlsym(x->lib, "ncclGroupEnd");
         x->GetErrorString = (decltype(x->GetErrorString))dlsym(x->lib, "ncclGetErrorString");
-        if (!x->CommInitAll || !x->CommDestroy || !x->AllReduce || !x->GroupStart || !x->GroupEnd)
+        x->CommAbort = (decltype(x->CommAbort))dlsym(x->lib, "ncclCommAbort");
+        x->CommGetAsyncError = (decltype(x->CommGetAsyncError))dlsym(x->lib, "ncclCommGetAsyncError");
+        if (!x->CommInitAll || !x->CommDestroy || !x->AllReduce || !x->GroupStart || !x->GroupEnd || !x->CommAbort)
             return fail(OA_E_RCCL, "librccl lacks the expected entry points");
     }
     std::vector<int> devs;
@@ -1144,7 +1296,7 @@ int exchange_init_rccl(oa_ctx *p)
         x->comms.clear();
         return fail(OA_E_RCCL, "ncclCommInitAll failed: %s", x->GetErrorString ? x->GetErrorString(r) : "?");
     }
-    return OA_OK;
+    return exchange_handshake_rccl(p);
 }
 
 // how many ranks RCCL's communicator spans (0 = RCCL is not what this context exchanges through)
@@ -1172,12 +1324,14 @@ int exchange_resolve(oa_ctx *p)
         x->mode = OA_EXCHANGE_MAILBOX;
         if (p->subs.size() < 2) x->auto_note = "one device: nothing to exchange";
         else if (!devices_distinct(p)) x->auto_note = "a device is listed more than once";
+        else if (x->rccl_aborted) { /* auto_note says why: a communicator that hung once is not trusted again unasked */ }
         else {
             const std::string keep = g_err;
             if (exchange_init_rccl(p) == OA_OK) x->mode = OA_EXCHANGE_RCCL;
             else { x->auto_note = g_err; g_err = keep; }
         }
     }
+    if (x->mode == OA_EXCHANGE_RCCL) x->agree_on = true;             // the test hook that switches the agreement off is for the mailbox only
     x->resolved = true;
     return OA_OK;
 }
@@ -1193,6 +1347,7 @@ void exchange_destroy(oa_ctx *p)
         if (x->device_box && r < x->box.size() && x->box[r]) (void)hipFree(x->box[r]);
     }
     if (x->h_box) (void)hipHostFree(x->h_box);
+    if (x->h_release) (void)hipHostFree(x->h_release);
     // the library handle stays open: unloading RCCL under a live HIP runtime is not worth the risk
     delete x;
     p->xch = nullptr;
@@ -1290,6 +1445,20 @@ int multi_iteration_group(oa_ctx *p, const std::vector<int> &group, bool timed)
         if (rc) return rc;
     }
     if (x->mode == OA_EXCHANGE_RCCL) {
+        if (x->comms.empty()) return fail(OA_E_RCCL, "multi-device exchange: the RCCL communicators were aborted");
+        // (test hook: this rank's stream stops here, ahead of its collective, until the watchdog releases it -- what a rank
+        //  whose peers never enter the collective looks like to the host; bounded, so that a test can never hang the GPU)
+        for (int i : group) {
+            oa_ctx *c = p->subs[(size_t)i];
+            if (c->rank == x->fault_stall_rank && c->enq_iters == x->fault_stall_iter && x->h_release) {
+                if ((rc = use_device(c))) return rc;
+                void *dp = nullptr;
+                HIPCHK(hipHostGetDevicePointer(&dp, x->h_release, 0));
+                hipLaunchKernelGGL(oa::k_fault_stall, dim3(1), dim3(64), 0, c->stream, (const int32_t *)dp, (unsigned long long)(20.0 * c->wall_clock_khz * 1e3));
+                HIPCHK(hipGetLastError());
+                x->fault_stall_rank = -1;                                // once
+            }
+        }
         // one thread, several devices: group semantics; one thread per device: plain calls (each rank's kernel waits
         // for its peers on the device, the host call only enqueues)
         const bool grouped = group.size() > 1;
@@ -1328,9 +1497,14 @@ template <typename F> int multi_for_groups(oa_ctx *p, F f)
     return p->pool->run(p->groups.size(), f);
 }
 
-void multi_abort(oa_ctx *p)
+// end whatever loop is open: wait for the streams (bounded, see multi_wait), close the loop on every child.
+// failed: a host thread gave up in the middle of enqueuing -- in RCCL mode the ranks' collective counts may differ
+void multi_abort(oa_ctx *p, bool failed = false)
 {
-    for (oa_ctx *c : p->subs) { if (hipSetDevice(c->device) == hipSuccess) (void)hipStreamSynchronize(c->stream); c->loop_active = false; }
+    const std::string keep = g_err;
+    (void)multi_wait(p, failed && p->xch && p->xch->mode == OA_EXCHANGE_RCCL && p->loop_active);
+    g_err = keep;
+    for (oa_ctx *c : p->subs) c->loop_active = false;
     p->loop_active = false;
 }
 
@@ -1352,6 +1526,9 @@ int multi_begin(oa_ctx *p, const oa_settings *st, int iters)
         if ((rc = use_device(c))) { multi_abort(p); return rc; }
         HIPCHK(hipEventRecord(c->ev_loop0, c->stream));
     }
+    x->agree_committed = 0;
+    x->agree_stop_at.store(-1);
+    if (x->h_release) __atomic_store_n(x->h_release, 0, __ATOMIC_RELEASE);
     p->settings = *st;
     p->loop_active = true;
     return OA_OK;
@@ -1369,11 +1546,16 @@ int multi_end(oa_ctx *p, oa_report *rep)
 {
     int rc = OA_OK;
     oa_report agg{};
+    for (oa_ctx *c : p->subs) {
+        if ((rc = use_device(c))) break;
+        if (hipEventRecord(c->ev_loop1, c->stream) != hipSuccess) { rc = fail(OA_E_HIP, "hipEventRecord failed"); break; }
+    }
+    if (!rc) rc = multi_wait(p);                                   // bounded in RCCL mode: a hung collective becomes OA_E_RCCL
+    if (rc) { for (oa_ctx *c : p->subs) c->loop_active = false; p->loop_active = false; return rc; }
     for (size_t i = 0; i < p->subs.size(); ++i) {
         oa_ctx *c = p->subs[i];
         oa_report r{};
         int rci = use_device(c);
-        if (!rci && hipEventRecord(c->ev_loop1, c->stream) != hipSuccess) rci = fail(OA_E_HIP, "hipEventRecord failed");
         if (!rci) rci = fill_report(c, &r);
         float ms = 0.f;
         if (!rci && hipEventElapsedTime(&ms, c->ev_loop0, c->ev_loop1) == hipSuccess) r.loop_ms = ms;
@@ -1392,28 +1574,55 @@ int multi_end(oa_ctx *p, oa_report *rep)
     return status_error(agg.status);
 }
 
+// May this host thread enqueue iteration `it`?  halt_seen: its own device has reported the halt.  See Exchange::agree_mu.
+bool agree_next(Exchange *x, int it, bool halt_seen)
+{
+    if (!x->agree_on) return !halt_seen;
+    std::lock_guard<std::mutex> lk(x->agree_mu);
+    int stop = x->agree_stop_at.load(std::memory_order_relaxed);
+    if (stop < 0 && halt_seen) { stop = x->agree_committed; x->agree_stop_at.store(stop, std::memory_order_release); }
+    if (stop >= 0) return it < stop;
+    x->agree_committed = std::max(x->agree_committed, it + 1);
+    return true;
+}
+
+// a host thread failed: nobody commits to anything new (the failing thread's own count is whatever it got to -- multi_run
+// then aborts the communicators instead of waiting for collectives that cannot complete)
+void agree_fail(Exchange *x)
+{
+    std::lock_guard<std::mutex> lk(x->agree_mu);
+    if (x->agree_stop_at.load(std::memory_order_relaxed) < 0) x->agree_stop_at.store(x->agree_committed, std::memory_order_release);
+}
+
 // the loop of one host thread's group: enqueue its children's iterations, at most `lag` ahead of the GPU, until the
-// budget is spent or the devices report the halt (every device takes the same decision from the same sums)
+// budget is spent or the threads have agreed on where the loop ends (every device takes the same decision from the same
+// sums, but the threads hear of it at different times: agree_next)
 int multi_group_loop(oa_ctx *p, size_t g, const oa_settings *st)
 {
     const std::vector<int> &group = p->groups[g];
     if (group.empty()) return OA_OK;
+    Exchange *x = p->xch;
     oa_ctx *c0 = p->subs[(size_t)group[0]];
     // (the adaptive grid path needs recent news from the device too: then the host stays close even without early exit)
     bool poll = c0->h_poll && env_int("OA_RUN_POLL", 1) && (st->early_exit || (search_plan(c0) == PLAN_GRID && c0->grid_path == 0));
     const int lag = 2;
     volatile int32_t *progress = c0->h_poll;
     for (int it = 0; it < st->iters; ++it) {
+        bool halt_seen = false;
         if (poll) {                                                     // see oa_run
             const auto t_wait = std::chrono::steady_clock::now();
-            while (!progress[0] && progress[1] < it - lag) {
+            while (!progress[0] && progress[1] < it - lag && x->agree_stop_at.load(std::memory_order_acquire) < 0) {
                 if (std::chrono::steady_clock::now() - t_wait > std::chrono::seconds(5)) { poll = false; break; }   // once is enough: enqueue the rest blindly
                 std::this_thread::yield();
             }
-            if (progress[0]) break;
+            if ((int)g == x->fault_lag_group && x->fault_lag_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(x->fault_lag_us));
+            halt_seen = progress[0] != 0;
         }
-        const int rc = multi_iteration_group(p, group, true);
-        if (rc) return rc;
+        if (!agree_next(x, it, halt_seen)) break;
+        int rc = OA_OK;
+        if ((int)g == x->fault_fail_group && it == x->fault_fail_iter) { x->fault_fail_group = -1; rc = fail(OA_E_HIP, "injected enqueue failure (OA_FAULT_FAIL_GROUP)"); }   // once
+        if (!rc) rc = multi_iteration_group(p, group, true);
+        if (rc) { agree_fail(x); return rc; }
     }
     return OA_OK;
 }
@@ -1423,7 +1632,7 @@ int multi_run(oa_ctx *p, const oa_settings *st, oa_report *rep)
     int rc = multi_begin(p, st, st->iters);
     if (rc) return rc;
     rc = multi_for_groups(p, [p, st](size_t g) -> int { return multi_group_loop(p, g, st); });
-    if (rc) { const std::string keep = g_err; multi_abort(p); g_err = keep; return rc; }
+    if (rc) { const std::string keep = g_err; multi_abort(p, true); g_err = keep; return rc; }
     return multi_end(p, rep);
 }
 }  // namespace
@@ -1527,7 +1736,19 @@ OA_EXPORT int oa_create_multi(oa_ctx **out, const int *devices, int n_dev)
         const double secs = std::max(0.05, env_double("OA_EXCHANGE_TIMEOUT_S", 30.0));
         x->timeout_ticks = (unsigned long long)(secs * p->subs[0]->wall_clock_khz * 1e3);
         x->seq_next = 0;
+        x->timeout_s = secs;
         x->fault_skip_rank = env_int("OA_FAULT_SKIP_POST_RANK", -1);
+        x->agree_on = env_int("OA_MULTI_AGREE", 1) != 0;
+        x->fault_lag_group = env_int("OA_FAULT_LAG_GROUP", -1);
+        x->fault_lag_us = env_int("OA_FAULT_LAG_US", 0);
+        x->fault_fail_group = env_int("OA_FAULT_FAIL_GROUP", -1);
+        x->fault_fail_iter = env_int("OA_FAULT_FAIL_ITER", -1);
+        x->fault_stall_rank = env_int("OA_FAULT_STALL_RANK", -1);
+        x->fault_stall_iter = env_int("OA_FAULT_STALL_ITER", 2);
+        if (x->fault_stall_rank >= 0) {
+            if (hipHostMalloc((void **)&x->h_release, sizeof(int32_t), hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); x->h_release = nullptr; }
+            else *x->h_release = 0;
+        }
         const char *m = getenv("OA_EXCHANGE");
         if (m && (!strcmp(m, "rccl") || !strcmp(m, "RCCL") || !strcmp(m, "1"))) x->requested = OA_EXCHANGE_RCCL;
         else if (m && (!strcmp(m, "mailbox") || !strcmp(m, "MAILBOX") || !strcmp(m, "0"))) x->requested = OA_EXCHANGE_MAILBOX;
@@ -2553,6 +2774,21 @@ OA_EXPORT int oa_get_stat(oa_ctx *c, int what, double *value)
 {
     if (!c || !value) return fail(OA_E_BAD_ARG, "oa_get_stat: null argument");
     if (what == OA_STAT_CACHE_BYTES) { *value = (double)dev_cache().cached_bytes; return OA_OK; }
+    if (what == OA_STAT_ENQUEUED_MIN || what == OA_STAT_ENQUEUED_MAX || what >= OA_STAT_ENQUEUED_CHILD) {
+        // iterations the host enqueued for the children in the last oa_run (the agreement of DESIGN.md 4.7: all equal)
+        if (c->subs.empty()) { *value = (double)c->iter_enq; return OA_OK; }
+        if (what >= OA_STAT_ENQUEUED_CHILD) {
+            const size_t i = (size_t)(what - OA_STAT_ENQUEUED_CHILD);
+            if (i >= c->subs.size()) return fail(OA_E_BAD_ARG, "oa_get_stat: child %zu of %zu", i, c->subs.size());
+            *value = (double)c->subs[i]->enq_iters;
+            return OA_OK;
+        }
+        long long lo = c->subs[0]->enq_iters, hi = lo;
+        for (oa_ctx *sub : c->subs) { lo = std::min(lo, sub->enq_iters); hi = std::max(hi, sub->enq_iters); }
+        *value = (double)(what == OA_STAT_ENQUEUED_MIN ? lo : hi);
+        return OA_OK;
+    }
+    if (what == OA_STAT_WATCHDOG_ABORTS) { *value = c->xch && !c->parent ? (double)c->xch->watchdog_aborts : 0.0; return OA_OK; }
     if (what == OA_STAT_EXCHANGE || what == OA_STAT_RCCL_RANKS || what == OA_STAT_ENQUEUE_US || what == OA_STAT_HOST_THREADS) {
         if (c->subs.empty()) { *value = what == OA_STAT_EXCHANGE ? -1.0 : (what == OA_STAT_HOST_THREADS ? 1.0 : 0.0); return OA_OK; }
         if (what == OA_STAT_HOST_THREADS) { *value = (double)std::max<size_t>(1, c->groups.size()); return OA_OK; }
@@ -3029,12 +3265,17 @@ OA_EXPORT int oa_iterate(oa_ctx *c, const oa_settings *st, double M_step[16], do
     oa_ctx *c0 = multi ? c->subs[0] : c;
     if (multi) {
         for (oa_ctx *sub : c->subs) sub->ev_used = 0;
-        rc = multi_for_groups(c, [c](size_t g) -> int {                  // every GPU's host thread: one iteration, then the state
+        const bool rccl = c->xch->mode == OA_EXCHANGE_RCCL;             // then the wait is the watchdog's (multi_wait), not fetch_state's
+        rc = multi_for_groups(c, [c, rccl](size_t g) -> int {            // every GPU's host thread: one iteration, then the state
             int rg = multi_iteration_group(c, c->groups[g], false);
-            for (int i : c->groups[g]) { if (rg) break; oa_ctx *sub = c->subs[(size_t)i]; if (!(rg = use_device(sub))) rg = fetch_state(sub); }
+            for (int i : c->groups[g]) { if (rg || rccl) break; oa_ctx *sub = c->subs[(size_t)i]; if (!(rg = use_device(sub))) rg = fetch_state(sub); }
             return rg;
         });
-        if (rc) { const std::string keep = g_err; multi_abort(c); g_err = keep; return rc; }
+        if (rc) { const std::string keep = g_err; multi_abort(c, true); g_err = keep; return rc; }
+        if (rccl) {
+            if ((rc = multi_wait(c))) { for (oa_ctx *sub : c->subs) sub->loop_active = false; c->loop_active = false; return rc; }
+            for (oa_ctx *sub : c->subs) { if ((rc = use_device(sub))) return rc; if ((rc = fetch_state(sub))) return rc; }
+        }
     } else {
         if ((rc = use_device(c))) return rc;
         c->ev_used = 0;

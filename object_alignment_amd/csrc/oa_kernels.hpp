@@ -1577,7 +1577,10 @@ __device__ __forceinline__ void solve_update_block(DevState *__restrict__ st, co
         for (int k = 0; k < 9; ++k) jv[k] = jv_valid ? cs->jac_v[k] : 0.0;
         const bool ok = solve_from_sums(s, cs->pivot, cs->with_scale != 0, M, jv, jv_valid);
         if (lane == 0) {
-            if (!ok) { st->status = -3; st->halt = 1; sh_go = 0; }  // K < 3 -> ValueError in the reference: OA_E_TOO_FEW_PAIRS
+            if (!ok) {                                              // K < 3 -> ValueError in the reference: OA_E_TOO_FEW_PAIRS
+                st->status = -3; st->halt = 1; sh_go = 0;
+                if (cs->host_halt) cs->host_halt[0] = 1;            // the enqueuing host stops here too (it would wait for progress that never comes)
+            }
             else {
                 for (int k = 0; k < 9; ++k) st->jac_v[k] = jv[k];
                 st->jac_valid = 1;
@@ -1703,6 +1706,18 @@ struct MailSlot {
     unsigned long long pad[7];       // 256 B per slot: a slot never shares a line with another rank's
 };
 constexpr int STATUS_EXCHANGE = -9;  // OA_E_RCCL: a rank's post did not arrive in time
+
+// test hook (OA_FAULT_STALL_RANK): the stream stops here until the host releases it -- or for max_ticks of wall_clock64 at
+// most, so that no test can hang a GPU
+__global__ void k_fault_stall(const int32_t *release, unsigned long long max_ticks)
+{
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(release, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
+        if (wall_clock64() - t0 > max_ticks) break;
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
 
 // step 1 on every device: fixed-order reduction of its per-workgroup partials, posted to the mailbox(es).
 // dests[0..n_dest): the mailboxes this rank writes its slot of.  Host mailbox: one (the shared pinned box).  Device

@@ -181,7 +181,8 @@ class IcpEngine:
 
     STATS = {"grid_cells": 1, "tri_grid_cells": 2, "tri_grid_entries": 3, "n_tris": 4, "surface": 5, "cache_bytes": 6,
              "brute_kernel": 7, "exchange": 8, "rccl_ranks": 9, "enqueue_us": 10, "host_threads": 11,
-             "fast_iterations": 12, "handover_entries": 13, "handover_wave_max": 14}
+             "fast_iterations": 12, "handover_entries": 13, "handover_wave_max": 14, "enqueued_min": 15, "enqueued_max": 16,
+             "watchdog_aborts": 17}
     EXCHANGE_NAMES = {-1: None, 0: "mailbox (pinned host memory)", 1: "rccl", 2: "mailbox (peer-mapped device memory)"}
 
     def exchange_info(self):
@@ -191,8 +192,13 @@ class IcpEngine:
 
     def stat(self, name) -> float:
         v = C.c_double(0.0)
-        capi.check(self._L.oa_get_stat(self._h, self.STATS[name], C.byref(v)))
+        capi.check(self._L.oa_get_stat(self._h, self.STATS[name] if isinstance(name, str) else int(name), C.byref(v)))
         return float(v.value)
+
+    def enqueued_iterations(self):
+        """Iterations the host enqueued for every child in the last run() (OA_STAT_ENQUEUED_CHILD + i): all equal, whatever
+        the host threads saw of their devices while they enqueued."""
+        return [int(self.stat(1000 + i)) for i in range(len(self.devices))] if self.multi else [int(self.stat("enqueued_max"))]
 
     def matrix_world(self) -> np.ndarray:
         out = np.empty((4, 4), np.float32)

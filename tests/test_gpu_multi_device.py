@@ -597,3 +597,110 @@ def test_bench_two_shards_reports_its_exchange(monkeypatch):
     cfg = d["config"]
     assert cfg["exchange"].startswith("mailbox") and cfg["rccl_ranks"] == 0
     assert cfg["host_enqueue_us_per_iteration"] > 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 4: the host threads agree on how many iterations they enqueue; the wait for the streams is bounded in RCCL mode
+# ---------------------------------------------------------------------------------------------------------------------
+def _small_job(eng, g):
+    eng.set_target(g["tgt"])
+    eng.set_source(g["src"], stride=1)
+
+
+def _agree_stress(*args):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "agree_stress.py")] + [str(a) for a in args], cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900, text=True)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert p.returncode == 0 and len(lines) == 1, p.stdout[-3000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("n_dev", [2, 4])
+def test_host_threads_agree_on_the_enqueued_count(n_dev):
+    """One persistent host thread per child (OA_MULTI_THREADS=1 + OA_MULTI_OWN_STREAMS=1: what distinct GPUs get), early
+    exit on, a 2562-point mesh -- an iteration takes ~20 us, so host and device race for real.  Every thread stops on what
+    ITS device reports, at its own time; the number of iterations each enqueues must still be the same on all of them,
+    because in RCCL mode every enqueued iteration holds a collective (round 3: each thread for itself).
+    250 loops; each must also be the fixture's loop.  (tools/agree_stress.py, its own process: every child's stream needs
+    a hardware queue of its own on the one-GPU box.)"""
+    d = _agree_stress("--children", n_dev, "--reps", 250)
+    assert d["host_threads"] == n_dev and d["reps"] == 250
+    assert d["loops_with_differing_counts"] == 0 and d["loops_with_wrong_result"] == 0, d
+    for key in d["enqueued_counts_histogram"]:
+        assert d["iterations_executed"] <= int(key) <= 30, d
+    print(d)
+
+
+def test_a_lagging_host_thread_hits_the_window_and_the_agreement_closes_it():
+    """OA_FAULT_LAG_GROUP: host thread 1 sleeps 300 us before every look at its halt flag.  Its device then halts before it
+    has enqueued anything ahead, while thread 0 is `lag` iterations ahead of the GPU -- the window of VERDICT r03 item 1,
+    hit on every loop.  With the agreement switched off (OA_MULTI_AGREE=0, honoured on the mailbox only -- round 3's code)
+    the two threads enqueue different numbers of iterations; with it, the same number.  The results are the fixture's
+    either way (on the mailbox a surplus iteration is an empty launch; with RCCL it would be a collective nobody joins)."""
+    old = _agree_stress("--children", 2, "--reps", 20, "--lag-group", 1, "--lag-us", 300, "--agree", 0)
+    new = _agree_stress("--children", 2, "--reps", 20, "--lag-group", 1, "--lag-us", 300, "--agree", 1)
+    assert old["loops_with_wrong_result"] == 0 and new["loops_with_wrong_result"] == 0
+    assert old["loops_with_differing_counts"] >= 10, old   # the window is real (and the test would notice if the hook stopped hitting it)
+    assert new["loops_with_differing_counts"] == 0, new
+
+
+def test_rccl_watchdog_turns_a_stalled_collective_into_an_error(golden_dir, monkeypatch):
+    """include/oa_icp.h promises OA_E_RCCL when a device's sums do not arrive within OA_EXCHANGE_TIMEOUT_S -- in RCCL mode
+    too.  OA_FAULT_STALL_RANK stops rank 0's stream ahead of the collective of iteration 2 (a bounded spin: what a rank
+    whose peers never enter the collective looks like from the host).  The watchdog sees no device finish an iteration for
+    1.5 s, aborts the communicators (ncclCommAbort), the streams drain, oa_run fails with OA_E_RCCL -- no hang -- and the
+    same context, asked for RCCL again, builds new communicators and runs the fixture's loop."""
+    import time
+    from object_alignment_amd import _capi
+    from object_alignment_amd.engine import IcpEngine
+    g = _load(golden_dir, "icp_loop_bumpy_converge")
+    monkeypatch.setenv("OA_EXCHANGE_TIMEOUT_S", "1.5")
+    monkeypatch.setenv("OA_FAULT_STALL_RANK", "0")
+    with IcpEngine(devices=[0], exchange="rccl") as eng:
+        assert eng.exchange_info()["rccl_ranks"] == 1
+        _small_job(eng, g)
+        eng.set_matrices(g["mx_align"], g["mx_base"])
+        t0 = time.perf_counter()
+        with pytest.raises(_capi.OaError) as ei:
+            eng.run(iters=30, thresh=0.5, target_d=0.01, use_target=True, early_exit=True)
+        dt = time.perf_counter() - t0
+        assert ei.value.code == _capi.OA_E_RCCL and "abort" in ei.value.msg
+        assert 1.0 < dt < 12.0, dt
+        assert eng.stat("watchdog_aborts") == 1
+        eng.set_exchange("rccl")                                     # new communicators (handshake included)
+        assert eng.exchange_info()["rccl_ranks"] == 1
+        res = _run_fixture(g, eng)
+        assert eng.stat("watchdog_aborts") == 1
+    assert res.iters_done == int(g["iters_done"]) and np.abs(res.matrix_world - g["final_world"]).max() <= F32_ULP
+
+
+@pytest.mark.parametrize("exchange", ["mailbox", "rccl"])
+def test_a_failing_host_thread_ends_the_loop_everywhere(golden_dir, monkeypatch, exchange):
+    """OA_FAULT_FAIL_GROUP: one host thread's enqueue fails at iteration 3.  The other threads stop committing to new
+    iterations at once (they do not enqueue on for seconds), the streams are waited for with a bound -- mailbox: the gather
+    kernels' own time limit; RCCL: the communicators are aborted right away, the ranks' collective counts may differ -- the
+    call returns the thread's error, and the context runs the next loop."""
+    import time
+    from object_alignment_amd import _capi
+    from object_alignment_amd.engine import IcpEngine
+    g = _load(golden_dir, "icp_loop_bumpy_converge")
+    devices = [0] if exchange == "rccl" else [0, 0, 0]
+    monkeypatch.setenv("OA_MULTI_THREADS", "1")
+    monkeypatch.setenv("OA_MULTI_OWN_STREAMS", "1")
+    monkeypatch.setenv("OA_EXCHANGE_TIMEOUT_S", "1.5")
+    monkeypatch.setenv("OA_FAULT_FAIL_GROUP", "0" if exchange == "rccl" else "1")
+    monkeypatch.setenv("OA_FAULT_FAIL_ITER", "3")
+    with IcpEngine(devices=devices, exchange=exchange) as eng:
+        _small_job(eng, g)
+        eng.set_matrices(g["mx_align"], g["mx_base"])
+        t0 = time.perf_counter()
+        with pytest.raises(_capi.OaError) as ei:
+            eng.run(iters=30, thresh=0.5, target_d=0.01, use_target=True, early_exit=True)
+        dt = time.perf_counter() - t0
+        assert ei.value.code == _capi.OA_E_HIP and "injected" in ei.value.msg
+        assert dt < 10.0, dt
+        assert eng.stat("watchdog_aborts") == (1 if exchange == "rccl" else 0)
+        if exchange == "rccl":
+            eng.set_exchange("rccl")
+        res = _run_fixture(g, eng)
+    assert res.iters_done == int(g["iters_done"]) and np.abs(res.matrix_world - g["final_world"]).max() <= F32_ULP
