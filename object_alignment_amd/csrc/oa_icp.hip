@@ -373,6 +373,7 @@ struct oa_ctx {
     double turn_frac = 0.1;          // OA_TURN_FRAC: the tree keeps its turn while the pose moves by more than this part of a cell
     bool debug = false;              // OA_DEBUG (read at oa_create)
     bool grid_stats = false;         // OA_GRID_STATS: instrumented triangle-grid launches print what the queries did
+    bool tri_share = true;           // OA_TRI_SHARE=0 (A/B): every lane of the triangle-grid search walks its own records (rounds 2-3)
     int turns_on = 1;                // OA_SEARCH_TURNS: tree while the pose moves, grid afterwards (mid-size shards, AUTO)
     bool seeded = false;             // a search has run since the last set_source / set_target (seeds exist)
     int *d_prev = nullptr;           // nearest index of the previous search (seed), -1 = none
@@ -1684,6 +1685,7 @@ OA_EXPORT int oa_create(oa_ctx **out, int device)
     c->turns_on = env_int("OA_SEARCH_TURNS", 1);
     c->debug = getenv("OA_DEBUG") != nullptr;
     c->grid_stats = env_int("OA_GRID_STATS", 0) != 0;
+    c->tri_share = env_int("OA_TRI_SHARE", 1) != 0;
     c->turn_frac = env_double("OA_TURN_FRAC", 0.1);
     c->use_filter = env_int("OA_NN_FILTER", 1) != 0;
     c->nn_mfma = env_int("OA_NN_MFMA", 0);
@@ -2303,8 +2305,8 @@ int build_tri_grid(oa_ctx *c)
         gp.h = h; gp.inv_h = 1.0 / h;
         gp.r_max = std::min(env_int("OA_GRID_RMAX", 3), 3);
         gp.seeded_start = env_int("OA_TRI_SEEDED_START", 1) ? 1 : 0;
-        gp.budget = env_int("OA_GRID_BUDGET", 192);
-        gp.budget_moving = (int)(gp.budget * env_double("OA_GRID_BUDGET_MOVING", 2.0));
+        gp.budget = std::max(1, std::min(env_int("OA_GRID_BUDGET", 192), 30000));
+        gp.budget_moving = std::max(1, std::min((int)(gp.budget * env_double("OA_GRID_BUDGET_MOVING", 2.0)), 60000));   // (range lengths are 16-bit in the kernel)
         gp.scale = scale;
         gp.slack = 1e-10 * scale + 1e-300;
         oa::grid_params_finish(gp);
@@ -2324,7 +2326,8 @@ int build_tri_grid(oa_ctx *c)
     if (n_cells <= 0 || entries == 0) return OA_OK;
     HIPCHK(d_off.alloc((size_t)n_cells + 1));
     HIPCHK(dev_malloc(&c->d_tcell_start, sizeof(int) * (size_t)(n_cells + 1)));
-    HIPCHK(dev_malloc(&c->d_tcell_rec, sizeof(float4) * 2 * (size_t)entries));
+    HIPCHK(dev_malloc(&c->d_tcell_rec, sizeof(float4) * 2 * ((size_t)entries + oa::TRI_REC_PAD)));
+    HIPCHK(hipMemsetAsync(c->d_tcell_rec + 2 * (size_t)entries, 0, sizeof(float4) * 2 * oa::TRI_REC_PAD, c->stream));   // triangle 0, see tri_scan_shared
     { int rcs = scan_counts(c, d_counts.p, n_cells, d_off.p); if (rcs) return rcs; }
     hipLaunchKernelGGL(oa::k_grid_starts, dim3((n_cells + 256) / 256), dim3(256), 0, c->stream, d_off.p, n_cells, c->d_tcell_start, d_counts.p);
     hipLaunchKernelGGL(oa::k_tri_grid_bin<true>, dim3((c->n_tris + 255) / 256), dim3(256), 0, c->stream, c->d_tri9, c->n_tris,
@@ -2366,13 +2369,20 @@ int launch_tri_search(oa_ctx *c, bool acc)
         if (lanes == 4) hipLaunchKernelGGL(oa::k_tri_search_grid<4>, gblocks, dim3(256), 0, c->stream, OA_TGRID_ARGS);
         else if (lanes == 2) hipLaunchKernelGGL(oa::k_tri_search_grid<2>, gblocks, dim3(256), 0, c->stream, OA_TGRID_ARGS);
         else if (c->grid_stats) {                                   // OA_GRID_STATS=1: instrumented launch, totals to stderr (synchronises)
-            DevTmp<unsigned long long> d_stats;
-            HIPCHK(d_stats.alloc(oa::TRI_STAT_N));
-            HIPCHK(hipMemsetAsync(d_stats, 0, sizeof(unsigned long long) * oa::TRI_STAT_N, c->stream));
-            hipLaunchKernelGGL((oa::k_tri_search_grid<1, true>), gblocks, dim3(256), 0, c->stream, OA_TGRID_ARGS, d_stats.p);
+            DevTmp<unsigned long long> d_stats;                     // one row of counters per wave (atomics on a dozen shared words slowed the launch 8x)
+            const size_t n_waves = (size_t)gblocks.x * 4;
+            HIPCHK(d_stats.alloc(oa::TRI_STAT_N * n_waves));
+            HIPCHK(hipMemsetAsync(d_stats, 0, sizeof(unsigned long long) * oa::TRI_STAT_N * n_waves, c->stream));
+            if (c->tri_share) hipLaunchKernelGGL((oa::k_tri_search_grid<1, true, true>), gblocks, dim3(256), 0, c->stream, OA_TGRID_ARGS, d_stats.p);
+            else hipLaunchKernelGGL((oa::k_tri_search_grid<1, true, false>), gblocks, dim3(256), 0, c->stream, OA_TGRID_ARGS, d_stats.p);
             HIPCHK(hipGetLastError());
-            unsigned long long h[oa::TRI_STAT_N];
-            { int rcr = read_small(c, h, d_stats, sizeof h); if (rcr) return rcr; }
+            unsigned long long h[oa::TRI_STAT_N] = { 0 };
+            {
+                std::vector<unsigned long long> rows(oa::TRI_STAT_N * n_waves);
+                int rcr = read_small(c, rows.data(), d_stats, sizeof(unsigned long long) * rows.size());
+                if (rcr) return rcr;
+                for (size_t w = 0; w < n_waves; ++w) for (int k = 0; k < oa::TRI_STAT_N; ++k) h[k] += rows[w * oa::TRI_STAT_N + (size_t)k];
+            }
             const double nq = (double)std::max(1ull, h[oa::TRI_STAT_QUERIES]), nw = (double)std::max(1ull, h[oa::TRI_STAT_WAVES]);
             fprintf(stderr, "[oa] tri grid stats: queries %llu | per query: rows %.2f entries %.2f (sphere passes %.2f) survivors %.2f evals %.2f | per wave: "
                             "eval trips %.1f max-lane entries %.1f max-lane rows %.1f | ring>=2 %.1f%% ring>=3 %.1f%% unsettled %.1f%% over budget %.1f%%\n",
@@ -2380,7 +2390,13 @@ int launch_tri_search(oa_ctx *c, bool acc)
                     h[oa::TRI_STAT_EVALS] / nq, h[oa::TRI_STAT_WAVE_TRIPS] / nw, h[oa::TRI_STAT_WAVE_MAX_ENTRIES] / nw,
                     h[oa::TRI_STAT_WAVE_MAX_ROWS] / nw, 100.0 * h[oa::TRI_STAT_RING2] / nq, 100.0 * h[oa::TRI_STAT_RING3] / nq,
                     100.0 * h[oa::TRI_STAT_UNSETTLED] / nq, 100.0 * h[oa::TRI_STAT_OVER] / nq);
+            const double ct = (double)std::max(1ull, h[oa::TRI_STAT_CYC_TOTAL]);
+            fprintf(stderr, "[oa] tri grid phases: per wave %.0f shader cycles, %.2f loop trips | prologue %.1f%% listing %.1f%% scan %.1f%% flush %.1f%% bookkeeping %.1f%% epilogue %.1f%%\n",
+                    ct / nw, h[oa::TRI_STAT_LOOP_TRIPS] / nw, 100.0 * h[oa::TRI_STAT_CYC_PROLOGUE] / ct, 100.0 * h[oa::TRI_STAT_CYC_LIST] / ct,
+                    100.0 * h[oa::TRI_STAT_CYC_SCAN] / ct, 100.0 * h[oa::TRI_STAT_CYC_FLUSH] / ct, 100.0 * h[oa::TRI_STAT_CYC_BOOK] / ct,
+                    100.0 * (ct - h[oa::TRI_STAT_CYC_PROLOGUE] - h[oa::TRI_STAT_CYC_LIST] - h[oa::TRI_STAT_CYC_SCAN] - h[oa::TRI_STAT_CYC_FLUSH] - h[oa::TRI_STAT_CYC_BOOK]) / ct);
         }
+        else if (!c->tri_share) hipLaunchKernelGGL((oa::k_tri_search_grid<1, false, false>), gblocks, dim3(256), 0, c->stream, OA_TGRID_ARGS);
         else hipLaunchKernelGGL(oa::k_tri_search_grid<1>, gblocks, dim3(256), 0, c->stream, OA_TGRID_ARGS);
 #undef OA_TGRID_ARGS
         HIPCHK(hipGetLastError());

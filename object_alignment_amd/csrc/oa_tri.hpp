@@ -234,16 +234,17 @@ __device__ __forceinline__ void tri_state_refresh(TriSearchState &s, double delt
 // A wave therefore pays ceil(contenders of all its lanes / 64) closest-point evaluations instead of the maximum over
 // its lanes per flush (PMC before: 65-80 evaluation trips per wave in the first iterations of a run, for 10-12
 // evaluations per query).
-constexpr int TRI_POOL = 320;      // pool entries per wave; a flush is due above TRI_POOL - 128
+constexpr int TRI_POOL = 256;      // pool entries per wave; a flush is due above TRI_POOL - 128
 constexpr int TRI_SEGS = 10;       // cell-list ranges of one batch of rows (9 rows of the first block, or 5 rows x 2 end cells)
 
 struct TriPool {                   // this wave's part of the workgroup's LDS
-    int *tid, *own;
+    int *tid;
+    unsigned char *own;
     float *key;
     unsigned long long *slot;      // one per lane: (bits(d2) << 32) | triangle of what others evaluated for it
+    unsigned long long *first;     // one per lane: (bits(bound) << 32) | pool entry of its most promising survivor (~0: none)
+    float4 *q4;                    // one per lane: its query and its reach (TriSearchState::reach), for whoever tests records on its behalf
     int n;                         // entries (wave-uniform)
-    int kslot;                     // this lane's most promising entry (-1: none)
-    float gmin;                    // its bound
 };
 
 // Lower bound of the squared distance from p to a triangle with record (rec0, rec1), given D2 = |p - c|^2 (float).
@@ -269,20 +270,22 @@ __device__ __forceinline__ float tri_record_bound2(float dx, float dy, float dz,
     return lb;                                                                    // (its last 1e-6 is in TriSearchState::thr)
 }
 
-// phase 1 for one record per lane (valid = this lane has one); called by the whole wave
-__device__ __forceinline__ void tri_candidate(const float *p, const float4 rec0, const float4 rec1, bool valid,
-                                              const TriSearchState &s, float eps_plane, TriPool &pool, int *surv = nullptr)
+// phase 1 for one record per lane (valid = this lane has one), tested FOR lane `owner` of the wave: (px, py, pz) is the
+// owner's query, reach / thr its thresholds (TriSearchState) -- the lane that runs the test need not be the owner
+// (tri_scan_shared deals the wave's records out evenly).  Called by the whole wave.
+__device__ __forceinline__ void tri_candidate(float px, float py, float pz, const float4 rec0, const float4 rec1, bool valid,
+                                              float reach, float thr, int owner, float eps_plane, TriPool &pool, int *surv = nullptr)
 {
     bool keep = false;
     float lb = 0.f;
     if (valid) {
-        const float dx = rec0.x - p[0], dy = rec0.y - p[1], dz = rec0.z - p[2];
+        const float dx = rec0.x - px, dy = rec0.y - py, dz = rec0.z - pz;
         const float D2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-        const float rs = rec0.w + s.reach;
+        const float rs = rec0.w + reach;
         if (!(D2 > rs * rs * 1.000003f)) {                         // else: farther than radius + reach, cannot beat or tie
             if (surv) *surv += 1 << 16;                            // (instrumented build: sphere passes in the high half)
             lb = tri_record_bound2(dx, dy, dz, rec0, rec1, D2, rs, eps_plane);
-            keep = !(lb > s.thr);                                  // else: the plane / disc bound rules it out
+            keep = !(lb > thr);                                    // else: the plane / disc bound rules it out
         }
     }
     const unsigned long long m = __ballot(keep);
@@ -291,9 +294,11 @@ __device__ __forceinline__ void tri_candidate(const float *p, const float4 rec0,
         const int lane = threadIdx.x & 63;
         const int dst = pool.n + __popcll(m & ((1ull << lane) - 1ull));
         pool.tid[dst] = __float_as_int(rec1.w);
-        pool.own[dst] = lane;
+        pool.own[dst] = (unsigned char)owner;
         pool.key[dst] = lb;
-        if (!(lb >= pool.gmin)) { pool.gmin = lb; pool.kslot = dst; }     // (gmin starts at +inf; a NaN bound -- never from a binned triangle -- goes first)
+        // the owner's most promising survivor: smallest bound (lb >= +0: its bits order like its value; a NaN bound -- never
+        // from a binned triangle -- sorts last and is evaluated with the rest)
+        atomicMin(&pool.first[owner], ((unsigned long long)__float_as_uint(lb) << 32) | (unsigned long long)(unsigned)dst);
     }
     pool.n += __popcll(m);
 }
@@ -323,8 +328,10 @@ __device__ __forceinline__ void tri_pool_flush(const float *p, const float4 *__r
     if (pool.n == 0) return;
     const int lane = threadIdx.x & 63;
     // A) the most promising survivor of every lane
-    if (pool.kslot >= 0 && !(pool.gmin > s.thr)) {
-        const uint32_t t = (uint32_t)pool.tid[pool.kslot];
+    const unsigned long long fs = __hip_atomic_load(&pool.first[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    const int kslot = fs == ~0ull ? -1 : (int)(uint32_t)fs;
+    if (kslot >= 0 && !(__uint_as_float((uint32_t)(fs >> 32)) > s.thr)) {
+        const uint32_t t = (uint32_t)pool.tid[kslot];
         const float4 u = tri9[3ll * t], v = tri9[3ll * t + 1], w = tri9[3ll * t + 2];
         tri_consider(p, u, v, w, t, s, delta, cutf, ev);
     }
@@ -338,12 +345,12 @@ __device__ __forceinline__ void tri_pool_flush(const float *p, const float4 *__r
         float key = 0.f;
         if (e < pool.n) { own = pool.own[e]; t = pool.tid[e]; key = pool.key[e]; }
         const float othr = __shfl(s.thr, own, 64);
-        const int oks = __shfl(pool.kslot, own, 64), obi = __shfl((int)s.bidx, own, 64);
+        const int oks = __shfl(kslot, own, 64), obi = __shfl((int)s.bidx, own, 64);
         if (e < pool.n) c = e != oks && t != obi && !(key > othr);
         const unsigned long long m = __ballot(c);
         if (c) {                                                   // dst <= e, and this trip's reads are done: in place is safe
             const int dst = n2 + __popcll(m & ((1ull << lane) - 1ull));
-            pool.own[dst] = own; pool.tid[dst] = t; pool.key[dst] = key;
+            pool.own[dst] = (unsigned char)own; pool.tid[dst] = t; pool.key[dst] = key;
         }
         n2 += __popcll(m);
     }
@@ -380,25 +387,35 @@ __device__ __forceinline__ void tri_pool_flush(const float *p, const float4 *__r
             }
         }
     }
-    pool.n = 0; pool.kslot = -1; pool.gmin = INFINITY;
+    pool.n = 0;
+    __hip_atomic_store(&pool.first[lane], ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    if (pool.q4) __hip_atomic_store(&pool.q4[lane].w, s.reach, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // what the helpers test against from here on
 }
 
-// Phase 1 over the cell-list ranges a lane has collected (seg[0 .. n_seg), [first, last + 1) positions of cell_rec):
-// every lane walks ITS ranges, four records per trip; the wave leaves when every lane is through.
-constexpr long long TRI_REC_MAX_ENTRIES = (1ll << 27) - 16;        // 32 bytes each, addressed through 32-bit byte offsets
+// Phase 1 over the cell-list ranges the lanes have collected (per thread: seg_j[0 .. n_seg) first positions in cell_rec,
+// seg_n[..] lengths).
+// 26-bit positions: a chunk of the shared scan is (position << 6) | owner lane in one word.  (Records are 32 bytes and are
+// addressed through 32-bit byte offsets: 2^27 would fit those.)  The host pads cell_rec with TRI_REC_PAD zeroed records --
+// triangle 0 -- so that a chunk may always read four records.
+constexpr long long TRI_REC_MAX_ENTRIES = (1ll << 26) - 16;
+constexpr int TRI_REC_PAD = 4;
+constexpr int TRI_SHARE_Q = 8;     // chunks (of four records) a lane hands to the wave per round of the shared scan
 __device__ __forceinline__ float4 tri_ld_rec(const float4 *__restrict__ base, int entry, int half)
 {
     return *(const float4 *)((const char *)base + ((unsigned)entry * 32u + (unsigned)half * 16u));
 }
 
+// every lane walks ITS ranges, four records per trip; the wave leaves when every lane is through: a wave pays
+// max-over-lanes(records) trips (round 2 / 3; kept for A/B: OA_TRI_SHARE=0)
 __device__ __forceinline__ void tri_scan_segments(const float *p, const float4 *__restrict__ cell_rec,
                                                   const float4 *__restrict__ tri9, TriSearchState &s, float eps_plane,
-                                                  int2 (*seg)[256], int &n_seg, TriPool &pool, double delta, float cutf,
-                                                  int *surv = nullptr, int *ev = nullptr, int *trips = nullptr)
+                                                  const int (*seg_j)[256], const unsigned short (*seg_n)[256], int &n_seg, TriPool &pool,
+                                                  double delta, float cutf, int *surv = nullptr, int *ev = nullptr, int *trips = nullptr)
 {
+    const int lane = threadIdx.x & 63;
     int k = 0, j = 0, end = 0;
     while (true) {
-        if (j >= end && k < n_seg) { const int2 sg = seg[k][threadIdx.x]; j = sg.x; end = sg.y; ++k; }
+        if (j >= end && k < n_seg) { j = seg_j[k][threadIdx.x]; end = j + (int)seg_n[k][threadIdx.x]; ++k; }
         const bool active = j < end;
         if (!__any(active)) break;
         // four records (32 bytes each) per lane: eight independent loads; the clamped repeats of the last record are not tested
@@ -410,13 +427,97 @@ __device__ __forceinline__ void tri_scan_segments(const float *p, const float4 *
             a0 = tri_ld_rec(cell_rec, jj, 0); a1 = tri_ld_rec(cell_rec, jj, 1); b0 = tri_ld_rec(cell_rec, e1, 0); b1 = tri_ld_rec(cell_rec, e1, 1);
             c0 = tri_ld_rec(cell_rec, e2, 0); c1 = tri_ld_rec(cell_rec, e2, 1); d0 = tri_ld_rec(cell_rec, e3, 0); d1 = tri_ld_rec(cell_rec, e3, 1);
         }
-        tri_candidate(p, a0, a1, active, s, eps_plane, pool, surv);
-        tri_candidate(p, b0, b1, active && j + 1 < end, s, eps_plane, pool, surv);
+        tri_candidate(p[0], p[1], p[2], a0, a1, active, s.reach, s.thr, lane, eps_plane, pool, surv);
+        tri_candidate(p[0], p[1], p[2], b0, b1, active && j + 1 < end, s.reach, s.thr, lane, eps_plane, pool, surv);
         if (pool.n > TRI_POOL - 128) tri_pool_flush(p, tri9, s, pool, delta, cutf, ev, trips);      // each test adds <= 64 entries
-        tri_candidate(p, c0, c1, active && j + 2 < end, s, eps_plane, pool, surv);
-        tri_candidate(p, d0, d1, active && j + 3 < end, s, eps_plane, pool, surv);
+        tri_candidate(p[0], p[1], p[2], c0, c1, active && j + 2 < end, s.reach, s.thr, lane, eps_plane, pool, surv);
+        tri_candidate(p[0], p[1], p[2], d0, d1, active && j + 3 < end, s.reach, s.thr, lane, eps_plane, pool, surv);
         if (pool.n > TRI_POOL - 128) tri_pool_flush(p, tri9, s, pool, delta, cutf, ev, trips);
         if (active) j += 4;
+    }
+    n_seg = 0;
+}
+
+// The same records, dealt out EVENLY and read COALESCED (round 4).
+// (i) The lists of a wave's 64 queries differ in length -- settled, the longest is twice the mean (60 records against 28), in
+// the first iterations 277 against 196 -- and the per-lane walk above keeps the whole wave for the longest.  (ii) In that
+// walk every lane reads its own 128 bytes per trip: each of the eight load instructions of a trip touches 64 different cache
+// lines, two tag look-ups per record, and the phase stamps of the instrumented build show the scan's time following the
+// number of such look-ups, not the instructions (profiles/r04b_surface_phases.txt).
+// Here the wave works through its records as one pool of work: in rounds, every lane cuts the next (up to) Q chunks of four
+// consecutive records off its own ranges and writes them -- (position << 6) | owner lane -- into the wave's chunk table in LDS
+// at its place in the wave-wide order (ballot prefix sums).  Then the table is walked 64 RECORDS per step: lane l takes record
+// l mod 4 of chunk l / 4, so the four lanes of a quad read one 128-byte stretch and the quads of a range's consecutive chunks
+// consecutive stretches (a load instruction touches ~16-24 lines instead of 64).  The lane fetches its chunk's owner's query
+// and reach from the wave's owner table in LDS (TriPool::q4: one 16-byte read), tests its record, and a survivor goes into
+// the wave's pool under its OWNER's name -- which is all phase 2 ever looked at.  Four steps per trip (four records per lane,
+// from four different chunks).  A wave pays ceil(records of all its lanes / 256) trips instead of max-over-lanes(records) / 4.
+// A chunk always covers four records: the last chunk of a range reads into the next cell's list (or the padding behind the
+// last one) -- triangles nobody asked for, tested all the same; the answer is the minimum over ALL triangles, so a test too
+// many cannot change it.  The threshold of the plane / disc bound is reach^2 here (>= TriSearchState::thr: reach >= r (1 + 3e-6),
+// thr = r^2 (1 + 3e-6)(1 + 1.1e-6) -- a hair looser, one multiplication instead of a second cross-lane value); an owner's reach
+// only changes in a flush, which the whole wave takes together and which republishes it.
+__device__ __forceinline__ void tri_scan_shared(const float *p, const float4 *__restrict__ cell_rec,
+                                                const float4 *__restrict__ tri9, TriSearchState &s, float eps_plane,
+                                                const int (*seg_j)[256], const unsigned short (*seg_n)[256], int &n_seg, unsigned *tab,
+                                                TriPool &pool, double delta, float cutf, int *surv = nullptr, int *ev = nullptr,
+                                                int *trips = nullptr)
+{
+    constexpr int Q = TRI_SHARE_Q;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int left = 0;                                                   // chunks this lane still has to hand out
+    for (int k = 0; k < n_seg; ++k) left += ((int)seg_n[k][threadIdx.x] + 3) >> 2;
+    int k = 0, j = 0, end = 0;
+    while (true) {
+        const int g = min(Q, left);
+        // wave-wide exclusive prefix sum and total of g (0 .. 8): one ballot per bit
+        int pos = 0, G = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const unsigned long long mb = __ballot((g >> b) & 1);
+            pos += __popcll(mb & lt) << b;
+            G += __popcll(mb) << b;
+        }
+        if (G == 0) break;
+#pragma unroll
+        for (int i = 0; i < Q; ++i) {
+            if (i < g) {
+                if (j >= end) { j = seg_j[k][threadIdx.x]; end = j + (int)seg_n[k][threadIdx.x]; ++k; }
+                tab[pos + i] = ((unsigned)j << 6) | (unsigned)lane;
+                j += 4;
+            }
+        }
+        left -= g;
+        const int q = lane & 3, c0 = lane >> 2;
+        for (int base = 0; base < G; base += 64) {                  // 64 chunks = 256 records per trip
+            bool act[4];
+            int own[4];
+            float4 r0[4], r1[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = base + 16 * u + c0;
+                act[u] = c < G;
+                const unsigned ent = act[u] ? tab[c] : (unsigned)lane;
+                own[u] = (int)(ent & 63u);
+                const int rec = (int)(ent >> 6) + q;
+                r0[u] = r1[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (act[u]) { r0[u] = tri_ld_rec(cell_rec, rec, 0); r1[u] = tri_ld_rec(cell_rec, rec, 1); }
+            }
+            // (the owners' entries two at a time: sixteen registers less in flight than all four)
+            {
+                const float4 oa4 = pool.q4[own[0]], ob4 = pool.q4[own[1]];
+                tri_candidate(oa4.x, oa4.y, oa4.z, r0[0], r1[0], act[0], oa4.w, oa4.w * oa4.w, own[0], eps_plane, pool, surv);
+                tri_candidate(ob4.x, ob4.y, ob4.z, r0[1], r1[1], act[1], ob4.w, ob4.w * ob4.w, own[1], eps_plane, pool, surv);
+            }
+            if (pool.n > TRI_POOL - 128) tri_pool_flush(p, tri9, s, pool, delta, cutf, ev, trips);      // each test adds <= 64 entries
+            {
+                const float4 oa4 = pool.q4[own[2]], ob4 = pool.q4[own[3]];
+                tri_candidate(oa4.x, oa4.y, oa4.z, r0[2], r1[2], act[2], oa4.w, oa4.w * oa4.w, own[2], eps_plane, pool, surv);
+                tri_candidate(ob4.x, ob4.y, ob4.z, r0[3], r1[3], act[3], ob4.w, ob4.w * ob4.w, own[3], eps_plane, pool, surv);
+            }
+            if (pool.n > TRI_POOL - 128) tri_pool_flush(p, tri9, s, pool, delta, cutf, ev, trips);
+        }
     }
     n_seg = 0;
 }
@@ -426,9 +527,10 @@ __device__ __forceinline__ void tri_scan_segments(const float *p, const float4 *
 // STATS (debug builds of the launch, OA_GRID_STATS=1): per-launch totals of what the queries did, see TRI_STAT_*
 enum { TRI_STAT_QUERIES, TRI_STAT_ROWS, TRI_STAT_ENTRIES, TRI_STAT_SURVIVORS, TRI_STAT_EVALS, TRI_STAT_WAVE_TRIPS,
        TRI_STAT_WAVE_MAX_ENTRIES, TRI_STAT_WAVE_MAX_ROWS, TRI_STAT_RING2, TRI_STAT_RING3, TRI_STAT_UNSETTLED, TRI_STAT_OVER, TRI_STAT_SPHERE,
-       TRI_STAT_WAVES, TRI_STAT_N };
+       TRI_STAT_WAVES, TRI_STAT_CYC_TOTAL, TRI_STAT_CYC_PROLOGUE, TRI_STAT_CYC_LIST, TRI_STAT_CYC_SCAN, TRI_STAT_CYC_FLUSH, TRI_STAT_CYC_BOOK,
+       TRI_STAT_LOOP_TRIPS, TRI_STAT_N };
 
-template <int L, bool STATS = false>
+template <int L, bool STATS = false, bool SHARE = true>
 #ifndef OA_TRI_MIN_WAVES
 #define OA_TRI_MIN_WAVES 4
 #endif
@@ -449,18 +551,30 @@ __global__ __launch_bounds__(256, OA_TRI_MIN_WAVES) void k_tri_search_grid(const
     static_assert(RPL <= TRI_SEGS && (L == 1 || 2 * RPL <= TRI_SEGS), "a batch of rows must fit the per-thread range list");
     if (st->halt) return;
     if (turn >= 0 && (st->tree_turn != 0) != (turn != 0)) return;  // not this kernel's turn (DevState::tree_turn)
-    __shared__ int pool_tid[4][TRI_POOL], pool_own[4][TRI_POOL];
+    __shared__ int pool_tid[4][TRI_POOL];
+    __shared__ unsigned char pool_own[4][TRI_POOL];
     __shared__ float pool_key[4][TRI_POOL];
-    __shared__ unsigned long long pool_slot[256];
-    __shared__ int2 seg[TRI_SEGS][256];
+    __shared__ unsigned long long pool_slot[256], pool_first[256];
+    __shared__ int seg_j[TRI_SEGS][256];
+    __shared__ unsigned short seg_n[TRI_SEGS][256];                 // (a range is never longer than the budget it was charged to: < 65536, build_tri_grid)
+    __shared__ unsigned chunk_tab[SHARE ? 4 : 1][SHARE ? 64 * TRI_SHARE_Q : 1];
+    __shared__ float4 owner_q4[SHARE ? 256 : 1];
     int n_seg = 0;
     TriPool pool;
     {
         const int wv = threadIdx.x >> 6;
         pool.tid = pool_tid[wv]; pool.own = pool_own[wv]; pool.key = pool_key[wv]; pool.slot = pool_slot + 64 * wv;
-        pool.n = 0; pool.kslot = -1; pool.gmin = INFINITY;
+        pool.first = pool_first + 64 * wv;
+        pool.q4 = SHARE ? owner_q4 + 64 * wv : nullptr;
+        pool.n = 0;
+        pool_first[threadIdx.x] = ~0ull;                            // (this wave's own words: no barrier needed)
     }
     int n_rows_loaded = 0, n_entries = 0, n_surv = 0, n_evals = 0, n_trips = 0, max_ring = 0;
+    // (instrumented build) shader-clock stamps at the phase boundaries, summed per wave
+    long long cyc_t0 = 0, cyc_mark = 0, cyc_list = 0, cyc_scan = 0, cyc_flush = 0, cyc_book = 0, cyc_prologue = 0;
+    int n_loop_trips = 0;
+    if (STATS) cyc_t0 = cyc_mark = (long long)__builtin_readcyclecounter();
+#define OA_TRI_STAMP(acc) do { if (STATS) { const long long now_ = (long long)__builtin_readcyclecounter(); acc += now_ - cyc_mark; cyc_mark = now_; } } while (0)
     const int gt = xcd_block_index() * (int)blockDim.x + threadIdx.x;      // one contiguous part of the queries per XCD
     int i = gt / L;
     const int sub = gt % L;                                         // the L lanes of a query are neighbours in a wave
@@ -488,6 +602,7 @@ __global__ __launch_bounds__(256, OA_TRI_MIN_WAVES) void k_tri_search_grid(const
     S.best = best; S.bidx = bidx;
     S.lim = fminf(best, cutf);
     tri_state_refresh(S, delta);
+    if (SHARE) owner_q4[threadIdx.x] = make_float4(pf[0], pf[1], pf[2], S.reach);
     bool settled = false, over = false;
     // candidates this query may look at (see GridParams; split between its lanes).  While the pose still moves by a good part of a cell per
     // iteration (first iteration, or last iteration's translation + rotation x object size above h / 4) the seeds are
@@ -507,8 +622,10 @@ __global__ __launch_bounds__(256, OA_TRI_MIN_WAVES) void k_tri_search_grid(const
     // them: a lane's ring / batch counters are plain state, and the only loop condition is __any(busy).
     int r = r_start, b0 = 0;
     bool busy = q.finite && alive;
+    OA_TRI_STAMP(cyc_prologue);
     while (__any(busy)) {
         bool ring_done = false;
+        if (STATS) ++n_loop_trips;
         if (busy && r == 1) {
             // the 3 x 3 block, as in k_nn_search_grid (GridBlock3): which rows can matter -- the row test of the general code
             // below -- then their ranges, UR rows in flight at a time
@@ -523,7 +640,7 @@ __global__ __launch_bounds__(256, OA_TRI_MIN_WAVES) void k_tri_search_grid(const
                 for (int u = 0; u < UR; ++u) {
                     if (jb[u] > ja[u] && budget >= 0) {
                         budget -= jb[u] - ja[u];                         // crowded cells: one wave of the tree search is faster
-                        if (budget >= 0) { seg[n_seg][threadIdx.x] = make_int2(ja[u], jb[u]); ++n_seg; if (STATS) n_entries += jb[u] - ja[u]; }
+                        if (budget >= 0) { seg_j[n_seg][threadIdx.x] = ja[u]; seg_n[n_seg][threadIdx.x] = (unsigned short)(jb[u] - ja[u]); ++n_seg; if (STATS) n_entries += jb[u] - ja[u]; }
                     }
                 }
             }
@@ -583,20 +700,25 @@ __global__ __launch_bounds__(256, OA_TRI_MIN_WAVES) void k_tri_search_grid(const
                     const int j0 = sg ? jc[k] : ja[k], j1 = sg ? jd[k] : jb[k];
                     if (j1 > j0 && budget >= 0) {
                         budget -= j1 - j0;                           // crowded cells: one wave of the tree search is faster
-                        if (budget >= 0) { seg[n_seg][threadIdx.x] = make_int2(j0, j1); ++n_seg; if (STATS) n_entries += j1 - j0; }
+                        if (budget >= 0) { seg_j[n_seg][threadIdx.x] = j0; seg_n[n_seg][threadIdx.x] = (unsigned short)(j1 - j0); ++n_seg; if (STATS) n_entries += j1 - j0; }
                     }
                 }
             }
             b0 += consumed * L;
             ring_done = b0 >= n_rows;
         }
+        OA_TRI_STAMP(cyc_list);
         // phase 1 and phase 2: the whole wave, every trip
-        tri_scan_segments(pf, cell_rec, tri9, S, gp.eps_plane, seg, n_seg, pool, delta, cutf,
-                          STATS ? &n_surv : nullptr, STATS ? &n_evals : nullptr, STATS ? &n_trips : nullptr);
+        if (SHARE) tri_scan_shared(pf, cell_rec, tri9, S, gp.eps_plane, seg_j, seg_n, n_seg, chunk_tab[threadIdx.x >> 6], pool, delta, cutf,
+                                   STATS ? &n_surv : nullptr, STATS ? &n_evals : nullptr, STATS ? &n_trips : nullptr);
+        else tri_scan_segments(pf, cell_rec, tri9, S, gp.eps_plane, seg_j, seg_n, n_seg, pool, delta, cutf,
+                               STATS ? &n_surv : nullptr, STATS ? &n_evals : nullptr, STATS ? &n_trips : nullptr);
         // phase 2 now if somebody needs its final word on this ring (or gives up), or the pool is filling up; otherwise the
         // survivors wait for the next batch's (every flush costs the wave at least one evaluation trip)
+        OA_TRI_STAMP(cyc_scan);
         if (__any(busy && (ring_done || budget < 0)) || pool.n > TRI_POOL / 4)
             tri_pool_flush(pf, tri9, S, pool, delta, cutf, STATS ? &n_evals : nullptr, STATS ? &n_trips : nullptr);
+        OA_TRI_STAMP(cyc_flush);
         over = busy && budget < 0;
         if (L > 1) {                                             // the lanes of the query agree on the best so far
             bool changed = false;
@@ -608,7 +730,7 @@ __global__ __launch_bounds__(256, OA_TRI_MIN_WAVES) void k_tri_search_grid(const
                 else if (ob == S.best && oi < S.bidx) S.bidx = oi;
                 over = (__shfl_xor((int)over, o, 64) != 0) || over;
             }
-            if (changed) { S.lim = fminf(S.best, cutf); tri_state_refresh(S, delta); }
+            if (changed) { S.lim = fminf(S.best, cutf); tri_state_refresh(S, delta); if (SHARE) owner_q4[threadIdx.x].w = S.reach; }
         }
         if (busy) {
             if (over) busy = false;
@@ -619,26 +741,38 @@ __global__ __launch_bounds__(256, OA_TRI_MIN_WAVES) void k_tri_search_grid(const
                 else { ++r; b0 = 0; if (r > gp.r_max) busy = false; }
             }
         }
+        OA_TRI_STAMP(cyc_book);
     }
-    if (STATS && stats && alive) {
-        atomicAdd(&stats[TRI_STAT_QUERIES], 1ull);
-        atomicAdd(&stats[TRI_STAT_ROWS], (unsigned long long)n_rows_loaded);
-        atomicAdd(&stats[TRI_STAT_ENTRIES], (unsigned long long)n_entries);
-        atomicAdd(&stats[TRI_STAT_SURVIVORS], (unsigned long long)(n_surv & 0xFFFF));
-        atomicAdd(&stats[TRI_STAT_SPHERE], (unsigned long long)((unsigned)n_surv >> 16));
-        atomicAdd(&stats[TRI_STAT_EVALS], (unsigned long long)n_evals);
-        if (max_ring >= 2) atomicAdd(&stats[TRI_STAT_RING2], 1ull);
-        if (max_ring >= 3) atomicAdd(&stats[TRI_STAT_RING3], 1ull);
-        if (!settled) atomicAdd(&stats[TRI_STAT_UNSETTLED], 1ull);
-        if (over) atomicAdd(&stats[TRI_STAT_OVER], 1ull);
+#undef OA_TRI_STAMP
+    if (STATS && stats) {
+        // per-wave totals first (shuffles), ONE atomic per counter and wave: a million threads adding to the same dozen words
+        // at the end of the launch slow the waves that are still searching
+        const long long cyc_total = (long long)__builtin_readcyclecounter() - cyc_t0;
+        int sv[10] = { alive ? 1 : 0, alive ? n_rows_loaded : 0, alive ? n_entries : 0, n_surv & 0xFFFF, (int)((unsigned)n_surv >> 16), n_evals,
+                       alive && max_ring >= 2, alive && max_ring >= 3, alive && !settled, alive && over };
+#pragma unroll
+        for (int k = 0; k < 10; ++k)
+            for (int o = 32; o > 0; o >>= 1) sv[k] += __shfl_xor(sv[k], o, 64);
         int me = n_entries, mr = n_rows_loaded;
         for (int o = 32; o > 0; o >>= 1) { me = max(me, __shfl_xor(me, o, 64)); mr = max(mr, __shfl_xor(mr, o, 64)); }
-        const unsigned long long act = __ballot(1);
-        if ((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1) {
-            atomicAdd(&stats[TRI_STAT_WAVE_TRIPS], (unsigned long long)n_trips);
-            atomicAdd(&stats[TRI_STAT_WAVE_MAX_ENTRIES], (unsigned long long)me);
-            atomicAdd(&stats[TRI_STAT_WAVE_MAX_ROWS], (unsigned long long)mr);
-            atomicAdd(&stats[TRI_STAT_WAVES], 1ull);
+        if ((threadIdx.x & 63) == 0) {
+            // one row of counters per wave, plain stores (the host adds the rows up)
+            unsigned long long *row = stats + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * TRI_STAT_N;
+            const int keys[10] = { TRI_STAT_QUERIES, TRI_STAT_ROWS, TRI_STAT_ENTRIES, TRI_STAT_SURVIVORS, TRI_STAT_SPHERE, TRI_STAT_EVALS,
+                                   TRI_STAT_RING2, TRI_STAT_RING3, TRI_STAT_UNSETTLED, TRI_STAT_OVER };
+#pragma unroll
+            for (int k = 0; k < 10; ++k) row[keys[k]] = (unsigned long long)sv[k];
+            row[TRI_STAT_WAVE_TRIPS] = (unsigned long long)n_trips;
+            row[TRI_STAT_WAVE_MAX_ENTRIES] = (unsigned long long)me;
+            row[TRI_STAT_WAVE_MAX_ROWS] = (unsigned long long)mr;
+            row[TRI_STAT_WAVES] = sv[0] ? 1ull : 0ull;
+            row[TRI_STAT_CYC_TOTAL] = (unsigned long long)cyc_total;
+            row[TRI_STAT_CYC_PROLOGUE] = (unsigned long long)cyc_prologue;
+            row[TRI_STAT_CYC_LIST] = (unsigned long long)cyc_list;
+            row[TRI_STAT_CYC_SCAN] = (unsigned long long)cyc_scan;
+            row[TRI_STAT_CYC_FLUSH] = (unsigned long long)cyc_flush;
+            row[TRI_STAT_CYC_BOOK] = (unsigned long long)cyc_book;
+            row[TRI_STAT_LOOP_TRIPS] = (unsigned long long)n_loop_trips;
         }
     }
     if (sub != 0 || !alive) return;

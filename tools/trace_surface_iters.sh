@@ -14,7 +14,7 @@ for r in rows:
     n = r["Kernel_Name"]
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     if "k_tri_search_grid" in n: line = ["grid %7.1f" % d]
-    elif "k_bvh_search<true>" in n and line: line.append("tree %7.1f" % d)
+    elif "k_bvh_search<true" in n and line: line.append("tree %7.1f" % d)
     elif "k_pair_accumulate" in n and line: line.append("acc %5.1f" % d)
     elif "k_reduce_solve_update" in n and line:
         line.append("solve %4.1f" % d); print("search %2d: " % it + "  ".join(line) + " us"); it += 1; line = []
