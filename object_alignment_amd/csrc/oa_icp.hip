@@ -2306,7 +2306,7 @@ int build_tri_grid(oa_ctx *c)
         gp.r_max = std::min(env_int("OA_GRID_RMAX", 3), 3);
         gp.seeded_start = env_int("OA_TRI_SEEDED_START", 1) ? 1 : 0;
         gp.budget = std::max(1, std::min(env_int("OA_GRID_BUDGET", 192), 30000));
-        gp.budget_moving = std::max(1, std::min((int)(gp.budget * env_double("OA_GRID_BUDGET_MOVING", 2.0)), 60000));   // (range lengths are 16-bit in the kernel)
+        gp.budget_moving = std::max(1, std::min((int)(gp.budget * env_double("OA_GRID_BUDGET_MOVING", 3.0)), 60000));   // (range lengths are 16-bit in the kernel; 2.0 until the scan was shared by the wave)
         gp.scale = scale;
         gp.slack = 1e-10 * scale + 1e-300;
         oa::grid_params_finish(gp);

@@ -471,52 +471,56 @@ __device__ __forceinline__ void tri_scan_shared(const float *p, const float4 *__
     int k = 0, j = 0, end = 0;
     while (true) {
         const int g = min(Q, left);
-        // wave-wide exclusive prefix sum and total of g (0 .. 8): one ballot per bit
-        int pos = 0, G = 0;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const unsigned long long mb = __ballot((g >> b) & 1);
-            pos += __popcll(mb & lt) << b;
-            G += __popcll(mb) << b;
-        }
-        if (G == 0) break;
+        // table order: the lanes' FIRST chunks, then their second ones, ... -- every owner gets its records tested a few at a
+        // time, with a flush (and a shorter reach) in between whenever the pool fills, as in the per-lane walk; owner by owner,
+        // the first 32 records of an owner would all be tested against the reach it started with (38 survivors per query in
+        // the first iteration instead of 23).  One ballot per rank gives the positions.
+        int G = 0;
 #pragma unroll
         for (int i = 0; i < Q; ++i) {
+            const unsigned long long mi = __ballot(i < g);
             if (i < g) {
                 if (j >= end) { j = seg_j[k][threadIdx.x]; end = j + (int)seg_n[k][threadIdx.x]; ++k; }
-                tab[pos + i] = ((unsigned)j << 6) | (unsigned)lane;
+                tab[G + __popcll(mi & lt)] = ((unsigned)j << 6) | (unsigned)lane;
                 j += 4;
             }
+            G += __popcll(mi);
         }
+        if (G == 0) break;
         left -= g;
         const int q = lane & 3, c0 = lane >> 2;
-        for (int base = 0; base < G; base += 64) {                  // 64 chunks = 256 records per trip
-            bool act[4];
-            int own[4];
-            float4 r0[4], r1[4];
+        // 32 chunks = 128 records per step, two records per lane (from two different chunks); the NEXT step's records are
+        // fetched before this step's are tested, so that a wave always has loads in flight while it computes (with the
+        // four-record trips it had eight loads in flight, then none: the scan is a chain of round trips, and with four waves
+        // per SIMD nothing else hides them)
+        struct Step { bool act[2]; int own[2]; float4 r0[2], r1[2]; };
+        auto fetch = [&](int base, Step &st) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 2; ++u) {
                 const int c = base + 16 * u + c0;
-                act[u] = c < G;
-                const unsigned ent = act[u] ? tab[c] : (unsigned)lane;
-                own[u] = (int)(ent & 63u);
-                const int rec = (int)(ent >> 6) + q;
-                r0[u] = r1[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (act[u]) { r0[u] = tri_ld_rec(cell_rec, rec, 0); r1[u] = tri_ld_rec(cell_rec, rec, 1); }
+                st.act[u] = c < G;
+                // (no branch around the loads: a lane without a chunk reads record 0 and drops it -- loads behind a branch
+                //  make the compiler wait for ALL outstanding loads before the first use, and the overlap is gone)
+                const unsigned ent = tab[st.act[u] ? c : 0];
+                st.own[u] = st.act[u] ? (int)(ent & 63u) : lane;
+                const int rec = st.act[u] ? (int)(ent >> 6) + q : 0;
+                st.r0[u] = tri_ld_rec(cell_rec, rec, 0); st.r1[u] = tri_ld_rec(cell_rec, rec, 1);
             }
-            // (the owners' entries two at a time: sixteen registers less in flight than all four)
-            {
-                const float4 oa4 = pool.q4[own[0]], ob4 = pool.q4[own[1]];
-                tri_candidate(oa4.x, oa4.y, oa4.z, r0[0], r1[0], act[0], oa4.w, oa4.w * oa4.w, own[0], eps_plane, pool, surv);
-                tri_candidate(ob4.x, ob4.y, ob4.z, r0[1], r1[1], act[1], ob4.w, ob4.w * ob4.w, own[1], eps_plane, pool, surv);
-            }
-            if (pool.n > TRI_POOL - 128) tri_pool_flush(p, tri9, s, pool, delta, cutf, ev, trips);      // each test adds <= 64 entries
-            {
-                const float4 oa4 = pool.q4[own[2]], ob4 = pool.q4[own[3]];
-                tri_candidate(oa4.x, oa4.y, oa4.z, r0[2], r1[2], act[2], oa4.w, oa4.w * oa4.w, own[2], eps_plane, pool, surv);
-                tri_candidate(ob4.x, ob4.y, ob4.z, r0[3], r1[3], act[3], ob4.w, ob4.w * ob4.w, own[3], eps_plane, pool, surv);
-            }
+        };
+        auto test = [&](const Step &st) {
+            const float4 oa4 = pool.q4[st.own[0]], ob4 = pool.q4[st.own[1]];
+            tri_candidate(oa4.x, oa4.y, oa4.z, st.r0[0], st.r1[0], st.act[0], oa4.w, oa4.w * oa4.w, st.own[0], eps_plane, pool, surv);
+            tri_candidate(ob4.x, ob4.y, ob4.z, st.r0[1], st.r1[1], st.act[1], ob4.w, ob4.w * ob4.w, st.own[1], eps_plane, pool, surv);
+            // (each test adds <= 64 entries; after a flush an owner's reach may be shorter than what later tests read: never longer)
             if (pool.n > TRI_POOL - 128) tri_pool_flush(p, tri9, s, pool, delta, cutf, ev, trips);
+        };
+        Step A, B;
+        fetch(0, A);
+        for (int base = 0; base < G; base += 64) {
+            fetch(base + 32, B);                                    // (past the end: nothing is loaded)
+            test(A);
+            fetch(base + 64, A);
+            test(B);
         }
     }
     n_seg = 0;
