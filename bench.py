@@ -69,6 +69,11 @@ def parse():
     ap.add_argument("--no-surface", action="store_true", help="skip the surface-mode leg (1M points vs a 2M-triangle mesh)")
     ap.add_argument("--no-grid", action="store_true", help="skip the grid-search leg")
     ap.add_argument("--no-mfma", action="store_true", help="skip the OA_NN_MFMA=1 experiment leg")
+    ap.add_argument("--no-c5", action="store_true", help="skip the BASELINE config 5 leg of a multi-GPU run")
+    ap.add_argument("--c5", action="store_true", help="run the config 5 leg at N = 1 too")
+    ap.add_argument("--c5-source", type=int, default=10_000_000)
+    ap.add_argument("--c5-target", type=int, default=2_000_000)
+    ap.add_argument("--c5-steps", type=int, default=20)
     return ap.parse_args()
 
 
@@ -197,6 +202,103 @@ def surface_leg(args, local_rank):
                                     "(GPU-side stamps: end of the previous iteration -> start of k_pair_accumulate), "
                                     "30-iteration average; latency-bound dependent lookups, not a streaming kernel",
                          "cell_list_entries": entries, "cells": cells}}
+
+
+# DESIGN.md 4.7's table, for the line that sits next to the measurement (ms per iteration, AUTO search, masked + normal-angle
+# test, first 10 iterations; the 1-GPU figure is measured -- profiles/r03e_baseline_configs.txt --, the 8-GPU one predicted from
+# the per-shard search time + ~30 us of reduce / exchange / solve)
+C5_PREDICTED_MS_PER_ITERATION = {1: 2.06, 8: 0.35}
+
+
+def c5_leg(args, n_gpus, in_process, world, rank, local_rank, devices, dev, backend):
+    """BASELINE config 5 beside the headline of a multi-GPU run: 10M source points on the synthetic surface, a seeded 10 %
+    cap excluded (the icp_exclude mask -> vlist, operators/icp_align.py:67-76), 2M target vertices, the normal-angle test
+    (45 degrees; an extension), library-default search (AUTO), source sharded over the N GPUs.  Bounded: `--c5-steps`
+    iterations from a cold start after a 2-iteration warm-up.  Returns the dict for `c5_path` (rank 0) or None."""
+    import torch
+    import torch.distributed as dist
+    from object_alignment_amd import synth
+    from object_alignment_amd.distributed import EngineShard, new_sums_tensor, run_sharded
+    from object_alignment_amd.engine import IcpEngine
+    from object_alignment_amd.operators.icp_align import vlist_from_weights
+    src, src_n = synth.bunny_surface_with_normals(args.c5_source, 0.5)
+    tgt, tgt_n = synth.bunny_surface_with_normals(args.c5_target, 0.0)
+    mxa = synth.rigid4(synth.rotation_from_rotvec([0.003, -0.002, 0.004]), [0.002, -0.001, 0.0015])
+    eye = np.identity(4, dtype=np.float32)
+    rng = np.random.default_rng(500)
+    axis = rng.normal(size=3)
+    axis /= np.linalg.norm(axis)
+    h = src.astype(np.float64) @ axis
+    cap = np.nonzero(h > np.quantile(h, 0.9))[0]                                  # the seeded 10 % cap
+    vlist = np.array(vlist_from_weights(len(src), exclude=[(int(v), 1.0) for v in cap]), dtype=np.int64)
+    eng = IcpEngine(devices=devices) if in_process else IcpEngine(local_rank)
+    try:
+        if not in_process:
+            eng.set_stream(torch.cuda.current_stream().cuda_stream)
+        t0 = time.perf_counter()
+        eng.set_target(tgt)
+        if in_process or world == 1:
+            eng.set_source(src, vlist=vlist, stride=1)
+        else:
+            eng.set_source(src, vlist=vlist, stride=1, shard_index=rank, shard_count=world)
+        eng.set_normals(src_n, tgt_n, 45.0)
+        for d in set(devices):
+            torch.cuda.synchronize(d)
+        upload_s = time.perf_counter() - t0
+        kw = dict(thresh=0.5, target_d=0.01, use_target=True, with_scale=False, early_exit=False)
+        sums = None if (in_process or world == 1) else new_sums_tensor(dev)
+
+        def loop(iters):
+            if in_process or world == 1:
+                return eng.run(iters=iters, **kw)
+            return run_sharded(EngineShard(eng, iters=iters, **kw), iters, sums, world_size=world)
+
+        def barrier():
+            if world > 1:
+                dist.barrier()
+            for d in set(devices):
+                torch.cuda.synchronize(d)
+
+        eng.set_matrices(mxa, eye)
+        loop(2)
+        eng.set_matrices(mxa, eye)
+        eng.reset_seeds()
+        barrier()
+        t0 = time.perf_counter()
+        r = loop(args.c5_steps)
+        barrier()
+        dt = time.perf_counter() - t0
+        nn = r.nn_ms_total / max(1, args.c5_steps)
+        nn_min = nn_max = nn
+        if in_process:
+            nn_min, nn_max = eng.stat("nn_ms_min") / args.c5_steps, eng.stat("nn_ms_max") / args.c5_steps
+            xinfo = eng.exchange_info()
+            exchange, rccl_ranks = xinfo["exchange"], xinfo["rccl_ranks"]
+        elif world > 1:
+            t = torch.tensor([dt, nn, -nn], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt, nn_max, nn_min = float(t[0]), float(t[1]), -float(t[2])
+            exchange = "torch.distributed all_reduce (%s)" % ("nccl = RCCL" if backend == "nccl" else backend)
+            rccl_ranks = world if backend == "nccl" else 0
+        else:
+            exchange, rccl_ranks = None, 0
+        if rank != 0:
+            return None
+        ms = 1e3 * dt / args.c5_steps
+        pred = C5_PREDICTED_MS_PER_ITERATION.get(n_gpus) if (args.c5_source, args.c5_target) == (10_000_000, 2_000_000) else None
+        return {"what": "BASELINE config 5: 10M <-> 2M, 10 % of the source masked out (icp_exclude -> vlist), normal-angle "
+                        "rejection at 45 degrees (extension), OA_SEARCH_AUTO, source sharded over the GPUs",
+                "n_source": int(len(src)), "n_selected": int(len(vlist)), "n_target": int(len(tgt)), "n_gpus": n_gpus,
+                "steps": args.c5_steps, "value": args.c5_steps / dt, "unit": "iterations/s", "ms_per_step": ms,
+                "ms_per_nn_search_per_device": {"min": nn_min, "max": nn_max},
+                "exchange": exchange, "rccl_ranks": rccl_ranks, "last_K": r.last_K, "mean_dist": r.mean_dist,
+                "upload_ms": 1e3 * upload_s,
+                "predicted_ms_per_step_design_4_7": pred,
+                "measured_over_predicted": (ms / pred) if pred else None,
+                "prediction_note": "DESIGN.md 4.7: 1 GPU measured in round 3 (2.06 ms), 8 GPUs PREDICTED (0.35 ms = shard search "
+                                   "0.32 + ~0.03 reduce / exchange / solve); no figure for 2 and 4 GPUs"}
+    finally:
+        eng.close()
 
 
 def mfma_leg(args, local_rank, src, tgt, mxa, mxb, kw, ref_matrix):
@@ -361,6 +463,15 @@ def main():
         except Exception as exc:                                  # never lose the headline line
             surf = {"error": repr(exc)}
 
+    c5 = None
+    if (n_gpus > 1 and not args.no_c5) or (n_gpus == 1 and args.c5):
+        try:
+            c5 = c5_leg(args, n_gpus, in_process, world, rank, local_rank, devices, dev, backend)
+        except Exception as exc:                                  # never lose the headline line
+            c5 = {"error": repr(exc)}
+            if world > 1:
+                raise                                             # (a rank that stays behind would hang the others' barrier)
+
     if rank == 0:
         assert res.iters_done == args.steps, (res.iters_done, args.steps)
         ns_local = -(-args.n_source // n_gpus)                              # points per GPU (the largest shard)
@@ -443,6 +554,8 @@ def main():
             out["mfma_experiment"] = mfma
         if surf is not None:
             out["surface_path"] = surf
+        if c5 is not None:
+            out["c5_path"] = c5
         if n_gpus == 1 and not args.no_cpu_baseline and args.cpu_iters > 0:
             out["cpu_baseline"] = cpu_baseline(src, tgt, mxa, mxb, min(args.cpu_iters, args.steps), res.step_M)
             try:

@@ -213,6 +213,8 @@ int oa_reset_seeds(oa_ctx *ctx);
 #define OA_STAT_ENQUEUED_MAX      16   /* least and the most over the children.  Equal by construction ("the invariant"):
                                        * in RCCL mode every enqueued iteration holds a collective every rank has to enter */
 #define OA_STAT_WATCHDOG_ABORTS   17   /* times this context's RCCL communicators were aborted (watchdog / asynchronous error) */
+#define OA_STAT_NN_MS_MIN         18   /* multi-device context: search time of the last oa_run (sum over its iterations, ms) on the */
+#define OA_STAT_NN_MS_MAX         19   /* fastest / the slowest device: how evenly the shards load the GPUs */
 #define OA_STAT_ENQUEUED_CHILD  1000   /* + i: the same count for child i alone */
 int oa_get_stat(oa_ctx *ctx, int what, double *value);
 int64_t oa_num_selected(oa_ctx *ctx);     /* selected source points held by this context (its shard) */

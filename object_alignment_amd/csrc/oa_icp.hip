@@ -374,6 +374,8 @@ struct oa_ctx {
     bool debug = false;              // OA_DEBUG (read at oa_create)
     bool grid_stats = false;         // OA_GRID_STATS: instrumented triangle-grid launches print what the queries did
     bool tri_share = true;           // OA_TRI_SHARE=0 (A/B): every lane of the triangle-grid search walks its own records (rounds 2-3)
+    bool tri_canon = true;           // OA_TRI_CANON=0 (A/B): surface loops accumulate through the grid-stride k_pair_accumulate (rounds 1-3)
+    bool tri_acc = true;             // OA_TRI_ACC=0 (A/B): the triangle grid search never accumulates in its epilogue
     int turns_on = 1;                // OA_SEARCH_TURNS: tree while the pose moves, grid afterwards (mid-size shards, AUTO)
     bool seeded = false;             // a search has run since the last set_source / set_target (seeds exist)
     int *d_prev = nullptr;           // nearest index of the previous search (seed), -1 = none
@@ -439,6 +441,7 @@ struct oa_ctx {
     std::vector<std::vector<int>> groups;   // parent: children per host thread in the LOOP (one group per GPU, see WorkerPool)
     std::vector<std::vector<int>> upload_groups;   // ... and in uploads / index builds (OA_MULTI_THREADS=1: one per child)
     WorkerPool *pool = nullptr;         // parent: the persistent host threads of groups 1 .. n-1 (group 0 = the caller)
+    double last_nn_ms = 0.0;            // child: search time of the last oa_run on this device (OA_STAT_NN_MS_MIN / _MAX)
     double enq_ns = 0.0;                // child: host time spent enqueuing its iterations in the last loop
     long long enq_iters = 0;
 };
@@ -628,21 +631,43 @@ inline int grid_lanes_for(const oa_ctx *c)
     return lanes;
 }
 
+// lanes per query of the triangle grid search, as for the vertex grid (measured on 256 CUs with the round-2 kernel,
+// profiles/r02n_grid_lanes_sweep.txt: small meshes 4 lanes up to ~32k queries, 2 up to ~180k; >= 250k triangles
+// 4 up to ~100k, 2 up to ~800k)
+inline int tri_lanes_for(const oa_ctx *c)
+{
+    int lanes = c->grid_lanes;
+    if (lanes != 1 && lanes != 2 && lanes != 4) {
+        const bool big = c->n_tris >= 250000;
+        lanes = (c->ns <= (big ? 400 : 128) * c->n_cu) ? 4 : ((c->ns <= (big ? 3200 : 700) * c->n_cu) ? 2 : 1);
+    }
+    return lanes;
+}
+// does the loop's surface search go through the triangle grid (and not through the tree alone, or brute force)?
+inline bool tri_grid_active(const oa_ctx *c)
+{
+    return c->surface && c->tri_grid_ok && c->tbvh_ok && c->grid_mode != 0 && !bvh_whole(c, c->tbvh_ok, tri_tree_max(c));
+}
+
 // Workgroups of the canonical accumulation (k_pair_accumulate_canon, and the epilogue of k_nn_search_grid<L, true>): one
 // thread per (slot, lane of the query).  0 = the shard is too large for it (> ACC_MAX_BLOCKS rows before combining) or the
 // target is a surface: the grid-stride k_pair_accumulate is used instead.
 // (512 threads per workgroup from 262k (query, lane) pairs on: half the rows for the reduction behind it; below that the
 //  finer workgroups balance better)
+// (surface targets, round 4: the triangle grid search accumulates in its epilogue too -- k_tri_search_grid<L, .., ACC> --, always
+//  in workgroups of 256 threads, with ITS lanes per query)
+inline int canon_lanes(const oa_ctx *c) { return c->surface ? tri_lanes_for(c) : grid_lanes_for(c); }
 inline int canon_threads(const oa_ctx *c)
 {
+    if (c->surface) return 256;
     if (c->acc_threads == 256 || c->acc_threads == 512) return c->acc_threads;   // OA_ACC_THREADS (A/B)
     return (long long)c->ns * grid_lanes_for(c) >= 262144 ? 512 : 256;
 }
 inline int canon_blocks(const oa_ctx *c)
 {
-    if (c->surface || c->ns <= 0) return 0;
+    if (c->ns <= 0 || (c->surface && !c->tri_canon)) return 0;
     const int t = canon_threads(c);
-    const long long b = ((long long)c->ns * grid_lanes_for(c) + t - 1) / t;
+    const long long b = ((long long)c->ns * canon_lanes(c) + t - 1) / t;
     return b <= oa::ACC_MAX_BLOCKS ? (int)b : 0;
 }
 
@@ -664,7 +689,12 @@ SearchPlan search_plan(const oa_ctx *c)
     // (the accumulating tree search needs twice the registers of the plain one: worth it while the shard is small enough
     //  that occupancy does not matter -- 12k queries against 1M vertices: 58 us fused, 47 us search + accumulate)
     const bool small = c->ns <= c->tree_acc_max;
-    if (c->surface) return (small && bvh_whole(c, c->tbvh_ok, tri_tree_max(c))) ? PLAN_TREE : PLAN_PLAIN;
+    if (c->surface) {
+        if (bvh_whole(c, c->tbvh_ok, tri_tree_max(c))) return small ? PLAN_TREE : PLAN_PLAIN;
+        // the triangle grid search with the accumulating epilogue: shards above the zone where tree and grid take turns
+        const bool dual = c->grid_mode == -1 && c->turns_on && c->ns <= tri_tree_early(c);
+        return (tri_grid_active(c) && !dual && canon_blocks(c) > 0 && c->tri_acc) ? PLAN_GRID : PLAN_PLAIN;
+    }
     if (bvh_whole(c, c->bvh_ok, vertex_tree_max(c))) return small ? PLAN_TREE : PLAN_PLAIN;
     if (!grid_active(c) || canon_blocks(c) == 0) return PLAN_PLAIN;
     return (c->grid_mode == -1 && c->turns_on && c->ns <= vertex_tree_early(c)) ? PLAN_DUAL : PLAN_GRID;
@@ -788,8 +818,8 @@ int launch_accumulate(oa_ctx *c, bool emit, int *nn_idx, float *nn_d2)
                            (unsigned long long *)nullptr);
     } else if (canon_blocks(c) > 0) {
         hipLaunchKernelGGL(oa::k_pair_accumulate_canon, dim3((unsigned)canon_blocks(c)), dim3((unsigned)canon_threads(c)), 0, c->stream, (const oa::DevState *)c->d_state,
-                           (const float4 *)c->d_src4, c->ns, grid_lanes_for(c), (const float *)c->d_tgt_xyz, c->d_keys, c->d_prev, c->d_win,
-                           (const float4 *)nullptr, nrm, c->d_partials,
+                           (const float4 *)c->d_src4, c->ns, canon_lanes(c), (const float *)c->d_tgt_xyz, c->d_keys, c->d_prev, c->surface ? (float4 *)nullptr : c->d_win,
+                           c->surface ? (const float4 *)c->d_tri9 : (const float4 *)nullptr, nrm, c->d_partials,
                            c->loop_active ? &c->d_state->t_acc_start : (unsigned long long *)nullptr);
     } else {
         hipLaunchKernelGGL(oa::k_pair_accumulate<false>, dim3(c->acc_blocks), dim3(oa::ACC_THREADS), 0, c->stream,
@@ -1562,6 +1592,7 @@ int multi_end(oa_ctx *p, oa_report *rep)
         if (!rci && hipEventElapsedTime(&ms, c->ev_loop0, c->ev_loop1) == hipSuccess) r.loop_ms = ms;
         c->loop_active = false;
         if (rci) { if (!rc) rc = rci; continue; }
+        c->last_nn_ms = r.nn_ms_total;
         if (i == 0) agg = r;
         else {
             agg.nn_ms_total = std::max(agg.nn_ms_total, r.nn_ms_total);      // the slowest device sets the pace
@@ -1686,6 +1717,8 @@ OA_EXPORT int oa_create(oa_ctx **out, int device)
     c->debug = getenv("OA_DEBUG") != nullptr;
     c->grid_stats = env_int("OA_GRID_STATS", 0) != 0;
     c->tri_share = env_int("OA_TRI_SHARE", 1) != 0;
+    c->tri_canon = env_int("OA_TRI_CANON", 1) != 0;
+    c->tri_acc = env_int("OA_TRI_ACC", 1) != 0;
     c->turn_frac = env_double("OA_TURN_FRAC", 0.1);
     c->use_filter = env_int("OA_NN_FILTER", 1) != 0;
     c->nn_mfma = env_int("OA_NN_MFMA", 0);
@@ -2348,24 +2381,28 @@ int launch_tri_search(oa_ctx *c, bool acc)
     if (bvh_whole(c, c->tbvh_ok, tri_tree_max(c))) return launch_bvh<true>(c, nullptr, nullptr, -1, acc);
     const bool use_grid = c->tri_grid_ok && c->tbvh_ok && c->grid_mode != 0;
     if (c->debug)
-        fprintf(stderr, "[oa] tri search: grid=%d ns=%d n_tris=%d state=%p src4=%p tri9=%p prev=%p keys=%p todo=%p/%p cells=%p/%p\n",
-                (int)use_grid, c->ns, c->n_tris, (void *)c->d_state, (void *)c->d_src4, (void *)c->d_tri9, (void *)c->d_prev,
+        fprintf(stderr, "[oa] tri search: grid=%d acc=%d ns=%d n_tris=%d state=%p src4=%p tri9=%p prev=%p keys=%p todo=%p/%p cells=%p/%p\n",
+                (int)use_grid, (int)acc, c->ns, c->n_tris, (void *)c->d_state, (void *)c->d_src4, (void *)c->d_tri9, (void *)c->d_prev,
                 (void *)c->d_keys, (void *)c->d_todo_list, (void *)c->d_todo_count, (void *)c->d_tcell_start, (void *)c->d_tcell_rec);
     if (use_grid) {
-        if (!c->loop_active) HIPCHK(hipMemsetAsync(c->d_todo_count, 0, 2 * sizeof(int), c->stream));
+        if (!acc && !c->loop_active) HIPCHK(hipMemsetAsync(c->d_todo_count, 0, 2 * sizeof(int), c->stream));
         const bool dual = c->grid_mode == -1 && c->turns_on && c->ns <= tri_tree_early(c);
         if (dual) { int rcb = launch_bvh<true>(c, nullptr, nullptr, 1); if (rcb) return rcb; }    // runs when DevState::tree_turn
         const int turn = dual ? 0 : -1;
-        // lanes per query, as for the vertex grid (measured on 256 CUs with the round-2 kernel,
-        // profiles/r02n_grid_lanes_sweep.txt: small meshes 4 lanes up to ~32k queries, 2 up to ~180k; >= 250k triangles
-        // 4 up to ~100k, 2 up to ~800k)
-        int lanes = c->grid_lanes;
-        if (lanes != 1 && lanes != 2 && lanes != 4) {
-            const bool big = c->n_tris >= 250000;
-            lanes = (c->ns <= (big ? 400 : 128) * c->n_cu) ? 4 : ((c->ns <= (big ? 3200 : 700) * c->n_cu) ? 2 : 1);
-        }
+        const int lanes = tri_lanes_for(c);
 #define OA_TGRID_ARGS c->d_state, c->d_src4, c->ns, c->tgp, c->d_tcell_start, c->d_tcell_rec, c->d_tri9, c->d_prev, c->d_keys, c->d_todo_list, c->d_todo_count, turn
         const dim3 gblocks((unsigned)(((long long)c->ns * lanes + 255) / 256));
+        if (acc) {
+            // the search finishes its own leftovers through the triangle tree and takes the pair test and the sums in its
+            // epilogue (search_plan: PLAN_GRID, fast path): no list launch, no accumulation launch
+#define OA_TGRID_ACC_ARGS OA_TGRID_ARGS, (unsigned long long *)nullptr, c->tbvh, (const float4 *)c->d_tbvh_box, (const float4 *)c->d_tbvh_prims, normal_test(c), c->d_partials
+            if (lanes == 4) hipLaunchKernelGGL((oa::k_tri_search_grid<4, false, true, true>), gblocks, dim3(256), 0, c->stream, OA_TGRID_ACC_ARGS);
+            else if (lanes == 2) hipLaunchKernelGGL((oa::k_tri_search_grid<2, false, true, true>), gblocks, dim3(256), 0, c->stream, OA_TGRID_ACC_ARGS);
+            else hipLaunchKernelGGL((oa::k_tri_search_grid<1, false, true, true>), gblocks, dim3(256), 0, c->stream, OA_TGRID_ACC_ARGS);
+#undef OA_TGRID_ACC_ARGS
+            HIPCHK(hipGetLastError());
+            return OA_OK;
+        }
         if (lanes == 4) hipLaunchKernelGGL(oa::k_tri_search_grid<4>, gblocks, dim3(256), 0, c->stream, OA_TGRID_ARGS);
         else if (lanes == 2) hipLaunchKernelGGL(oa::k_tri_search_grid<2>, gblocks, dim3(256), 0, c->stream, OA_TGRID_ARGS);
         else if (c->grid_stats) {                                   // OA_GRID_STATS=1: instrumented launch, totals to stderr (synchronises)
@@ -2802,6 +2839,13 @@ OA_EXPORT int oa_get_stat(oa_ctx *c, int what, double *value)
         long long lo = c->subs[0]->enq_iters, hi = lo;
         for (oa_ctx *sub : c->subs) { lo = std::min(lo, sub->enq_iters); hi = std::max(hi, sub->enq_iters); }
         *value = (double)(what == OA_STAT_ENQUEUED_MIN ? lo : hi);
+        return OA_OK;
+    }
+    if (what == OA_STAT_NN_MS_MIN || what == OA_STAT_NN_MS_MAX) {
+        if (c->subs.empty()) return fail(OA_E_STATE, "oa_get_stat: per-device search times are a multi-device context's");
+        double lo = c->subs[0]->last_nn_ms, hi = lo;
+        for (oa_ctx *sub : c->subs) { lo = std::min(lo, sub->last_nn_ms); hi = std::max(hi, sub->last_nn_ms); }
+        *value = what == OA_STAT_NN_MS_MIN ? lo : hi;
         return OA_OK;
     }
     if (what == OA_STAT_WATCHDOG_ABORTS) { *value = c->xch && !c->parent ? (double)c->xch->watchdog_aborts : 0.0; return OA_OK; }

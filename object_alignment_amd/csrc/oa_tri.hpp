@@ -534,7 +534,14 @@ enum { TRI_STAT_QUERIES, TRI_STAT_ROWS, TRI_STAT_ENTRIES, TRI_STAT_SURVIVORS, TR
        TRI_STAT_WAVES, TRI_STAT_CYC_TOTAL, TRI_STAT_CYC_PROLOGUE, TRI_STAT_CYC_LIST, TRI_STAT_CYC_SCAN, TRI_STAT_CYC_FLUSH, TRI_STAT_CYC_BOOK,
        TRI_STAT_LOOP_TRIPS, TRI_STAT_N };
 
-template <int L, bool STATS = false, bool SHARE = true>
+// ACC (the loop's iterations, round 4 -- as k_nn_search_grid<L, true>): ONE launch does what took three.  (i) A query the
+// rings did not settle is finished through the triangle tree right here, by the wave that owns it (bvh_wave_query<true>,
+// seeded with the grid's partial answer exactly as k_bvh_search seeds it from keys[]; its scratch lies over the wave's
+// range lists, which are dead by then).  (ii) The closest point on the winning triangle, the pair test and the iteration's
+// fp64 sums are taken in the epilogue: one row of `partials` per workgroup, the rows k_pair_accumulate_canon writes for the
+// same shard, bit for bit (the host switches between the two from one iteration to the next, oa_icp.hip: grid_fast_now).
+// prev[] gets the winner (the next search's seed); keys[] is not written: nothing reads it inside the loop.
+template <int L, bool STATS = false, bool SHARE = true, bool ACC = false>
 #ifndef OA_TRI_MIN_WAVES
 #define OA_TRI_MIN_WAVES 4
 #endif
@@ -543,10 +550,13 @@ __global__ __launch_bounds__(256, OA_TRI_MIN_WAVES) void k_tri_search_grid(const
                                                          const int *__restrict__ cell_start,
                                                          const float4 *__restrict__ cell_rec,
                                                          const float4 *__restrict__ tri9,
-                                                         const int *__restrict__ prev,
+                                                         int *__restrict__ prev,
                                                          unsigned long long *__restrict__ keys,
                                                          int *__restrict__ todo_list, int *__restrict__ todo_count, int turn,
-                                                         unsigned long long *__restrict__ stats = nullptr)
+                                                         unsigned long long *__restrict__ stats = nullptr,
+                                                         BvhParams bp = BvhParams{}, const float4 *__restrict__ boxes = nullptr,
+                                                         const float4 *__restrict__ prims = nullptr, NormalTest nrm = NormalTest{},
+                                                         double *__restrict__ partials = nullptr)
 {
     // rows per lane and batch: nine rows of a ring at a time (dealt out to the L lanes of the query).  The rows of the
     // first block of a search are whole ranges (one per row); interior rows of later rings contribute their two end
@@ -559,8 +569,8 @@ __global__ __launch_bounds__(256, OA_TRI_MIN_WAVES) void k_tri_search_grid(const
     __shared__ unsigned char pool_own[4][TRI_POOL];
     __shared__ float pool_key[4][TRI_POOL];
     __shared__ unsigned long long pool_slot[256], pool_first[256];
-    __shared__ int seg_j[TRI_SEGS][256];
-    __shared__ unsigned short seg_n[TRI_SEGS][256];                 // (a range is never longer than the budget it was charged to: < 65536, build_tri_grid)
+    __shared__ __attribute__((aligned(16))) int seg_j[TRI_SEGS][256];
+    __shared__ __attribute__((aligned(16))) unsigned short seg_n[TRI_SEGS][256];                 // (a range is never longer than the budget it was charged to: < 65536, build_tri_grid)
     __shared__ unsigned chunk_tab[SHARE ? 4 : 1][SHARE ? 64 * TRI_SHARE_Q : 1];
     __shared__ float4 owner_q4[SHARE ? 256 : 1];
     int n_seg = 0;
@@ -579,7 +589,8 @@ __global__ __launch_bounds__(256, OA_TRI_MIN_WAVES) void k_tri_search_grid(const
     int n_loop_trips = 0;
     if (STATS) cyc_t0 = cyc_mark = (long long)__builtin_readcyclecounter();
 #define OA_TRI_STAMP(acc) do { if (STATS) { const long long now_ = (long long)__builtin_readcyclecounter(); acc += now_ - cyc_mark; cyc_mark = now_; } } while (0)
-    const int gt = xcd_block_index() * (int)blockDim.x + threadIdx.x;      // one contiguous part of the queries per XCD
+    const int vb = xcd_block_index();                                      // one contiguous part of the queries per XCD
+    const int gt = vb * (int)blockDim.x + threadIdx.x;
     int i = gt / L;
     const int sub = gt % L;                                         // the L lanes of a query are neighbours in a wave
     // Lanes past the last query stay: phase 2 deals pool entries to ALL 64 lanes of the wave (entry e to lane e mod 64),
@@ -613,11 +624,13 @@ __global__ __launch_bounds__(256, OA_TRI_MIN_WAVES) void k_tri_search_grid(const
     // stale and most queries need the second ring: handing them all to the tree costs more than letting the grid
     // look at twice as many candidates.
     int budget = gp.budget;
+    int budget_extra = 0;                                            // what the larger budget added (wave-uniform)
     {
         const int last = (st->n + 4) % 5;
         const double moved = st->use_target && st->n > 0 ? (st->ring_t[last] + st->ring_r[last] * gp.scale) * st->local_per_world : 0.0;
         if (st->n == 0 || moved > 0.25 * gp.h) budget = gp.budget_moving;
         if (L > 1) budget = budget / L + 8;
+        budget_extra = budget - (L > 1 ? gp.budget / L + 8 : gp.budget);
     }
     const int r_start = (S.bidx != IDX_NONE && gp.seeded_start) ? 1 : 0;   // as in k_nn_search_grid
     // ONE wave-uniform loop: every trip, every lane that still has work lists the cell ranges of its next batch of rows
@@ -779,9 +792,69 @@ __global__ __launch_bounds__(256, OA_TRI_MIN_WAVES) void k_tri_search_grid(const
             row[TRI_STAT_LOOP_TRIPS] = (unsigned long long)n_loop_trips;
         }
     }
-    if (sub != 0 || !alive) return;
-    keys[i] = ((unsigned long long)__float_as_uint(S.best) << 32) | S.bidx;
-    if (!settled) todo_list[atomicAdd(todo_count, 1)] = i;
+    // how crowded the hand-over is per wave, against the BASE budget (see k_nn_search_grid): what the host looks at before
+    // it lets a later search finish its own leftovers
+    bool tight = budget < budget_extra;
+    if (L > 1) {
+#pragma unroll
+        for (int o = 1; o < L; o <<= 1) tight = (__shfl_xor((int)tight, o, 64) != 0) || tight;
+    }
+    const bool mine = sub == 0 && alive;
+    if (!ACC) {
+        const unsigned long long crowd = __ballot(mine && q.finite && (!settled || tight));
+        if (crowd && (threadIdx.x & 63) == 0) atomicMax(todo_count + 1, __popcll(crowd));
+        if (!mine) return;
+        keys[i] = ((unsigned long long)__float_as_uint(S.best) << 32) | S.bidx;
+        if (!settled) todo_list[atomicAdd(todo_count, 1)] = i;
+        return;
+    }
+    // ---- ACC: finish, record, accumulate -- all threads stay to the end (wave-wide descents, workgroup-wide reduction)
+    {
+        unsigned long long todo = __ballot(mine && !settled && q.finite);
+        const unsigned long long crowd = __ballot(mine && q.finite && (!settled || tight));
+        if (crowd && (threadIdx.x & 63) == 0) atomicMax(todo_count + 1, __popcll(crowd));
+        if (todo) {
+            if ((threadIdx.x & 63) == 0) atomicAdd(todo_count, __popcll(todo));
+            // this wave's columns of the range lists are free now: per level 256 B of bounds (seg_j), the mask and the node (seg_n)
+            const int lane = threadIdx.x & 63, col0 = threadIdx.x & ~63;
+            const BvhLds lds{ (float *)&seg_j[0][col0], 256, (unsigned long long *)&seg_n[0][col0], 64, (int *)((char *)&seg_n[0][col0] + 8), 128 };
+            while (todo) {
+                const int l = __ffsll((long long)todo) - 1;
+                todo &= todo - 1ull;
+                const float qp[3] = { __shfl(pf[0], l, 64), __shfl(pf[1], l, 64), __shfl(pf[2], l, 64) };
+                float b = __shfl(S.best, l, 64);
+                uint32_t bi = (uint32_t)__shfl((int)S.bidx, l, 64);
+                float tx = 0.f, ty = 0.f, tz = 0.f;
+                const uint32_t bi0 = bi;
+                bvh_wave_query<true>(bp, boxes, prims, qp, __shfl(cutf, l, 64), b, bi, tx, ty, tz, lds, lane);
+                if (lane == l && bi != bi0) { S.best = b; S.bidx = bi; }
+            }
+        }
+    }
+    bool valid = false;
+    float vbx = 0.f, vby = 0.f, vbz = 0.f;
+    double dist = 0.0;
+    if (mine) {
+        prev[i] = (S.bidx == IDX_NONE) ? -1 : (int)S.bidx;           // the next search's seed
+        if (S.bidx != IDX_NONE) {
+            float ta[3], tb[3], tc[3], rr[3], tn[3] = { 0.f, 0.f, 0.f };
+            load_tri(tri9, S.bidx, ta, tb, tc);
+            closest_on_tri(pf, ta, tb, tc, rr);
+            if (nrm.src_n) {                                         // geometric face normal (Blender normal_tri_v3 order)
+                const float e1[3] = { ta[0] - tb[0], ta[1] - tb[1], ta[2] - tb[2] };
+                const float e2[3] = { tb[0] - tc[0], tb[1] - tc[1], tb[2] - tc[2] };
+                tn[0] = e1[1] * e2[2] - e1[2] * e2[1];
+                tn[1] = e1[2] * e2[0] - e1[0] * e2[2];
+                tn[2] = e1[0] * e2[1] - e1[1] * e2[0];
+            }
+            valid = pair_eval(st, pf[0], pf[1], pf[2], rr[0], rr[1], rr[2], nrm, i, tn, st->thresh, vbx, vby, vbz, dist);
+        }
+    }
+    const double pvx = st->pivot[0], pvy = st->pivot[1], pvz = st->pivot[2];
+    const float4 a4 = mine ? src4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();                                                // every wave is through with its range lists: the reduction's scratch lies over them
+    block_store_pair(valid, (double)a4.x - pvx, (double)a4.y - pvy, (double)a4.z - pvz, (double)vbx - pvx, (double)vby - pvy,
+                     (double)vbz - pvz, dist - st->d_pivot, (double (*)[NSUMS])&seg_j[0][0], partials + (long long)vb * NSUMS);
 }
 
 // brute force over all triangles for every source point (OA_SEARCH_BRUTE; the oracle's oo_nn_tri_brute on the device)

@@ -61,31 +61,17 @@ def _coords_of(obj) -> np.ndarray:
         flat = np.empty(len(verts) * 3, dtype=np.float32)
         verts.foreach_get("co", flat)
         return flat.reshape(-1, 3)
-    # duck-typed vertices: the per-vertex interpreter loop costs ~1 us a vertex, so the converted array is remembered
-    # on the object -- and trusted only while a probe of ~64 vertices spread over the mesh still matches it
+    # duck-typed vertices: converted on EVERY call, as the reference re-reads vertices[i].co on every call
+    # (/root/reference/functions/general.py:280-284).  Rounds 2-3 remembered the converted array on the object and trusted it
+    # while a probe of ~64 vertices still matched -- an in-place edit of any other vertex went unseen.  One
+    # flat generator pass is ~0.4 us a vertex; callers with large static clouds hand over an AlignObject (an array).
     n = len(verts)
-    cached = getattr(obj, "_oa_xyz_cache", None)
-    if cached is not None and len(cached) == n:
-        probe = range(0, n, max(1, n // 64))
-        if all(cached[i, 0] == np.float32(verts[i].co[0]) and cached[i, 1] == np.float32(verts[i].co[1])
-               and cached[i, 2] == np.float32(verts[i].co[2]) for i in probe):
-            return cached
-    xyz = np.array([[v.co[0], v.co[1], v.co[2]] for v in verts], dtype=np.float32).reshape(-1, 3)
-    try:
-        obj._oa_xyz_cache = xyz
-    except Exception:
-        pass
-    return xyz
+    return np.fromiter((c for v in verts for c in (v.co[0], v.co[1], v.co[2])), dtype=np.float32, count=3 * n).reshape(-1, 3)
 
 
 def invalidate_cached_geometry(obj=None):
-    """Forget what the host side remembers about `obj` (or about everything): converted coordinates, converted
-    vertex lists.  Call after editing geometry or vertex groups in place if the probes above could miss the edit."""
-    if obj is not None and hasattr(obj, "_oa_xyz_cache"):
-        try:
-            del obj._oa_xyz_cache
-        except Exception:
-            pass
+    """Forget what the host side remembers about vertex lists (converted int64 arrays).  Kept for callers of rounds 2-3;
+    nothing is trusted without a full comparison any more, so this is never needed for correctness."""
     _VLIST_CACHE.clear()
 
 
@@ -201,14 +187,18 @@ class GpuBVH:
 
 def _content_hash(a) -> int:
     """64-bit hash of an array's bytes: xxh3 when the module is there (~10 GB/s: 1 ms for a 1M-vertex mesh), else
-    zlib.crc32 + adler32 (~1-2 GB/s).  NaN-safe and order-sensitive by construction (bytes, not values)."""
-    buf = memoryview(np.ascontiguousarray(a)).cast("B")
+    blake2b (~1 GB/s).  NaN-safe and order-sensitive by construction (bytes, not values); an empty array hashes its shape
+    (a zero-size 2-D view cannot be cast to bytes)."""
+    a = np.ascontiguousarray(a)
+    if a.size == 0:
+        return hash(("empty", a.shape, a.dtype.str)) & 0xFFFFFFFFFFFFFFFF
+    buf = a.reshape(-1).view(np.uint8)
     try:
         import xxhash
         return xxhash.xxh3_64_intdigest(buf)
     except ImportError:
-        import zlib
-        return (zlib.crc32(buf) << 32) | zlib.adler32(buf)
+        import hashlib
+        return int.from_bytes(hashlib.blake2b(buf, digest_size=8).digest(), "little")
 
 
 _VLIST_CACHE = {}
@@ -216,20 +206,20 @@ _VLIST_CACHE = {}
 
 def _vlist_array(vlist):
     """int64 array of a vertex list.  The operators hand over a Python list (as the reference builds it) and reuse it
-    every iteration: converting a million-element list costs ~60 ms, so the converted array is remembered per list
-    object (identity + length + a sample of its elements)."""
+    every iteration: converting a million-element list costs ~60 ms, so the converted array is remembered per list object
+    -- together with a COPY of the list, and it is only reused when the list still equals that copy, element for element
+    (`list == list` runs in C with an identity shortcut per element: ~3-5 ms for a million indices; the reference re-reads
+    vlist on every call, /root/reference/functions/general.py:274-284, so any in-place edit has to be seen.  Round 3
+    compared 32 probed elements: VERDICT r3)."""
     if isinstance(vlist, np.ndarray):
         return np.ascontiguousarray(vlist, dtype=np.int64)
-    n = len(vlist)
-    step = max(1, n // 31)
-    probe = (n, tuple(vlist[i] for i in range(0, n, step)), vlist[-1] if n else None)
     hit = _VLIST_CACHE.get(id(vlist))
-    if hit is not None and hit[2] is vlist and hit[0] == probe:   # the list itself is kept alive: its id cannot be recycled
+    if hit is not None and hit[2] is vlist and hit[0] == vlist:   # (the list itself is kept alive: its id cannot be recycled)
         return hit[1]
     arr = np.ascontiguousarray(vlist, dtype=np.int64)
     if len(_VLIST_CACHE) > 8:
         _VLIST_CACHE.clear()
-    _VLIST_CACHE[id(vlist)] = (probe, arr, vlist)
+    _VLIST_CACHE[id(vlist)] = (list(vlist), arr, vlist)
     return arr
 
 

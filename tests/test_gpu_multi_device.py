@@ -361,7 +361,8 @@ def test_bench_self_launches_multi_gpu():
     """`python bench.py --gpus 2` with no launcher: one process, the multi-device context; one JSON line, n_gpus 2."""
     env = dict(os.environ, OA_BENCH_SAME_DEVICE="1")
     cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--n-source", "120000",
-           "--n-target", "100000", "--no-cpu-baseline", "--no-surface"]
+           "--n-target", "100000", "--no-cpu-baseline", "--no-surface", "--c5-source", "300000", "--c5-target", "100000",
+           "--c5-steps", "3"]
     p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, text=True)
     assert p.returncode == 0, p.stdout[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
@@ -369,6 +370,13 @@ def test_bench_self_launches_multi_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["unit"] == "iterations/s" and d["value"] > 0
     assert "in-library" in d["config"]["parallelism"]
+    # the BASELINE config 5 leg of a multi-GPU run (masked source + normal-angle test, AUTO search), at a reduced size here
+    c5 = d["c5_path"]
+    assert "error" not in c5, c5
+    assert c5["n_gpus"] == 2 and c5["steps"] == 3 and c5["ms_per_step"] > 0 and c5["n_selected"] == 270000
+    assert c5["exchange"].startswith("mailbox") and c5["rccl_ranks"] == 0
+    assert 0 < c5["ms_per_nn_search_per_device"]["min"] <= c5["ms_per_nn_search_per_device"]["max"]
+    assert c5["predicted_ms_per_step_design_4_7"] is None           # (the prediction is for the full-size configuration)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -1528,6 +1528,23 @@ def test_make_pairs_sees_in_place_edits_of_the_source():
     A3, _, _ = make_pairs(fresh, base, bvh, vl, 0.5)
     A4, _, _ = make_pairs(fresh, base, bvh, vl2, 0.5)
     assert np.array_equal(A3, A2) and not np.array_equal(A4, A3) and np.array_equal(np.sort(A4, axis=1), np.sort(A3, axis=1))
+    # a Python LIST edited in place -- what the operators hand over -- at a position round 3's 32-element probe never looked at
+    # (VERDICT r3); and a duck-typed mesh edited in place at a vertex its 64-vertex probe never looked at
+    import types
+    pyl = list(range(0, 1500))
+    A5, _, _ = make_pairs(fresh, base, bvh, pyl, 0.5)
+    pyl[777] = 3                                                    # vertex 777 leaves, vertex 3 is listed twice
+    A6, _, _ = make_pairs(fresh, base, bvh, pyl, 0.5)
+    A7, _, _ = make_pairs(fresh, base, bvh, np.array(pyl, dtype=np.int64), 0.5)
+    assert np.array_equal(A6, A7) and not np.array_equal(A5, A6)
+    verts = [types.SimpleNamespace(co=[float(c) for c in row]) for row in fresh.xyz]
+    duck = types.SimpleNamespace(data=types.SimpleNamespace(vertices=verts), matrix_world=mxa)
+    A8, B8, _ = make_pairs(duck, base, bvh, vl, 0.5)
+    assert np.array_equal(A8, A3)
+    moved = (fresh.xyz[501] * np.float32(1.002)).astype(np.float32)
+    verts[501].co[:] = [float(c) for c in moved]
+    A9, _, _ = make_pairs(duck, base, bvh, np.arange(1500, dtype=np.int64), 0.5)
+    assert np.array_equal(A9[:, 501], moved.astype(np.float64))
 
 
 @pytest.mark.gpu
@@ -1619,3 +1636,60 @@ def test_wave_reduction_keeps_the_bits_of_the_shuffle_form():
     out = subprocess.run([exe[0], "2048"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "identical" in out.stdout and "0 of" in out.stdout, out.stdout
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 4: what is closable of f1 -- the tie rule never shows in co1
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["ico", "lattice", "ties"])
+def test_surface_pairs_do_not_depend_on_the_triangle_order(orc, case):
+    """`BVHTree.find_nearest` (/root/reference/functions/general.py:297-304) returns the closest surface point co1; which of
+    several equidistant triangles Blender's traversal reports is unknowable here, and this build's rule is "lowest
+    triangle index".  Only co1 is consumed (`n`, `face_index` are not, :297-304), so the rule matters exactly where two
+    triangles at the same float32 distance have DIFFERENT closest points.  Shuffle the triangle order: every triangle keeps
+    its corners and its arithmetic, only the indices change.  Then
+      - the float32 distances must be bitwise the same (the minimum over the same set of values),
+      - the winners may differ only where the distances tie exactly,
+      - make_pairs' A and B -- co1 mapped to align-local space -- are compared bit for bit; the queries where they differ are
+        counted and characterised: each must be a tie between triangles whose closest points differ (two distinct
+        equidistant surface points: the query sits on the medial axis of the two, a measure-zero set for generic data),
+      - and where there is no such query, the whole loop ends with bitwise the same matrices."""
+    from object_alignment_amd.engine import IcpEngine
+    verts, tris, q = _surface_cases()[case]
+    rng = np.random.default_rng(17)
+    perm = rng.permutation(len(tris))                              # new triangle k is old triangle perm[k]
+    tris2 = np.ascontiguousarray(tris[perm])
+    eye = np.identity(4, dtype=np.float32)
+    mxa = np.identity(4, dtype=np.float32)
+    out = []
+    for t in (tris, tris2):
+        with IcpEngine(0) as e:
+            e.set_target_mesh(verts, t)
+            e.set_source(q)
+            e.set_matrices(mxa, eye)
+            idx, d2, _ = e.nn_search()
+            A, B, _ = e.make_pairs(1e30)
+            res = e.run(iters=4, thresh=1e30, early_exit=False)
+        out.append((idx, d2, A, B, A.shape[1], res))
+    (i0, d0, A0, B0, K0, r0), (i1, d1, A1, B1, K1, r1) = out
+    assert np.array_equal(d0, d1)                                   # same set of per-triangle distances, same minimum
+    same_winner = perm[i1] == i0
+    assert K0 == K1 == len(q) and np.array_equal(A0, A1)
+    differs = np.flatnonzero((B0 != B1).any(axis=0))
+    # every query whose co1 moved is an exact tie between two different triangles ...
+    assert not same_winner[differs].any()
+    for qi in differs:
+        # ... at the same float32 distance, with different closest points (the oracle's closest point on ONE triangle each)
+        _, pa, da = orc.nn_tri_brute(q[qi:qi + 1], verts, tris[i0[qi]][None])
+        _, pb, db = orc.nn_tri_brute(q[qi:qi + 1], verts, tris2[i1[qi]][None])
+        assert da[0] == db[0] == d0[qi]
+        assert not np.array_equal(pa, pb)
+    frac = len(differs) / float(len(q))
+    print("surface tie rule, case %s: %d of %d queries answer with another triangle after the shuffle (exact float32 ties); "
+          "co1 differs for %d (%.4f %%): two distinct equidistant surface points" % (case, int((~same_winner).sum()), len(q),
+                                                                                     len(differs), 100.0 * frac))
+    if case != "ties":
+        assert frac <= 1e-3                                        # generic data: (next to) never
+    if len(differs) == 0:
+        assert np.array_equal(r0.step_M, r1.step_M) and np.array_equal(r0.matrix_world, r1.matrix_world)
