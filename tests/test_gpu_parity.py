@@ -1651,45 +1651,75 @@ def test_surface_pairs_do_not_depend_on_the_triangle_order(orc, case):
     its corners and its arithmetic, only the indices change.  Then
       - the float32 distances must be bitwise the same (the minimum over the same set of values),
       - the winners may differ only where the distances tie exactly,
-      - make_pairs' A and B -- co1 mapped to align-local space -- are compared bit for bit; the queries where they differ are
-        counted and characterised: each must be a tie between triangles whose closest points differ (two distinct
-        equidistant surface points: the query sits on the medial axis of the two, a measure-zero set for generic data),
-      - and where there is no such query, the whole loop ends with bitwise the same matrices."""
+      - make_pairs' A and B -- co1 mapped to align-local space -- are compared bit for bit, at the initial pose and at the poses
+        of four iterations; the queries where they differ are counted and characterised: each must be an exact tie between
+        triangles whose closest points differ -- either the same geometric point of a shared edge / corner, rounded differently
+        by the two triangles' float32 arithmetic (a few ulp), or two distinct equidistant points (symmetric data only),
+      - and where there is no such query, the whole loop ends with bitwise the same matrices; else within 1e-4."""
     from object_alignment_amd.engine import IcpEngine
     verts, tris, q = _surface_cases()[case]
     rng = np.random.default_rng(17)
     perm = rng.permutation(len(tris))                              # new triangle k is old triangle perm[k]
     tris2 = np.ascontiguousarray(tris[perm])
     eye = np.identity(4, dtype=np.float32)
-    mxa = np.identity(4, dtype=np.float32)
-    out = []
-    for t in (tris, tris2):
-        with IcpEngine(0) as e:
-            e.set_target_mesh(verts, t)
+    n_swapped = n_moved = n_rounding = n_distinct = 0
+    max_rounding_ulp = 0.0
+    with IcpEngine(0) as e0, IcpEngine(0) as e1:
+        e0.set_target_mesh(verts, tris)
+        e1.set_target_mesh(verts, tris2)
+        for e in (e0, e1):
             e.set_source(q)
-            e.set_matrices(mxa, eye)
-            idx, d2, _ = e.nn_search()
-            A, B, _ = e.make_pairs(1e30)
-            res = e.run(iters=4, thresh=1e30, early_exit=False)
-        out.append((idx, d2, A, B, A.shape[1], res))
-    (i0, d0, A0, B0, K0, r0), (i1, d1, A1, B1, K1, r1) = out
-    assert np.array_equal(d0, d1)                                   # same set of per-triangle distances, same minimum
-    same_winner = perm[i1] == i0
-    assert K0 == K1 == len(q) and np.array_equal(A0, A1)
-    differs = np.flatnonzero((B0 != B1).any(axis=0))
-    # every query whose co1 moved is an exact tie between two different triangles ...
-    assert not same_winner[differs].any()
-    for qi in differs:
-        # ... at the same float32 distance, with different closest points (the oracle's closest point on ONE triangle each)
-        _, pa, da = orc.nn_tri_brute(q[qi:qi + 1], verts, tris[i0[qi]][None])
-        _, pb, db = orc.nn_tri_brute(q[qi:qi + 1], verts, tris2[i1[qi]][None])
-        assert da[0] == db[0] == d0[qi]
-        assert not np.array_equal(pa, pb)
-    frac = len(differs) / float(len(q))
-    print("surface tie rule, case %s: %d of %d queries answer with another triangle after the shuffle (exact float32 ties); "
-          "co1 differs for %d (%.4f %%): two distinct equidistant surface points" % (case, int((~same_winner).sum()), len(q),
-                                                                                     len(differs), 100.0 * frac))
+        pose = np.identity(4, dtype=np.float32)
+        for it in range(5):                                        # the initial pose and the poses of four iterations
+            out = []
+            for e in (e0, e1):
+                e.set_matrices(pose, eye)
+                idx, d2, _ = e.nn_search()
+                A, B, _ = e.make_pairs(1e30)
+                out.append((idx, d2, A, B))
+            (i0, d0, A0, B0), (i1, d1, A1, B1) = out
+            assert np.array_equal(d0, d1), it                       # same set of per-triangle distances, same minimum
+            same_winner = perm[i1] == i0
+            assert A0.shape[1] == A1.shape[1] == len(q) and np.array_equal(A0, A1)
+            differs = np.flatnonzero((B0 != B1).any(axis=0))
+            assert not same_winner[differs].any()                   # co1 can only move where another triangle won ...
+            qw = _cofind(orc, q, pose, eye)
+            for qi in differs:
+                # ... at the same float32 distance, with a different closest point (the oracle's, on ONE triangle each)
+                _, pa, da = orc.nn_tri_brute(qw[qi:qi + 1], verts, tris[i0[qi]][None])
+                _, pb, db = orc.nn_tri_brute(qw[qi:qi + 1], verts, tris2[i1[qi]][None])
+                assert da[0] == db[0] == d0[qi]
+                assert not np.array_equal(pa, pb)
+                # two kinds: the SAME geometric point -- on an edge or at a corner the two triangles share -- rounded
+                # differently by the two triangles' float32 arithmetic (a few ulp apart), or two genuinely different points at
+                # the same float32 distance (the query on the medial axis of the two: symmetric data only)
+                gap = float(np.abs(pa.astype(np.float64) - pb.astype(np.float64)).max())
+                ulp = float(np.spacing(np.float32(max(1e-30, np.abs(pa).max(), np.abs(qw[qi]).max()))))
+                if gap <= 8.0 * ulp:
+                    n_rounding += 1
+                    max_rounding_ulp = max(max_rounding_ulp, gap / ulp)
+                else:
+                    n_distinct += 1
+            n_swapped += int((~same_winner).sum())
+            n_moved += len(differs)
+            # the next pose: one iteration of the ORIGINAL order's loop
+            e0.set_matrices(pose, eye)
+            e0.iterate(thresh=1e30)
+            pose = e0.matrix_world()
+        # the two loops, each on its own: bitwise the same matrices unless some query's co1 moved on the way
+        res = []
+        for e in (e0, e1):
+            e.set_matrices(np.identity(4, dtype=np.float32), eye)
+            res.append(e.run(iters=4, thresh=1e30, early_exit=False))
+    total = 5 * len(q)
+    print("surface tie rule, case %s: over 5 poses x %d queries, %d answered with another triangle after the shuffle (exact float32 "
+          "ties); co1 differed for %d (%.4f %%): %d the same point of a shared edge / corner rounded differently (<= %.1f ulp apart), "
+          "%d two distinct equidistant points" % (case, len(q), n_swapped, n_moved, 100.0 * n_moved / total, n_rounding,
+                                                  max_rounding_ulp, n_distinct))
     if case != "ties":
-        assert frac <= 1e-3                                        # generic data: (next to) never
-    if len(differs) == 0:
-        assert np.array_equal(r0.step_M, r1.step_M) and np.array_equal(r0.matrix_world, r1.matrix_world)
+        assert n_moved <= 2e-3 * total                             # generic data: (next to) never ...
+        assert n_distinct == 0                                     # ... and then only a rounding of the same point
+    if n_moved == 0:
+        assert np.array_equal(res[0].step_M, res[1].step_M) and np.array_equal(res[0].matrix_world, res[1].matrix_world)
+    else:
+        assert np.abs(res[0].matrix_world - res[1].matrix_world).max() <= 1e-4
