@@ -73,11 +73,12 @@ def load():
         import torch  # noqa: F401
     except ImportError:
         pass
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("OA_ICP_LIB") or LIB_PATH                # (another BUILD of the same library: the sanitizer pass, A/B experiments)
+    if not os.path.exists(path):
         raise RuntimeError(
             "object_alignment_amd: %s is missing -- build the HIP extension first "
-            "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback" % LIB_PATH)
-    L = C.CDLL(LIB_PATH)
+            "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback" % path)
+    L = C.CDLL(path)
     vp, fp, dp, ip = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int64)
     L.oa_device_count.restype = C.c_int
     L.oa_create.argtypes = [C.POINTER(vp), C.c_int]

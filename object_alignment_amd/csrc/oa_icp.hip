@@ -1131,8 +1131,12 @@ struct oa_exchange {
     std::atomic<int> agree_stop_at{ -1 };          // -1: not frozen yet
     bool agree_on = true;                          // OA_MULTI_AGREE=0 (test hook, ignored in RCCL mode): round 3's every-thread-for-itself stop
     int fault_lag_group = -1, fault_lag_us = 0;    // OA_FAULT_LAG_GROUP / OA_FAULT_LAG_US: that host thread sleeps before every look at its halt flag (test hook)
-    int fault_fail_group = -1, fault_fail_iter = -1;   // OA_FAULT_FAIL_GROUP / OA_FAULT_FAIL_ITER: that host thread's enqueue fails at that iteration (test hook)
-    int fault_stall_rank = -1, fault_stall_iter = 2;   // OA_FAULT_STALL_RANK / _ITER: that rank's stream stops ahead of its collective, as if its peers never arrived (test hook)
+    // (atomics: every host thread looks at these, the one they name clears them once they have fired -- a plain int was a
+    //  data race, found by the ThreadSanitizer pass of round 4, profiles/r04d_sanitizers.txt)
+    std::atomic<int> fault_fail_group{ -1 };           // OA_FAULT_FAIL_GROUP / OA_FAULT_FAIL_ITER: that host thread's enqueue fails at that iteration (test hook)
+    int fault_fail_iter = -1;
+    std::atomic<int> fault_stall_rank{ -1 };           // OA_FAULT_STALL_RANK / _ITER: that rank's stream stops ahead of its collective, as if its peers never arrived (test hook)
+    int fault_stall_iter = 2;
     int32_t *h_release = nullptr;                  // pinned word the stalled stream watches: exchange_abort_rccl releases it
     // RCCL
     void *lib = nullptr;
@@ -1481,13 +1485,13 @@ int multi_iteration_group(oa_ctx *p, const std::vector<int> &group, bool timed)
         //  whose peers never enter the collective looks like to the host; bounded, so that a test can never hang the GPU)
         for (int i : group) {
             oa_ctx *c = p->subs[(size_t)i];
-            if (c->rank == x->fault_stall_rank && c->enq_iters == x->fault_stall_iter && x->h_release) {
+            if (c->rank == x->fault_stall_rank.load(std::memory_order_relaxed) && c->enq_iters == x->fault_stall_iter && x->h_release) {
                 if ((rc = use_device(c))) return rc;
                 void *dp = nullptr;
                 HIPCHK(hipHostGetDevicePointer(&dp, x->h_release, 0));
                 hipLaunchKernelGGL(oa::k_fault_stall, dim3(1), dim3(64), 0, c->stream, (const int32_t *)dp, (unsigned long long)(20.0 * c->wall_clock_khz * 1e3));
                 HIPCHK(hipGetLastError());
-                x->fault_stall_rank = -1;                                // once
+                x->fault_stall_rank.store(-1, std::memory_order_relaxed);   // once
             }
         }
         // one thread, several devices: group semantics; one thread per device: plain calls (each rank's kernel waits
@@ -1652,7 +1656,10 @@ int multi_group_loop(oa_ctx *p, size_t g, const oa_settings *st)
         }
         if (!agree_next(x, it, halt_seen)) break;
         int rc = OA_OK;
-        if ((int)g == x->fault_fail_group && it == x->fault_fail_iter) { x->fault_fail_group = -1; rc = fail(OA_E_HIP, "injected enqueue failure (OA_FAULT_FAIL_GROUP)"); }   // once
+        if (it == x->fault_fail_iter) {
+            int want = (int)g;
+            if (x->fault_fail_group.compare_exchange_strong(want, -1)) rc = fail(OA_E_HIP, "injected enqueue failure (OA_FAULT_FAIL_GROUP)");   // once
+        }
         if (!rc) rc = multi_iteration_group(p, group, true);
         if (rc) { agree_fail(x); return rc; }
     }
@@ -1776,11 +1783,11 @@ OA_EXPORT int oa_create_multi(oa_ctx **out, const int *devices, int n_dev)
         x->agree_on = env_int("OA_MULTI_AGREE", 1) != 0;
         x->fault_lag_group = env_int("OA_FAULT_LAG_GROUP", -1);
         x->fault_lag_us = env_int("OA_FAULT_LAG_US", 0);
-        x->fault_fail_group = env_int("OA_FAULT_FAIL_GROUP", -1);
+        x->fault_fail_group.store(env_int("OA_FAULT_FAIL_GROUP", -1));
         x->fault_fail_iter = env_int("OA_FAULT_FAIL_ITER", -1);
-        x->fault_stall_rank = env_int("OA_FAULT_STALL_RANK", -1);
+        x->fault_stall_rank.store(env_int("OA_FAULT_STALL_RANK", -1));
         x->fault_stall_iter = env_int("OA_FAULT_STALL_ITER", 2);
-        if (x->fault_stall_rank >= 0) {
+        if (x->fault_stall_rank.load() >= 0) {
             if (hipHostMalloc((void **)&x->h_release, sizeof(int32_t), hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); x->h_release = nullptr; }
             else *x->h_release = 0;
         }
