@@ -374,6 +374,7 @@ struct oa_ctx {
     bool debug = false;              // OA_DEBUG (read at oa_create)
     bool grid_stats = false;         // OA_GRID_STATS: instrumented triangle-grid launches print what the queries did
     bool tri_share = true;           // OA_TRI_SHARE=0 (A/B): every lane of the triangle-grid search walks its own records (rounds 2-3)
+    int list_blocks_per_cu = 16;     // OA_LIST_BLOCKS_PER_CU: workgroups (of four waves) per CU of the tree search over the hand-over list
     bool tri_canon = true;           // OA_TRI_CANON=0 (A/B): surface loops accumulate through the grid-stride k_pair_accumulate (rounds 1-3)
     bool tri_acc = true;             // OA_TRI_ACC=0 (A/B): the triangle grid search never accumulates in its epilogue
     int turns_on = 1;                // OA_SEARCH_TURNS: tree while the pose moves, grid afterwards (mid-size shards, AUTO)
@@ -592,7 +593,7 @@ inline unsigned bvh_blocks(const oa_ctx *c, bool listed, bool acc = false)
 {
     const int items = listed ? std::min(c->ns, 1 << 17) : c->ns;
     if (acc) return (unsigned)std::max(1, std::min((items + 15) / 16, c->n_cu * 4));   // workgroups of 16 waves
-    return (unsigned)std::max(1, std::min((items + 3) / 4, c->n_cu * 16));   // 16 waves per SIMD: enough to fill the chip, cheap to dispatch when the list is empty
+    return (unsigned)std::max(1, std::min((items + 3) / 4, c->n_cu * (listed ? c->list_blocks_per_cu : 16)));   // 16 waves per SIMD: enough to fill the chip, cheap to dispatch when the list is empty
 }
 
 oa::NormalTest normal_test(const oa_ctx *c)
@@ -1725,6 +1726,7 @@ OA_EXPORT int oa_create(oa_ctx **out, int device)
     c->grid_stats = env_int("OA_GRID_STATS", 0) != 0;
     c->tri_share = env_int("OA_TRI_SHARE", 1) != 0;
     c->tri_canon = env_int("OA_TRI_CANON", 1) != 0;
+    c->list_blocks_per_cu = std::max(1, std::min(64, env_int("OA_LIST_BLOCKS_PER_CU", 16)));
     c->tri_acc = env_int("OA_TRI_ACC", 1) != 0;
     c->turn_frac = env_double("OA_TURN_FRAC", 0.1);
     c->use_filter = env_int("OA_NN_FILTER", 1) != 0;

@@ -234,7 +234,7 @@ __device__ __forceinline__ void tri_state_refresh(TriSearchState &s, double delt
 // A wave therefore pays ceil(contenders of all its lanes / 64) closest-point evaluations instead of the maximum over
 // its lanes per flush (PMC before: 65-80 evaluation trips per wave in the first iterations of a run, for 10-12
 // evaluations per query).
-constexpr int TRI_POOL = 256;      // pool entries per wave; a flush is due above TRI_POOL - 128
+constexpr int TRI_POOL = 288;      // pool entries per wave; a flush is due above TRI_POOL - 128
 constexpr int TRI_SEGS = 10;       // cell-list ranges of one batch of rows (9 rows of the first block, or 5 rows x 2 end cells)
 
 struct TriPool {                   // this wave's part of the workgroup's LDS
@@ -399,7 +399,7 @@ __device__ __forceinline__ void tri_pool_flush(const float *p, const float4 *__r
 // triangle 0 -- so that a chunk may always read four records.
 constexpr long long TRI_REC_MAX_ENTRIES = (1ll << 26) - 16;
 constexpr int TRI_REC_PAD = 4;
-constexpr int TRI_SHARE_Q = 8;     // chunks (of four records) a lane hands to the wave per round of the shared scan
+constexpr int TRI_SHARE_Q = 6;     // chunks (of four records) a lane hands to the wave per round of the shared scan
 __device__ __forceinline__ float4 tri_ld_rec(const float4 *__restrict__ base, int entry, int half)
 {
     return *(const float4 *)((const char *)base + ((unsigned)entry * 32u + (unsigned)half * 16u));
@@ -648,7 +648,10 @@ __global__ __launch_bounds__(256, OA_TRI_MIN_WAVES) void k_tri_search_grid(const
             // below -- then their ranges, UR rows in flight at a time
             GridBlock3 blk = grid_block3_select<L>(gp, q, sub, r_start == 1, S.reach2f, 0.f, S.reach2f, 0.999998f);
             if (STATS) n_rows_loaded += __popc(blk.rows);
-            constexpr int UR = grid_block3_unroll(L);
+#ifndef OA_TRI_BLOCK3_UR
+#define OA_TRI_BLOCK3_UR grid_block3_unroll(L)
+#endif
+            constexpr int UR = OA_TRI_BLOCK3_UR;
             while (blk.rows) {
                 int ja[UR], jb[UR];
 #pragma unroll

@@ -6,7 +6,11 @@ matrices, then checks, for search modes brute, grid and bvh:
   * oa_nn_search == oracle brute force (index and float32 d2, bit exact) -- vertex mode and surface mode;
   * oa_make_pairs == oracle make_pairs (A, B bit exact; d_stats to 1e-9);
   * for well-conditioned clouds, three iterations of the device loop == the oracle's loop (K per iteration equal,
-    per-iteration transforms to 1e-7) -- seeds, search radius and the grid -> tree hand-over across iterations.
+    per-iteration transforms to 1e-7) -- seeds, search radius and the grid -> tree hand-over across iterations;
+  * for the same clouds, the loop's PATH VARIANTS: the grid search that finishes its own leftovers and accumulates
+    in its epilogue (OA_GRID_PATH=fast), the four-launch form (safe) and the adaptive choice, which depends on what the host
+    last heard from the device, must leave bitwise the same per-iteration matrices -- one context and three shards, with and
+    without the normal-angle test, vertex and surface targets.
 Usage: python tools/fuzz_parity.py [trials] [seed]
 """
 import os
@@ -72,8 +76,17 @@ def main():
     engines = {m: IcpEngine(0) for m in ("brute", "grid", "bvh")}
     for m, e in engines.items():
         e.set_search_mode(m)
+    variants = {}                                                  # (path, shards) -> grid-mode engine with that OA_GRID_PATH
+    for path in ("fast", "safe", "adaptive"):
+        if path != "adaptive":
+            os.environ["OA_GRID_PATH"] = path
+        for shards in (1, 3):
+            variants[(path, shards)] = IcpEngine(0) if shards == 1 else IcpEngine(devices=[0] * shards)
+            variants[(path, shards)].set_search_mode("grid")
+        os.environ.pop("OA_GRID_PATH", None)
     bad = 0
     loops = 0
+    variant_runs = 0
     t0 = time.time()
     for t in range(trials):
         kt, ks = rng.choice(kinds), rng.choice(kinds)
@@ -116,8 +129,10 @@ def main():
                 ok_p = abs(ds[0] - rds[0]) <= 1e-9 * abs(rds[0]) and abs(ds[1] - rds[1]) <= 1e-8 * abs(rds[1]) + 1e-13 * abs(rds[0])
                 detail = "d_stats %r vs %r" % (ds, rds) if not ok_p else ""
             ok_l, detail_l = True, ""
+            loop_ran = False
             if ok and ok_p and kt in ("uniform", "gauss", "sphere") and ks in ("uniform", "gauss", "sphere") and rA.shape[1] >= 50 and nt >= 17 and well_posed(rA, rB):
                 loops += 1
+                loop_ran = True
                 if mode == "brute":
                     ref_loop = orc.icp_run(src, tgt, mxa, mxb, iters=3, sample=stride, thresh=thresh, target_d=1e-300,
                                            vlist=vlist, tris=tris)
@@ -157,6 +172,38 @@ def main():
                     print("stride", stride, "vlist", None if vlist is None else len(vlist), "thresh", thresh, "\nmxa\n", mxa, "\nmxb\n", mxb)
                     for k in range(min(len(sM), n_it)):
                         print("iter", k, "max |dM|", np.abs(sM[k] - ref_loop["step_M"][k]).max(), "\n", sM[k], "\n", ref_loop["step_M"][k])
+            if loop_ran and ok_l and mode == "grid":
+                # path variants of the loop: fast == safe == adaptive, bit for bit
+                nrm_src = rng.normal(size=(ns, 3)).astype(np.float32)
+                nrm_tgt = rng.normal(size=(nt, 3)).astype(np.float32)
+                for with_normals in (False, True):
+                    got = {}
+                    for key, ve in variants.items():
+                        if surface:
+                            ve.set_target_mesh(tgt, tris)
+                        else:
+                            ve.set_target(tgt)
+                        ve.set_source(src, vlist=vlist, stride=stride)
+                        if with_normals:
+                            ve.set_normals(nrm_src, None if surface else nrm_tgt, 75.0)
+                        ve.set_matrices(mxa, mxb)
+                        try:
+                            r = ve.run(iters=3, thresh=thresh, target_d=1e-300)
+                            got[key] = (r.step_K.copy(), r.step_M.copy(), r.matrix_world.copy())
+                        except ValueError:
+                            got[key] = (np.array([-1]), np.zeros((1, 4, 4)), np.zeros((4, 4), np.float32))
+                        variant_runs += 1
+                    for shards in (1, 3):
+                        a = got[("fast", shards)]
+                        for other in ("safe", "adaptive"):
+                            b = got[(other, shards)]
+                            same = np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+                            if not same:
+                                ok_l = False
+                                detail_l = "path variants differ: fast vs %s, %d shard(s), normals %s" % (other, shards, with_normals)
+                    if not with_normals and ok_l and not np.array_equal(got[("adaptive", 1)][1], sM):
+                        ok_l = False
+                        detail_l = "a second grid-mode engine differs from the first"
             if not (ok and ok_p and ok_l):
                 bad += 1
                 nd = int(np.count_nonzero(idx != ridx))
@@ -165,9 +212,10 @@ def main():
                                                         rA.shape[1], detail, ok_l, detail_l), flush=True)
         if (t + 1) % 10 == 0:
             print("trial %d/%d  mismatches %d  (%.0f s)" % (t + 1, trials, bad, time.time() - t0), flush=True)
-    for e in engines.values():
+    for e in list(engines.values()) + list(variants.values()):
         e.close()
-    print("FUZZ DONE: %d trials, %d mismatches (%d three-iteration loop comparisons)" % (trials, bad, loops))
+    print("FUZZ DONE: %d trials, %d mismatches (%d three-iteration loop comparisons, %d path-variant loops: fast / safe / adaptive x 1 / 3 "
+          "shards x normals off / on)" % (trials, bad, loops, variant_runs))
     sys.exit(1 if bad else 0)
 
 
