@@ -343,7 +343,12 @@ constexpr int GRID_SEGS = 10;      // ranges of one batch: 9 rows of the first b
 // BT = threads per workgroup: 256, or 512 for the accumulating variant on large shards -- half as many rows of partials for
 // the reduction behind it (1M points 63.6 -> 60.3 us per iteration), the same six waves per SIMD (three
 // workgroups of eight waves per CU instead of six of four); small shards lose with the coarser workgroups (100k: +1.5 us).
-template <int L, bool ACC = false, int BT = 256>
+// STATS (instrumented build of the accumulating variant, OA_GRID_STATS=1): shader-clock stamps at the phase boundaries and
+// candidate counts, one row of GRID_STAT_N counters per wave in `stats`
+enum { GRID_STAT_WAVES, GRID_STAT_CYC_TOTAL, GRID_STAT_CYC_PROLOGUE, GRID_STAT_CYC_LIST, GRID_STAT_CYC_SCAN, GRID_STAT_CYC_BOOK,
+       GRID_STAT_CYC_FINISH, GRID_STAT_CYC_EPILOGUE, GRID_STAT_LOOP_TRIPS, GRID_STAT_SCAN_TRIPS, GRID_STAT_CANDIDATES,
+       GRID_STAT_MAX_LANE_CANDIDATES, GRID_STAT_N };
+template <int L, bool ACC = false, int BT = 256, bool STATS = false>
 #ifndef OA_GRID_MIN_WAVES
 #define OA_GRID_MIN_WAVES 6
 #endif
@@ -356,8 +361,13 @@ __global__ __launch_bounds__(BT, OA_GRID_MIN_WAVES) void k_nn_search_grid(const 
                                                         int *__restrict__ todo_list, int *__restrict__ todo_count, int turn,
                                                         BvhParams bp = BvhParams{}, const float4 *__restrict__ boxes = nullptr,
                                                         const float4 *__restrict__ prims = nullptr, NormalTest nrm = NormalTest{},
-                                                        double *__restrict__ partials = nullptr)
+                                                        double *__restrict__ partials = nullptr,
+                                                        unsigned long long *__restrict__ stats = nullptr)
 {
+    long long cyc_t0 = 0, cyc_mark = 0, cyc_prologue = 0, cyc_list = 0, cyc_scan = 0, cyc_book = 0, cyc_finish = 0;
+    int n_loop_trips = 0, n_scan_trips = 0, n_cand = 0;
+    if (STATS) cyc_t0 = cyc_mark = (long long)__builtin_readcyclecounter();
+#define OA_GRID_STAMP(acc) do { if (STATS) { const long long now_ = (long long)__builtin_readcyclecounter(); acc += now_ - cyc_mark; cyc_mark = now_; } } while (0)
     constexpr int RPL = (9 + L - 1) / L;                            // rows per lane and batch
     static_assert(RPL <= GRID_SEGS && (L == 1 || 2 * RPL <= GRID_SEGS), "a batch of rows must fit the per-thread range list");
     if (st->halt) return;
@@ -410,8 +420,10 @@ __global__ __launch_bounds__(BT, OA_GRID_MIN_WAVES) void k_nn_search_grid(const 
     const int r_start = (bidx != IDX_NONE && gp.seeded_start) ? 1 : 0;
     int r = r_start, b0 = 0, n_seg = 0;
     bool busy = q.finite && alive;
+    OA_GRID_STAMP(cyc_prologue);
     while (__any(busy)) {
         bool ring_done = false;
+        if (STATS) ++n_loop_trips;
         if (busy && r == 1) {
             // the 3 x 3 block (GridBlock3): which rows can matter, then their ranges, UR rows in flight at a time -- one or two
             // rows survive once the pose has settled
@@ -484,12 +496,14 @@ __global__ __launch_bounds__(BT, OA_GRID_MIN_WAVES) void k_nn_search_grid(const 
             b0 += consumed * L;
             ring_done = b0 >= n_rows;
         }
+        OA_GRID_STAMP(cyc_list);
         {   // every lane walks ITS ranges, four vertices per trip (the clamped repeats of the last vertex change nothing)
             int k = 0, j = 0, end = 0;
             while (true) {
                 if (j >= end && k < n_seg) { const int2 sgm = seg[k][threadIdx.x]; j = sgm.x; end = sgm.y; ++k; }
                 const bool active = j < end;
                 if (!__any(active)) break;
+                if (STATS) { ++n_scan_trips; if (active) n_cand += min(4, end - j); }
                 if (active) {
                     const int last = end - 1;
                     const int e1 = min(j + 1, last), e2 = min(j + 2, last), e3 = min(j + 3, last);
@@ -503,6 +517,7 @@ __global__ __launch_bounds__(BT, OA_GRID_MIN_WAVES) void k_nn_search_grid(const 
             }
             n_seg = 0;
         }
+        OA_GRID_STAMP(cyc_scan);
         over = busy && budget < 0;
         if (L > 1) {                                             // the lanes of the query agree on the best so far
 #pragma unroll
@@ -524,6 +539,7 @@ __global__ __launch_bounds__(BT, OA_GRID_MIN_WAVES) void k_nn_search_grid(const 
                 else { ++r; b0 = 0; if (r > gp.r_max) busy = false; }
             }
         }
+        OA_GRID_STAMP(cyc_book);
     }
     bool tight = budget < budget_extra;                             // used more than the base budget allows
     if (L > 1) {
@@ -577,6 +593,7 @@ __global__ __launch_bounds__(BT, OA_GRID_MIN_WAVES) void k_nn_search_grid(const 
         }
     }
     if (changed) win[i] = wq;                                     // the next search's seed (and what a one-shot call would read)
+    OA_GRID_STAMP(cyc_finish);
     bool valid = false;
     float vbx = 0.f, vby = 0.f, vbz = 0.f;
     double dist = 0.0;
@@ -593,6 +610,27 @@ __global__ __launch_bounds__(BT, OA_GRID_MIN_WAVES) void k_nn_search_grid(const 
     const float4 a4 = src_again[i];
     block_store_pair(valid, (double)a4.x - pvx, (double)a4.y - pvy, (double)a4.z - pvz, (double)vbx - pvx, (double)vby - pvy,
                      (double)vbz - pvz, dist - st->d_pivot, red, partials + (long long)vb * NSUMS);
+    if (STATS && stats) {
+        const long long now = (long long)__builtin_readcyclecounter();
+        int sum = n_cand, mx = n_cand;
+        for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o, 64); mx = max(mx, __shfl_xor(mx, o, 64)); }
+        if ((threadIdx.x & 63) == 0) {
+            unsigned long long *row = stats + ((size_t)blockIdx.x * (BT / 64) + (threadIdx.x >> 6)) * GRID_STAT_N;
+            row[GRID_STAT_WAVES] = 1ull;
+            row[GRID_STAT_CYC_TOTAL] = (unsigned long long)(now - cyc_t0);
+            row[GRID_STAT_CYC_PROLOGUE] = (unsigned long long)cyc_prologue;
+            row[GRID_STAT_CYC_LIST] = (unsigned long long)cyc_list;
+            row[GRID_STAT_CYC_SCAN] = (unsigned long long)cyc_scan;
+            row[GRID_STAT_CYC_BOOK] = (unsigned long long)cyc_book;
+            row[GRID_STAT_CYC_FINISH] = (unsigned long long)cyc_finish;
+            row[GRID_STAT_CYC_EPILOGUE] = (unsigned long long)(now - cyc_mark);
+            row[GRID_STAT_LOOP_TRIPS] = (unsigned long long)n_loop_trips;
+            row[GRID_STAT_SCAN_TRIPS] = (unsigned long long)n_scan_trips;
+            row[GRID_STAT_CANDIDATES] = (unsigned long long)sum;
+            row[GRID_STAT_MAX_LANE_CANDIDATES] = (unsigned long long)mx;
+        }
+    }
+#undef OA_GRID_STAMP
 }
 
 __global__ void k_count_nonzero(const int *__restrict__ a, int n, int *__restrict__ out)

@@ -752,6 +752,25 @@ int launch_nn_impl(oa_ctx *c, bool acc)
             if (canon_threads(c) == 512) {
                 if (lanes == 4) hipLaunchKernelGGL((oa::k_nn_search_grid<4, true, 512>), ablocks, dim3(512), 0, c->stream, OA_GRID_ACC_ARGS);
                 else if (lanes == 2) hipLaunchKernelGGL((oa::k_nn_search_grid<2, true, 512>), ablocks, dim3(512), 0, c->stream, OA_GRID_ACC_ARGS);
+                else if (c->grid_stats) {                                // OA_GRID_STATS=1: instrumented launch, phase shares to stderr (synchronises)
+                    DevTmp<unsigned long long> d_stats;
+                    const size_t n_waves = (size_t)ablocks.x * 8;
+                    HIPCHK(d_stats.alloc(oa::GRID_STAT_N * n_waves));
+                    HIPCHK(hipMemsetAsync(d_stats, 0, sizeof(unsigned long long) * oa::GRID_STAT_N * n_waves, c->stream));
+                    hipLaunchKernelGGL((oa::k_nn_search_grid<1, true, 512, true>), ablocks, dim3(512), 0, c->stream, OA_GRID_ACC_ARGS, d_stats.p);
+                    HIPCHK(hipGetLastError());
+                    std::vector<unsigned long long> rows(oa::GRID_STAT_N * n_waves);
+                    { int rcr = read_small(c, rows.data(), d_stats, sizeof(unsigned long long) * rows.size()); if (rcr) return rcr; }
+                    unsigned long long h[oa::GRID_STAT_N] = { 0 };
+                    for (size_t w = 0; w < n_waves; ++w) for (int k = 0; k < oa::GRID_STAT_N; ++k) h[k] += rows[w * oa::GRID_STAT_N + (size_t)k];
+                    const double nw = (double)std::max(1ull, h[oa::GRID_STAT_WAVES]), ct = (double)std::max(1ull, h[oa::GRID_STAT_CYC_TOTAL]);
+                    fprintf(stderr, "[oa] vertex grid phases: per wave %.0f shader cycles, %.2f loop trips, %.2f scan trips, %.1f candidates per query (longest lane of a wave %.1f) | "
+                                    "prologue %.1f%% listing %.1f%% scan %.1f%% bookkeeping %.1f%% finish %.1f%% epilogue %.1f%%\n",
+                            ct / nw, h[oa::GRID_STAT_LOOP_TRIPS] / nw, h[oa::GRID_STAT_SCAN_TRIPS] / nw, h[oa::GRID_STAT_CANDIDATES] / (64.0 * nw),
+                            h[oa::GRID_STAT_MAX_LANE_CANDIDATES] / nw, 100.0 * h[oa::GRID_STAT_CYC_PROLOGUE] / ct, 100.0 * h[oa::GRID_STAT_CYC_LIST] / ct,
+                            100.0 * h[oa::GRID_STAT_CYC_SCAN] / ct, 100.0 * h[oa::GRID_STAT_CYC_BOOK] / ct, 100.0 * h[oa::GRID_STAT_CYC_FINISH] / ct,
+                            100.0 * h[oa::GRID_STAT_CYC_EPILOGUE] / ct);
+                }
                 else hipLaunchKernelGGL((oa::k_nn_search_grid<1, true, 512>), ablocks, dim3(512), 0, c->stream, OA_GRID_ACC_ARGS);
             } else {
                 if (lanes == 4) hipLaunchKernelGGL((oa::k_nn_search_grid<4, true, 256>), ablocks, dim3(256), 0, c->stream, OA_GRID_ACC_ARGS);
