@@ -135,6 +135,57 @@ __global__ void k_grid_scatter(const float *__restrict__ xyz, int nt, const int 
     sorted[pos] = make_float4(xyz[3ll * i], xyz[3ll * i + 1], xyz[3ll * i + 2], __int_as_float(i));
 }
 
+// ---- safe radii (round 4): when the seed alone settles a query --------------------------------------------------------
+// For target t let S(t) = the distance to the nearest OTHER target.  A query p with |p - t| < S(t) / 2 has t as its
+// nearest target, strictly: any other t' is at |p - t'| >= |t - t'| - |p - t| > S / 2.  The build stores, per position
+// of `sorted`, safe2 = (S / 2)^2 (1 - 1e-4) as a float; the margin covers the float metric's rounding on both sides
+// (d2_metric is in difference form: relative error < 3e-7 of the true squared distance), so d2_metric(p, t) < safe2
+// implies d2_metric(p, t') > d2_metric(p, t) for every other target -- no tie either: brute force would report exactly
+// (d2, t).  S is a LOWER bound: the minimum over the 3 x 3 x 3 block of cells around t's cell, capped by the distance
+// to everything outside the block (>= h - slack); 0 = "never" for duplicates, crowded blocks (the build does not walk
+// more than SAFE_SCAN_MAX candidates per target) and radii below the float normal range (underflow in the metric).
+// The search (k_nn_search_grid) keeps {index, safe2} of a slot's winner next to its winner record (`wsafe`); an
+// entry whose index is not the seed's says nothing -- other kernels write winner records and know nothing of this.
+constexpr int SAFE_SCAN_MAX = 1024;
+__global__ void k_grid_safe_radius(const float4 *__restrict__ sorted, int nt, GridParams gp, const int *__restrict__ cell_start,
+                                   float *__restrict__ safe_sorted)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nt) return;
+    const float4 t = sorted[j];
+    const int cx = grid_cell_coord((double)t.x, gp.lo[0], gp.inv_h, gp.n[0]);
+    const int cy = grid_cell_coord((double)t.y, gp.lo[1], gp.inv_h, gp.n[1]);
+    const int cz = grid_cell_coord((double)t.z, gp.lo[2], gp.inv_h, gp.n[2]);
+    const int xa = max(cx - 1, 0), xb = min(cx + 1, gp.n[0] - 1);
+    int total = 0;
+    for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) {
+        const int z = cz + dz, y = cy + dy;
+        if (z < 0 || z >= gp.n[2] || y < 0 || y >= gp.n[1]) continue;
+        const int row = (z * gp.n[1] + y) * gp.n[0];
+        total += cell_start[row + xb + 1] - cell_start[row + xa];
+    }
+    float out = 0.f;
+    if (total <= SAFE_SCAN_MAX) {
+        const float cap = fmaxf(gp.hf * 0.999999f - gp.slackf, 0.f);
+        float m = cap * cap;
+        for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) {
+            const int z = cz + dz, y = cy + dy;
+            if (z < 0 || z >= gp.n[2] || y < 0 || y >= gp.n[1]) continue;
+            const int row = (z * gp.n[1] + y) * gp.n[0];
+            const int ka = cell_start[row + xa], kb = cell_start[row + xb + 1];
+            for (int k = ka; k < kb; ++k) {
+                if (k == j) continue;
+                const float4 o = sorted[k];
+                const float d = d2_metric(t.x, t.y, t.z, o.x, o.y, o.z);
+                if (d < m) m = d;                                   // (a non-finite neighbour can never win a search: ignored)
+            }
+        }
+        out = 0.25f * m * 0.9999f;
+        if (!(out >= 1e-30f)) out = 0.f;
+    }
+    safe_sorted[j] = out;
+}
+
 // ---- the query's frame in the grid -----------------------------------------------------------------------------------
 // Located once per query in double (projection onto the grid's box, own cell, position inside that cell); everything
 // per row / per ring afterwards is float arithmetic on three numbers per axis.  All distances derived from it are
@@ -197,6 +248,9 @@ __device__ __forceinline__ void grid_row_span(float fx, float h, float inv_h, fl
         return;
     }
     // gap(-d) = (d - 1) h + fx - slack <= sw  <=>  d <= (sw - fx + slack) / h + 1   (and the mirror image to the right)
+    // (fx is laundered: the compiler otherwise hoists h - fx out of the ring loop and, at 80 registers, spills it -- one
+    //  subtraction in a path only the rings r >= 2 take)
+    asm volatile("" : "+v"(fx));
     const float sw = grid_sqrt_up(w2) + slack;
     const float fr = (float)r;
     const float tl = fminf(fmaxf(__builtin_floorf((sw - fx) * inv_h * 1.000001f) + 1.0f, 0.f), fr);
@@ -231,6 +285,15 @@ __device__ __forceinline__ int grid_ld_cell(const int *__restrict__ base, int id
 __device__ __forceinline__ float4 grid_ld_vertex(const float4 *__restrict__ base, int idx)
 {
     return *(const float4 *)((const char *)base + (unsigned)idx * 16u);
+}
+
+__device__ __forceinline__ uint32_t grid_ld_safe(const float *__restrict__ base, int idx)
+{
+    return *(const uint32_t *)((const char *)base + (unsigned)idx * 4u);
+}
+__device__ __forceinline__ void grid_st_safe(uint2 *__restrict__ base, int slot, uint32_t idx, uint32_t safe_bits)
+{
+    *(uint2 *)((char *)base + (unsigned)slot * 8u) = make_uint2(idx, safe_bits);
 }
 
 // ---- the 3 x 3 rows around the own cell (ring 1) -- where a seeded query starts and, once the pose has settled, ends ---------
@@ -347,7 +410,7 @@ constexpr int GRID_SEGS = 10;      // ranges of one batch: 9 rows of the first b
 // candidate counts, one row of GRID_STAT_N counters per wave in `stats`
 enum { GRID_STAT_WAVES, GRID_STAT_CYC_TOTAL, GRID_STAT_CYC_PROLOGUE, GRID_STAT_CYC_LIST, GRID_STAT_CYC_SCAN, GRID_STAT_CYC_BOOK,
        GRID_STAT_CYC_FINISH, GRID_STAT_CYC_EPILOGUE, GRID_STAT_LOOP_TRIPS, GRID_STAT_SCAN_TRIPS, GRID_STAT_CANDIDATES,
-       GRID_STAT_MAX_LANE_CANDIDATES, GRID_STAT_N };
+       GRID_STAT_MAX_LANE_CANDIDATES, GRID_STAT_ACCEPTED, GRID_STAT_N };
 template <int L, bool ACC = false, int BT = 256, bool STATS = false>
 #ifndef OA_GRID_MIN_WAVES
 #define OA_GRID_MIN_WAVES 6
@@ -362,10 +425,12 @@ __global__ __launch_bounds__(BT, OA_GRID_MIN_WAVES) void k_nn_search_grid(const 
                                                         BvhParams bp = BvhParams{}, const float4 *__restrict__ boxes = nullptr,
                                                         const float4 *__restrict__ prims = nullptr, NormalTest nrm = NormalTest{},
                                                         double *__restrict__ partials = nullptr,
-                                                        unsigned long long *__restrict__ stats = nullptr)
+                                                        unsigned long long *__restrict__ stats = nullptr,
+                                                        const float *__restrict__ safe_sorted = nullptr,
+                                                        uint2 *__restrict__ wsafe = nullptr)
 {
     long long cyc_t0 = 0, cyc_mark = 0, cyc_prologue = 0, cyc_list = 0, cyc_scan = 0, cyc_book = 0, cyc_finish = 0;
-    int n_loop_trips = 0, n_scan_trips = 0, n_cand = 0;
+    int n_loop_trips = 0, n_scan_trips = 0, n_cand = 0, n_accepted = 0;
     if (STATS) cyc_t0 = cyc_mark = (long long)__builtin_readcyclecounter();
 #define OA_GRID_STAMP(acc) do { if (STATS) { const long long now_ = (long long)__builtin_readcyclecounter(); acc += now_ - cyc_mark; cyc_mark = now_; } } while (0)
     constexpr int RPL = (9 + L - 1) / L;                            // rows per lane and batch
@@ -389,18 +454,33 @@ __global__ __launch_bounds__(BT, OA_GRID_MIN_WAVES) void k_nn_search_grid(const 
     float best = INFINITY;
     uint32_t bidx = IDX_NONE;
     int bj = -1;
+    // ... and, when the slot's {index, safe2} entry speaks of this very seed and the query lies inside the seed's safe
+    // radius, the seed IS the answer (k_grid_safe_radius): no cell is listed, no vertex scanned.  The lanes of a wave that
+    // still search share it with fewer neighbours: fewer lines per load, fewer trips for the longest lane.
+    bool accepted = false;
     if (__float_as_int(sw.w) >= 0) {
         const float d = d2_metric(px, py, pz, sw.x, sw.y, sw.z);
         if (d < INFINITY) { best = d; bidx = (uint32_t)__float_as_int(sw.w); }
+        if (wsafe) {
+            const uint2 ws = *(const uint2 *)((const char *)wsafe + (unsigned)i * 8u);    // (32-bit offset from a uniform base, as grid_ld_vertex)
+            accepted = ws.x == (uint32_t)__float_as_int(sw.w) && d < __uint_as_float(ws.y);
+        }
     }
 
-    const GridQuery q = grid_locate(gp, px, py, pz);
+    // (a wave whose seeds settled all its queries -- a quarter of them at 1M <-> 1M once the pose has converged -- skips the
+    //  query frames and the search radius: fp64 work nothing would read)
+    GridQuery q;
+    q.c[0] = q.c[1] = q.c[2] = 0; q.f[0] = q.f[1] = q.f[2] = 0.f; q.off2 = 0.f; q.finite = false;
+    float cutf = INFINITY;
+    if (__any(alive && !accepted)) {
+        q = grid_locate(gp, px, py, pz);
+        cutf = search_cutoff2(st, px, py, pz);
+    }
     const float h = gp.hf, inv_h = gp.inv_hf, slack = gp.slackf;
     // `lim` = what an unseen vertex has to beat: the best so far, or the search radius beyond which the pair test
     // (dist < thresh) fails anyway, whichever is smaller
-    const float cutf = search_cutoff2(st, px, py, pz);
     float lim = fminf(best, cutf);
-    bool settled = false, over = false;
+    bool settled = accepted, over = false;
     // candidates this query may look at before the tree takes it over (split between its lanes); doubled while the
     // pose still moves by a good part of a cell per iteration (stale seeds: most queries need the second ring) -- see
     // k_tri_search_grid
@@ -419,7 +499,8 @@ __global__ __launch_bounds__(BT, OA_GRID_MIN_WAVES) void k_nn_search_grid(const 
     // i.e. two round trips of the wave it shares with 63 others.
     const int r_start = (bidx != IDX_NONE && gp.seeded_start) ? 1 : 0;
     int r = r_start, b0 = 0, n_seg = 0;
-    bool busy = q.finite && alive;
+    bool busy = q.finite && alive && !accepted;
+    if (STATS) n_accepted = __popcll(__ballot(accepted && alive && sub == 0));
     OA_GRID_STAMP(cyc_prologue);
     while (__any(busy)) {
         bool ring_done = false;
@@ -551,7 +632,10 @@ __global__ __launch_bounds__(BT, OA_GRID_MIN_WAVES) void k_nn_search_grid(const 
         keys[i] = ((unsigned long long)__float_as_uint(best) << 32) | bidx;
         // the winner record is read by k_pair_accumulate, the tree search and the next search; a winner that is still the
         // seed (the usual case once the loop converges) is already there
-        if (bj >= 0) win[i] = sorted[bj];
+        if (bj >= 0) {
+            win[i] = sorted[bj];
+            if (wsafe) grid_st_safe(wsafe, i, bidx, grid_ld_safe(safe_sorted, bj));
+        }
         if (!settled) todo_list[atomicAdd(todo_count, 1)] = i;      // finished exactly by the tree search (k_bvh_search)
         // How crowded the hand-over is per wave: what the host looks at before it lets a later search finish its own leftovers
         // (grid_fast_now).  Counted against the BASE budget: a search that ran on the doubled one -- the first of a loop, or
@@ -563,6 +647,12 @@ __global__ __launch_bounds__(BT, OA_GRID_MIN_WAVES) void k_nn_search_grid(const 
     // ---- ACC: finish, record, accumulate -- all threads stay to the end (wave-wide descents, workgroup-wide reduction)
     __shared__ double red[BT / 64][NSUMS];
     const bool mine = sub == 0 && alive;
+    // the source point again (a coalesced, cached 16-byte load) rather than three registers held through the whole scan:
+    // the pointer is laundered so that the compiler does not merge this load with the one at the top.  Issued here, with
+    // the winner's record, so that the two round trips overlap (and the pair test hides what is left of this one)
+    const float4 *src_again = src4;
+    asm volatile("" : "+s"(src_again));
+    const float4 a4 = src_again[i];
     float4 wq = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));  // the winner's record: the seed's, or the scan's
     if (mine && bidx != IDX_NONE) wq = bj >= 0 ? sorted[bj] : win[i];      // (bj < 0: still the seed, re-read rather than kept in registers through the scan)
     bool changed = mine && bj >= 0;
@@ -588,11 +678,15 @@ __global__ __launch_bounds__(BT, OA_GRID_MIN_WAVES) void k_nn_search_grid(const 
                 float tx = __shfl(wq.x, l, 64), ty = __shfl(wq.y, l, 64), tz = __shfl(wq.z, l, 64);
                 const uint32_t bi0 = bi;
                 bvh_wave_query<false>(bp, boxes, prims, qp, __shfl(cutf, l, 64), b, bi, tx, ty, tz, lds, lane);
-                if (lane == l && bi != bi0) { best = b; bidx = bi; wq = make_float4(tx, ty, tz, __int_as_float((int)bi)); changed = true; }
+                if (lane == l && bi != bi0) { best = b; bidx = bi; wq = make_float4(tx, ty, tz, __int_as_float((int)bi)); changed = true; bj = -1; }
             }
         }
     }
-    if (changed) win[i] = wq;                                     // the next search's seed (and what a one-shot call would read)
+    if (changed) {                                                // the next search's seed (and what a one-shot call would read)
+        win[i] = wq;
+        // its safe radius, when the scan found it (bj = its position in `sorted`); a winner the tree reported has none on record
+        if (wsafe) grid_st_safe(wsafe, i, bidx, bj >= 0 ? grid_ld_safe(safe_sorted, bj) : 0u);
+    }
     OA_GRID_STAMP(cyc_finish);
     bool valid = false;
     float vbx = 0.f, vby = 0.f, vbz = 0.f;
@@ -603,11 +697,6 @@ __global__ __launch_bounds__(BT, OA_GRID_MIN_WAVES) void k_nn_search_grid(const 
         valid = pair_eval(st, px, py, pz, wq.x, wq.y, wq.z, nrm, i, tn, st->thresh, vbx, vby, vbz, dist);
     }
     const double pvx = st->pivot[0], pvy = st->pivot[1], pvz = st->pivot[2];
-    // the source point again (a coalesced, cached 16-byte load) rather than three registers held through the whole scan:
-    // the pointer is laundered so that the compiler does not merge this load with the one at the top
-    const float4 *src_again = src4;
-    asm volatile("" : "+s"(src_again));
-    const float4 a4 = src_again[i];
     block_store_pair(valid, (double)a4.x - pvx, (double)a4.y - pvy, (double)a4.z - pvz, (double)vbx - pvx, (double)vby - pvy,
                      (double)vbz - pvz, dist - st->d_pivot, red, partials + (long long)vb * NSUMS);
     if (STATS && stats) {
@@ -628,6 +717,7 @@ __global__ __launch_bounds__(BT, OA_GRID_MIN_WAVES) void k_nn_search_grid(const 
             row[GRID_STAT_SCAN_TRIPS] = (unsigned long long)n_scan_trips;
             row[GRID_STAT_CANDIDATES] = (unsigned long long)sum;
             row[GRID_STAT_MAX_LANE_CANDIDATES] = (unsigned long long)mx;
+            row[GRID_STAT_ACCEPTED] = (unsigned long long)n_accepted;
         }
     }
 #undef OA_GRID_STAMP

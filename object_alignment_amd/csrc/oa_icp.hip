@@ -381,6 +381,9 @@ struct oa_ctx {
     bool seeded = false;             // a search has run since the last set_source / set_target (seeds exist)
     int *d_prev = nullptr;           // nearest index of the previous search (seed), -1 = none
     float4 *d_win = nullptr;         // vertex mode: per slot, the last winner's coordinates + index in .w (-1 = none)
+    uint2 *d_wsafe = nullptr;        // vertex grid: per slot {index, safe2 bits} of a winner the grid scan found (k_grid_safe_radius); 0xFF.. = none
+    float *d_safe_sorted = nullptr;  // vertex grid: safe2 per position of d_sorted
+    bool grid_safe = true;           // OA_GRID_SAFE=0 (A/B): the vertex grid search never takes a seed on its safe radius
     int *d_sel = nullptr;            // vertex index held by each source slot
     float4 *d_src4o = nullptr;       // the same points in the caller's (vlist) order -- only oa_make_pairs needs it
     int *d_perm = nullptr;           // sorted slot -> caller-order slot (nullptr: not sorted)
@@ -746,43 +749,49 @@ int launch_nn_impl(oa_ctx *c, bool acc)
         const int lanes = grid_lanes_for(c);
 #define OA_GRID_ARGS c->d_state, c->d_src4, c->ns, c->gp, c->d_cell_start, c->d_sorted, c->d_win, c->d_keys, c->d_todo_list, c->d_todo_count, turn
 #define OA_GRID_ACC_ARGS OA_GRID_ARGS, c->bvh, (const float4 *)c->d_bvh_box, (const float4 *)c->d_bvh_prims, normal_test(c), c->d_partials
+        // {index, safe2} per slot beside the winner records: both or neither (OA_GRID_SAFE=0)
+        const float *safe_sorted = c->grid_safe ? c->d_safe_sorted : nullptr;
+        uint2 *wsafe = safe_sorted ? c->d_wsafe : nullptr;
+        if (!wsafe) safe_sorted = nullptr;
+#define OA_GRID_SAFE_ARGS safe_sorted, wsafe
         const dim3 gblocks((unsigned)(((long long)c->ns * lanes + 255) / 256));
         if (acc) {
             const dim3 ablocks((unsigned)canon_blocks(c));
             if (canon_threads(c) == 512) {
-                if (lanes == 4) hipLaunchKernelGGL((oa::k_nn_search_grid<4, true, 512>), ablocks, dim3(512), 0, c->stream, OA_GRID_ACC_ARGS);
-                else if (lanes == 2) hipLaunchKernelGGL((oa::k_nn_search_grid<2, true, 512>), ablocks, dim3(512), 0, c->stream, OA_GRID_ACC_ARGS);
+                if (lanes == 4) hipLaunchKernelGGL((oa::k_nn_search_grid<4, true, 512>), ablocks, dim3(512), 0, c->stream, OA_GRID_ACC_ARGS, (unsigned long long *)nullptr, OA_GRID_SAFE_ARGS);
+                else if (lanes == 2) hipLaunchKernelGGL((oa::k_nn_search_grid<2, true, 512>), ablocks, dim3(512), 0, c->stream, OA_GRID_ACC_ARGS, (unsigned long long *)nullptr, OA_GRID_SAFE_ARGS);
                 else if (c->grid_stats) {                                // OA_GRID_STATS=1: instrumented launch, phase shares to stderr (synchronises)
                     DevTmp<unsigned long long> d_stats;
                     const size_t n_waves = (size_t)ablocks.x * 8;
                     HIPCHK(d_stats.alloc(oa::GRID_STAT_N * n_waves));
                     HIPCHK(hipMemsetAsync(d_stats, 0, sizeof(unsigned long long) * oa::GRID_STAT_N * n_waves, c->stream));
-                    hipLaunchKernelGGL((oa::k_nn_search_grid<1, true, 512, true>), ablocks, dim3(512), 0, c->stream, OA_GRID_ACC_ARGS, d_stats.p);
+                    hipLaunchKernelGGL((oa::k_nn_search_grid<1, true, 512, true>), ablocks, dim3(512), 0, c->stream, OA_GRID_ACC_ARGS, d_stats.p, OA_GRID_SAFE_ARGS);
                     HIPCHK(hipGetLastError());
                     std::vector<unsigned long long> rows(oa::GRID_STAT_N * n_waves);
                     { int rcr = read_small(c, rows.data(), d_stats, sizeof(unsigned long long) * rows.size()); if (rcr) return rcr; }
                     unsigned long long h[oa::GRID_STAT_N] = { 0 };
                     for (size_t w = 0; w < n_waves; ++w) for (int k = 0; k < oa::GRID_STAT_N; ++k) h[k] += rows[w * oa::GRID_STAT_N + (size_t)k];
                     const double nw = (double)std::max(1ull, h[oa::GRID_STAT_WAVES]), ct = (double)std::max(1ull, h[oa::GRID_STAT_CYC_TOTAL]);
-                    fprintf(stderr, "[oa] vertex grid phases: per wave %.0f shader cycles, %.2f loop trips, %.2f scan trips, %.1f candidates per query (longest lane of a wave %.1f) | "
+                    fprintf(stderr, "[oa] vertex grid phases: %llu of %d queries settled by the seed's safe radius | per wave %.0f shader cycles, %.2f loop trips, %.2f scan trips, %.1f candidates per query (longest lane of a wave %.1f) | "
                                     "prologue %.1f%% listing %.1f%% scan %.1f%% bookkeeping %.1f%% finish %.1f%% epilogue %.1f%%\n",
-                            ct / nw, h[oa::GRID_STAT_LOOP_TRIPS] / nw, h[oa::GRID_STAT_SCAN_TRIPS] / nw, h[oa::GRID_STAT_CANDIDATES] / (64.0 * nw),
+                            h[oa::GRID_STAT_ACCEPTED], c->ns, ct / nw, h[oa::GRID_STAT_LOOP_TRIPS] / nw, h[oa::GRID_STAT_SCAN_TRIPS] / nw, h[oa::GRID_STAT_CANDIDATES] / (64.0 * nw),
                             h[oa::GRID_STAT_MAX_LANE_CANDIDATES] / nw, 100.0 * h[oa::GRID_STAT_CYC_PROLOGUE] / ct, 100.0 * h[oa::GRID_STAT_CYC_LIST] / ct,
                             100.0 * h[oa::GRID_STAT_CYC_SCAN] / ct, 100.0 * h[oa::GRID_STAT_CYC_BOOK] / ct, 100.0 * h[oa::GRID_STAT_CYC_FINISH] / ct,
                             100.0 * h[oa::GRID_STAT_CYC_EPILOGUE] / ct);
                 }
-                else hipLaunchKernelGGL((oa::k_nn_search_grid<1, true, 512>), ablocks, dim3(512), 0, c->stream, OA_GRID_ACC_ARGS);
+                else hipLaunchKernelGGL((oa::k_nn_search_grid<1, true, 512>), ablocks, dim3(512), 0, c->stream, OA_GRID_ACC_ARGS, (unsigned long long *)nullptr, OA_GRID_SAFE_ARGS);
             } else {
-                if (lanes == 4) hipLaunchKernelGGL((oa::k_nn_search_grid<4, true, 256>), ablocks, dim3(256), 0, c->stream, OA_GRID_ACC_ARGS);
-                else if (lanes == 2) hipLaunchKernelGGL((oa::k_nn_search_grid<2, true, 256>), ablocks, dim3(256), 0, c->stream, OA_GRID_ACC_ARGS);
-                else hipLaunchKernelGGL((oa::k_nn_search_grid<1, true, 256>), ablocks, dim3(256), 0, c->stream, OA_GRID_ACC_ARGS);
+                if (lanes == 4) hipLaunchKernelGGL((oa::k_nn_search_grid<4, true, 256>), ablocks, dim3(256), 0, c->stream, OA_GRID_ACC_ARGS, (unsigned long long *)nullptr, OA_GRID_SAFE_ARGS);
+                else if (lanes == 2) hipLaunchKernelGGL((oa::k_nn_search_grid<2, true, 256>), ablocks, dim3(256), 0, c->stream, OA_GRID_ACC_ARGS, (unsigned long long *)nullptr, OA_GRID_SAFE_ARGS);
+                else hipLaunchKernelGGL((oa::k_nn_search_grid<1, true, 256>), ablocks, dim3(256), 0, c->stream, OA_GRID_ACC_ARGS, (unsigned long long *)nullptr, OA_GRID_SAFE_ARGS);
             }
             HIPCHK(hipGetLastError());
             return OA_OK;
         }
-        if (lanes == 4) hipLaunchKernelGGL((oa::k_nn_search_grid<4, false>), gblocks, dim3(256), 0, c->stream, OA_GRID_ARGS);
-        else if (lanes == 2) hipLaunchKernelGGL((oa::k_nn_search_grid<2, false>), gblocks, dim3(256), 0, c->stream, OA_GRID_ARGS);
-        else hipLaunchKernelGGL((oa::k_nn_search_grid<1, false>), gblocks, dim3(256), 0, c->stream, OA_GRID_ARGS);
+        if (lanes == 4) hipLaunchKernelGGL((oa::k_nn_search_grid<4, false>), gblocks, dim3(256), 0, c->stream, OA_GRID_ARGS, oa::BvhParams{}, (const float4 *)nullptr, (const float4 *)nullptr, oa::NormalTest{}, (double *)nullptr, (unsigned long long *)nullptr, OA_GRID_SAFE_ARGS);
+        else if (lanes == 2) hipLaunchKernelGGL((oa::k_nn_search_grid<2, false>), gblocks, dim3(256), 0, c->stream, OA_GRID_ARGS, oa::BvhParams{}, (const float4 *)nullptr, (const float4 *)nullptr, oa::NormalTest{}, (double *)nullptr, (unsigned long long *)nullptr, OA_GRID_SAFE_ARGS);
+        else hipLaunchKernelGGL((oa::k_nn_search_grid<1, false>), gblocks, dim3(256), 0, c->stream, OA_GRID_ARGS, oa::BvhParams{}, (const float4 *)nullptr, (const float4 *)nullptr, oa::NormalTest{}, (double *)nullptr, (unsigned long long *)nullptr, OA_GRID_SAFE_ARGS);
+#undef OA_GRID_SAFE_ARGS
 #undef OA_GRID_ACC_ARGS
 #undef OA_GRID_ARGS
         HIPCHK(hipGetLastError());
@@ -1744,6 +1753,7 @@ OA_EXPORT int oa_create(oa_ctx **out, int device)
     c->debug = getenv("OA_DEBUG") != nullptr;
     c->grid_stats = env_int("OA_GRID_STATS", 0) != 0;
     c->tri_share = env_int("OA_TRI_SHARE", 1) != 0;
+    c->grid_safe = env_int("OA_GRID_SAFE", 1) != 0;
     c->tri_canon = env_int("OA_TRI_CANON", 1) != 0;
     c->list_blocks_per_cu = std::max(1, std::min(64, env_int("OA_LIST_BLOCKS_PER_CU", 16)));
     c->tri_acc = env_int("OA_TRI_ACC", 1) != 0;
@@ -1886,7 +1896,7 @@ OA_EXPORT void oa_destroy(oa_ctx *c)
     (void)hipDeviceSynchronize();
     tl_stream_known = false;                                        // the stream below is about to go away
 #define OA_FREE(x) dev_free(c->x, true)
-    OA_FREE(d_tgt_xyz); OA_FREE(d_tg); OA_FREE(d_tf); OA_FREE(d_tf3); OA_FREE(d_tfm); OA_FREE(d_members); OA_FREE(d_pos); OA_FREE(d_prev); OA_FREE(d_win); OA_FREE(d_cell_start);
+    OA_FREE(d_tgt_xyz); OA_FREE(d_tg); OA_FREE(d_tf); OA_FREE(d_tf3); OA_FREE(d_tfm); OA_FREE(d_members); OA_FREE(d_pos); OA_FREE(d_prev); OA_FREE(d_win); OA_FREE(d_wsafe); OA_FREE(d_safe_sorted); OA_FREE(d_cell_start);
     OA_FREE(d_sorted); OA_FREE(d_todo_list); OA_FREE(d_todo_count); OA_FREE(d_src4); OA_FREE(d_keys); OA_FREE(d_state);
     OA_FREE(d_partials); OA_FREE(d_sums); OA_FREE(d_solve);
     OA_FREE(d_valid); OA_FREE(d_b); OA_FREE(d_dist); OA_FREE(d_counts); OA_FREE(d_offsets); OA_FREE(d_A); OA_FREE(d_B);
@@ -2000,7 +2010,7 @@ int build_filter(oa_ctx *c)
 int build_grid(oa_ctx *c)
 {
     c->grid_ok = false;
-    dev_free(c->d_cell_start); dev_free(c->d_sorted);
+    dev_free(c->d_cell_start); dev_free(c->d_sorted); dev_free(c->d_safe_sorted);
     if (!c->filter_ok || c->grid_mode == 0 || c->nt < 2) return OA_OK;
     if ((long long)c->nt > oa::GRID_MAX_TARGETS) return OA_OK;       // k_nn_search_grid addresses `sorted` through 32-bit byte offsets; the tree takes over
     double ext[3], vol = 1.0, scale = 0.0;
@@ -2065,6 +2075,10 @@ int build_grid(oa_ctx *c)
     hipLaunchKernelGGL(oa::k_grid_starts, dim3((n_cells + 256) / 256), dim3(256), 0, c->stream, d_off.p, n_cells, c->d_cell_start, d_counts.p);
     hipLaunchKernelGGL(oa::k_grid_scatter, dim3((c->nt + 255) / 256), dim3(256), 0, c->stream, c->d_tgt_xyz, c->nt, d_cell_of.p, c->d_cell_start, d_counts.p, c->d_sorted);
     HIPCHK(hipGetLastError());
+    // safe radii per position of `sorted` (k_grid_safe_radius): a seed within its own settles the query without a scan
+    HIPCHK(dev_malloc(&c->d_safe_sorted, sizeof(float) * (size_t)c->nt));
+    hipLaunchKernelGGL(oa::k_grid_safe_radius, dim3((c->nt + 255) / 256), dim3(256), 0, c->stream, (const float4 *)c->d_sorted, c->nt, gp, (const int *)c->d_cell_start, c->d_safe_sorted);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     c->gp = gp; c->n_cells = n_cells; c->grid_ok = true;
     return OA_OK;
@@ -2100,6 +2114,7 @@ int set_target_common(oa_ctx *c, const float *xyz, int64_t n, int on_device, boo
     if (c->d_prev) {   // seeds index the old target
         hipLaunchKernelGGL(oa::k_fill_int, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, c->d_prev, c->ns_pad, -1);
         HIPCHK(hipMemsetAsync(c->d_win, 0xFF, sizeof(float4) * (size_t)c->ns_pad, c->stream));
+        if (c->d_wsafe) HIPCHK(hipMemsetAsync(c->d_wsafe, 0xFF, sizeof(uint2) * (size_t)c->ns_pad, c->stream));   // safe radii belong to the old target's indices
         HIPCHK(hipStreamSynchronize(c->stream));
     }
     if (n == 0) return OA_OK;
@@ -2536,7 +2551,7 @@ int source_reset(oa_ctx *c, long long count, long long begin, long long n_verts)
 {
     HIPCHK(hipStreamSynchronize(c->stream));
     c->loop_active = false;                                         // an open oa_iterate sequence ends with the old source
-    dev_free(c->d_src4); dev_free(c->d_keys); dev_free(c->d_prev); dev_free(c->d_win); dev_free(c->d_sel); dev_free(c->d_src_n);
+    dev_free(c->d_src4); dev_free(c->d_keys); dev_free(c->d_prev); dev_free(c->d_win); dev_free(c->d_wsafe); dev_free(c->d_sel); dev_free(c->d_src_n);
     dev_free(c->d_src4o); dev_free(c->d_perm); dev_free(c->d_members); dev_free(c->d_pos);
     c->h_members.clear();
     c->shard_begin = begin;
@@ -2556,6 +2571,8 @@ int source_reset(oa_ctx *c, long long count, long long begin, long long n_verts)
     HIPCHK(dev_malloc(&c->d_prev, sizeof(int) * (size_t)c->ns_pad));
     HIPCHK(dev_malloc(&c->d_win, sizeof(float4) * (size_t)c->ns_pad));
     HIPCHK(hipMemsetAsync(c->d_win, 0xFF, sizeof(float4) * (size_t)c->ns_pad, c->stream));
+    HIPCHK(dev_malloc(&c->d_wsafe, sizeof(uint2) * (size_t)c->ns_pad));
+    HIPCHK(hipMemsetAsync(c->d_wsafe, 0xFF, sizeof(uint2) * (size_t)c->ns_pad, c->stream));
     c->seeded = false;
     HIPCHK(dev_malloc(&c->d_sel, sizeof(int) * (size_t)c->ns_pad));
     HIPCHK(hipMemsetAsync(c->d_sel, 0, sizeof(int) * (size_t)c->ns_pad, c->stream));
@@ -2848,6 +2865,7 @@ OA_EXPORT int oa_reset_seeds(oa_ctx *c)
     hipLaunchKernelGGL(oa::k_fill_int, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, c->d_prev, c->ns_pad, -1);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(c->d_win, 0xFF, sizeof(float4) * (size_t)c->ns_pad, c->stream));
+    if (c->d_wsafe) HIPCHK(hipMemsetAsync(c->d_wsafe, 0xFF, sizeof(uint2) * (size_t)c->ns_pad, c->stream));
     return OA_OK;
 }
 
