@@ -135,57 +135,6 @@ __global__ void k_grid_scatter(const float *__restrict__ xyz, int nt, const int 
     sorted[pos] = make_float4(xyz[3ll * i], xyz[3ll * i + 1], xyz[3ll * i + 2], __int_as_float(i));
 }
 
-// ---- safe radii (round 4): when the seed alone settles a query --------------------------------------------------------
-// For target t let S(t) = the distance to the nearest OTHER target.  A query p with |p - t| < S(t) / 2 has t as its
-// nearest target, strictly: any other t' is at |p - t'| >= |t - t'| - |p - t| > S / 2.  The build stores, per position
-// of `sorted`, safe2 = (S / 2)^2 (1 - 1e-4) as a float; the margin covers the float metric's rounding on both sides
-// (d2_metric is in difference form: relative error < 3e-7 of the true squared distance), so d2_metric(p, t) < safe2
-// implies d2_metric(p, t') > d2_metric(p, t) for every other target -- no tie either: brute force would report exactly
-// (d2, t).  S is a LOWER bound: the minimum over the 3 x 3 x 3 block of cells around t's cell, capped by the distance
-// to everything outside the block (>= h - slack); 0 = "never" for duplicates, crowded blocks (the build does not walk
-// more than SAFE_SCAN_MAX candidates per target) and radii below the float normal range (underflow in the metric).
-// The search (k_nn_search_grid) keeps {index, safe2} of a slot's winner next to its winner record (`wsafe`); an
-// entry whose index is not the seed's says nothing -- other kernels write winner records and know nothing of this.
-constexpr int SAFE_SCAN_MAX = 1024;
-__global__ void k_grid_safe_radius(const float4 *__restrict__ sorted, int nt, GridParams gp, const int *__restrict__ cell_start,
-                                   float *__restrict__ safe_sorted)
-{
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= nt) return;
-    const float4 t = sorted[j];
-    const int cx = grid_cell_coord((double)t.x, gp.lo[0], gp.inv_h, gp.n[0]);
-    const int cy = grid_cell_coord((double)t.y, gp.lo[1], gp.inv_h, gp.n[1]);
-    const int cz = grid_cell_coord((double)t.z, gp.lo[2], gp.inv_h, gp.n[2]);
-    const int xa = max(cx - 1, 0), xb = min(cx + 1, gp.n[0] - 1);
-    int total = 0;
-    for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) {
-        const int z = cz + dz, y = cy + dy;
-        if (z < 0 || z >= gp.n[2] || y < 0 || y >= gp.n[1]) continue;
-        const int row = (z * gp.n[1] + y) * gp.n[0];
-        total += cell_start[row + xb + 1] - cell_start[row + xa];
-    }
-    float out = 0.f;
-    if (total <= SAFE_SCAN_MAX) {
-        const float cap = fmaxf(gp.hf * 0.999999f - gp.slackf, 0.f);
-        float m = cap * cap;
-        for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) {
-            const int z = cz + dz, y = cy + dy;
-            if (z < 0 || z >= gp.n[2] || y < 0 || y >= gp.n[1]) continue;
-            const int row = (z * gp.n[1] + y) * gp.n[0];
-            const int ka = cell_start[row + xa], kb = cell_start[row + xb + 1];
-            for (int k = ka; k < kb; ++k) {
-                if (k == j) continue;
-                const float4 o = sorted[k];
-                const float d = d2_metric(t.x, t.y, t.z, o.x, o.y, o.z);
-                if (d < m) m = d;                                   // (a non-finite neighbour can never win a search: ignored)
-            }
-        }
-        out = 0.25f * m * 0.9999f;
-        if (!(out >= 1e-30f)) out = 0.f;
-    }
-    safe_sorted[j] = out;
-}
-
 // ---- the query's frame in the grid -----------------------------------------------------------------------------------
 // Located once per query in double (projection onto the grid's box, own cell, position inside that cell); everything
 // per row / per ring afterwards is float arithmetic on three numbers per axis.  All distances derived from it are
@@ -285,6 +234,59 @@ __device__ __forceinline__ int grid_ld_cell(const int *__restrict__ base, int id
 __device__ __forceinline__ float4 grid_ld_vertex(const float4 *__restrict__ base, int idx)
 {
     return *(const float4 *)((const char *)base + (unsigned)idx * 16u);
+}
+
+// ---- safe radii (round 4): when the seed alone settles a query --------------------------------------------------------
+// For target t let S(t) = the distance to the nearest OTHER target.  A query p with |p - t| < S(t) / 2 has t as its
+// nearest target, strictly: any other t' is at |p - t'| >= |t - t'| - |p - t| > S / 2.  The build stores, per target
+// (original index), safe2 = (S / 2)^2 (1 - 1e-4) as a float; the margin covers the float metric's rounding on both sides
+// (d2_metric is in difference form: relative error < 3e-7 of the true squared distance), so d2_metric(p, t) < safe2
+// implies d2_metric(p, t') > d2_metric(p, t) for every other target -- no tie either: brute force would report exactly
+// (d2, t).  S is a LOWER bound: the minimum over the 3 x 3 x 3 block of cells around t's cell, capped by the distance
+// to everything outside the block (>= h - slack); 0 = "never" for duplicates, crowded blocks (the build does not walk
+// more than SAFE_SCAN_MAX candidates per target) and radii below the float normal range (underflow in the metric).
+// The search (k_nn_search_grid) keeps {index, safe2} of a slot's winner next to its winner record (`wsafe`, one gather
+// from the radii when the winner changes); an entry whose index is not the seed's says nothing -- other kernels write
+// winner records and know nothing of this -- and is brought up to date by the search that finds it so.
+constexpr int SAFE_SCAN_MAX = 1024;
+__global__ void k_grid_safe_radius(const float4 *__restrict__ sorted, int nt, GridParams gp, const int *__restrict__ cell_start,
+                                   float *__restrict__ safe_by_idx)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nt) return;
+    const float4 t = sorted[j];
+    const int cx = grid_cell_coord((double)t.x, gp.lo[0], gp.inv_h, gp.n[0]);
+    const int cy = grid_cell_coord((double)t.y, gp.lo[1], gp.inv_h, gp.n[1]);
+    const int cz = grid_cell_coord((double)t.z, gp.lo[2], gp.inv_h, gp.n[2]);
+    const int xa = max(cx - 1, 0), xb = min(cx + 1, gp.n[0] - 1);
+    // the nine rows' ranges of `sorted` (cells are x-fastest: three cells of a row are one range), all loads in flight together
+    int ka[9], kb[9], total = 0;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        const int z = cz + r / 3 - 1, y = cy + r % 3 - 1;
+        const bool in = z >= 0 && z < gp.n[2] && y >= 0 && y < gp.n[1];
+        const int row = in ? (z * gp.n[1] + y) * gp.n[0] : 0;
+        ka[r] = in ? grid_ld_cell(cell_start, row + xa) : 0;
+        kb[r] = in ? grid_ld_cell(cell_start, row + xb + 1) : 0;
+    }
+#pragma unroll
+    for (int r = 0; r < 9; ++r) total += kb[r] - ka[r];
+    float out = 0.f;
+    if (total <= SAFE_SCAN_MAX) {
+        const float cap = fmaxf(gp.hf * 0.999999f - gp.slackf, 0.f);
+        float m = cap * cap;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            for (int k = ka[r]; k < kb[r]; ++k) {
+                const float4 o = grid_ld_vertex(sorted, k);
+                const float d = d2_metric(t.x, t.y, t.z, o.x, o.y, o.z);
+                if (d < m && k != j) m = d;                         // (a non-finite neighbour can never win a search: ignored)
+            }
+        }
+        out = 0.25f * m * 0.9999f;
+        if (!(out >= 1e-30f)) out = 0.f;
+    }
+    safe_by_idx[(uint32_t)__float_as_int(t.w)] = out;           // by ORIGINAL index: the searches look it up for a slot's winner
 }
 
 __device__ __forceinline__ uint32_t grid_ld_safe(const float *__restrict__ base, int idx)
@@ -410,7 +412,7 @@ constexpr int GRID_SEGS = 10;      // ranges of one batch: 9 rows of the first b
 // candidate counts, one row of GRID_STAT_N counters per wave in `stats`
 enum { GRID_STAT_WAVES, GRID_STAT_CYC_TOTAL, GRID_STAT_CYC_PROLOGUE, GRID_STAT_CYC_LIST, GRID_STAT_CYC_SCAN, GRID_STAT_CYC_BOOK,
        GRID_STAT_CYC_FINISH, GRID_STAT_CYC_EPILOGUE, GRID_STAT_LOOP_TRIPS, GRID_STAT_SCAN_TRIPS, GRID_STAT_CANDIDATES,
-       GRID_STAT_MAX_LANE_CANDIDATES, GRID_STAT_ACCEPTED, GRID_STAT_N };
+       GRID_STAT_MAX_LANE_CANDIDATES, GRID_STAT_ACCEPTED, GRID_STAT_CYC_EPI_PAIR, GRID_STAT_CYC_EPI_REDUCE, GRID_STAT_CYC_EPI_BARRIER, GRID_STAT_N };
 template <int L, bool ACC = false, int BT = 256, bool STATS = false>
 #ifndef OA_GRID_MIN_WAVES
 #define OA_GRID_MIN_WAVES 6
@@ -426,7 +428,7 @@ __global__ __launch_bounds__(BT, OA_GRID_MIN_WAVES) void k_nn_search_grid(const 
                                                         const float4 *__restrict__ prims = nullptr, NormalTest nrm = NormalTest{},
                                                         double *__restrict__ partials = nullptr,
                                                         unsigned long long *__restrict__ stats = nullptr,
-                                                        const float *__restrict__ safe_sorted = nullptr,
+                                                        const float *__restrict__ safe_by_idx = nullptr,
                                                         uint2 *__restrict__ wsafe = nullptr)
 {
     long long cyc_t0 = 0, cyc_mark = 0, cyc_prologue = 0, cyc_list = 0, cyc_scan = 0, cyc_book = 0, cyc_finish = 0;
@@ -632,10 +634,10 @@ __global__ __launch_bounds__(BT, OA_GRID_MIN_WAVES) void k_nn_search_grid(const 
         keys[i] = ((unsigned long long)__float_as_uint(best) << 32) | bidx;
         // the winner record is read by k_pair_accumulate, the tree search and the next search; a winner that is still the
         // seed (the usual case once the loop converges) is already there
-        if (bj >= 0) {
-            win[i] = sorted[bj];
-            if (wsafe) grid_st_safe(wsafe, i, bidx, grid_ld_safe(safe_sorted, bj));
-        }
+        if (bj >= 0) win[i] = sorted[bj];
+        // the winner's safe radius beside its record: a new winner's, or the seed's when the slot's entry spoke of another vertex
+        // (the entry's index is read again here rather than a flag held through the scan)
+        if (wsafe && bidx != IDX_NONE && grid_ld_safe((const float *)wsafe, 2 * i) != bidx) grid_st_safe(wsafe, i, bidx, grid_ld_safe(safe_by_idx, (int)bidx));
         if (!settled) todo_list[atomicAdd(todo_count, 1)] = i;      // finished exactly by the tree search (k_bvh_search)
         // How crowded the hand-over is per wave: what the host looks at before it lets a later search finish its own leftovers
         // (grid_fast_now).  Counted against the BASE budget: a search that ran on the doubled one -- the first of a loop, or
@@ -653,6 +655,9 @@ __global__ __launch_bounds__(BT, OA_GRID_MIN_WAVES) void k_nn_search_grid(const 
     const float4 *src_again = src4;
     asm volatile("" : "+s"(src_again));
     const float4 a4 = src_again[i];
+    // ... and the index of the slot's safe-radius entry (rather than a flag held through the scan)
+    uint32_t ws_idx = IDX_NONE;
+    if (wsafe) ws_idx = grid_ld_safe((const float *)wsafe, 2 * i);
     float4 wq = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));  // the winner's record: the seed's, or the scan's
     if (mine && bidx != IDX_NONE) wq = bj >= 0 ? sorted[bj] : win[i];      // (bj < 0: still the seed, re-read rather than kept in registers through the scan)
     bool changed = mine && bj >= 0;
@@ -678,15 +683,13 @@ __global__ __launch_bounds__(BT, OA_GRID_MIN_WAVES) void k_nn_search_grid(const 
                 float tx = __shfl(wq.x, l, 64), ty = __shfl(wq.y, l, 64), tz = __shfl(wq.z, l, 64);
                 const uint32_t bi0 = bi;
                 bvh_wave_query<false>(bp, boxes, prims, qp, __shfl(cutf, l, 64), b, bi, tx, ty, tz, lds, lane);
-                if (lane == l && bi != bi0) { best = b; bidx = bi; wq = make_float4(tx, ty, tz, __int_as_float((int)bi)); changed = true; bj = -1; }
+                if (lane == l && bi != bi0) { best = b; bidx = bi; wq = make_float4(tx, ty, tz, __int_as_float((int)bi)); changed = true; }
             }
         }
     }
-    if (changed) {                                                // the next search's seed (and what a one-shot call would read)
-        win[i] = wq;
-        // its safe radius, when the scan found it (bj = its position in `sorted`); a winner the tree reported has none on record
-        if (wsafe) grid_st_safe(wsafe, i, bidx, bj >= 0 ? grid_ld_safe(safe_sorted, bj) : 0u);
-    }
+    if (changed) win[i] = wq;                                     // the next search's seed (and what a one-shot call would read)
+    // the winner's safe radius beside its record: a new winner's, or the seed's when the slot's entry spoke of another vertex
+    if (wsafe && mine && bidx != IDX_NONE && ws_idx != bidx) grid_st_safe(wsafe, i, bidx, grid_ld_safe(safe_by_idx, (int)bidx));
     OA_GRID_STAMP(cyc_finish);
     bool valid = false;
     float vbx = 0.f, vby = 0.f, vbz = 0.f;
@@ -697,8 +700,10 @@ __global__ __launch_bounds__(BT, OA_GRID_MIN_WAVES) void k_nn_search_grid(const 
         valid = pair_eval(st, px, py, pz, wq.x, wq.y, wq.z, nrm, i, tn, st->thresh, vbx, vby, vbz, dist);
     }
     const double pvx = st->pivot[0], pvy = st->pivot[1], pvz = st->pivot[2];
+    long long epi_stamps[2] = { 0, 0 };
+    const long long cyc_pair = STATS ? (long long)__builtin_readcyclecounter() : 0;     // loads + pair test done (epilogue started at cyc_mark)
     block_store_pair(valid, (double)a4.x - pvx, (double)a4.y - pvy, (double)a4.z - pvz, (double)vbx - pvx, (double)vby - pvy,
-                     (double)vbz - pvz, dist - st->d_pivot, red, partials + (long long)vb * NSUMS);
+                     (double)vbz - pvz, dist - st->d_pivot, red, partials + (long long)vb * NSUMS, STATS ? epi_stamps : nullptr);
     if (STATS && stats) {
         const long long now = (long long)__builtin_readcyclecounter();
         int sum = n_cand, mx = n_cand;
@@ -718,17 +723,29 @@ __global__ __launch_bounds__(BT, OA_GRID_MIN_WAVES) void k_nn_search_grid(const 
             row[GRID_STAT_CANDIDATES] = (unsigned long long)sum;
             row[GRID_STAT_MAX_LANE_CANDIDATES] = (unsigned long long)mx;
             row[GRID_STAT_ACCEPTED] = (unsigned long long)n_accepted;
+            row[GRID_STAT_CYC_EPI_PAIR] = (unsigned long long)(cyc_pair - cyc_mark);
+            row[GRID_STAT_CYC_EPI_REDUCE] = (unsigned long long)(epi_stamps[0] - cyc_pair);
+            row[GRID_STAT_CYC_EPI_BARRIER] = (unsigned long long)(epi_stamps[1] - epi_stamps[0]);
         }
     }
 #undef OA_GRID_STAMP
 }
 
+// (one atomic per WORKGROUP of a grid-stride launch: with one per wave -- 8000 of them on one word for the 500k cells of a
+//  1M-vertex target -- the counter's serialised atomics were 92 us of a 0.8 ms target upload)
 __global__ void k_count_nonzero(const int *__restrict__ a, int n, int *__restrict__ out)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool nz = (i < n) && a[i] != 0;
-    const unsigned long long m = __ballot(nz);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, __popcll(m));
+    __shared__ int part[16];
+    int cnt = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) cnt += a[i] != 0 ? 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int sum = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) sum += part[w];
+        if (sum) atomicAdd(out, sum);
+    }
 }
 
 #endif  // __HIPCC__

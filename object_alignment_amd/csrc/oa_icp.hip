@@ -382,8 +382,11 @@ struct oa_ctx {
     int *d_prev = nullptr;           // nearest index of the previous search (seed), -1 = none
     float4 *d_win = nullptr;         // vertex mode: per slot, the last winner's coordinates + index in .w (-1 = none)
     uint2 *d_wsafe = nullptr;        // vertex grid: per slot {index, safe2 bits} of a winner the grid scan found (k_grid_safe_radius); 0xFF.. = none
-    float *d_safe_sorted = nullptr;  // vertex grid: safe2 per position of d_sorted
-    bool grid_safe = true;           // OA_GRID_SAFE=0 (A/B): the vertex grid search never takes a seed on its safe radius
+    float *d_safe_by_idx = nullptr;  // vertex grid: safe2 per target vertex (original index)
+    int grid_safe = 1;               // OA_GRID_SAFE: 0 = the vertex grid search never takes a seed on its safe radius (A/B); 1 = the radii are
+                                     // built once a target has seen SAFE_LAZY_ITERS loop iterations of a large shard (a 5-iteration call
+                                     // would pay 50 us to save 10); 2 = built with the grid
+    long long target_iters = 0;      // accumulating grid searches enqueued since the target was set
     int *d_sel = nullptr;            // vertex index held by each source slot
     float4 *d_src4o = nullptr;       // the same points in the caller's (vlist) order -- only oa_make_pairs needs it
     int *d_perm = nullptr;           // sorted slot -> caller-order slot (nullptr: not sorted)
@@ -586,6 +589,8 @@ inline bool bvh_whole(const oa_ctx *c, bool ok, int auto_max)
     return c->grid_mode == 2 || (c->grid_mode == -1 && c->ns <= auto_max);
 }
 int build_grid(oa_ctx *c);
+int build_safe_radii(oa_ctx *c);
+constexpr long long SAFE_LAZY_ITERS = 8;   // OA_GRID_SAFE=1: loop iterations a target has to see before its safe radii are built
 int build_tri_grid(oa_ctx *c);
 int build_bvh(oa_ctx *c, bool tri);
 int scan_counts(oa_ctx *c, const int *d_counts, int n, long long *d_off);
@@ -750,10 +755,14 @@ int launch_nn_impl(oa_ctx *c, bool acc)
 #define OA_GRID_ARGS c->d_state, c->d_src4, c->ns, c->gp, c->d_cell_start, c->d_sorted, c->d_win, c->d_keys, c->d_todo_list, c->d_todo_count, turn
 #define OA_GRID_ACC_ARGS OA_GRID_ARGS, c->bvh, (const float4 *)c->d_bvh_box, (const float4 *)c->d_bvh_prims, normal_test(c), c->d_partials
         // {index, safe2} per slot beside the winner records: both or neither (OA_GRID_SAFE=0)
-        const float *safe_sorted = c->grid_safe ? c->d_safe_sorted : nullptr;
-        uint2 *wsafe = safe_sorted ? c->d_wsafe : nullptr;
-        if (!wsafe) safe_sorted = nullptr;
-#define OA_GRID_SAFE_ARGS safe_sorted, wsafe
+        if (acc && c->grid_safe == 1 && !c->d_safe_by_idx && ++c->target_iters > SAFE_LAZY_ITERS && (long long)c->ns * lanes >= 262144) {
+            const int rcs = build_safe_radii(c);
+            if (rcs) return rcs;
+        }
+        const float *safe_by_idx = c->grid_safe ? c->d_safe_by_idx : nullptr;
+        uint2 *wsafe = safe_by_idx ? c->d_wsafe : nullptr;
+        if (!wsafe) safe_by_idx = nullptr;
+#define OA_GRID_SAFE_ARGS safe_by_idx, wsafe
         const dim3 gblocks((unsigned)(((long long)c->ns * lanes + 255) / 256));
         if (acc) {
             const dim3 ablocks((unsigned)canon_blocks(c));
@@ -773,11 +782,12 @@ int launch_nn_impl(oa_ctx *c, bool acc)
                     for (size_t w = 0; w < n_waves; ++w) for (int k = 0; k < oa::GRID_STAT_N; ++k) h[k] += rows[w * oa::GRID_STAT_N + (size_t)k];
                     const double nw = (double)std::max(1ull, h[oa::GRID_STAT_WAVES]), ct = (double)std::max(1ull, h[oa::GRID_STAT_CYC_TOTAL]);
                     fprintf(stderr, "[oa] vertex grid phases: %llu of %d queries settled by the seed's safe radius | per wave %.0f shader cycles, %.2f loop trips, %.2f scan trips, %.1f candidates per query (longest lane of a wave %.1f) | "
-                                    "prologue %.1f%% listing %.1f%% scan %.1f%% bookkeeping %.1f%% finish %.1f%% epilogue %.1f%%\n",
+                                    "prologue %.1f%% listing %.1f%% scan %.1f%% bookkeeping %.1f%% finish %.1f%% epilogue %.1f%% (loads + pair test %.1f%%, wave reduction %.1f%%, barrier %.1f%%)\n",
                             h[oa::GRID_STAT_ACCEPTED], c->ns, ct / nw, h[oa::GRID_STAT_LOOP_TRIPS] / nw, h[oa::GRID_STAT_SCAN_TRIPS] / nw, h[oa::GRID_STAT_CANDIDATES] / (64.0 * nw),
                             h[oa::GRID_STAT_MAX_LANE_CANDIDATES] / nw, 100.0 * h[oa::GRID_STAT_CYC_PROLOGUE] / ct, 100.0 * h[oa::GRID_STAT_CYC_LIST] / ct,
                             100.0 * h[oa::GRID_STAT_CYC_SCAN] / ct, 100.0 * h[oa::GRID_STAT_CYC_BOOK] / ct, 100.0 * h[oa::GRID_STAT_CYC_FINISH] / ct,
-                            100.0 * h[oa::GRID_STAT_CYC_EPILOGUE] / ct);
+                            100.0 * h[oa::GRID_STAT_CYC_EPILOGUE] / ct, 100.0 * h[oa::GRID_STAT_CYC_EPI_PAIR] / ct, 100.0 * h[oa::GRID_STAT_CYC_EPI_REDUCE] / ct,
+                            100.0 * h[oa::GRID_STAT_CYC_EPI_BARRIER] / ct);
                 }
                 else hipLaunchKernelGGL((oa::k_nn_search_grid<1, true, 512>), ablocks, dim3(512), 0, c->stream, OA_GRID_ACC_ARGS, (unsigned long long *)nullptr, OA_GRID_SAFE_ARGS);
             } else {
@@ -1753,7 +1763,7 @@ OA_EXPORT int oa_create(oa_ctx **out, int device)
     c->debug = getenv("OA_DEBUG") != nullptr;
     c->grid_stats = env_int("OA_GRID_STATS", 0) != 0;
     c->tri_share = env_int("OA_TRI_SHARE", 1) != 0;
-    c->grid_safe = env_int("OA_GRID_SAFE", 1) != 0;
+    c->grid_safe = std::max(0, std::min(2, env_int("OA_GRID_SAFE", 1)));
     c->tri_canon = env_int("OA_TRI_CANON", 1) != 0;
     c->list_blocks_per_cu = std::max(1, std::min(64, env_int("OA_LIST_BLOCKS_PER_CU", 16)));
     c->tri_acc = env_int("OA_TRI_ACC", 1) != 0;
@@ -1896,7 +1906,7 @@ OA_EXPORT void oa_destroy(oa_ctx *c)
     (void)hipDeviceSynchronize();
     tl_stream_known = false;                                        // the stream below is about to go away
 #define OA_FREE(x) dev_free(c->x, true)
-    OA_FREE(d_tgt_xyz); OA_FREE(d_tg); OA_FREE(d_tf); OA_FREE(d_tf3); OA_FREE(d_tfm); OA_FREE(d_members); OA_FREE(d_pos); OA_FREE(d_prev); OA_FREE(d_win); OA_FREE(d_wsafe); OA_FREE(d_safe_sorted); OA_FREE(d_cell_start);
+    OA_FREE(d_tgt_xyz); OA_FREE(d_tg); OA_FREE(d_tf); OA_FREE(d_tf3); OA_FREE(d_tfm); OA_FREE(d_members); OA_FREE(d_pos); OA_FREE(d_prev); OA_FREE(d_win); OA_FREE(d_wsafe); OA_FREE(d_safe_by_idx); OA_FREE(d_cell_start);
     OA_FREE(d_sorted); OA_FREE(d_todo_list); OA_FREE(d_todo_count); OA_FREE(d_src4); OA_FREE(d_keys); OA_FREE(d_state);
     OA_FREE(d_partials); OA_FREE(d_sums); OA_FREE(d_solve);
     OA_FREE(d_valid); OA_FREE(d_b); OA_FREE(d_dist); OA_FREE(d_counts); OA_FREE(d_offsets); OA_FREE(d_A); OA_FREE(d_B);
@@ -2006,11 +2016,23 @@ int build_filter(oa_ctx *c)
     return OA_OK;
 }
 
+// safe radii per target vertex (k_grid_safe_radius): a seed within its own settles the query without a scan.  One
+// launch on the context's stream, no wait: the searches that use the radii are enqueued behind it.
+int build_safe_radii(oa_ctx *c)
+{
+    if (!c->grid_ok || c->d_safe_by_idx || c->nt < 2) return OA_OK;
+    HIPCHK(dev_malloc(&c->d_safe_by_idx, sizeof(float) * (size_t)c->nt));
+    hipLaunchKernelGGL(oa::k_grid_safe_radius, dim3((c->nt + 255) / 256), dim3(256), 0, c->stream, (const float4 *)c->d_sorted, c->nt, c->gp,
+                       (const int *)c->d_cell_start, c->d_safe_by_idx);
+    HIPCHK(hipGetLastError());
+    return OA_OK;
+}
+
 // uniform grid over the target for k_nn_search_grid (needs the finite bbox build_filter found)
 int build_grid(oa_ctx *c)
 {
     c->grid_ok = false;
-    dev_free(c->d_cell_start); dev_free(c->d_sorted); dev_free(c->d_safe_sorted);
+    dev_free(c->d_cell_start); dev_free(c->d_sorted); dev_free(c->d_safe_by_idx);
     if (!c->filter_ok || c->grid_mode == 0 || c->nt < 2) return OA_OK;
     if ((long long)c->nt > oa::GRID_MAX_TARGETS) return OA_OK;       // k_nn_search_grid addresses `sorted` through 32-bit byte offsets; the tree takes over
     double ext[3], vol = 1.0, scale = 0.0;
@@ -2059,7 +2081,7 @@ int build_grid(oa_ctx *c)
         HIPCHK(hipMemsetAsync(d_counts, 0, sizeof(int) * ((size_t)n_cells + 1), c->stream));
         HIPCHK(hipMemsetAsync(d_nz, 0, sizeof(int), c->stream));
         hipLaunchKernelGGL(oa::k_grid_count, dim3((c->nt + 255) / 256), dim3(256), 0, c->stream, c->d_tgt_xyz, c->nt, gp, d_cell_of.p, d_counts.p);
-        hipLaunchKernelGGL(oa::k_count_nonzero, dim3((n_cells + 255) / 256), dim3(256), 0, c->stream, d_counts.p, n_cells, d_nz.p);
+        hipLaunchKernelGGL(oa::k_count_nonzero, dim3((unsigned)std::min(512, (n_cells + 1023) / 1024)), dim3(1024), 0, c->stream, d_counts.p, n_cells, d_nz.p);
         HIPCHK(hipGetLastError());
         int occupied = 0;
         { int rcr = read_small(c, &occupied, d_nz, sizeof(int)); if (rcr) return rcr; }
@@ -2075,12 +2097,10 @@ int build_grid(oa_ctx *c)
     hipLaunchKernelGGL(oa::k_grid_starts, dim3((n_cells + 256) / 256), dim3(256), 0, c->stream, d_off.p, n_cells, c->d_cell_start, d_counts.p);
     hipLaunchKernelGGL(oa::k_grid_scatter, dim3((c->nt + 255) / 256), dim3(256), 0, c->stream, c->d_tgt_xyz, c->nt, d_cell_of.p, c->d_cell_start, d_counts.p, c->d_sorted);
     HIPCHK(hipGetLastError());
-    // safe radii per position of `sorted` (k_grid_safe_radius): a seed within its own settles the query without a scan
-    HIPCHK(dev_malloc(&c->d_safe_sorted, sizeof(float) * (size_t)c->nt));
-    hipLaunchKernelGGL(oa::k_grid_safe_radius, dim3((c->nt + 255) / 256), dim3(256), 0, c->stream, (const float4 *)c->d_sorted, c->nt, gp, (const int *)c->d_cell_start, c->d_safe_sorted);
-    HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     c->gp = gp; c->n_cells = n_cells; c->grid_ok = true;
+    c->target_iters = 0;
+    if (c->grid_safe == 2) return build_safe_radii(c);
     return OA_OK;
 }
 

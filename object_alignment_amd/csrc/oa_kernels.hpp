@@ -1208,7 +1208,8 @@ __device__ __forceinline__ void wave_reduce_scatter(double (&v)[N], int lane, do
 // costs +8 us with 16 of them and +16..23 us with 64, with or without fences.  So: one row per workgroup, one wide
 // single-workgroup reduction behind it.)
 __device__ __forceinline__ void block_store_pair(bool valid, double a0, double a1, double a2, double b0, double b1, double b2,
-                                                 double dd, double (*red)[NSUMS], double *__restrict__ row)
+                                                 double dd, double (*red)[NSUMS], double *__restrict__ row,
+                                                 long long *stamps = nullptr)      // instrumented builds: clock after the wave's part, after the barrier
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (!valid) { a0 = a1 = a2 = b0 = b1 = b2 = dd = 0.0; }
@@ -1222,7 +1223,9 @@ __device__ __forceinline__ void block_store_pair(bool valid, double a0, double a
         wave_reduce_scatter<8>(h, lane, &red[wave][12]);
     }
     if (lane < 4) red[wave][20 + lane] = 0.0;                                                                   // reserved
+    if (stamps) stamps[0] = (long long)__builtin_readcyclecounter();
     __syncthreads();
+    if (stamps) stamps[1] = (long long)__builtin_readcyclecounter();
     if (threadIdx.x < NSUMS) {
         double v = red[0][threadIdx.x];
         for (int w = 1; w < (int)(blockDim.x >> 6); ++w) v += red[w][threadIdx.x];

@@ -48,8 +48,8 @@ def test_safe_radius_edge_queries_equal_brute_force(lanes, monkeypatch):
     poses = [synth.rigid4(None, [1e-5, -2e-5, 1.5e-5]), eye, synth.rigid4(None, [-3e-6, 2e-6, 1e-6]), eye,
              synth.rigid4(synth.rotation_from_rotvec([1e-5, -1e-5, 2e-5]), [0.0, 0.0, 0.0]), eye]
     out = {}
-    for tag, mode, env in (("safe", "grid", "1"), ("nosafe", "grid", "0"), ("brute", "brute", "1")):
-        monkeypatch.setenv("OA_GRID_SAFE", env)
+    for tag, mode, env in (("safe", "grid", "2"), ("nosafe", "grid", "0"), ("brute", "brute", "2")):
+        monkeypatch.setenv("OA_GRID_SAFE", env)                 # 2: radii built with the grid (the default builds them after 8 loop iterations)
         with IcpEngine(0) as e:
             e.set_search_mode(mode)
             e.set_target(tgt)
@@ -84,8 +84,8 @@ def test_safe_radius_loops_same_bits_as_without(orc, case, monkeypatch):
     if case == "dups":
         tgt = np.ascontiguousarray(np.concatenate([tgt, tgt[::7], tgt[::11] * np.float32(1.0 + 1e-7)]).astype(np.float32))
     out = {}
-    for tag, env in (("safe_on", {"OA_GRID_SAFE": "1"}), ("safe_off", {"OA_GRID_SAFE": "0"}),
-                     ("on_fast", {"OA_GRID_SAFE": "1", "OA_GRID_PATH": "fast"}), ("on_safe_path", {"OA_GRID_SAFE": "1", "OA_GRID_PATH": "safe"})):
+    for tag, env in (("safe_on", {"OA_GRID_SAFE": "2"}), ("safe_off", {"OA_GRID_SAFE": "0"}),
+                     ("on_fast", {"OA_GRID_SAFE": "2", "OA_GRID_PATH": "fast"}), ("on_safe_path", {"OA_GRID_SAFE": "2", "OA_GRID_PATH": "safe"})):
         monkeypatch.delenv("OA_GRID_PATH", raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -109,7 +109,9 @@ def test_safe_radius_loops_same_bits_as_without(orc, case, monkeypatch):
 @pytest.mark.gpu
 def test_safe_radius_is_taken_once_the_pose_settles(capfd, monkeypatch):
     """The instrumented build (OA_GRID_STATS=1) reports how many queries the rule settled: most of a noisy copy of the
-    target once the pose has converged, none with OA_GRID_SAFE=0 -- and the two runs end with the same bits."""
+    target once the pose has converged (OA_GRID_SAFE=2: radii built with the grid), the same from the tenth iteration on
+    with the default (radii built after eight iterations of a large shard: short calls never pay for them), none with
+    OA_GRID_SAFE=0 -- and the three runs end with the same bits."""
     from object_alignment_amd import synth
     from object_alignment_amd.engine import IcpEngine
     src, tgt, mxa, mxb = synth.c3_random_pair(300_000, seed=77)
@@ -117,21 +119,24 @@ def test_safe_radius_is_taken_once_the_pose_settles(capfd, monkeypatch):
     monkeypatch.setenv("OA_GRID_PATH", "fast")
     monkeypatch.setenv("OA_GRID_LANES", "1")                         # (the instrumented kernel is the one-lane-per-query form)
     got = {}
-    for env in ("1", "0"):
-        monkeypatch.setenv("OA_GRID_SAFE", env)
+    for env in ("2", "1", "0"):
+        monkeypatch.setenv("OA_GRID_SAFE", env)                 # 2: radii built with the grid (the default builds them after 8 loop iterations)
         capfd.readouterr()
         with IcpEngine(0) as e:
             e.set_search_mode("grid")
             e.set_target(tgt)
             e.set_source(src, stride=1)
             e.set_matrices(mxa, mxb)
-            r = e.run(iters=6, thresh=0.5, early_exit=False)
+            r = e.run(iters=14, thresh=0.5, early_exit=False)
         err = capfd.readouterr().err
         counts = [(int(a), int(b)) for a, b in re.findall(r"vertex grid phases: (\d+) of (\d+) queries settled by the seed's safe radius", err)]
         got[env] = (r, counts)
-    on, off = got["1"][1], got["0"][1]
-    assert len(on) >= 6 and len(off) >= 6, (on, off)
+    on, lazy, off = got["2"][1], got["1"][1], got["0"][1]
+    assert len(on) >= 14 and len(lazy) >= 14 and len(off) >= 14, (on, lazy, off)
     assert on[0][0] == 0                                            # a cold start has no seeds
-    assert on[-1][0] > 0.8 * on[-1][1], on
+    assert on[5][0] > 0.8 * on[5][1], on
+    # the default builds the radii once the target has seen 8 iterations; the search behind that one records them, the next uses them
+    assert all(c == 0 for c, _ in lazy[:8]) and lazy[-1][0] > 0.8 * lazy[-1][1], lazy
     assert all(c == 0 for c, _ in off), off
-    assert np.array_equal(got["1"][0].step_M, got["0"][0].step_M) and np.array_equal(got["1"][0].matrix_world, got["0"][0].matrix_world)
+    for tag in ("1", "0"):
+        assert np.array_equal(got["2"][0].step_M, got[tag][0].step_M) and np.array_equal(got["2"][0].matrix_world, got[tag][0].matrix_world)

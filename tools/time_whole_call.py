@@ -18,10 +18,13 @@ eye = np.identity(4, dtype=np.float32)
 cases["41k points on an 82k-triangle mesh (surface)"] = (synth.bunny_surface(41_000, offset=0.37), tv, tt, pose, eye, 0.05)
 cases["200k points on an 82k-triangle mesh (surface)"] = (synth.bunny_surface(200_000, offset=0.37), tv, tt, pose, eye, 0.05)
 
+only = os.environ.get("ONLY")                                        # substring of a case name (profiling one case); REPS = repetitions
+if only:
+    cases = {k: v for k, v in cases.items() if only in k}
 with IcpEngine(0) as e:
     for name, (src, tgt, tris, mxa, mxb, thresh) in cases.items():
         best, parts, res = 1e9, None, None
-        for rep in range(8):
+        for rep in range(int(os.environ.get("REPS", "8"))):
             t0 = time.perf_counter()
             if tris is None:
                 e.set_target(tgt)
