@@ -593,7 +593,7 @@ int build_safe_radii(oa_ctx *c);
 constexpr long long SAFE_LAZY_ITERS = 8;   // OA_GRID_SAFE=1: loop iterations a target has to see before its safe radii are built
 int build_tri_grid(oa_ctx *c);
 int build_bvh(oa_ctx *c, bool tri);
-int scan_counts(oa_ctx *c, const int *d_counts, int n, long long *d_off);
+int scan_counts(oa_ctx *c, const int *d_counts, int n, long long *d_off, DevTmp<char> &tmp);
 int launch_tri_search(oa_ctx *c, bool acc = false);
 
 // one wave per query: 4 queries per workgroup, workgroups loop when there are more queries than that
@@ -2093,7 +2093,8 @@ int build_grid(oa_ctx *c)
     if (n_cells <= 0) return OA_OK;
     HIPCHK(dev_malloc(&c->d_cell_start, sizeof(int) * (size_t)(n_cells + 1)));
     HIPCHK(dev_malloc(&c->d_sorted, sizeof(float4) * (size_t)c->nt));
-    { int rcs = scan_counts(c, d_counts.p, n_cells, d_off.p); if (rcs) return rcs; }
+    DevTmp<char> scan_tmp;                                           // released on return, behind the wait below
+    { int rcs = scan_counts(c, d_counts.p, n_cells, d_off.p, scan_tmp); if (rcs) return rcs; }
     hipLaunchKernelGGL(oa::k_grid_starts, dim3((n_cells + 256) / 256), dim3(256), 0, c->stream, d_off.p, n_cells, c->d_cell_start, d_counts.p);
     hipLaunchKernelGGL(oa::k_grid_scatter, dim3((c->nt + 255) / 256), dim3(256), 0, c->stream, c->d_tgt_xyz, c->nt, d_cell_of.p, c->d_cell_start, d_counts.p, c->d_sorted);
     HIPCHK(hipGetLastError());
@@ -2155,8 +2156,7 @@ int set_target_common(oa_ctx *c, const float *xyz, int64_t n, int on_device, boo
     hipLaunchKernelGGL(oa::k_pack_target, dim3((c->n_groups_pad + 255) / 256), dim3(256), 0, c->stream, c->d_tgt_xyz,
                        c->nt, c->n_groups_pad, c->d_tg);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(c->stream));
-    int rcf = build_filter(c);
+    int rcf = build_filter(c);                                      // (waits for the stream when it reads the bounding box: the copy above is done by then)
     if (rcf) return rcf;
     if (vertex_index) {
         if ((rcf = build_grid(c))) return rcf;
@@ -2176,16 +2176,16 @@ OA_EXPORT int oa_set_target(oa_ctx *c, const float *xyz, int64_t n, int on_devic
 namespace {
 struct IntToLL { __host__ __device__ long long operator()(int v) const { return (long long)v; } };
 
-// offsets[0..n] = exclusive prefix sums of counts[0..n-1] (offsets[n] = total); counts must hold n + 1 ints, the last 0
-int scan_counts(oa_ctx *c, const int *d_counts, int n, long long *d_off)
+// offsets[0..n] = exclusive prefix sums of counts[0..n-1] (offsets[n] = total); counts must hold n + 1 ints, the last 0.
+// Enqueued, not waited for: `tmp` (the scan's temporary storage) belongs to the caller, who keeps it until the stream has
+// been synchronised (the wait in here was a 20-50 us hole in every grid build).
+int scan_counts(oa_ctx *c, const int *d_counts, int n, long long *d_off, DevTmp<char> &tmp)
 {
     auto in = rocprim::make_transform_iterator(d_counts, IntToLL{});
     size_t bytes = 0;
     HIPCHK(rocprim::exclusive_scan(nullptr, bytes, in, d_off, 0ll, (size_t)n + 1, rocprim::plus<long long>(), c->stream));
-    DevTmp<char> tmp;
     HIPCHK(tmp.alloc(bytes));
     HIPCHK(rocprim::exclusive_scan((void *)tmp.p, bytes, in, d_off, 0ll, (size_t)n + 1, rocprim::plus<long long>(), c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));                      // tmp is released on return
     return OA_OK;
 }
 
@@ -2424,7 +2424,8 @@ int build_tri_grid(oa_ctx *c)
     HIPCHK(dev_malloc(&c->d_tcell_start, sizeof(int) * (size_t)(n_cells + 1)));
     HIPCHK(dev_malloc(&c->d_tcell_rec, sizeof(float4) * 2 * ((size_t)entries + oa::TRI_REC_PAD)));
     HIPCHK(hipMemsetAsync(c->d_tcell_rec + 2 * (size_t)entries, 0, sizeof(float4) * 2 * oa::TRI_REC_PAD, c->stream));   // triangle 0, see tri_scan_shared
-    { int rcs = scan_counts(c, d_counts.p, n_cells, d_off.p); if (rcs) return rcs; }
+    DevTmp<char> scan_tmp;                                           // released on return, behind the wait below
+    { int rcs = scan_counts(c, d_counts.p, n_cells, d_off.p, scan_tmp); if (rcs) return rcs; }
     hipLaunchKernelGGL(oa::k_grid_starts, dim3((n_cells + 256) / 256), dim3(256), 0, c->stream, d_off.p, n_cells, c->d_tcell_start, d_counts.p);
     hipLaunchKernelGGL(oa::k_tri_grid_bin<true>, dim3((c->n_tris + 255) / 256), dim3(256), 0, c->stream, c->d_tri9, c->n_tris,
                        gp, d_counts.p, (const int *)c->d_tcell_start, c->d_tcell_rec, (unsigned long long *)nullptr);
