@@ -445,7 +445,7 @@ def main():
             g_steps = max(args.steps, 200)
             gres, g_elapsed, g_nn_ms = timed(g_steps, max(args.warmup, 5))
             gcheck, _, _ = timed(args.steps, 0)
-            grid = (g_steps, g_elapsed, g_nn_ms, bool(np.array_equal(gcheck.matrix_world, res.matrix_world)))
+            grid = (g_steps, g_elapsed, g_nn_ms, bool(np.array_equal(gcheck.matrix_world, res.matrix_world)), bool(eng.stat("safe_radii")))
         except Exception as exc:                                  # never lose the headline line
             grid = ("error: %r" % (exc,),)
 
@@ -532,8 +532,8 @@ def main():
             "upload_ms": 1e3 * upload_s,
             "loop_ms_hipevents": res.loop_ms,
         }
-        if grid is not None and len(grid) == 4:
-            g_steps, g_elapsed, g_nn_ms, same = grid
+        if grid is not None and len(grid) == 5:
+            g_steps, g_elapsed, g_nn_ms, same, safe_radii = grid
             g_bytes = 40.0 * ns_local + 16.0 * args.n_target        # source float4 + winner record + key, sorted target image
             ge, gstamp = pmc_entry("grid_" + key, KERNELS["grid"])
             out["grid_path"] = {
@@ -541,6 +541,7 @@ def main():
                 "value": g_steps / g_elapsed, "unit": "iterations/s", "steps": g_steps,
                 "ms_per_step": 1e3 * g_elapsed / g_steps, "ms_per_nn_search": g_nn_ms,
                 "final_matrix_bitwise_equal_to_brute_force": same,
+                "safe_radii": safe_radii,                              # seeds inside their safe radius settle their query without a scan
                 "roofline": {"bound": "hbm", "achieved": g_bytes / (g_nn_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": g_bytes / (g_nn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                              "algorithmic_bytes_per_launch": g_bytes, "traffic": ge["bytes_per_launch"] if ge else None,

@@ -2944,6 +2944,7 @@ OA_EXPORT int oa_get_stat(oa_ctx *c, int what, double *value)
     case OA_STAT_FAST_ITERATIONS: *value = (double)c->fast_iters; return OA_OK;
     case OA_STAT_HANDOVER_ENTRIES: *value = c->h_poll ? (double)c->h_poll[2] : 0.0; return OA_OK;
     case OA_STAT_HANDOVER_WAVE_MAX: *value = c->h_poll ? (double)c->h_poll[3] : 0.0; return OA_OK;
+    case OA_STAT_SAFE_RADII: *value = (c->grid_safe && c->d_safe_by_idx) ? 1.0 : 0.0; return OA_OK;
     default: return fail(OA_E_BAD_ARG, "oa_get_stat: unknown key %d", what);
     }
 }

@@ -165,7 +165,15 @@ def main():
                 elif ok_l:
                     # the whole-shard tree search of a small shard accumulates per wave (another summation order): to rounding
                     # (relative to the coordinates' magnitude: a translation of 0.5 between clouds at 1e5 carries 1e-11 of noise)
-                    ok_l = bool(np.abs(sM - brute_M).max() <= 1e-12 * max(1.0, float(np.abs(brute_M).max()), mag))
+                    # -- for the FIRST step.  Later steps start from a float32 matrix_world, and a float64 entry on a rounding
+                    # boundary may round the other way in the two runs: one float32 ulp (6e-8) in, as much out (seen once in
+                    # 500 trials: 2500 points against 500, second step 1.3e-11 apart)
+                    tol = 1e-12 * max(1.0, float(np.abs(brute_M).max()), mag)
+                    d_first = float(np.abs(sM[0] - brute_M[0]).max()) if len(sM) else 0.0
+                    d_later = float(np.abs(sM[1:] - brute_M[1:]).max()) if len(sM) > 1 else 0.0
+                    ok_l = bool(d_first <= tol and d_later <= 1e6 * tol)
+                    if not ok_l:
+                        dM = max(d_first, d_later)
                 detail_l = "" if ok_l else "loop K %s vs %s, dM %.3g" % ([int(k) for k in sK], [int(k) for k in ref_loop["step_K"]], dM)
                 if not ok_l and os.environ.get("FUZZ_DEBUG"):
                     np.set_printoptions(precision=9, linewidth=200)
