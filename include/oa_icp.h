@@ -216,7 +216,7 @@ int oa_reset_seeds(oa_ctx *ctx);
 #define OA_STAT_NN_MS_MIN         18   /* multi-device context: search time of the last oa_run (sum over its iterations, ms) on the */
 #define OA_STAT_NN_MS_MAX         19   /* fastest / the slowest device: how evenly the shards load the GPUs */
 #define OA_STAT_SAFE_RADII        20   /* 1 = the vertex grid's safe radii are built for the current target (a seed inside its own settles the
-                                       * query without a scan; built after 8 loop iterations of a large shard; first device) */
+                                       * query without a scan or a descent; built once the target has seen 8 loop iterations; first device) */
 #define OA_STAT_ENQUEUED_CHILD  1000   /* + i: the same count for child i alone */
 int oa_get_stat(oa_ctx *ctx, int what, double *value);
 int64_t oa_num_selected(oa_ctx *ctx);     /* selected source points held by this context (its shard) */

@@ -298,8 +298,11 @@ __global__ __launch_bounds__(ACC ? 1024 : 256) void k_bvh_search(const DevState 
                                                     int *__restrict__ prev, float4 *__restrict__ win,
                                                     unsigned long long *__restrict__ keys,
                                                     const int *__restrict__ list, const int *__restrict__ list_count, int turn,
-                                                    NormalTest nrm = NormalTest{}, double *__restrict__ partials = nullptr)
+                                                    NormalTest nrm = NormalTest{}, double *__restrict__ partials = nullptr,
+                                                    const float *__restrict__ safe_by_idx = nullptr, uint2 *__restrict__ wsafe = nullptr)
 {
+    // safe_by_idx / wsafe (whole-shard vertex searches): a seed inside its SAFE RADIUS is the answer, the descent is skipped
+    // (k_grid_safe_radius, oa_grid.hpp) -- one wave per query here, so every accepted query saves its wave the whole walk
     if (st->halt) return;
     if (turn >= 0 && (st->tree_turn != 0) != (turn != 0)) return;  // not this kernel's turn (DevState::tree_turn)
     constexpr int WPB = ACC ? 16 : 4;                               // waves per workgroup
@@ -327,6 +330,8 @@ __global__ __launch_bounds__(ACC ? 1024 : 256) void k_bvh_search(const DevState 
         // vertex mode: (bx, by, bz) follow the winner's coordinates; win[i] is the slot's winner record (coordinates +
         // index) -- the seed of a whole search, the grid search's partial answer in list mode
         float bx = 0.f, by = 0.f, bz = 0.f;
+        bool accepted = false;
+        uint32_t ws_idx = IDX_NONE;                                 // whose radius the slot's entry holds
         if (list) {
             const unsigned long long k0 = keys[i];
             const float b0 = __uint_as_float((uint32_t)(k0 >> 32));
@@ -348,12 +353,21 @@ __global__ __launch_bounds__(ACC ? 1024 : 256) void k_bvh_search(const DevState 
             if (__float_as_int(sw.w) >= 0) {
                 const float d = d2_metric(p[0], p[1], p[2], sw.x, sw.y, sw.z);
                 if (d < INFINITY) { best = d; bidx = (uint32_t)__float_as_int(sw.w); bx = sw.x; by = sw.y; bz = sw.z; }
+                if (wsafe) {
+                    const uint2 ws = wsafe[i];
+                    ws_idx = ws.x;
+                    accepted = ws.x == (uint32_t)__float_as_int(sw.w) && d < __uint_as_float(ws.y);
+                }
             }
         }
-        const float cutf = search_cutoff2(st, p[0], p[1], p[2]);
-        bvh_wave_query<TRI>(bp, boxes, prims, p, cutf, best, bidx, bx, by, bz, lds, lane);
+        if (!accepted) {
+            const float cutf = search_cutoff2(st, p[0], p[1], p[2]);
+            bvh_wave_query<TRI>(bp, boxes, prims, p, cutf, best, bidx, bx, by, bz, lds, lane);
+        }
+        // the winner's safe radius beside its record: a new winner's, or the seed's when the slot's entry spoke of another vertex
+        if (!TRI && !list && wsafe && lane == 0 && bidx != IDX_NONE && ws_idx != bidx) wsafe[i] = make_uint2(bidx, __float_as_uint(safe_by_idx[bidx]));
         if (ACC) {
-            if (lane == 0) {
+            if (lane == 0 && !accepted) {
                 if (TRI) prev[i] = (bidx == IDX_NONE) ? -1 : (int)bidx;      // the next search's seed
                 else win[i] = make_float4(bx, by, bz, __int_as_float((int)bidx));
             }

@@ -383,9 +383,9 @@ struct oa_ctx {
     float4 *d_win = nullptr;         // vertex mode: per slot, the last winner's coordinates + index in .w (-1 = none)
     uint2 *d_wsafe = nullptr;        // vertex grid: per slot {index, safe2 bits} of a winner the grid scan found (k_grid_safe_radius); 0xFF.. = none
     float *d_safe_by_idx = nullptr;  // vertex grid: safe2 per target vertex (original index)
-    int grid_safe = 1;               // OA_GRID_SAFE: 0 = the vertex grid search never takes a seed on its safe radius (A/B); 1 = the radii are
-                                     // built once a target has seen SAFE_LAZY_ITERS loop iterations of a large shard (a 5-iteration call
-                                     // would pay 50 us to save 10); 2 = built with the grid
+    int grid_safe = 1;               // OA_GRID_SAFE: 0 = the vertex searches (grid, whole-shard tree) never take a seed on its safe radius (A/B);
+                                     // 1 = the radii are built once a target has seen SAFE_LAZY_ITERS accumulating searches (a 5-iteration
+                                     // call at 1M vertices would pay 50-80 us to save 10); 2 = built with the grid
     long long target_iters = 0;      // accumulating grid searches enqueued since the target was set
     int *d_sel = nullptr;            // vertex index held by each source slot
     float4 *d_src4o = nullptr;       // the same points in the caller's (vlist) order -- only oa_make_pairs needs it
@@ -616,10 +616,17 @@ template <bool TRI>
 int launch_bvh(oa_ctx *c, const int *list, const int *list_count, int turn = -1, bool acc = false)
 {
     const unsigned blocks = bvh_blocks(c, list != nullptr, acc);
+    // whole-shard vertex searches take seeds on their safe radii: both arrays or neither
+    const float *safe_by_idx = nullptr;
+    uint2 *wsafe = nullptr;
+    if (!TRI && !list && c->grid_safe) {
+        if (acc && c->grid_safe == 1 && !c->d_safe_by_idx && ++c->target_iters > SAFE_LAZY_ITERS) { const int rcs = build_safe_radii(c); if (rcs) return rcs; }
+        if (c->d_safe_by_idx && c->d_wsafe) { safe_by_idx = c->d_safe_by_idx; wsafe = c->d_wsafe; }
+    }
 #define OA_BVH_ARGS c->d_state, c->d_src4, c->ns, TRI ? c->tbvh : c->bvh, TRI ? c->d_tbvh_box : c->d_bvh_box, TRI ? c->d_tbvh_prims : c->d_bvh_prims, \
                     c->d_tri9, c->d_prev, TRI ? (float4 *)nullptr : c->d_win, c->d_keys, list, list_count, turn
-    if (acc) hipLaunchKernelGGL((oa::k_bvh_search<TRI, true>), dim3(blocks), dim3(1024), 0, c->stream, OA_BVH_ARGS, normal_test(c), c->d_partials);
-    else hipLaunchKernelGGL((oa::k_bvh_search<TRI, false>), dim3(blocks), dim3(256), 0, c->stream, OA_BVH_ARGS, oa::NormalTest{}, (double *)nullptr);
+    if (acc) hipLaunchKernelGGL((oa::k_bvh_search<TRI, true>), dim3(blocks), dim3(1024), 0, c->stream, OA_BVH_ARGS, normal_test(c), c->d_partials, safe_by_idx, wsafe);
+    else hipLaunchKernelGGL((oa::k_bvh_search<TRI, false>), dim3(blocks), dim3(256), 0, c->stream, OA_BVH_ARGS, oa::NormalTest{}, (double *)nullptr, safe_by_idx, wsafe);
 #undef OA_BVH_ARGS
     HIPCHK(hipGetLastError());
     return OA_OK;
@@ -755,7 +762,7 @@ int launch_nn_impl(oa_ctx *c, bool acc)
 #define OA_GRID_ARGS c->d_state, c->d_src4, c->ns, c->gp, c->d_cell_start, c->d_sorted, c->d_win, c->d_keys, c->d_todo_list, c->d_todo_count, turn
 #define OA_GRID_ACC_ARGS OA_GRID_ARGS, c->bvh, (const float4 *)c->d_bvh_box, (const float4 *)c->d_bvh_prims, normal_test(c), c->d_partials
         // {index, safe2} per slot beside the winner records: both or neither (OA_GRID_SAFE=0)
-        if (acc && c->grid_safe == 1 && !c->d_safe_by_idx && ++c->target_iters > SAFE_LAZY_ITERS && (long long)c->ns * lanes >= 262144) {
+        if (acc && c->grid_safe == 1 && !c->d_safe_by_idx && ++c->target_iters > SAFE_LAZY_ITERS) {
             const int rcs = build_safe_radii(c);
             if (rcs) return rcs;
         }

@@ -39,7 +39,7 @@ def test_safe_radius_edge_queries_equal_brute_force(lanes, monkeypatch):
     times half the nearest-neighbour distance of a target -- on the segment towards that neighbour (the bisector plane,
     where the two targets tie) and in random directions; duplicates (radius 0), one-ulp neighbours and a crowded block
     (radius withheld) are among the targets.  Grid search with the rule, grid search without it and brute force: the same
-    (index, d2) bits at every pose."""
+    (index, d2) bits at every pose -- and the whole-shard tree search, which takes seeds on the same radii."""
     from object_alignment_amd import synth
     from object_alignment_amd.engine import IcpEngine
     monkeypatch.setenv("OA_GRID_LANES", lanes)
@@ -48,7 +48,8 @@ def test_safe_radius_edge_queries_equal_brute_force(lanes, monkeypatch):
     poses = [synth.rigid4(None, [1e-5, -2e-5, 1.5e-5]), eye, synth.rigid4(None, [-3e-6, 2e-6, 1e-6]), eye,
              synth.rigid4(synth.rotation_from_rotvec([1e-5, -1e-5, 2e-5]), [0.0, 0.0, 0.0]), eye]
     out = {}
-    for tag, mode, env in (("safe", "grid", "2"), ("nosafe", "grid", "0"), ("brute", "brute", "2")):
+    for tag, mode, env in (("safe", "grid", "2"), ("nosafe", "grid", "0"), ("tree_safe", "bvh", "2"), ("tree_nosafe", "bvh", "0"),
+                           ("brute", "brute", "2")):
         monkeypatch.setenv("OA_GRID_SAFE", env)                 # 2: radii built with the grid (the default builds them after 8 loop iterations)
         with IcpEngine(0) as e:
             e.set_search_mode(mode)
@@ -61,19 +62,19 @@ def test_safe_radius_edge_queries_equal_brute_force(lanes, monkeypatch):
                 res.append((idx.copy(), d2.copy()))
             out[tag] = res
     for k in range(len(poses)):
-        for tag in ("safe", "nosafe"):
+        for tag in ("safe", "nosafe", "tree_safe", "tree_nosafe"):
             assert np.array_equal(out[tag][k][0], out["brute"][k][0]), (tag, k, int((out[tag][k][0] != out["brute"][k][0]).sum()))
             assert np.array_equal(out[tag][k][1].view(np.uint32), out["brute"][k][1].view(np.uint32)), (tag, k)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["settled", "far_start", "half_target", "lanes4", "dups"])
+@pytest.mark.parametrize("case", ["settled", "far_start", "half_target", "lanes4", "dups", "tree"])
 def test_safe_radius_loops_same_bits_as_without(orc, case, monkeypatch):
     """Loops with and without the rule (OA_GRID_SAFE=0), fast and safe grid paths: bitwise the same steps and matrices --
     and the oracle's K per step."""
     from object_alignment_amd import synth
     from object_alignment_amd.engine import IcpEngine
-    n = 60_000 if case != "lanes4" else 9_000
+    n = {"lanes4": 9_000, "tree": 3_000}.get(case, 60_000)          # ("tree": the accumulating whole-shard tree search of a small shard)
     src, tgt, mxa, mxb = synth.c2_bunny_pair(n)
     thresh, iters = 0.5, 6
     if case == "far_start":
@@ -90,7 +91,7 @@ def test_safe_radius_loops_same_bits_as_without(orc, case, monkeypatch):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         with IcpEngine(0) as e:
-            e.set_search_mode("grid")
+            e.set_search_mode("bvh" if case == "tree" else "grid")
             e.set_target(tgt)
             e.set_source(src, stride=1)
             e.set_matrices(mxa, mxb)
@@ -110,7 +111,7 @@ def test_safe_radius_loops_same_bits_as_without(orc, case, monkeypatch):
 def test_safe_radius_is_taken_once_the_pose_settles(capfd, monkeypatch):
     """The instrumented build (OA_GRID_STATS=1) reports how many queries the rule settled: most of a noisy copy of the
     target once the pose has converged (OA_GRID_SAFE=2: radii built with the grid), the same from the tenth iteration on
-    with the default (radii built after eight iterations of a large shard: short calls never pay for them), none with
+    with the default (radii built after eight iterations: short calls never pay for them), none with
     OA_GRID_SAFE=0 -- and the three runs end with the same bits."""
     from object_alignment_amd import synth
     from object_alignment_amd.engine import IcpEngine
