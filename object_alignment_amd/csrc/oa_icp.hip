@@ -591,6 +591,19 @@ inline bool bvh_whole(const oa_ctx *c, bool ok, int auto_max)
 int build_grid(oa_ctx *c);
 int build_safe_radii(oa_ctx *c);
 constexpr long long SAFE_LAZY_ITERS = 8;   // OA_GRID_SAFE=1: loop iterations a target has to see before its safe radii are built
+// OA_GRID_SAFE=1: the radii are built once the target has seen SAFE_LAZY_ITERS accumulating searches.  counting: called for
+// an accumulating search that is about to be enqueued -- a context of its own builds right there, between two iterations
+// of its running loop (one launch on its stream, the searches queue behind it).  A CHILD of a multi-device group only
+// counts: inside a group's loop an allocation can wait -- for another child's stream, when the cache hands over a block
+// that stream released, or inside hipMalloc -- while that stream's gather kernel waits for the very post this thread has
+// not enqueued yet (the loop then ends with OA_E_RCCL after OA_EXCHANGE_TIMEOUT_S; seen with OA_FAULT_LAG_GROUP, where one
+// thread is always behind).  Children build at the start of their next loop (begin_loop: every stream is idle there).
+int safe_radii_lazy(oa_ctx *c, bool counting)
+{
+    if (c->grid_safe != 1 || c->d_safe_by_idx) return OA_OK;
+    if (counting) { ++c->target_iters; if (c->parent) return OA_OK; }
+    return c->target_iters > SAFE_LAZY_ITERS ? build_safe_radii(c) : OA_OK;
+}
 int build_tri_grid(oa_ctx *c);
 int build_bvh(oa_ctx *c, bool tri);
 int scan_counts(oa_ctx *c, const int *d_counts, int n, long long *d_off, DevTmp<char> &tmp);
@@ -620,7 +633,7 @@ int launch_bvh(oa_ctx *c, const int *list, const int *list_count, int turn = -1,
     const float *safe_by_idx = nullptr;
     uint2 *wsafe = nullptr;
     if (!TRI && !list && c->grid_safe) {
-        if (acc && c->grid_safe == 1 && !c->d_safe_by_idx && ++c->target_iters > SAFE_LAZY_ITERS) { const int rcs = build_safe_radii(c); if (rcs) return rcs; }
+        if (acc) { const int rcs = safe_radii_lazy(c, true); if (rcs) return rcs; }
         if (c->d_safe_by_idx && c->d_wsafe) { safe_by_idx = c->d_safe_by_idx; wsafe = c->d_wsafe; }
     }
 #define OA_BVH_ARGS c->d_state, c->d_src4, c->ns, TRI ? c->tbvh : c->bvh, TRI ? c->d_tbvh_box : c->d_bvh_box, TRI ? c->d_tbvh_prims : c->d_bvh_prims, \
@@ -762,10 +775,7 @@ int launch_nn_impl(oa_ctx *c, bool acc)
 #define OA_GRID_ARGS c->d_state, c->d_src4, c->ns, c->gp, c->d_cell_start, c->d_sorted, c->d_win, c->d_keys, c->d_todo_list, c->d_todo_count, turn
 #define OA_GRID_ACC_ARGS OA_GRID_ARGS, c->bvh, (const float4 *)c->d_bvh_box, (const float4 *)c->d_bvh_prims, normal_test(c), c->d_partials
         // {index, safe2} per slot beside the winner records: both or neither (OA_GRID_SAFE=0)
-        if (acc && c->grid_safe == 1 && !c->d_safe_by_idx && ++c->target_iters > SAFE_LAZY_ITERS) {
-            const int rcs = build_safe_radii(c);
-            if (rcs) return rcs;
-        }
+        if (acc) { const int rcs = safe_radii_lazy(c, true); if (rcs) return rcs; }
         const float *safe_by_idx = c->grid_safe ? c->d_safe_by_idx : nullptr;
         uint2 *wsafe = safe_by_idx ? c->d_wsafe : nullptr;
         if (!wsafe) safe_by_idx = nullptr;
@@ -1029,6 +1039,7 @@ int begin_loop(oa_ctx *c, const oa_settings *st, int iters)
     *c->h_state_pin = c->h_state;                               // pinned staging copy (the stream is idle, see above)
     HIPCHK(hipMemcpyAsync(c->d_state, c->h_state_pin, sizeof(oa::DevState), hipMemcpyHostToDevice, c->stream));
     if (c->d_todo_count) HIPCHK(hipMemsetAsync(c->d_todo_count, 0, 2 * sizeof(int), c->stream));   // kept at zero by k_solve_update
+    if (!c->surface && (rc = safe_radii_lazy(c, false))) return rc;   // a multi-device child's turn to build them (never inside its group's loop)
     hipLaunchKernelGGL(oa::k_stamp_start, dim3(1), dim3(64), 0, c->stream, c->d_state);
     HIPCHK(hipGetLastError());
     c->ev_used = 0;

@@ -652,6 +652,31 @@ def test_a_lagging_host_thread_hits_the_window_and_the_agreement_closes_it():
     assert new["loops_with_differing_counts"] == 0, new
 
 
+def test_children_build_their_safe_radii_between_loops_never_inside_one(golden_dir, monkeypatch):
+    """OA_GRID_SAFE=1 builds the radii lazily, after 8 accumulating searches -- for a context of its own between two
+    iterations of the running loop.  A child of a multi-device group must not allocate there (the allocation can wait for a
+    sibling's stream whose gather kernel waits for the post this very thread has not enqueued yet: the lagging-thread test
+    above ended with OA_E_RCCL after the exchange's time limit when it did); it only counts and builds at the start of its
+    NEXT loop, where every stream is idle.  Grid search forced, so that the searches that count are the grid's."""
+    from object_alignment_amd.engine import IcpEngine
+    g = _load(golden_dir, "icp_loop_bumpy_converge")
+    monkeypatch.setenv("OA_MULTI_THREADS", "1")
+    monkeypatch.setenv("OA_MULTI_OWN_STREAMS", "1")
+    monkeypatch.setenv("OA_GRID_SAFE", "1")
+    with IcpEngine(devices=[0, 0]) as eng:
+        eng.set_search_mode("grid")
+        _small_job(eng, g)
+        seen = []
+        for _ in range(4):
+            eng.set_matrices(g["mx_align"], g["mx_base"])
+            res = eng.run(iters=30, thresh=0.5, target_d=0.01, use_target=True, early_exit=True)
+            seen.append(int(eng.stat("safe_radii")))
+            assert res.iters_done == int(g["iters_done"]) and np.abs(res.matrix_world - g["final_world"]).max() <= 2.5e-7
+        # loop 1 enqueues 7-9 searches per child: at most "not yet" after it, built by the start of loop 3 at the latest,
+        # and a loop never ends with another answer than it started with
+        assert seen[0] == 0 and seen[-1] == 1 and seen == sorted(seen), seen
+
+
 def test_rccl_watchdog_turns_a_stalled_collective_into_an_error(golden_dir, monkeypatch):
     """include/oa_icp.h promises OA_E_RCCL when a device's sums do not arrive within OA_EXCHANGE_TIMEOUT_S -- in RCCL mode
     too.  OA_FAULT_STALL_RANK stops rank 0's stream ahead of the collective of iteration 2 (a bounded spin: what a rank
