@@ -23,6 +23,7 @@ typedef enum { ncclSum = 0 } ncclRedOp_t;
 #include "oa_bvh.hpp"
 #include "oa_affine.hpp"
 #include "oa_mfma.hpp"
+#include "oa_sort.hpp"
 #include "../../include/oa_icp.h"
 
 #include <algorithm>
@@ -590,6 +591,26 @@ inline bool bvh_whole(const oa_ctx *c, bool ok, int auto_max)
 }
 int build_grid(oa_ctx *c);
 int build_safe_radii(oa_ctx *c);
+// Stable sort of (30-bit Morton key, index) pairs on the context's stream, no wait: v_out = the sorted indices (v_in holds
+// 0, 1, 2, ... at every call site; k_out, the sorted keys, is written by rocprim only -- nobody reads it).  Between SORT_LSD_MIN
+// and SORT_LSD_MAX pairs the library's own three-pass LSD argsort (oa_sort.hpp; tools/sort_bench.hip has the crossovers),
+// outside rocprim's; both stable, hence the same permutation (OA_SORT_LSD=0: rocprim always, the A/B).
+int sort_pairs30(oa_ctx *c, const unsigned *k_in, unsigned *k_out, const int *v_in, int *v_out, size_t n)
+{
+    static const long long lsd_min = env_int("OA_SORT_LSD", 1) ? (long long)env_int("OA_SORT_LSD_MIN", 65536) : -1;
+    static const long long lsd_max = (long long)env_int("OA_SORT_LSD_MAX", 3 << 20);
+    DevTmp<char> tmp;
+    if (lsd_min >= 0 && (long long)n >= lsd_min && (long long)n <= lsd_max) {
+        HIPCHK(tmp.alloc(oa::sort_order_tmp_bytes(n)));
+        HIPCHK(oa::sort_order_lsd((void *)tmp.p, k_in, v_out, n, 30, c->stream));
+        return OA_OK;
+    }
+    size_t bytes = 0;
+    HIPCHK(rocprim::radix_sort_pairs(nullptr, bytes, k_in, k_out, v_in, v_out, n, 0, 30, c->stream));
+    HIPCHK(tmp.alloc(bytes));
+    HIPCHK(rocprim::radix_sort_pairs((void *)tmp.p, bytes, k_in, k_out, v_in, v_out, n, 0, 30, c->stream));
+    return OA_OK;
+}
 constexpr long long SAFE_LAZY_ITERS = 8;   // OA_GRID_SAFE=1: loop iterations a target has to see before its safe radii are built
 // OA_GRID_SAFE=1: the radii are built once the target has seen SAFE_LAZY_ITERS accumulating searches.  counting: called for
 // an accumulating search that is about to be enqueued -- a context of its own builds right there, between two iterations
@@ -2251,11 +2272,7 @@ int build_bvh(oa_ctx *c, bool tri)
     else hipLaunchKernelGGL(oa::k_bvh_keys<false>, grd, blk, 0, c->stream, (const float *)c->d_tgt_xyz, (const float4 *)nullptr,
                             n, lo[0], lo[1], lo[2], sc[0], sc[1], sc[2], k_in.p, v_in.p);
     HIPCHK(hipGetLastError());
-    size_t bytes = 0;
-    HIPCHK(rocprim::radix_sort_pairs(nullptr, bytes, k_in.p, k_out.p, v_in.p, v_out.p, (size_t)n, 0, 30, c->stream));
-    DevTmp<char> tmp;
-    HIPCHK(tmp.alloc(bytes));
-    HIPCHK(rocprim::radix_sort_pairs((void *)tmp.p, bytes, k_in.p, k_out.p, v_in.p, v_out.p, (size_t)n, 0, 30, c->stream));
+    { const int rcs = sort_pairs30(c, k_in.p, k_out.p, v_in.p, v_out.p, (size_t)n); if (rcs) return rcs; }
     HIPCHK(dev_malloc(&d_prims, sizeof(float4) * (tri ? 3 : 1) * (size_t)n_pad));
     HIPCHK(dev_malloc(&d_box, sizeof(float4) * 2 * (size_t)total));
     const dim3 grd_pad((unsigned)((n_pad + 255) / 256));
@@ -2328,11 +2345,7 @@ int spatial_shard_members(oa_ctx *c, const float *d_xyz, long long n_verts, cons
     hipLaunchKernelGGL(oa::k_morton_keys, dim3((n + 255) / 256), dim3(256), 0, c->stream, (const float4 *)all4.p, n,
                        lo[0], lo[1], lo[2], sc[0], sc[1], sc[2], k_in.p, v_in.p);
     HIPCHK(hipGetLastError());
-    size_t bytes = 0;
-    HIPCHK(rocprim::radix_sort_pairs(nullptr, bytes, k_in.p, k_out.p, v_in.p, order.p, (size_t)n, 0, 30, c->stream));
-    DevTmp<char> tmp;
-    HIPCHK(tmp.alloc(bytes));
-    HIPCHK(rocprim::radix_sort_pairs((void *)tmp.p, bytes, k_in.p, k_out.p, v_in.p, order.p, (size_t)n, 0, 30, c->stream));
+    { const int rcs = sort_pairs30(c, k_in.p, k_out.p, v_in.p, order.p, (size_t)n); if (rcs) return rcs; }
     // this shard's range of the order, back in ascending selection position (= the caller's order inside the shard)
     HIPCHK(members.alloc((size_t)count));
     size_t bytes2 = 0;
@@ -2357,11 +2370,7 @@ int sort_source_slots(oa_ctx *c, const float *d_xyz, long long n_verts)
     hipLaunchKernelGGL(oa::k_morton_keys, dim3((c->ns + 255) / 256), dim3(256), 0, c->stream, (const float4 *)c->d_src4, c->ns,
                        lo[0], lo[1], lo[2], sc[0], sc[1], sc[2], k_in.p, v_in.p);
     HIPCHK(hipGetLastError());
-    size_t bytes = 0;
-    HIPCHK(rocprim::radix_sort_pairs(nullptr, bytes, k_in.p, k_out.p, v_in.p, c->d_perm, (size_t)c->ns, 0, 30, c->stream));
-    DevTmp<char> tmp;
-    HIPCHK(tmp.alloc(bytes));
-    HIPCHK(rocprim::radix_sort_pairs((void *)tmp.p, bytes, k_in.p, k_out.p, v_in.p, c->d_perm, (size_t)c->ns, 0, 30, c->stream));
+    { const int rcs = sort_pairs30(c, k_in.p, k_out.p, v_in.p, c->d_perm, (size_t)c->ns); if (rcs) return rcs; }
     // d_src4 / d_sel become the sorted images; the packed originals move to d_src4o / a temporary
     DevTmp<int> selo;
     HIPCHK(selo.alloc((size_t)c->ns_pad));
@@ -2735,11 +2744,7 @@ int build_selection_order(oa_ctx *c, const float *xyz, int64_t n_verts, int on_d
     hipLaunchKernelGGL(oa::k_morton_keys, dim3((n + 255) / 256), dim3(256), 0, c->stream, (const float4 *)all4.p, n,
                        lo[0], lo[1], lo[2], sc[0], sc[1], sc[2], k_in.p, v_in.p);
     HIPCHK(hipGetLastError());
-    size_t bytes = 0;
-    HIPCHK(rocprim::radix_sort_pairs(nullptr, bytes, k_in.p, k_out.p, v_in.p, o.pos.p, (size_t)n, 0, 30, c->stream));
-    DevTmp<char> tmp;
-    HIPCHK(tmp.alloc(bytes));
-    HIPCHK(rocprim::radix_sort_pairs((void *)tmp.p, bytes, k_in.p, k_out.p, v_in.p, o.pos.p, (size_t)n, 0, 30, c->stream));
+    { const int rcs = sort_pairs30(c, k_in.p, k_out.p, v_in.p, o.pos.p, (size_t)n); if (rcs) return rcs; }
     hipLaunchKernelGGL(oa::k_apply_perm, dim3((n + 255) / 256), dim3(256), 0, c->stream, (const float4 *)all4.p, (const int *)all_sel.p,
                        (const int *)o.pos.p, n, n, o.pts.p, o.sel.p);
     HIPCHK(hipGetLastError());
