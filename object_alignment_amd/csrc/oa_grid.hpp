@@ -731,8 +731,9 @@ __global__ __launch_bounds__(BT, OA_GRID_MIN_WAVES) void k_nn_search_grid(const 
 #undef OA_GRID_STAMP
 }
 
-// (one atomic per WORKGROUP of a grid-stride launch: with one per wave -- 8000 of them on one word for the 500k cells of a
-//  1M-vertex target -- the counter's serialised atomics were 92 us of a 0.8 ms target upload)
+// non-zero entries of a[0 .. n): one count per WORKGROUP of a grid-stride launch, out[blockIdx.x] -- the host adds them up
+// (they go straight to mapped host memory, oa_icp.hip: result_buffer).  History: one atomic per wave -- 8000 of them on one
+// word for the 500k cells of a 1M-vertex target -- was 92 us of a 0.8 ms target upload; one per workgroup 8 us; none now.
 __global__ void k_count_nonzero(const int *__restrict__ a, int n, int *__restrict__ out)
 {
     __shared__ int part[16];
@@ -744,7 +745,7 @@ __global__ void k_count_nonzero(const int *__restrict__ a, int n, int *__restric
     if (threadIdx.x == 0) {
         int sum = 0;
         for (int w = 0; w < (int)(blockDim.x >> 6); ++w) sum += part[w];
-        if (sum) atomicAdd(out, sum);
+        out[blockIdx.x] = sum;
     }
 }
 

@@ -411,6 +411,8 @@ struct oa_ctx {
     oa::StepRecord *h_hist_map = nullptr;   // pinned, device-mapped history (read after a stream sync, no copy)
     oa::DevState *h_state_pin = nullptr;    // pinned staging of DevState (pageable copies cost ~30 us each way)
     char *h_scratch = nullptr;              // pinned scratch for small read-backs (read_small)
+    char *h_result = nullptr;               // pinned, device-mapped: kernels store small results here (result_buffer)
+    void *d_result_view = nullptr;
     std::vector<oa::StepRecord> h_hist;   // host copy of the executed iterations' records, filled by fill_report
     bool h_hist_valid = false;
     int max_records = 0;
@@ -521,6 +523,25 @@ int ensure_common(oa_ctx *c)
 
 // small device -> host read-back through a pinned scratch buffer, then a stream sync (a pageable destination costs
 // ~30 us per copy; uploads do half a dozen of these)
+// Small per-workgroup results (bounding-box partials, block maxima, counts) that the HOST reduces: the kernel stores them
+// straight into pinned, device-mapped host memory, the host waits for the stream and reads -- no device buffer, no copy
+// operation (an upload is bound by its number of enqueued operations, ~5 us each, and every read-back was two).
+// result_ptr: where the kernel writes (device view) / where the host reads (host view); nullptr when `bytes` do not fit.
+constexpr size_t RESULT_BYTES = 1 << 16;
+int result_buffer(oa_ctx *c, size_t bytes, void **dev_view, const void **host_view)
+{
+    *dev_view = nullptr; *host_view = nullptr;
+    if (bytes > RESULT_BYTES || !env_int("OA_MAPPED_RESULTS", 1)) return OA_OK;
+    if (!c->h_result) {
+        HIPCHK(hipHostMalloc((void **)&c->h_result, RESULT_BYTES, hipHostMallocMapped));
+        void *dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, c->h_result, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(c->h_result); c->h_result = nullptr; return OA_OK; }
+        c->d_result_view = dp;
+    }
+    *dev_view = c->d_result_view; *host_view = c->h_result;
+    return OA_OK;
+}
+
 int read_small(oa_ctx *c, void *dst, const void *d_src, size_t bytes)
 {
     constexpr size_t SCRATCH = 1 << 16;
@@ -625,7 +646,7 @@ int safe_radii_lazy(oa_ctx *c, bool counting)
     if (counting) { ++c->target_iters; if (c->parent) return OA_OK; }
     return c->target_iters > SAFE_LAZY_ITERS ? build_safe_radii(c) : OA_OK;
 }
-int build_tri_grid(oa_ctx *c);
+int build_tri_grid(oa_ctx *c, const double *diag_sum_known = nullptr);
 int build_bvh(oa_ctx *c, bool tri);
 int scan_counts(oa_ctx *c, const int *d_counts, int n, long long *d_off, DevTmp<char> &tmp);
 int launch_tri_search(oa_ctx *c, bool acc = false);
@@ -1956,6 +1977,7 @@ OA_EXPORT void oa_destroy(oa_ctx *c)
     if (c->h_hist_map) (void)hipHostFree(c->h_hist_map);
     if (c->h_state_pin) (void)hipHostFree(c->h_state_pin);
     if (c->h_scratch) (void)hipHostFree(c->h_scratch);
+    if (c->h_result) (void)hipHostFree(c->h_result);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->ev_loop0) (void)hipEventDestroy(c->ev_loop0);
     if (c->h_poll) (void)hipHostFree(c->h_poll);
@@ -1999,17 +2021,33 @@ OA_EXPORT int oa_set_stream(oa_ctx *c, void *stream)
 // uploads
 // ================================================================================================
 namespace {
+// nb x 6 bounding-box partials of a float[3n] array, on the host (the stream has been waited for on return)
+int bbox_partials(oa_ctx *c, const float *d_xyz, long long n, int nb, float *out)
+{
+    void *dv; const void *hv;
+    int rc = result_buffer(c, sizeof(float) * 6 * (size_t)nb, &dv, &hv);
+    if (rc) return rc;
+    if (dv) {
+        hipLaunchKernelGGL(oa::k_bbox_partial, dim3(nb), dim3(256), 0, c->stream, d_xyz, (int)n, (float *)dv);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(c->stream));
+        memcpy(out, hv, sizeof(float) * 6 * (size_t)nb);
+        return OA_OK;
+    }
+    DevTmp<float> d_bb;
+    HIPCHK(d_bb.alloc(6 * (size_t)nb));
+    hipLaunchKernelGGL(oa::k_bbox_partial, dim3(nb), dim3(256), 0, c->stream, d_xyz, (int)n, d_bb.p);
+    HIPCHK(hipGetLastError());
+    return read_small(c, out, d_bb, sizeof(float) * 6 * (size_t)nb);
+}
+
 // filter image for k_nn_search_filtered: bbox centre, centred -2q / |q|^2 arrays, max |q - centre|
 int build_filter(oa_ctx *c)
 {
     c->filter_ok = false;
     const int nb = 256;
-    DevTmp<float> d_bb;
-    HIPCHK(d_bb.alloc(6 * nb));
-    hipLaunchKernelGGL(oa::k_bbox_partial, dim3(nb), dim3(256), 0, c->stream, c->d_tgt_xyz, c->nt, d_bb.p);
-    HIPCHK(hipGetLastError());
     std::vector<float> bb(6 * nb);
-    { int rcr = read_small(c, bb.data(), d_bb, sizeof(float) * 6 * nb); if (rcr) return rcr; }
+    { int rcb = bbox_partials(c, c->d_tgt_xyz, c->nt, nb, bb.data()); if (rcb) return rcb; }
     double lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
     bool finite = true;
     for (int b = 0; b < nb; ++b)
@@ -2031,12 +2069,18 @@ int build_filter(oa_ctx *c)
     DevTmp<double> d_mx;
     HIPCHK(dev_malloc(&c->d_tf, sizeof(float4) * 3 * (size_t)c->n_groups_pad));
     HIPCHK(dev_malloc(&c->d_tf3, sizeof(float4) * 2 * (size_t)c->n_groups_pad));
-    HIPCHK(d_mx.alloc((size_t)blocks));
-    hipLaunchKernelGGL(oa::k_pack_filter, dim3(blocks), dim3(256), 0, c->stream, c->d_tgt_xyz, c->nt, c->n_groups_pad,
-                       c->tc[0], c->tc[1], c->tc[2], c->fax[0], c->fax[1], c->fax[2], c->d_tf, c->d_tf3, d_mx.p);
-    HIPCHK(hipGetLastError());
     std::vector<double> mx((size_t)blocks);
-    { int rcr = read_small(c, mx.data(), d_mx, sizeof(double) * (size_t)blocks); if (rcr) return rcr; }
+    {
+        // the workgroups' maxima straight into mapped host memory when they fit (result_buffer), else through a device buffer
+        void *dv; const void *hv;
+        { int rcv = result_buffer(c, sizeof(double) * (size_t)blocks, &dv, &hv); if (rcv) return rcv; }
+        if (!dv) HIPCHK(d_mx.alloc((size_t)blocks));
+        hipLaunchKernelGGL(oa::k_pack_filter, dim3(blocks), dim3(256), 0, c->stream, c->d_tgt_xyz, c->nt, c->n_groups_pad,
+                           c->tc[0], c->tc[1], c->tc[2], c->fax[0], c->fax[1], c->fax[2], c->d_tf, c->d_tf3, dv ? (double *)dv : d_mx.p);
+        HIPCHK(hipGetLastError());
+        if (dv) { HIPCHK(hipStreamSynchronize(c->stream)); memcpy(mx.data(), hv, sizeof(double) * (size_t)blocks); }
+        else { int rcr = read_small(c, mx.data(), d_mx, sizeof(double) * (size_t)blocks); if (rcr) return rcr; }
+    }
     double m = 0.0;
     for (double v : mx) if (v > m) m = v;
     c->qmax = sqrt(m) * (1.0 + 1e-6);
@@ -2086,10 +2130,9 @@ int build_grid(oa_ctx *c)
     if (!(h > 0.0) || !(h < INFINITY)) return OA_OK;
     const long long max_cells = 1ll << 24;
     static_assert((1ll << 24) <= oa::GRID_MAX_CELLS, "cell_start is addressed through 32-bit byte offsets");
-    DevTmp<int> d_cell_of, d_counts, d_nz;
+    DevTmp<int> d_cell_of, d_counts;
     DevTmp<long long> d_off;
     HIPCHK(d_cell_of.alloc((size_t)c->nt));
-    HIPCHK(d_nz.alloc(1));
     oa::GridParams gp{};
     int n_cells = 0;
     for (int attempt = 0; attempt < 6; ++attempt) {
@@ -2115,15 +2158,23 @@ int build_grid(oa_ctx *c)
         gp.scale = scale;
         oa::grid_params_finish(gp);
         n_cells = (int)total;
-        HIPCHK(d_counts.alloc((size_t)n_cells + 1));
+        // [n_cells]: the scan's closing zero; behind it the occupied-cell counts of k_count_nonzero's workgroups when they do not
+        // go to mapped host memory (one memset for all of it: an upload is bound by its number of operations)
+        const int nz_blocks = std::min(512, (n_cells + 1023) / 1024);
+        HIPCHK(d_counts.alloc((size_t)n_cells + 1 + (size_t)nz_blocks));
         HIPCHK(d_off.alloc((size_t)n_cells + 1));
+        void *dv; const void *hv;
+        { int rcv = result_buffer(c, sizeof(int) * (size_t)nz_blocks, &dv, &hv); if (rcv) return rcv; }
+        int *d_nz = dv ? (int *)dv : d_counts.p + n_cells + 1;
         HIPCHK(hipMemsetAsync(d_counts, 0, sizeof(int) * ((size_t)n_cells + 1), c->stream));
-        HIPCHK(hipMemsetAsync(d_nz, 0, sizeof(int), c->stream));
         hipLaunchKernelGGL(oa::k_grid_count, dim3((c->nt + 255) / 256), dim3(256), 0, c->stream, c->d_tgt_xyz, c->nt, gp, d_cell_of.p, d_counts.p);
-        hipLaunchKernelGGL(oa::k_count_nonzero, dim3((unsigned)std::min(512, (n_cells + 1023) / 1024)), dim3(1024), 0, c->stream, d_counts.p, n_cells, d_nz.p);
+        hipLaunchKernelGGL(oa::k_count_nonzero, dim3((unsigned)nz_blocks), dim3(1024), 0, c->stream, d_counts.p, n_cells, d_nz);
         HIPCHK(hipGetLastError());
-        int occupied = 0;
-        { int rcr = read_small(c, &occupied, d_nz, sizeof(int)); if (rcr) return rcr; }
+        std::vector<int> nz((size_t)nz_blocks);
+        if (dv) { HIPCHK(hipStreamSynchronize(c->stream)); memcpy(nz.data(), hv, sizeof(int) * (size_t)nz_blocks); }
+        else { int rcr = read_small(c, nz.data(), d_nz, sizeof(int) * (size_t)nz_blocks); if (rcr) return rcr; }
+        long long occupied = 0;
+        for (int v : nz) occupied += v;
         const double avg = occupied > 0 ? (double)c->nt / occupied : 0.0;
         // surfaces fill few cells: refine until occupied cells hold a handful of vertices each
         if (avg > 6.0 && total * 8 <= max_cells && attempt < 5) { h *= 0.5; continue; }
@@ -2172,9 +2223,10 @@ int set_target_common(oa_ctx *c, const float *xyz, int64_t n, int on_device, boo
     c->n_groups_pad = 0;
     c->seeded = false;
     if (c->d_prev) {   // seeds index the old target
-        hipLaunchKernelGGL(oa::k_fill_int, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, c->d_prev, c->ns_pad, -1);
-        HIPCHK(hipMemsetAsync(c->d_win, 0xFF, sizeof(float4) * (size_t)c->ns_pad, c->stream));
-        if (c->d_wsafe) HIPCHK(hipMemsetAsync(c->d_wsafe, 0xFF, sizeof(uint2) * (size_t)c->ns_pad, c->stream));   // safe radii belong to the old target's indices
+        // (the safe radii beside the winner records belong to the old target's indices too)
+        hipLaunchKernelGGL(oa::k_init_slots, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, c->d_prev, c->d_win, c->d_wsafe,
+                           (unsigned long long *)nullptr, (int *)nullptr, (int *)nullptr, c->ns_pad);
+        HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(c->stream));
     }
     if (n == 0) return OA_OK;
@@ -2303,12 +2355,8 @@ int morton_frame(oa_ctx *c, const float *d_xyz, long long n_verts, float lo[3], 
 {
     ok = false;
     const int nb = 256;
-    DevTmp<float> d_bb;
-    HIPCHK(d_bb.alloc(6 * nb));
-    hipLaunchKernelGGL(oa::k_bbox_partial, dim3(nb), dim3(256), 0, c->stream, d_xyz, (int)n_verts, d_bb.p);
-    HIPCHK(hipGetLastError());
     std::vector<float> bb(6 * nb);
-    { int rcr = read_small(c, bb.data(), d_bb, sizeof(float) * 6 * nb); if (rcr) return rcr; }
+    { int rcb = bbox_partials(c, d_xyz, n_verts, nb, bb.data()); if (rcb) return rcb; }
     float hi[3] = { -INFINITY, -INFINITY, -INFINITY };
     lo[0] = lo[1] = lo[2] = INFINITY;
     for (int b = 0; b < nb; ++b)
@@ -2371,32 +2419,39 @@ int sort_source_slots(oa_ctx *c, const float *d_xyz, long long n_verts)
                        lo[0], lo[1], lo[2], sc[0], sc[1], sc[2], k_in.p, v_in.p);
     HIPCHK(hipGetLastError());
     { const int rcs = sort_pairs30(c, k_in.p, k_out.p, v_in.p, c->d_perm, (size_t)c->ns); if (rcs) return rcs; }
-    // d_src4 / d_sel become the sorted images; the packed originals move to d_src4o / a temporary
-    DevTmp<int> selo;
-    HIPCHK(selo.alloc((size_t)c->ns_pad));
-    HIPCHK(dev_malloc(&c->d_src4o, sizeof(float4) * (size_t)c->ns_pad));
-    HIPCHK(hipMemcpyAsync(c->d_src4o, c->d_src4, sizeof(float4) * (size_t)c->ns_pad, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(selo, c->d_sel, sizeof(int) * (size_t)c->ns_pad, hipMemcpyDeviceToDevice, c->stream));
+    // d_src4 / d_sel become the sorted images: the packed buffers change names (they ARE the caller-order copy now) and
+    // k_apply_perm fills new ones -- every slot up to ns_pad -- instead of two device-to-device copies in front of it
+    dev_free(c->d_src4o);
+    c->d_src4o = c->d_src4; c->d_src4 = nullptr;
+    int *selo = c->d_sel; c->d_sel = nullptr;
+    HIPCHK(dev_malloc(&c->d_src4, sizeof(float4) * (size_t)c->ns_pad));
+    HIPCHK(dev_malloc(&c->d_sel, sizeof(int) * (size_t)c->ns_pad));
     hipLaunchKernelGGL(oa::k_apply_perm, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, (const float4 *)c->d_src4o,
-                       (const int *)selo.p, (const int *)c->d_perm, c->ns, c->ns_pad, c->d_src4, c->d_sel);
+                       (const int *)selo, (const int *)c->d_perm, c->ns, c->ns_pad, c->d_src4, c->d_sel);
     HIPCHK(hipGetLastError());
+    dev_free(selo);                                                // (stream ordered: behind the launch above)
     HIPCHK(hipStreamSynchronize(c->stream));
     return OA_OK;
 }
 
 // uniform grid over the triangles' bounding boxes
-int build_tri_grid(oa_ctx *c)
+// diag_sum_known: the sum of the triangles' bounding-box diagonals when the caller has it already (oa_set_target_mesh reads
+// it back together with its index check: one host round trip instead of two)
+int build_tri_grid(oa_ctx *c, const double *diag_sum_known)
 {
     c->tri_grid_ok = false;
     dev_free(c->d_tcell_start); dev_free(c->d_tcell_rec);
     if (!c->filter_ok || c->grid_mode == 0 || c->n_tris < 64) return OA_OK;
-    DevTmp<double> d_sum;
-    HIPCHK(d_sum.alloc(1));
-    HIPCHK(hipMemsetAsync(d_sum, 0, sizeof(double), c->stream));
-    hipLaunchKernelGGL(oa::k_tri_diag_sum, dim3((c->n_tris + 255) / 256), dim3(256), 0, c->stream, c->d_tri9, c->n_tris, d_sum.p);
-    HIPCHK(hipGetLastError());
     double diag_sum = 0.0;
-    { int rcr = read_small(c, &diag_sum, d_sum, sizeof(double)); if (rcr) return rcr; }
+    if (diag_sum_known) diag_sum = *diag_sum_known;
+    else {
+        DevTmp<double> d_sum;
+        HIPCHK(d_sum.alloc(1));
+        HIPCHK(hipMemsetAsync(d_sum, 0, sizeof(double), c->stream));
+        hipLaunchKernelGGL(oa::k_tri_diag_sum, dim3((c->n_tris + 255) / 256), dim3(256), 0, c->stream, c->d_tri9, c->n_tris, d_sum.p);
+        HIPCHK(hipGetLastError());
+        { int rcr = read_small(c, &diag_sum, d_sum, sizeof(double)); if (rcr) return rcr; }
+    }
     double ext[3], scale = 0.0, max_ext = 0.0;
     for (int a = 0; a < 3; ++a) {
         ext[a] = c->bb_hi[a] - c->bb_lo[a];
@@ -2410,8 +2465,6 @@ int build_tri_grid(oa_ctx *c)
     const long long max_cells = 1ll << std::max(16, std::min(29, env_int("OA_TRI_MAX_CELLS_LOG2", 24)));
     DevTmp<int> d_counts;
     DevTmp<long long> d_off;
-    DevTmp<unsigned long long> d_total;
-    HIPCHK(d_total.alloc(1));
     oa::GridParams gp{};
     int n_cells = 0;
     unsigned long long entries = 0;
@@ -2435,11 +2488,13 @@ int build_tri_grid(oa_ctx *c)
         oa::grid_params_finish(gp);
         gp.eps_plane = (float)(8.0 * 5.9604644775390625e-08 * scale + 1e-37);
         n_cells = (int)total;
-        HIPCHK(d_counts.alloc((size_t)n_cells + 1));
-        HIPCHK(hipMemsetAsync(d_counts, 0, sizeof(int) * ((size_t)n_cells + 1), c->stream));
-        HIPCHK(hipMemsetAsync(d_total, 0, sizeof(unsigned long long), c->stream));
+        // (the entry total behind the counts, 8-byte aligned: one memset for both)
+        const size_t total_at = ((size_t)n_cells + 2) & ~(size_t)1;
+        HIPCHK(d_counts.alloc(total_at + 2));
+        unsigned long long *d_total = (unsigned long long *)(d_counts.p + total_at);
+        HIPCHK(hipMemsetAsync(d_counts, 0, sizeof(int) * (total_at + 2), c->stream));
         hipLaunchKernelGGL(oa::k_tri_grid_bin<false>, dim3((c->n_tris + 255) / 256), dim3(256), 0, c->stream, c->d_tri9,
-                           c->n_tris, gp, d_counts.p, (const int *)nullptr, (float4 *)nullptr, d_total.p);
+                           c->n_tris, gp, d_counts.p, (const int *)nullptr, (float4 *)nullptr, d_total);
         HIPCHK(hipGetLastError());
         { int rcr = read_small(c, &entries, d_total, sizeof(entries)); if (rcr) return rcr; }
         // triangles much larger than a cell explode the lists: coarsen
@@ -2554,22 +2609,28 @@ OA_EXPORT int oa_set_target_mesh(oa_ctx *c, const float *xyz, int64_t n_verts, i
     int rc = set_target_common(c, xyz, n_verts, on_device, false);  // vertex images + bbox + filter; no vertex grid / tree
     if (rc) return rc;
     if (n_verts < 1) return fail(OA_E_BAD_ARG, "oa_set_target_mesh: no vertices");
-    DevTmp<int> d_tris, d_bad;
+    DevTmp<int> d_tris;
+    DevTmp<double> d_chk;                                           // [0]: (as int) corners that index outside the vertices; [1]: sum of the bounding-box diagonals
     HIPCHK(d_tris.alloc(3 * (size_t)n_tris));
-    HIPCHK(d_bad.alloc(1));
+    HIPCHK(d_chk.alloc(2));
     HIPCHK(hipMemcpyAsync(d_tris, tris, sizeof(int) * 3 * (size_t)n_tris, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(int), c->stream));
+    HIPCHK(hipMemsetAsync(d_chk, 0, 2 * sizeof(double), c->stream));
     HIPCHK(dev_malloc(&c->d_tri9, sizeof(float4) * 3 * (size_t)n_tris));
     hipLaunchKernelGGL(oa::k_pack_tris, dim3((unsigned)((n_tris + 255) / 256)), dim3(256), 0, c->stream, c->d_tgt_xyz,
-                       (int)n_verts, (const int *)d_tris.p, (int)n_tris, c->d_tri9, d_bad.p);
+                       (int)n_verts, (const int *)d_tris.p, (int)n_tris, c->d_tri9, (int *)d_chk.p);
+    // the triangle grid's cell size comes from the mean bounding-box diagonal: summed here, so that the index check and the
+    // sum come back in ONE host round trip (a bad index leaves a triangle of garbage corners: the sum is not used then)
+    hipLaunchKernelGGL(oa::k_tri_diag_sum, dim3((unsigned)((n_tris + 255) / 256)), dim3(256), 0, c->stream, c->d_tri9, (int)n_tris, d_chk.p + 1);
     HIPCHK(hipGetLastError());
+    double chk[2] = { 0.0, 0.0 };
+    { int rcr = read_small(c, chk, d_chk, sizeof(chk)); if (rcr) return rcr; }
     int bad = 0;
-    { int rcr = read_small(c, &bad, d_bad, sizeof(int)); if (rcr) return rcr; }
+    memcpy(&bad, &chk[0], sizeof(int));
     if (bad) { dev_free(c->d_tri9); return fail(OA_E_BAD_ARG, "oa_set_target_mesh: %d triangle corners index outside 0..%lld", bad, (long long)n_verts - 1); }
     c->n_tris = (int)n_tris;
     c->surface = true;
     if ((rc = build_bvh(c, true))) return rc;
-    return build_tri_grid(c);
+    return build_tri_grid(c, &chk[1]);
 }
 
 namespace {
@@ -2618,18 +2679,15 @@ int source_reset(oa_ctx *c, long long count, long long begin, long long n_verts)
     HIPCHK(dev_malloc(&c->d_keys, sizeof(unsigned long long) * (size_t)c->ns_pad));
     HIPCHK(dev_malloc(&c->d_prev, sizeof(int) * (size_t)c->ns_pad));
     HIPCHK(dev_malloc(&c->d_win, sizeof(float4) * (size_t)c->ns_pad));
-    HIPCHK(hipMemsetAsync(c->d_win, 0xFF, sizeof(float4) * (size_t)c->ns_pad, c->stream));
     HIPCHK(dev_malloc(&c->d_wsafe, sizeof(uint2) * (size_t)c->ns_pad));
-    HIPCHK(hipMemsetAsync(c->d_wsafe, 0xFF, sizeof(uint2) * (size_t)c->ns_pad, c->stream));
     c->seeded = false;
     HIPCHK(dev_malloc(&c->d_sel, sizeof(int) * (size_t)c->ns_pad));
-    HIPCHK(hipMemsetAsync(c->d_sel, 0, sizeof(int) * (size_t)c->ns_pad, c->stream));
     dev_free(c->d_todo_list); dev_free(c->d_todo_count);
     HIPCHK(dev_malloc(&c->d_todo_list, sizeof(int) * (size_t)c->ns_pad));
     HIPCHK(dev_malloc(&c->d_todo_count, 2 * sizeof(int)));      // {entries of the hand-over list, most handed over by one wave}
-    HIPCHK(hipMemsetAsync(c->d_todo_count, 0, 2 * sizeof(int), c->stream));
-    hipLaunchKernelGGL(oa::k_fill_int, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, c->d_prev, c->ns_pad, -1);
-    hipLaunchKernelGGL(oa::k_fill_keys, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, c->d_keys, c->ns_pad);
+    // no seeds, empty keys, sel = 0, hand-over counters at zero: one launch
+    hipLaunchKernelGGL(oa::k_init_slots, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, c->d_prev, c->d_win, c->d_wsafe, c->d_keys, c->d_sel,
+                       c->d_todo_count, c->ns_pad);
     HIPCHK(hipGetLastError());
     c->pivot[0] = c->pivot[1] = c->pivot[2] = 0.0;
     return OA_OK;
@@ -2906,10 +2964,9 @@ OA_EXPORT int oa_reset_seeds(oa_ctx *c)
     if (!c->d_prev) return OA_OK;
     int rc = use_device(c);
     if (rc) return rc;
-    hipLaunchKernelGGL(oa::k_fill_int, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, c->d_prev, c->ns_pad, -1);
+    hipLaunchKernelGGL(oa::k_init_slots, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, c->d_prev, c->d_win, c->d_wsafe,
+                       (unsigned long long *)nullptr, (int *)nullptr, (int *)nullptr, c->ns_pad);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemsetAsync(c->d_win, 0xFF, sizeof(float4) * (size_t)c->ns_pad, c->stream));
-    if (c->d_wsafe) HIPCHK(hipMemsetAsync(c->d_wsafe, 0xFF, sizeof(uint2) * (size_t)c->ns_pad, c->stream));
     return OA_OK;
 }
 

@@ -540,6 +540,24 @@ __global__ void k_fill_keys(unsigned long long *keys, int n)
     if (i < n) keys[i] = KEY_EMPTY;
 }
 
+// everything a shard's slots start from, in ONE launch (it was six operations -- four memsets and two fills -- and an upload
+// is bound by the host's ~5 us per enqueued operation): no seed (prev = -1, win = all ones: index -1, wsafe = all ones),
+// empty keys, sel = 0 and the hand-over counters at zero.  Null pointers are skipped (oa_reset_seeds, a new target: the
+// seeds only).
+__global__ void k_init_slots(int *__restrict__ prev, float4 *__restrict__ win, uint2 *__restrict__ wsafe,
+                             unsigned long long *__restrict__ keys, int *__restrict__ sel, int *__restrict__ todo_count, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && todo_count) { todo_count[0] = 0; todo_count[1] = 0; }
+    if (i >= n) return;
+    const float ones = __uint_as_float(0xFFFFFFFFu);
+    if (prev) prev[i] = -1;
+    if (win) win[i] = make_float4(ones, ones, ones, ones);
+    if (wsafe) wsafe[i] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+    if (keys) keys[i] = KEY_EMPTY;
+    if (sel) sel[i] = 0;
+}
+
 __global__ void k_fill_int(int *a, int n, int v)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
