@@ -69,6 +69,7 @@ def parse():
     ap.add_argument("--no-surface", action="store_true", help="skip the surface-mode leg (1M points vs a 2M-triangle mesh)")
     ap.add_argument("--no-grid", action="store_true", help="skip the grid-search leg")
     ap.add_argument("--no-mfma", action="store_true", help="skip the OA_NN_MFMA=1 experiment leg")
+    ap.add_argument("--no-whole-call", action="store_true", help="skip the whole-call leg (operator calls from host arrays, upload included)")
     ap.add_argument("--no-c5", action="store_true", help="skip the BASELINE config 5 leg of a multi-GPU run")
     ap.add_argument("--c5", action="store_true", help="run the config 5 leg at N = 1 too")
     ap.add_argument("--c5-source", type=int, default=10_000_000)
@@ -149,6 +150,39 @@ def cpu_tiers(src, tgt, mxa, mxb):
         "gpairs_per_s": n3 * len(tgt) / t3 / 1e9, "cores": orc.max_threads(),
         "sample": "%d x %d pairs, same fp32 metric" % (n3, len(tgt)),
         "extrapolated_s_per_iteration": t3 / n3 * len(src)}
+    return out
+
+
+def whole_call_leg(local_rank, src, tgt, mxa, mxb):
+    """Whole operator calls from HOST arrays -- upload over PCIe + index builds + a 50-iteration run with the reference's early
+    exit (operators/icp_align.py:96-151) -- on a context that is kept between calls: what the add-on's user waits for.  Never
+    `value` (the metric excludes the one-time upload); reported so that DESIGN.md's whole-call figures have a driver-run twin.
+    Best of 5 calls each; the 1M <-> 1M pair is the bench workload, the 100k pair BASELINE config 2."""
+    import time
+    from object_alignment_amd import synth
+    from object_alignment_amd.engine import IcpEngine
+    out = {"what": "host arrays -> aligned matrix: set_target + set_source + run(iters=50, early exit); PCIe-inclusive, "
+                   "AUTO search; best of 5 calls on a warm context", "unit": "ms"}
+    cases = {"c3_1M_1M": (src, tgt, mxa, mxb)}
+    s2, t2, a2, b2 = synth.c2_bunny_pair(100_000)
+    cases["c2_100k_100k"] = (s2, t2, a2, b2)
+    with IcpEngine(local_rank) as e:
+        e.set_search_mode("auto")
+        for name, (s_, t_, a_, b_) in cases.items():
+            best, parts, res = 1e9, None, None
+            for _ in range(5):
+                t0 = time.perf_counter()
+                e.set_target(t_)
+                t1 = time.perf_counter()
+                e.set_source(s_, stride=1)
+                e.set_matrices(a_, b_)
+                t2_ = time.perf_counter()
+                r = e.run(iters=50, thresh=0.5, target_d=0.01, use_target=True, early_exit=True)
+                t3 = time.perf_counter()
+                if t3 - t0 < best:
+                    best, parts, res = t3 - t0, (t1 - t0, t2_ - t1, t3 - t2_), r
+            out[name] = {"ms": 1e3 * best, "set_target_ms": 1e3 * parts[0], "set_source_ms": 1e3 * parts[1], "run_ms": 1e3 * parts[2],
+                         "iterations": int(res.iters_done), "converged": bool(res.converged), "last_K": int(res.last_K)}
     return out
 
 
@@ -463,6 +497,13 @@ def main():
         except Exception as exc:                                  # never lose the headline line
             surf = {"error": repr(exc)}
 
+    whole = None
+    if n_gpus == 1 and not args.no_whole_call:
+        try:
+            whole = whole_call_leg(local_rank, src, tgt, mxa, mxb)
+        except Exception as exc:                                  # never lose the headline line
+            whole = {"error": repr(exc)}
+
     c5 = None
     if (n_gpus > 1 and not args.no_c5) or (n_gpus == 1 and args.c5):
         try:
@@ -555,6 +596,8 @@ def main():
             out["mfma_experiment"] = mfma
         if surf is not None:
             out["surface_path"] = surf
+        if whole is not None:
+            out["whole_call"] = whole
         if c5 is not None:
             out["c5_path"] = c5
         if n_gpus == 1 and not args.no_cpu_baseline and args.cpu_iters > 0:

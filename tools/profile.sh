@@ -10,7 +10,7 @@ OUT="$REPO/gpurun_out"
 STEPS="${STEPS:-5}"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --steps $STEPS --warmup 1 --no-cpu-baseline --no-surface"
+BENCH="python $REPO/bench.py --steps $STEPS --warmup 1 --no-cpu-baseline --no-surface --no-whole-call"
 rm -rf "$OUT"/prof_stats "$OUT"/prof_pmc_* "$OUT"/prof_surf_*
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_stats" -- $BENCH > "$OUT/prof_stats.log" 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -21,7 +21,7 @@ rocprofv3 --pmc SQ_WAVES SQ_INSTS_VMEM SQ_WAIT_ANY SQ_WAVE_CYCLES --output-forma
 # N = 2 / 4 / 8 shards, all on this GPU (OA_BENCH_SAME_DEVICE=1), so that an N > 1 bench line has PMC figures of its own shard size
 rm -rf "$OUT"/prof_n[248]_*
 for n in 2 4 8; do
-  BN="env OA_BENCH_SAME_DEVICE=1 python $REPO/bench.py --gpus $n --steps $STEPS --warmup 1 --no-cpu-baseline --no-surface --no-grid --no-mfma"
+  BN="env OA_BENCH_SAME_DEVICE=1 python $REPO/bench.py --gpus $n --steps $STEPS --warmup 1 --no-cpu-baseline --no-surface --no-grid --no-mfma --no-whole-call"
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $c --output-format csv -d "$OUT/prof_n${n}_$c" -- $BN > "$OUT/prof_n${n}_$c.log" 2>&1
   done
