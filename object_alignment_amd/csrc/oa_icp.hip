@@ -2333,12 +2333,12 @@ int build_bvh(oa_ctx *c, bool tri)
     else hipLaunchKernelGGL(oa::k_bvh_gather<false>, grd_pad, blk, 0, c->stream, (const float *)c->d_tgt_xyz, (const float4 *)nullptr,
                             (const int *)v_out.p, n, n_pad, d_prims);
     HIPCHK(hipGetLastError());
-    const dim3 grd1((unsigned)((bp.cnt[1] + 255) / 256));
+    const dim3 grd1((unsigned)((bp.cnt[1] + 3) / 4));               // one wave per box
     if (tri) hipLaunchKernelGGL(oa::k_bvh_leaf_boxes<true>, grd1, blk, 0, c->stream, (const float4 *)d_prims, n_pad, bp.cnt[1], d_box + 2ll * bp.off[1]);
     else hipLaunchKernelGGL(oa::k_bvh_leaf_boxes<false>, grd1, blk, 0, c->stream, (const float4 *)d_prims, n_pad, bp.cnt[1], d_box + 2ll * bp.off[1]);
     HIPCHK(hipGetLastError());
     for (int l = 2; l <= bp.levels; ++l) {
-        hipLaunchKernelGGL(oa::k_bvh_upper_boxes, dim3((unsigned)((bp.cnt[l] + 255) / 256)), blk, 0, c->stream,
+        hipLaunchKernelGGL(oa::k_bvh_upper_boxes, dim3((unsigned)((bp.cnt[l] + 3) / 4)), blk, 0, c->stream,
                            (const float4 *)(d_box + 2ll * bp.off[l - 1]), bp.cnt[l - 1], bp.cnt[l], d_box + 2ll * bp.off[l]);
         HIPCHK(hipGetLastError());
     }

@@ -55,8 +55,16 @@ __global__ void k_tri_diag_sum(const float4 *__restrict__ tri9, int n_tris, doub
         d = sqrt(s);
         if (!(d < INFINITY)) d = 0.0;
     }
+    // one atomic per WORKGROUP (one per wave -- 1280 on one word for 82k triangles -- was 17 us on the critical path of a mesh upload)
+    __shared__ double part[16];
     d = wave_sum(d);
-    if ((threadIdx.x & 63) == 0 && d > 0.0) atomicAdd(out, d);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += part[w];
+        if (t > 0.0) atomicAdd(out, t);
+    }
 }
 
 __device__ __forceinline__ void tri_cell_range(const float4 *__restrict__ tri9, int t, const GridParams &gp, int lo[3], int hi[3], bool &ok)
@@ -142,11 +150,11 @@ __global__ void k_tri_grid_bin(const float4 *__restrict__ tri9, int n_tris, Grid
                                unsigned long long *__restrict__ total)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_tris) return;
-    int lo[3], hi[3];
-    bool ok;
-    tri_cell_range(tri9, t, gp, lo, hi, ok);
-    if (!ok) return;
+    int lo[3] = { 0, 0, 0 }, hi[3] = { -1, -1, -1 };               // (empty ranges: a thread without a triangle stays for the count's barrier)
+    bool ok = false;
+    if (t < n_tris) tri_cell_range(tri9, t, gp, lo, hi, ok);
+    if (!ok) { lo[0] = lo[1] = lo[2] = 0; hi[0] = hi[1] = hi[2] = -1; }
+    if (FILL && !ok) return;
     float4 rec0 = make_float4(0.f, 0.f, 0.f, 0.f), rec1 = rec0;
     if (FILL) {
         float a[3], b[3], c[3];
@@ -165,7 +173,18 @@ __global__ void k_tri_grid_bin(const float4 *__restrict__ tri9, int n_tris, Grid
                 } else atomicAdd(&counts[cidx], 1);
                 ++n;
             }
-    if (!FILL && total) atomicAdd(total, n);
+    if (!FILL && total) {
+        // one atomic per WORKGROUP on the shared total (the launch's critical path ends in a read-back of it)
+        __shared__ unsigned long long part[16];
+        for (int o = 32; o > 0; o >>= 1) n += __shfl_down(n, o, 64);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = n;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long sum = 0;
+            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) sum += part[w];
+            if (sum) atomicAdd(total, sum);
+        }
+    }
 }
 
 __device__ __forceinline__ void tri_eval(const float *p, const float4 *__restrict__ tri9, uint32_t t, float &best, uint32_t &bidx)
