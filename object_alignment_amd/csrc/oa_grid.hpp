@@ -101,7 +101,10 @@ __device__ __forceinline__ float grid_sqrt_up(float x)
     return __builtin_amdgcn_sqrtf(x) * 1.000001f + 1e-18f;         // + 1e-18: x below the float normal range (sqrt < 1.1e-19)
 }
 
-__global__ void k_grid_count(const float *__restrict__ xyz, int nt, GridParams gp, int *__restrict__ cell_of,
+// cell_of: 2 ints per vertex -- its cell and its RANK among the cell's vertices (what the counting atomic returns): the
+// scatter then needs no second round of a million atomics on cursors (50 -> ~20 us of a 1M-vertex upload).  The rank is
+// the atomics' arrival order -- as arbitrary as the cursors' was; the order inside a cell is immaterial ((d2, index) min).
+__global__ void k_grid_count(const float *__restrict__ xyz, int nt, GridParams gp, int2 *__restrict__ cell_of,
                              int *__restrict__ counts)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -110,28 +113,27 @@ __global__ void k_grid_count(const float *__restrict__ xyz, int nt, GridParams g
     const int cy = grid_cell_coord((double)xyz[3ll * i + 1], gp.lo[1], gp.inv_h, gp.n[1]);
     const int cz = grid_cell_coord((double)xyz[3ll * i + 2], gp.lo[2], gp.inv_h, gp.n[2]);
     const int c = (cz * gp.n[1] + cy) * gp.n[0] + cx;
-    cell_of[i] = c;
-    atomicAdd(&counts[c], 1);
+    cell_of[i] = make_int2(c, atomicAdd(&counts[c], 1));
 }
 
-// offsets (exclusive scan of counts, long long from k_scan_counts) -> int cell_start; fill cursors zeroed
+// offsets (exclusive scan of counts, long long from k_scan_counts) -> int cell_start; cursor (the triangle grid's fill pass
+// counts its cells' entries again): zeroed, or nullptr
 __global__ void k_grid_starts(const long long *__restrict__ offsets, int n_cells, int *__restrict__ cell_start,
                               int *__restrict__ cursor)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i > n_cells) return;
     cell_start[i] = (int)offsets[i];
-    if (i < n_cells) cursor[i] = 0;
+    if (cursor && i < n_cells) cursor[i] = 0;
 }
 
-__global__ void k_grid_scatter(const float *__restrict__ xyz, int nt, const int *__restrict__ cell_of,
-                               const int *__restrict__ cell_start, int *__restrict__ cursor,
-                               float4 *__restrict__ sorted)
+__global__ void k_grid_scatter(const float *__restrict__ xyz, int nt, const int2 *__restrict__ cell_of,
+                               const int *__restrict__ cell_start, float4 *__restrict__ sorted)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nt) return;
-    const int c = cell_of[i];
-    const int pos = cell_start[c] + atomicAdd(&cursor[c], 1);    // order inside a cell is irrelevant: (d2, index) min
+    const int2 cr = cell_of[i];
+    const int pos = cell_start[cr.x] + cr.y;
     sorted[pos] = make_float4(xyz[3ll * i], xyz[3ll * i + 1], xyz[3ll * i + 2], __int_as_float(i));
 }
 

@@ -2130,7 +2130,8 @@ int build_grid(oa_ctx *c)
     if (!(h > 0.0) || !(h < INFINITY)) return OA_OK;
     const long long max_cells = 1ll << 24;
     static_assert((1ll << 24) <= oa::GRID_MAX_CELLS, "cell_start is addressed through 32-bit byte offsets");
-    DevTmp<int> d_cell_of, d_counts;
+    DevTmp<int2> d_cell_of;                                         // per vertex {cell, rank inside the cell}
+    DevTmp<int> d_counts;
     DevTmp<long long> d_off;
     HIPCHK(d_cell_of.alloc((size_t)c->nt));
     oa::GridParams gp{};
@@ -2185,8 +2186,8 @@ int build_grid(oa_ctx *c)
     HIPCHK(dev_malloc(&c->d_sorted, sizeof(float4) * (size_t)c->nt));
     DevTmp<char> scan_tmp;                                           // released on return, behind the wait below
     { int rcs = scan_counts(c, d_counts.p, n_cells, d_off.p, scan_tmp); if (rcs) return rcs; }
-    hipLaunchKernelGGL(oa::k_grid_starts, dim3((n_cells + 256) / 256), dim3(256), 0, c->stream, d_off.p, n_cells, c->d_cell_start, d_counts.p);
-    hipLaunchKernelGGL(oa::k_grid_scatter, dim3((c->nt + 255) / 256), dim3(256), 0, c->stream, c->d_tgt_xyz, c->nt, d_cell_of.p, c->d_cell_start, d_counts.p, c->d_sorted);
+    hipLaunchKernelGGL(oa::k_grid_starts, dim3((n_cells + 256) / 256), dim3(256), 0, c->stream, d_off.p, n_cells, c->d_cell_start, (int *)nullptr);
+    hipLaunchKernelGGL(oa::k_grid_scatter, dim3((c->nt + 255) / 256), dim3(256), 0, c->stream, c->d_tgt_xyz, c->nt, (const int2 *)d_cell_of.p, (const int *)c->d_cell_start, c->d_sorted);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     c->gp = gp; c->n_cells = n_cells; c->grid_ok = true;
