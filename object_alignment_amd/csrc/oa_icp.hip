@@ -2446,12 +2446,15 @@ int build_tri_grid(oa_ctx *c, const double *diag_sum_known)
     double diag_sum = 0.0;
     if (diag_sum_known) diag_sum = *diag_sum_known;
     else {
+        constexpr size_t SLOT_WORDS = (size_t)oa::TOTAL_SLOTS * oa::TOTAL_STRIDE;
         DevTmp<double> d_sum;
-        HIPCHK(d_sum.alloc(1));
-        HIPCHK(hipMemsetAsync(d_sum, 0, sizeof(double), c->stream));
+        HIPCHK(d_sum.alloc(SLOT_WORDS));
+        HIPCHK(hipMemsetAsync(d_sum, 0, sizeof(double) * SLOT_WORDS, c->stream));
         hipLaunchKernelGGL(oa::k_tri_diag_sum, dim3((c->n_tris + 255) / 256), dim3(256), 0, c->stream, c->d_tri9, c->n_tris, d_sum.p);
         HIPCHK(hipGetLastError());
-        { int rcr = read_small(c, &diag_sum, d_sum, sizeof(double)); if (rcr) return rcr; }
+        double slots[SLOT_WORDS];
+        { int rcr = read_small(c, slots, d_sum, sizeof(slots)); if (rcr) return rcr; }
+        for (int k = 0; k < oa::TOTAL_SLOTS; ++k) diag_sum += slots[(size_t)k * oa::TOTAL_STRIDE];
     }
     double ext[3], scale = 0.0, max_ext = 0.0;
     for (int a = 0; a < 3; ++a) {
@@ -2491,13 +2494,20 @@ int build_tri_grid(oa_ctx *c, const double *diag_sum_known)
         n_cells = (int)total;
         // (the entry total behind the counts, 8-byte aligned: one memset for both)
         const size_t total_at = ((size_t)n_cells + 2) & ~(size_t)1;
-        HIPCHK(d_counts.alloc(total_at + 2));
+        constexpr size_t SLOT_WORDS = (size_t)oa::TOTAL_SLOTS * oa::TOTAL_STRIDE;       // 8-byte words of the spread total (oa_tri.hpp)
+        HIPCHK(d_counts.alloc(total_at + 2 * SLOT_WORDS));
         unsigned long long *d_total = (unsigned long long *)(d_counts.p + total_at);
-        HIPCHK(hipMemsetAsync(d_counts, 0, sizeof(int) * (total_at + 2), c->stream));
+        HIPCHK(hipMemsetAsync(d_counts, 0, sizeof(int) * (total_at + 2 * SLOT_WORDS), c->stream));
         hipLaunchKernelGGL(oa::k_tri_grid_bin<false>, dim3((c->n_tris + 255) / 256), dim3(256), 0, c->stream, c->d_tri9,
                            c->n_tris, gp, d_counts.p, (const int *)nullptr, (float4 *)nullptr, d_total);
         HIPCHK(hipGetLastError());
-        { int rcr = read_small(c, &entries, d_total, sizeof(entries)); if (rcr) return rcr; }
+        {
+            unsigned long long slots[SLOT_WORDS];
+            int rcr = read_small(c, slots, d_total, sizeof(slots));
+            if (rcr) return rcr;
+            entries = 0;
+            for (int k = 0; k < oa::TOTAL_SLOTS; ++k) entries += slots[(size_t)k * oa::TOTAL_STRIDE];
+        }
         // triangles much larger than a cell explode the lists: coarsen
         if (entries > 32ull * (unsigned long long)c->n_tris + (1ull << 20) || entries > (unsigned long long)oa::TRI_REC_MAX_ENTRIES) { h *= 2.0; n_cells = 0; continue; }
         break;
@@ -2611,11 +2621,12 @@ OA_EXPORT int oa_set_target_mesh(oa_ctx *c, const float *xyz, int64_t n_verts, i
     if (rc) return rc;
     if (n_verts < 1) return fail(OA_E_BAD_ARG, "oa_set_target_mesh: no vertices");
     DevTmp<int> d_tris;
-    DevTmp<double> d_chk;                                           // [0]: (as int) corners that index outside the vertices; [1]: sum of the bounding-box diagonals
+    constexpr size_t SLOT_WORDS = (size_t)oa::TOTAL_SLOTS * oa::TOTAL_STRIDE;
+    DevTmp<double> d_chk;                                           // [0]: (as int) corners that index outside the vertices; [1 ...]: the spread sum of the bounding-box diagonals (oa_tri.hpp: TOTAL_SLOTS)
     HIPCHK(d_tris.alloc(3 * (size_t)n_tris));
-    HIPCHK(d_chk.alloc(2));
+    HIPCHK(d_chk.alloc(1 + SLOT_WORDS));
     HIPCHK(hipMemcpyAsync(d_tris, tris, sizeof(int) * 3 * (size_t)n_tris, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemsetAsync(d_chk, 0, 2 * sizeof(double), c->stream));
+    HIPCHK(hipMemsetAsync(d_chk, 0, (1 + SLOT_WORDS) * sizeof(double), c->stream));
     HIPCHK(dev_malloc(&c->d_tri9, sizeof(float4) * 3 * (size_t)n_tris));
     hipLaunchKernelGGL(oa::k_pack_tris, dim3((unsigned)((n_tris + 255) / 256)), dim3(256), 0, c->stream, c->d_tgt_xyz,
                        (int)n_verts, (const int *)d_tris.p, (int)n_tris, c->d_tri9, (int *)d_chk.p);
@@ -2623,15 +2634,17 @@ OA_EXPORT int oa_set_target_mesh(oa_ctx *c, const float *xyz, int64_t n_verts, i
     // sum come back in ONE host round trip (a bad index leaves a triangle of garbage corners: the sum is not used then)
     hipLaunchKernelGGL(oa::k_tri_diag_sum, dim3((unsigned)((n_tris + 255) / 256)), dim3(256), 0, c->stream, c->d_tri9, (int)n_tris, d_chk.p + 1);
     HIPCHK(hipGetLastError());
-    double chk[2] = { 0.0, 0.0 };
+    double chk[1 + SLOT_WORDS];
     { int rcr = read_small(c, chk, d_chk, sizeof(chk)); if (rcr) return rcr; }
     int bad = 0;
     memcpy(&bad, &chk[0], sizeof(int));
+    double diag_sum = 0.0;
+    for (int k = 0; k < oa::TOTAL_SLOTS; ++k) diag_sum += chk[1 + (size_t)k * oa::TOTAL_STRIDE];
     if (bad) { dev_free(c->d_tri9); return fail(OA_E_BAD_ARG, "oa_set_target_mesh: %d triangle corners index outside 0..%lld", bad, (long long)n_verts - 1); }
     c->n_tris = (int)n_tris;
     c->surface = true;
     if ((rc = build_bvh(c, true))) return rc;
-    return build_tri_grid(c, &chk[1]);
+    return build_tri_grid(c, &diag_sum);
 }
 
 namespace {

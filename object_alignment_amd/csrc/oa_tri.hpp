@@ -38,6 +38,11 @@ __global__ void k_pack_tris(const float *__restrict__ xyz, int n_verts, const in
     tri9[3ll * t + 2] = make_float4(q[8], 0.f, 0.f, 0.f);
 }
 
+// Totals of the mesh builds (sum of diagonals, number of cell-list entries) are accumulated in TOTAL_SLOTS words, 128 bytes
+// apart, workgroup b adding to slot b mod TOTAL_SLOTS; the host adds the slots.  One word for everybody serialises: 7646
+// workgroup atomics on it were ~90 us of a 1.96M-triangle launch (one per wave before that: 17 us already at 82k triangles).
+constexpr int TOTAL_SLOTS = 64, TOTAL_STRIDE = 16;                  // (stride in 8-byte words)
+
 // sum of triangle bounding-box diagonals (for the cell size) -- double atomics are fine here (one-time, not a result)
 __global__ void k_tri_diag_sum(const float4 *__restrict__ tri9, int n_tris, double *__restrict__ out)
 {
@@ -55,7 +60,7 @@ __global__ void k_tri_diag_sum(const float4 *__restrict__ tri9, int n_tris, doub
         d = sqrt(s);
         if (!(d < INFINITY)) d = 0.0;
     }
-    // one atomic per WORKGROUP (one per wave -- 1280 on one word for 82k triangles -- was 17 us on the critical path of a mesh upload)
+    // one atomic per WORKGROUP, spread over TOTAL_SLOTS words
     __shared__ double part[16];
     d = wave_sum(d);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = d;
@@ -63,7 +68,7 @@ __global__ void k_tri_diag_sum(const float4 *__restrict__ tri9, int n_tris, doub
     if (threadIdx.x == 0) {
         double t = 0.0;
         for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += part[w];
-        if (t > 0.0) atomicAdd(out, t);
+        if (t > 0.0) atomicAdd(out + (size_t)(blockIdx.x % TOTAL_SLOTS) * TOTAL_STRIDE, t);
     }
 }
 
@@ -174,7 +179,7 @@ __global__ void k_tri_grid_bin(const float4 *__restrict__ tri9, int n_tris, Grid
                 ++n;
             }
     if (!FILL && total) {
-        // one atomic per WORKGROUP on the shared total (the launch's critical path ends in a read-back of it)
+        // one atomic per WORKGROUP, spread over TOTAL_SLOTS words (the launch's critical path ends in a read-back of them)
         __shared__ unsigned long long part[16];
         for (int o = 32; o > 0; o >>= 1) n += __shfl_down(n, o, 64);
         if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = n;
@@ -182,7 +187,7 @@ __global__ void k_tri_grid_bin(const float4 *__restrict__ tri9, int n_tris, Grid
         if (threadIdx.x == 0) {
             unsigned long long sum = 0;
             for (int w = 0; w < (int)(blockDim.x >> 6); ++w) sum += part[w];
-            if (sum) atomicAdd(total, sum);
+            if (sum) atomicAdd(total + (size_t)(blockIdx.x % TOTAL_SLOTS) * TOTAL_STRIDE, sum);
         }
     }
 }
