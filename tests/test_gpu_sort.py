@@ -62,6 +62,8 @@ def test_loops_do_not_depend_on_which_sort_ordered_the_slots():
     assert ours.keys() == theirs.keys() and len(ours) == 9
     assert ours == theirs, {k: (ours[k][:12], theirs[k][:12]) for k in ours if ours[k] != theirs[k]}
     assert default == theirs
+    # ... nor on how the builds' small results reach the host (kernels storing into mapped host memory / device buffer + copy)
+    assert _run({"OA_MAPPED_RESULTS": "0"}) == theirs
 
 
 def test_sort_bench_permutations():
