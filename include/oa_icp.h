@@ -217,6 +217,11 @@ int oa_reset_seeds(oa_ctx *ctx);
 #define OA_STAT_NN_MS_MAX         19   /* fastest / the slowest device: how evenly the shards load the GPUs */
 #define OA_STAT_SAFE_RADII        20   /* 1 = the vertex grid's safe radii are built for the current target (a seed inside its own settles the
                                        * query without a scan or a descent; built once the target has seen 8 loop iterations; first device) */
+#define OA_STAT_TRI_RING          21   /* 1 = the triangle neighbour lists are built for the current mesh (a query within its seed triangle's accept
+                                       * radius is settled by the seed and the triangles that touch it; built once the mesh has
+                                       * seen 4 loop searches, OA_TRI_RING=2: with the grid; first device) */
+#define OA_STAT_TRI_RING_ACCEPTS  22   /* diagnostic (one extra launch + a wait): source points of this shard that the neighbour lists would settle at
+                                       * the current pose with the current seeds; multi-device context: the sum over the shards */
 #define OA_STAT_ENQUEUED_CHILD  1000   /* + i: the same count for child i alone */
 int oa_get_stat(oa_ctx *ctx, int what, double *value);
 int64_t oa_num_selected(oa_ctx *ctx);     /* selected source points held by this context (its shard) */

@@ -35,6 +35,8 @@ struct GridParams {
     // covers `slack` above plus every float rounding between the double cell frame and a gap (< 2e-6 h), rounded up
     float  hf, inv_hf, slackf;
     float  eps_plane;        // triangle grid: how far a triangle's corners may lie from the plane of its record (oa_tri.hpp)
+    int    drop_over;        // triangle grid: a query whose listed cells exceed its budget scans none of them (OA_TRI_DROP_OVER)
+    double moving_h;         // the pose "still moves" (budget_moving applies) while last step's translation + rotation x size exceeds this
 };
 
 // host: fill the float fields from h / slack
@@ -493,7 +495,7 @@ __global__ __launch_bounds__(BT, OA_GRID_MIN_WAVES) void k_nn_search_grid(const 
     {
         const int last = (st->n + 4) % 5;
         const double moved = st->use_target && st->n > 0 ? (st->ring_t[last] + st->ring_r[last] * gp.scale) * st->local_per_world : 0.0;
-        if (st->n == 0 || moved > 0.25 * gp.h) budget = gp.budget_moving;
+        if (st->n == 0 || moved > gp.moving_h) budget = gp.budget_moving;
         if (L > 1) budget = budget / L + 8;
         budget_extra = budget - (L > 1 ? gp.budget / L + 8 : gp.budget);
     }

@@ -20,6 +20,7 @@ typedef enum { ncclSum = 0 } ncclRedOp_t;
 #include "oa_kernels.hpp"
 #include "oa_grid.hpp"
 #include "oa_tri.hpp"
+#include "oa_tri_ring.hpp"
 #include "oa_bvh.hpp"
 #include "oa_affine.hpp"
 #include "oa_mfma.hpp"
@@ -342,7 +343,9 @@ struct oa_ctx {
     int n_cells = 0;
     int *d_cell_start = nullptr;
     float4 *d_sorted = nullptr;
-    int *d_todo_list = nullptr, *d_todo_count = nullptr;
+    int *d_todo_list = nullptr, *d_todo_count = nullptr;   // d_todo_count: {entries, most per wave} of the hand-over list; [2], [3]: the two counters of d_ulist (k_tri_accept)
+    int *d_ulist = nullptr;          // surface mode: the queries their seed and its neighbours did not settle (k_tri_accept -> k_tri_search_grid)
+    int u_slot = 0;                  // which of the two counters the next k_tri_accept launch fills (it zeroes the other one)
     // surface mode (closest point on triangle, oa_tri.hpp)
     bool surface = false, tri_grid_ok = false;
     int n_tris = 0;
@@ -351,6 +354,14 @@ struct oa_ctx {
     int *d_tcell_start = nullptr;
     float4 *d_tcell_rec = nullptr;   // two float4 per cell-list entry: {disc centre, radius} {unit normal, triangle index}
     long long n_tri_entries = 0;     // entries of the triangle grid's cell lists
+    // seed + neighbours settle a query (oa_tri_ring.hpp): per triangle its neighbours' indices; the accept radius lives in d_tri9
+    int *d_tri_ring = nullptr;
+    bool tri_ring_ok = false;        // built for the current mesh
+    int tri_ring = 0;                // OA_TRI_RING (EXPERIMENT, off: exact, measured, not faster -- DESIGN.md 4.5): 0 = never; 1 = built once a mesh has seen TRI_RING_LAZY_ITERS searches of a loop; 2 = built with the grid
+    double tri_ring_cap = 0.25;      // OA_TRI_RING_CAP: clearances are looked for up to this fraction of a cell edge
+    bool tri_split_lanes = true;     // OA_TRI_SPLIT_LANES=0 (A/B): the list is always searched with the shard's own lanes per query
+    bool tri_split = true;           // OA_TRI_SPLIT=0 (A/B): the seed + neighbours test stays in the grid search's prologue (no k_tri_accept launch)
+    long long tri_iters = 0;         // loop searches enqueued since the mesh was set
     // bounding-box trees (oa_bvh.hpp): over the vertices, and over the triangles in surface mode
     bool bvh_ok = false, tbvh_ok = false;
     oa::BvhParams bvh, tbvh;
@@ -647,6 +658,18 @@ int safe_radii_lazy(oa_ctx *c, bool counting)
     return c->target_iters > SAFE_LAZY_ITERS ? build_safe_radii(c) : OA_OK;
 }
 int build_tri_grid(oa_ctx *c, const double *diag_sum_known = nullptr);
+int build_tri_ring(oa_ctx *c);
+// OA_TRI_RING=1: the neighbour lists are built once the mesh has served TRI_RING_LAZY_ITERS searches of a loop -- while the pose
+// still moves by a good part of a triangle no query is within its seed's accept radius, and a short early-exit call should not
+// pay for the build.  The buffer is allocated with the grid (never inside a loop: an allocation can wait for another stream,
+// see safe_radii_lazy); the build itself is one launch on the context's stream, the searches queue behind it.
+constexpr long long TRI_RING_LAZY_ITERS = 4;
+int tri_ring_lazy(oa_ctx *c, bool counting)
+{
+    if (c->tri_ring != 1 || c->tri_ring_ok || !c->d_tri_ring) return OA_OK;
+    if (counting) ++c->tri_iters;
+    return c->tri_iters > TRI_RING_LAZY_ITERS ? build_tri_ring(c) : OA_OK;
+}
 int build_bvh(oa_ctx *c, bool tri);
 int scan_counts(oa_ctx *c, const int *d_counts, int n, long long *d_off, DevTmp<char> &tmp);
 int launch_tri_search(oa_ctx *c, bool acc = false);
@@ -764,6 +787,8 @@ SearchPlan search_plan(const oa_ctx *c)
         if (bvh_whole(c, c->tbvh_ok, tri_tree_max(c))) return small ? PLAN_TREE : PLAN_PLAIN;
         // the triangle grid search with the accumulating epilogue: shards above the zone where tree and grid take turns
         const bool dual = c->grid_mode == -1 && c->turns_on && c->ns <= tri_tree_early(c);
+        // (with the neighbour lists: k_tri_accept + the search of what it leaves, which has no accumulating form)
+        if (c->tri_ring_ok && c->tri_split && c->seeded) return PLAN_PLAIN;
         return (tri_grid_active(c) && !dual && canon_blocks(c) > 0 && c->tri_acc) ? PLAN_GRID : PLAN_PLAIN;
     }
     if (bvh_whole(c, c->bvh_ok, vertex_tree_max(c))) return small ? PLAN_TREE : PLAN_PLAIN;
@@ -1080,7 +1105,8 @@ int begin_loop(oa_ctx *c, const oa_settings *st, int iters)
     init_loop_state(c, st, iters);
     *c->h_state_pin = c->h_state;                               // pinned staging copy (the stream is idle, see above)
     HIPCHK(hipMemcpyAsync(c->d_state, c->h_state_pin, sizeof(oa::DevState), hipMemcpyHostToDevice, c->stream));
-    if (c->d_todo_count) HIPCHK(hipMemsetAsync(c->d_todo_count, 0, 2 * sizeof(int), c->stream));   // kept at zero by k_solve_update
+    if (c->d_todo_count) HIPCHK(hipMemsetAsync(c->d_todo_count, 0, 4 * sizeof(int), c->stream));   // kept at zero by k_solve_update ([2], [3]: by k_tri_accept)
+    c->u_slot = 0;
     if (!c->surface && (rc = safe_radii_lazy(c, false))) return rc;   // a multi-device child's turn to build them (never inside its group's loop)
     hipLaunchKernelGGL(oa::k_stamp_start, dim3(1), dim3(64), 0, c->stream, c->d_state);
     HIPCHK(hipGetLastError());
@@ -1824,6 +1850,10 @@ OA_EXPORT int oa_create(oa_ctx **out, int device)
     c->grid_stats = env_int("OA_GRID_STATS", 0) != 0;
     c->tri_share = env_int("OA_TRI_SHARE", 1) != 0;
     c->grid_safe = std::max(0, std::min(2, env_int("OA_GRID_SAFE", 1)));
+    c->tri_ring = std::max(0, std::min(2, env_int("OA_TRI_RING", 0)));
+    c->tri_ring_cap = env_double("OA_TRI_RING_CAP", 0.25);
+    c->tri_split = env_int("OA_TRI_SPLIT", 1) != 0;
+    c->tri_split_lanes = env_int("OA_TRI_SPLIT_LANES", 1) != 0;
     c->tri_canon = env_int("OA_TRI_CANON", 1) != 0;
     c->list_blocks_per_cu = std::max(1, std::min(64, env_int("OA_LIST_BLOCKS_PER_CU", 16)));
     c->tri_acc = env_int("OA_TRI_ACC", 1) != 0;
@@ -1967,11 +1997,11 @@ OA_EXPORT void oa_destroy(oa_ctx *c)
     tl_stream_known = false;                                        // the stream below is about to go away
 #define OA_FREE(x) dev_free(c->x, true)
     OA_FREE(d_tgt_xyz); OA_FREE(d_tg); OA_FREE(d_tf); OA_FREE(d_tf3); OA_FREE(d_tfm); OA_FREE(d_members); OA_FREE(d_pos); OA_FREE(d_prev); OA_FREE(d_win); OA_FREE(d_wsafe); OA_FREE(d_safe_by_idx); OA_FREE(d_cell_start);
-    OA_FREE(d_sorted); OA_FREE(d_todo_list); OA_FREE(d_todo_count); OA_FREE(d_src4); OA_FREE(d_keys); OA_FREE(d_state);
+    OA_FREE(d_sorted); OA_FREE(d_todo_list); OA_FREE(d_todo_count); OA_FREE(d_ulist); OA_FREE(d_src4); OA_FREE(d_keys); OA_FREE(d_state);
     OA_FREE(d_partials); OA_FREE(d_sums); OA_FREE(d_solve);
     OA_FREE(d_valid); OA_FREE(d_b); OA_FREE(d_dist); OA_FREE(d_counts); OA_FREE(d_offsets); OA_FREE(d_A); OA_FREE(d_B);
     OA_FREE(d_bvh_box); OA_FREE(d_bvh_prims); OA_FREE(d_tbvh_box); OA_FREE(d_tbvh_prims);
-    OA_FREE(d_tri9); OA_FREE(d_tcell_start); OA_FREE(d_tcell_rec);
+    OA_FREE(d_tri9); OA_FREE(d_tcell_start); OA_FREE(d_tcell_rec); OA_FREE(d_tri_ring);
     OA_FREE(d_sel); OA_FREE(d_src_n); OA_FREE(d_tgt_n); OA_FREE(d_src4o); OA_FREE(d_perm);
 #undef OA_FREE
     if (c->h_hist_map) (void)hipHostFree(c->h_hist_map);
@@ -2155,6 +2185,7 @@ int build_grid(oa_ctx *c)
         //  search above 128 once the doubling for a moving pose ends, and every one of them costs the iteration its fast path)
         gp.budget = env_int("OA_GRID_BUDGET", 256);
         gp.budget_moving = (int)(gp.budget * env_double("OA_GRID_BUDGET_MOVING", 2.0));
+        gp.moving_h = 0.25 * gp.h;
         gp.slack = 1e-10 * scale + 1e-300;
         gp.scale = scale;
         oa::grid_params_finish(gp);
@@ -2214,7 +2245,8 @@ int set_target_common(oa_ctx *c, const float *xyz, int64_t n, int on_device, boo
     HIPCHK(hipStreamSynchronize(c->stream));
     c->loop_active = false;                                         // an open oa_iterate sequence ends with the old target
     dev_free(c->d_tgt_xyz); dev_free(c->d_tg); dev_free(c->d_tf); dev_free(c->d_tf3); dev_free(c->d_tfm);
-    dev_free(c->d_tri9); dev_free(c->d_tcell_start); dev_free(c->d_tcell_rec);
+    dev_free(c->d_tri9); dev_free(c->d_tcell_start); dev_free(c->d_tcell_rec); dev_free(c->d_tri_ring);
+    c->tri_ring_ok = false;
     dev_free(c->d_bvh_box); dev_free(c->d_bvh_prims); dev_free(c->d_tbvh_box); dev_free(c->d_tbvh_prims);
     c->surface = false; c->tri_grid_ok = false; c->n_tris = 0; c->bvh_ok = false; c->tbvh_ok = false;
     dev_free(c->d_tgt_n);
@@ -2441,8 +2473,10 @@ int sort_source_slots(oa_ctx *c, const float *d_xyz, long long n_verts)
 int build_tri_grid(oa_ctx *c, const double *diag_sum_known)
 {
     c->tri_grid_ok = false;
-    dev_free(c->d_tcell_start); dev_free(c->d_tcell_rec);
+    c->tri_ring_ok = false; c->tri_iters = 0;
+    dev_free(c->d_tcell_start); dev_free(c->d_tcell_rec); dev_free(c->d_tri_ring);
     if (!c->filter_ok || c->grid_mode == 0 || c->n_tris < 64) return OA_OK;
+    if ((long long)c->n_tris > (long long)oa::TRI_REC_INDEX_MASK) return OA_OK;     // (28-bit indices in the records: the tree takes such meshes)
     double diag_sum = 0.0;
     if (diag_sum_known) diag_sum = *diag_sum_known;
     else {
@@ -2491,6 +2525,8 @@ int build_tri_grid(oa_ctx *c, const double *diag_sum_known)
         gp.slack = 1e-10 * scale + 1e-300;
         oa::grid_params_finish(gp);
         gp.eps_plane = (float)(8.0 * 5.9604644775390625e-08 * scale + 1e-37);
+        gp.drop_over = env_int("OA_TRI_DROP_OVER", 1);
+        gp.moving_h = env_double("OA_TRI_MOVING_FRAC", 0.25) * gp.h;
         n_cells = (int)total;
         // (the entry total behind the counts, 8-byte aligned: one memset for both)
         const size_t total_at = ((size_t)n_cells + 2) & ~(size_t)1;
@@ -2530,6 +2566,39 @@ int build_tri_grid(oa_ctx *c, const double *diag_sum_known)
     if (c->debug)
         fprintf(stderr, "[oa] tri grid: h=%g cells=%dx%dx%d entries=%llu (%.2f per triangle)\n", gp.h, gp.n[0], gp.n[1], gp.n[2],
                 entries, (double)entries / c->n_tris);
+    if (c->tri_ring) {
+        HIPCHK(dev_malloc(&c->d_tri_ring, sizeof(int) * (size_t)oa::TRI_RING_STRIDE * (size_t)c->n_tris));
+        if (c->tri_ring == 2) return build_tri_ring(c);
+    }
+    return OA_OK;
+}
+
+// neighbour lists + accept radii (oa_tri_ring.hpp): one launch on the context's stream, no wait.  The accept radii are written
+// into d_tri9's spare lane, which k_pack_tris left at 0 = "never".
+int build_tri_ring(oa_ctx *c)
+{
+    if (!c->tri_grid_ok || !c->d_tri_ring || c->tri_ring_ok) return OA_OK;
+    const double cap = std::max(0.01, std::min(c->tri_ring_cap, 1.0)) * c->tgp.h;
+    const dim3 blocks((unsigned)((c->n_tris + 255) / 256));
+    if (c->grid_stats || c->debug) {
+        DevTmp<unsigned long long> d_stats;
+        HIPCHK(d_stats.alloc(oa::RING_STAT_N));
+        HIPCHK(hipMemsetAsync(d_stats, 0, sizeof(unsigned long long) * oa::RING_STAT_N, c->stream));
+        hipLaunchKernelGGL(oa::k_tri_ring_build<true>, blocks, dim3(256), 0, c->stream, c->d_tri9, c->n_tris, c->tgp, (const int *)c->d_tcell_start,
+                           (const float4 *)c->d_tcell_rec, cap, c->d_tri_ring, d_stats.p);
+        HIPCHK(hipGetLastError());
+        unsigned long long h[oa::RING_STAT_N];
+        { int rcr = read_small(c, h, d_stats, sizeof(h)); if (rcr) return rcr; }
+        const double nt = (double)std::max(1ull, h[oa::RING_STAT_TRIS]);
+        fprintf(stderr, "[oa] tri ring: %llu triangles, %.2f%% never accept, %.2f%% at the cap (%.3g); per triangle: %.1f records read, %.1f triangles tested, %.2f neighbours\n",
+                h[oa::RING_STAT_TRIS], 100.0 * h[oa::RING_STAT_NEVER] / nt, 100.0 * h[oa::RING_STAT_CAPPED] / nt, cap, h[oa::RING_STAT_RECORDS] / nt,
+                h[oa::RING_STAT_TESTS] / nt, h[oa::RING_STAT_NEIGHBOURS] / nt);
+    } else {
+        hipLaunchKernelGGL(oa::k_tri_ring_build<false>, blocks, dim3(256), 0, c->stream, c->d_tri9, c->n_tris, c->tgp, (const int *)c->d_tcell_start,
+                           (const float4 *)c->d_tcell_rec, cap, c->d_tri_ring, (unsigned long long *)nullptr);
+        HIPCHK(hipGetLastError());
+    }
+    c->tri_ring_ok = true;
     return OA_OK;
 }
 
@@ -2542,17 +2611,51 @@ int launch_tri_search(oa_ctx *c, bool acc)
                 (int)use_grid, (int)acc, c->ns, c->n_tris, (void *)c->d_state, (void *)c->d_src4, (void *)c->d_tri9, (void *)c->d_prev,
                 (void *)c->d_keys, (void *)c->d_todo_list, (void *)c->d_todo_count, (void *)c->d_tcell_start, (void *)c->d_tcell_rec);
     if (use_grid) {
-        if (!acc && !c->loop_active) HIPCHK(hipMemsetAsync(c->d_todo_count, 0, 2 * sizeof(int), c->stream));
+        if (!acc && !c->loop_active) { HIPCHK(hipMemsetAsync(c->d_todo_count, 0, 4 * sizeof(int), c->stream)); c->u_slot = 0; }
+        if (c->loop_active) { const int rcr = tri_ring_lazy(c, true); if (rcr) return rcr; }
+        const int *ring = c->tri_ring_ok ? c->d_tri_ring : nullptr;
         const bool dual = c->grid_mode == -1 && c->turns_on && c->ns <= tri_tree_early(c);
+        // With the neighbour lists and seeds: k_tri_accept settles what seed + neighbours settle and lists the rest, the grid
+        // search works through the list (oa_tri.hpp).  Not for the accumulating form (its rows go by workgroup), nor while tree
+        // and grid take turns (DevState::tree_turn): those keep the test in the search's own prologue.
+        const bool split = ring && !acc && !dual && c->seeded && c->tri_split && c->d_ulist;
+        const int *qlist = nullptr, *qcount = nullptr;
+        if (split) {
+            hipLaunchKernelGGL(oa::k_tri_accept, dim3((unsigned)((c->ns + 255) / 256)), dim3(256), 0, c->stream, (const oa::DevState *)c->d_state,
+                               (const float4 *)c->d_src4, c->ns, (float)c->tgp.scale * 1.000001f, (const float4 *)c->d_tri9, (const int *)c->d_prev, ring,
+                               c->d_keys, c->d_ulist, c->d_todo_count + 2, c->u_slot);
+            HIPCHK(hipGetLastError());
+            qlist = c->d_ulist; qcount = c->d_todo_count + 2 + c->u_slot;
+            c->u_slot ^= 1;
+            ring = nullptr;                                          // (the list's queries failed that test already)
+        }
         if (dual) { int rcb = launch_bvh<true>(c, nullptr, nullptr, 1); if (rcb) return rcb; }    // runs when DevState::tree_turn
         const int turn = dual ? 0 : -1;
         const int lanes = tri_lanes_for(c);
 #define OA_TGRID_ARGS c->d_state, c->d_src4, c->ns, c->tgp, c->d_tcell_start, c->d_tcell_rec, c->d_tri9, c->d_prev, c->d_keys, c->d_todo_list, c->d_todo_count, turn
         const dim3 gblocks((unsigned)(((long long)c->ns * lanes + 255) / 256));
+        if (split) {
+            // the list's length decides the lanes per query, on the device (k_tri_search_grid: qmin / qmax): a 4-lane launch for
+            // lists of up to `small` queries, and the shard's own geometry for longer ones
+            const int small = std::min(c->ns, (c->n_tris >= 250000 ? 400 : 128) * c->n_cu);
+#define OA_TGRID_LIST_TAIL(lo, hi) (unsigned long long *)nullptr, oa::BvhParams{}, (const float4 *)nullptr, (const float4 *)nullptr, oa::NormalTest{}, (double *)nullptr, (const int *)nullptr, qlist, qcount, lo, hi
+            if (lanes != 4 && c->tri_split_lanes) {
+                hipLaunchKernelGGL(oa::k_tri_search_grid<4>, dim3((unsigned)(((long long)small * 4 + 255) / 256)), dim3(256), 0, c->stream, OA_TGRID_ARGS, OA_TGRID_LIST_TAIL(0, small));
+                if (lanes == 2) hipLaunchKernelGGL(oa::k_tri_search_grid<2>, gblocks, dim3(256), 0, c->stream, OA_TGRID_ARGS, OA_TGRID_LIST_TAIL(small, 0x7FFFFFFF));
+                else hipLaunchKernelGGL(oa::k_tri_search_grid<1>, gblocks, dim3(256), 0, c->stream, OA_TGRID_ARGS, OA_TGRID_LIST_TAIL(small, 0x7FFFFFFF));
+            } else {
+                if (lanes == 4) hipLaunchKernelGGL(oa::k_tri_search_grid<4>, gblocks, dim3(256), 0, c->stream, OA_TGRID_ARGS, OA_TGRID_LIST_TAIL(0, 0x7FFFFFFF));
+                else if (lanes == 2) hipLaunchKernelGGL(oa::k_tri_search_grid<2>, gblocks, dim3(256), 0, c->stream, OA_TGRID_ARGS, OA_TGRID_LIST_TAIL(0, 0x7FFFFFFF));
+                else hipLaunchKernelGGL(oa::k_tri_search_grid<1>, gblocks, dim3(256), 0, c->stream, OA_TGRID_ARGS, OA_TGRID_LIST_TAIL(0, 0x7FFFFFFF));
+            }
+#undef OA_TGRID_LIST_TAIL
+            HIPCHK(hipGetLastError());
+            return launch_bvh<true>(c, c->d_todo_list, c->d_todo_count);       // the far queries: tree search
+        }
         if (acc) {
             // the search finishes its own leftovers through the triangle tree and takes the pair test and the sums in its
             // epilogue (search_plan: PLAN_GRID, fast path): no list launch, no accumulation launch
-#define OA_TGRID_ACC_ARGS OA_TGRID_ARGS, (unsigned long long *)nullptr, c->tbvh, (const float4 *)c->d_tbvh_box, (const float4 *)c->d_tbvh_prims, normal_test(c), c->d_partials
+#define OA_TGRID_ACC_ARGS OA_TGRID_ARGS, (unsigned long long *)nullptr, c->tbvh, (const float4 *)c->d_tbvh_box, (const float4 *)c->d_tbvh_prims, normal_test(c), c->d_partials, ring
             if (lanes == 4) hipLaunchKernelGGL((oa::k_tri_search_grid<4, false, true, true>), gblocks, dim3(256), 0, c->stream, OA_TGRID_ACC_ARGS);
             else if (lanes == 2) hipLaunchKernelGGL((oa::k_tri_search_grid<2, false, true, true>), gblocks, dim3(256), 0, c->stream, OA_TGRID_ACC_ARGS);
             else hipLaunchKernelGGL((oa::k_tri_search_grid<1, false, true, true>), gblocks, dim3(256), 0, c->stream, OA_TGRID_ACC_ARGS);
@@ -2560,15 +2663,16 @@ int launch_tri_search(oa_ctx *c, bool acc)
             HIPCHK(hipGetLastError());
             return OA_OK;
         }
-        if (lanes == 4) hipLaunchKernelGGL(oa::k_tri_search_grid<4>, gblocks, dim3(256), 0, c->stream, OA_TGRID_ARGS);
-        else if (lanes == 2) hipLaunchKernelGGL(oa::k_tri_search_grid<2>, gblocks, dim3(256), 0, c->stream, OA_TGRID_ARGS);
+#define OA_TGRID_TAIL oa::BvhParams{}, (const float4 *)nullptr, (const float4 *)nullptr, oa::NormalTest{}, (double *)nullptr, ring, qlist, qcount
+        if (lanes == 4) hipLaunchKernelGGL(oa::k_tri_search_grid<4>, gblocks, dim3(256), 0, c->stream, OA_TGRID_ARGS, (unsigned long long *)nullptr, OA_TGRID_TAIL);
+        else if (lanes == 2) hipLaunchKernelGGL(oa::k_tri_search_grid<2>, gblocks, dim3(256), 0, c->stream, OA_TGRID_ARGS, (unsigned long long *)nullptr, OA_TGRID_TAIL);
         else if (c->grid_stats) {                                   // OA_GRID_STATS=1: instrumented launch, totals to stderr (synchronises)
             DevTmp<unsigned long long> d_stats;                     // one row of counters per wave (atomics on a dozen shared words slowed the launch 8x)
             const size_t n_waves = (size_t)gblocks.x * 4;
             HIPCHK(d_stats.alloc(oa::TRI_STAT_N * n_waves));
             HIPCHK(hipMemsetAsync(d_stats, 0, sizeof(unsigned long long) * oa::TRI_STAT_N * n_waves, c->stream));
-            if (c->tri_share) hipLaunchKernelGGL((oa::k_tri_search_grid<1, true, true>), gblocks, dim3(256), 0, c->stream, OA_TGRID_ARGS, d_stats.p);
-            else hipLaunchKernelGGL((oa::k_tri_search_grid<1, true, false>), gblocks, dim3(256), 0, c->stream, OA_TGRID_ARGS, d_stats.p);
+            if (c->tri_share) hipLaunchKernelGGL((oa::k_tri_search_grid<1, true, true>), gblocks, dim3(256), 0, c->stream, OA_TGRID_ARGS, d_stats.p, OA_TGRID_TAIL);
+            else hipLaunchKernelGGL((oa::k_tri_search_grid<1, true, false>), gblocks, dim3(256), 0, c->stream, OA_TGRID_ARGS, d_stats.p, OA_TGRID_TAIL);
             HIPCHK(hipGetLastError());
             unsigned long long h[oa::TRI_STAT_N] = { 0 };
             {
@@ -2590,8 +2694,9 @@ int launch_tri_search(oa_ctx *c, bool acc)
                     100.0 * h[oa::TRI_STAT_CYC_SCAN] / ct, 100.0 * h[oa::TRI_STAT_CYC_FLUSH] / ct, 100.0 * h[oa::TRI_STAT_CYC_BOOK] / ct,
                     100.0 * (ct - h[oa::TRI_STAT_CYC_PROLOGUE] - h[oa::TRI_STAT_CYC_LIST] - h[oa::TRI_STAT_CYC_SCAN] - h[oa::TRI_STAT_CYC_FLUSH] - h[oa::TRI_STAT_CYC_BOOK]) / ct);
         }
-        else if (!c->tri_share) hipLaunchKernelGGL((oa::k_tri_search_grid<1, false, false>), gblocks, dim3(256), 0, c->stream, OA_TGRID_ARGS);
-        else hipLaunchKernelGGL(oa::k_tri_search_grid<1>, gblocks, dim3(256), 0, c->stream, OA_TGRID_ARGS);
+        else if (!c->tri_share) hipLaunchKernelGGL((oa::k_tri_search_grid<1, false, false>), gblocks, dim3(256), 0, c->stream, OA_TGRID_ARGS, (unsigned long long *)nullptr, OA_TGRID_TAIL);
+        else hipLaunchKernelGGL(oa::k_tri_search_grid<1>, gblocks, dim3(256), 0, c->stream, OA_TGRID_ARGS, (unsigned long long *)nullptr, OA_TGRID_TAIL);
+#undef OA_TGRID_TAIL
 #undef OA_TGRID_ARGS
         HIPCHK(hipGetLastError());
         if (c->debug) {                                            // how many queries the grid handed over (debug only: syncs)
@@ -2696,9 +2801,12 @@ int source_reset(oa_ctx *c, long long count, long long begin, long long n_verts)
     HIPCHK(dev_malloc(&c->d_wsafe, sizeof(uint2) * (size_t)c->ns_pad));
     c->seeded = false;
     HIPCHK(dev_malloc(&c->d_sel, sizeof(int) * (size_t)c->ns_pad));
-    dev_free(c->d_todo_list); dev_free(c->d_todo_count);
+    dev_free(c->d_todo_list); dev_free(c->d_todo_count); dev_free(c->d_ulist);
     HIPCHK(dev_malloc(&c->d_todo_list, sizeof(int) * (size_t)c->ns_pad));
-    HIPCHK(dev_malloc(&c->d_todo_count, 2 * sizeof(int)));      // {entries of the hand-over list, most handed over by one wave}
+    HIPCHK(dev_malloc(&c->d_ulist, sizeof(int) * (size_t)c->ns_pad));
+    HIPCHK(dev_malloc(&c->d_todo_count, 4 * sizeof(int)));      // {entries of the hand-over list, most handed over by one wave, the two counters of d_ulist}
+    HIPCHK(hipMemsetAsync(c->d_todo_count, 0, 4 * sizeof(int), c->stream));
+    c->u_slot = 0;
     // no seeds, empty keys, sel = 0, hand-over counters at zero: one launch
     hipLaunchKernelGGL(oa::k_init_slots, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, c->d_prev, c->d_win, c->d_wsafe, c->d_keys, c->d_sel,
                        c->d_todo_count, c->ns_pad);
@@ -3009,6 +3117,32 @@ OA_EXPORT int oa_get_stat(oa_ctx *c, int what, double *value)
         *value = what == OA_STAT_NN_MS_MIN ? lo : hi;
         return OA_OK;
     }
+    if (what == OA_STAT_TRI_RING_ACCEPTS) {
+        // the prologue's test of k_tri_search_grid, counted: device state (pose) and seeds as the last search / loop left them
+        *value = 0.0;
+        if (!c->subs.empty()) {
+            for (oa_ctx *sub : c->subs) { double v = 0.0; const int rc = oa_get_stat(sub, what, &v); if (rc) return rc; *value += v; }
+            return OA_OK;
+        }
+        if (!c->surface || !c->tri_ring_ok || !c->d_tri_ring || !c->d_prev || !c->d_state || c->ns <= 0 || !c->seeded) return OA_OK;
+        int rc = use_device(c);
+        if (rc) return rc;
+        DevTmp<unsigned long long> d_n;
+        HIPCHK(d_n.alloc(16));
+        HIPCHK(hipMemsetAsync(d_n, 0, 16 * sizeof(unsigned long long), c->stream));
+        hipLaunchKernelGGL(oa::k_tri_ring_count, dim3((unsigned)((c->ns + 255) / 256)), dim3(256), 0, c->stream, (const oa::DevState *)c->d_state,
+                           (const float4 *)c->d_src4, c->ns, c->tgp.scale, (const float4 *)c->d_tri9, (const int *)c->d_prev, d_n.p,
+                           c->debug ? d_n.p : (unsigned long long *)nullptr);
+        HIPCHK(hipGetLastError());
+        unsigned long long n[16];
+        if ((rc = read_small(c, n, d_n, sizeof(n)))) return rc;
+        *value = (double)n[0];
+        if (c->debug)
+            fprintf(stderr, "[oa] tri ring: %llu of %d queries settled by seed + neighbours; the others: %llu no seed, %llu seeds that never accept, %llu not certified, "
+                            "distance + margins within 1x / 2x / 4x / 8x of the radius %llu / %llu / %llu / %llu, farther %llu\n",
+                    n[0], c->ns, n[1], n[2], n[3], n[4], n[5], n[6], n[7], n[8]);
+        return OA_OK;
+    }
     if (what == OA_STAT_WATCHDOG_ABORTS) { *value = c->xch && !c->parent ? (double)c->xch->watchdog_aborts : 0.0; return OA_OK; }
     if (what == OA_STAT_EXCHANGE || what == OA_STAT_RCCL_RANKS || what == OA_STAT_ENQUEUE_US || what == OA_STAT_HOST_THREADS) {
         if (c->subs.empty()) { *value = what == OA_STAT_EXCHANGE ? -1.0 : (what == OA_STAT_HOST_THREADS ? 1.0 : 0.0); return OA_OK; }
@@ -3039,6 +3173,7 @@ OA_EXPORT int oa_get_stat(oa_ctx *c, int what, double *value)
     case OA_STAT_HANDOVER_ENTRIES: *value = c->h_poll ? (double)c->h_poll[2] : 0.0; return OA_OK;
     case OA_STAT_HANDOVER_WAVE_MAX: *value = c->h_poll ? (double)c->h_poll[3] : 0.0; return OA_OK;
     case OA_STAT_SAFE_RADII: *value = (c->grid_safe && c->d_safe_by_idx) ? 1.0 : 0.0; return OA_OK;
+    case OA_STAT_TRI_RING: *value = (c->tri_ring && c->tri_ring_ok) ? 1.0 : 0.0; return OA_OK;
     default: return fail(OA_E_BAD_ARG, "oa_get_stat: unknown key %d", what);
     }
 }

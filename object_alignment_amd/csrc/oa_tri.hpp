@@ -147,6 +147,12 @@ __device__ __forceinline__ void tri_record(const float *a, const float *b, const
     rec1 = make_float4(nf[0], nf[1], nf[2], __uint_as_float(t));
 }
 
+// The index word of a record also says whether the record's cell is the LOWEST cell of its triangle along x / y / z: a scan
+// over a box of cells meets a triangle once per cell it shares with the box, and "lowest cell of the triangle or lowest cell
+// of the box, along every axis" picks exactly one of those records without loading the triangle (oa_tri_ring.hpp).  The
+// searches mask the flags off where they take the index (tri_candidate); build_tri_grid refuses meshes of 2^28 triangles.
+constexpr uint32_t TRI_REC_INDEX_MASK = 0x0FFFFFFFu, TRI_REC_FLAG_X = 1u << 28, TRI_REC_FLAG_Y = 1u << 29, TRI_REC_FLAG_Z = 1u << 30;
+
 // pass 0: counts[cell] += 1 for every cell overlapped; pass 1: write the triangle's record (disc, normal, index -- the
 // search discards most candidates from these 32 contiguous bytes) at cell_start[cell] + cursor++
 template <bool FILL>
@@ -174,7 +180,9 @@ __global__ void k_tri_grid_bin(const float4 *__restrict__ tri9, int n_tris, Grid
                 if (FILL) {
                     const long long pos = cell_start[cidx] + atomicAdd(&counts[cidx], 1);
                     cell_rec[2 * pos] = rec0;
-                    cell_rec[2 * pos + 1] = rec1;
+                    float4 r1 = rec1;
+                    r1.w = __uint_as_float((uint32_t)t | (x == lo[0] ? TRI_REC_FLAG_X : 0u) | (y == lo[1] ? TRI_REC_FLAG_Y : 0u) | (z == lo[2] ? TRI_REC_FLAG_Z : 0u));
+                    cell_rec[2 * pos + 1] = r1;
                 } else atomicAdd(&counts[cidx], 1);
                 ++n;
             }
@@ -317,7 +325,7 @@ __device__ __forceinline__ void tri_candidate(float px, float py, float pz, cons
         if (surv) ++*surv;
         const int lane = threadIdx.x & 63;
         const int dst = pool.n + __popcll(m & ((1ull << lane) - 1ull));
-        pool.tid[dst] = __float_as_int(rec1.w);
+        pool.tid[dst] = (int)(__float_as_uint(rec1.w) & TRI_REC_INDEX_MASK);
         pool.own[dst] = (unsigned char)owner;
         pool.key[dst] = lb;
         // the owner's most promising survivor: smallest bound (lb >= +0: its bits order like its value; a NaN bound -- never
@@ -550,6 +558,121 @@ __device__ __forceinline__ void tri_scan_shared(const float *p, const float4 *__
     n_seg = 0;
 }
 
+// ---- seed + neighbours settle a query (round 5; the build and the proof: oa_tri_ring.hpp) -------------------------------------
+constexpr int TRI_RING_MAX = 15;          // neighbours listed per triangle: ring[16 t .. 16 t + 14], ring[16 t + 15] = how many
+constexpr int TRI_RING_STRIDE = 16;       // ints per triangle (one 64-byte line)
+
+// closest_on_tri (oa_kernels.hpp) for a SEED: the same point, bit for bit, plus `certified` = the barycentric weights the
+// point was put together from lie inside the simplex whatever the rounding: a corner; an edge point with its parameter in
+// [0, 1] (a quotient of two non-negative floats whose denominator is their sum, or d1 / (d1 - d3) with d1 >= 0 >= d3); or an
+// interior point with va, vb, vc all positive.  Then r is within 16 u |coords| of a true point of the triangle.
+__device__ __forceinline__ bool tri_seed_certified(const float *p, const float *a, const float *b, const float *c)
+{
+    const float abx = b[0] - a[0], aby = b[1] - a[1], abz = b[2] - a[2], acx = c[0] - a[0], acy = c[1] - a[1], acz = c[2] - a[2];
+    const float apx = p[0] - a[0], apy = p[1] - a[1], apz = p[2] - a[2], bpx = p[0] - b[0], bpy = p[1] - b[1], bpz = p[2] - b[2];
+    const float cpx = p[0] - c[0], cpy = p[1] - c[1], cpz = p[2] - c[2];
+#define OA_DOT3(ux, uy, uz, vx, vy, vz) (((ux) * (vx) + (uy) * (vy)) + (uz) * (vz))
+    const float d1 = OA_DOT3(abx, aby, abz, apx, apy, apz), d2 = OA_DOT3(acx, acy, acz, apx, apy, apz);
+    const float d3 = OA_DOT3(abx, aby, abz, bpx, bpy, bpz), d4 = OA_DOT3(acx, acy, acz, bpx, bpy, bpz);
+    const float d5 = OA_DOT3(abx, aby, abz, cpx, cpy, cpz), d6 = OA_DOT3(acx, acy, acz, cpx, cpy, cpz);
+#undef OA_DOT3
+    const float vc = d1 * d4 - d3 * d2, vb = d5 * d2 - d1 * d6, va = d3 * d6 - d5 * d4;
+    const float d43 = d4 - d3, d56 = d5 - d6;
+    const bool at_a = d1 <= 0.0f && d2 <= 0.0f;
+    const bool at_b = d3 >= 0.0f && d4 <= d3;
+    const bool on_ab = vc <= 0.0f && d1 >= 0.0f && d3 <= 0.0f;
+    const bool at_c = d6 >= 0.0f && d5 <= d6;
+    const bool on_ac = vb <= 0.0f && d2 >= 0.0f && d6 <= 0.0f;
+    const bool on_bc = va <= 0.0f && d43 >= 0.0f && d56 >= 0.0f;
+    // (the edge parameters: numerator >= 0 and denominator = numerator + something >= 0, so the quotient is in [0, 1] or NaN --
+    //  and a NaN point never becomes anybody's best)
+    if (at_a || at_b || on_ab || at_c || on_ac || on_bc) return true;
+    return va > 0.0f && vb > 0.0f && vc > 0.0f;
+}
+
+// the test of the header.  deltaf >= the search's delta (64 u (scale + |p|_1) + slack)
+__device__ __forceinline__ bool tri_ring_accepts(float d2, float accept, float deltaf)
+{
+    const float tt = accept - 2.5f * deltaf;
+    return tt > 0.f && d2 < tt * tt * 0.99998f;                     // (sqrt(d2) (1 + 1e-5) < tt, squared and rounded down)
+}
+
+// The seed + its neighbours for EVERY query of the shard, one thread each, and nothing else: what they settle gets its answer
+// here (keys[]: (bits(d2) << 32) | triangle, the searches' own format), what they do not goes on a list that k_tri_search_grid
+// works through (qlist).  Two launches instead of one because the grid search is built around its wave: listing cells, the
+// shared scan, the pool and its flushes cost a wave nearly the same whether 3 or 64 of its lanes still search (measured: with
+// 95 % of the queries settled in the search's own prologue a launch took what it took before) -- and its 40 KB of LDS per
+// workgroup cap the chip at four such waves per SIMD.  Here: no LDS, half the registers; the list packs the rest densely.
+// ucount[slot] counts this launch's list (the launch zeroes the OTHER slot for the next one: the host alternates).
+__global__ __launch_bounds__(256) void k_tri_accept(const DevState *__restrict__ st, const float4 *__restrict__ src4, int ns, float scalef,
+                                                    const float4 *__restrict__ tri9, const int *__restrict__ prev,
+                                                    const int *__restrict__ ring, unsigned long long *__restrict__ keys,
+                                                    int *__restrict__ ulist, int *__restrict__ ucount, int slot)
+{
+    if (st->halt) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) ucount[slot ^ 1] = 0;
+    const int i = xcd_block_index() * (int)blockDim.x + threadIdx.x;
+    const bool alive = i < ns;
+    bool accepted = false;
+    float best = INFINITY;
+    uint32_t bidx = IDX_NONE;
+    float pf[3] = { 0.f, 0.f, 0.f };
+    int s = -1;
+    if (alive) {
+        const float4 p4 = src4[i];
+        co_find(st, p4.x, p4.y, p4.z, pf[0], pf[1], pf[2]);
+        s = prev[i];
+    }
+    if (s >= 0) {
+        float a[3], b[3], c[3], r[3];
+        const float4 u = tri9[3ll * s], v = tri9[3ll * s + 1], w = tri9[3ll * s + 2];
+        a[0] = u.x; a[1] = u.y; a[2] = u.z; b[0] = u.w; b[1] = v.x; b[2] = v.y; c[0] = v.z; c[1] = v.w; c[2] = w.x;
+        closest_on_tri(pf, a, b, c, r);
+        const float d = tri_dist2(pf, r);
+        if (d < INFINITY) { best = d; bidx = (uint32_t)s; }
+        const float deltaf = (fabsf(pf[0]) + fabsf(pf[1]) + fabsf(pf[2]) + scalef) * 3.8148e-6f + scalef * 1.1e-10f;
+        accepted = d < INFINITY && tri_ring_accepts(d, w.y, deltaf);
+        if (accepted) accepted = tri_seed_certified(pf, a, b, c);
+    }
+    if (__any(accepted)) {
+        const int4 *rp = (const int4 *)(ring + (size_t)TRI_RING_STRIDE * (size_t)(accepted ? s : 0));
+        const int cnt = accepted ? rp[3].w : 0;
+        int4 m = rp[0];
+        for (int k0 = 0; __any(k0 < cnt); k0 += 4) {
+            const int4 mn = rp[min((k0 >> 2) + 1, 3)];               // the next four, in flight during these
+            const int id[4] = { m.x, m.y, m.z, m.w };
+            float4 tu[4], tv[4], tw[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                            // (a lane that is through reads triangle 0 and drops it: no branch around the loads)
+                const long long tt = (k0 + j < cnt) ? (long long)id[j] : 0ll;
+                tu[j] = tri9[3 * tt]; tv[j] = tri9[3 * tt + 1]; tw[j] = tri9[3 * tt + 2];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (k0 + j < cnt) {
+                    const float a[3] = { tu[j].x, tu[j].y, tu[j].z }, b[3] = { tu[j].w, tv[j].x, tv[j].y }, c[3] = { tv[j].z, tv[j].w, tw[j].x };
+                    float r[3];
+                    closest_on_tri(pf, a, b, c, r);
+                    const float d = tri_dist2(pf, r);
+                    const uint32_t t = (uint32_t)id[j];
+                    if (d < best || (d == best && t < bidx && d < INFINITY)) { best = d; bidx = t; }
+                }
+            }
+            m = mn;
+        }
+    }
+    if (accepted) keys[i] = ((unsigned long long)__float_as_uint(best) << 32) | bidx;
+    // the others, packed: one atomic per wave
+    const unsigned long long todo = __ballot(alive && !accepted);
+    if (todo) {
+        const int lane = threadIdx.x & 63;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&ucount[slot], __popcll(todo));
+        base = __shfl(base, 0, 64);
+        if (alive && !accepted) ulist[base + __popcll(todo & ((1ull << lane) - 1ull))] = i;
+    }
+}
+
 // L = 1, 2 or 4 lanes per query, as in k_nn_search_grid: the rows of a ring are dealt out to the lanes, every lane runs
 // both phases on its rows with its own state, and the lanes merge (d2, index) after every batch of rows.
 // STATS (debug builds of the launch, OA_GRID_STATS=1): per-launch totals of what the queries did, see TRI_STAT_*
@@ -580,7 +703,10 @@ __global__ __launch_bounds__(256, OA_TRI_MIN_WAVES) void k_tri_search_grid(const
                                                          unsigned long long *__restrict__ stats = nullptr,
                                                          BvhParams bp = BvhParams{}, const float4 *__restrict__ boxes = nullptr,
                                                          const float4 *__restrict__ prims = nullptr, NormalTest nrm = NormalTest{},
-                                                         double *__restrict__ partials = nullptr)
+                                                         double *__restrict__ partials = nullptr,
+                                                         const int *__restrict__ ring = nullptr,
+                                                         const int *__restrict__ qlist = nullptr, const int *__restrict__ qcount = nullptr,
+                                                         int qmin = 0, int qmax = 0x7FFFFFFF)
 {
     // rows per lane and batch: nine rows of a ring at a time (dealt out to the L lanes of the query).  The rows of the
     // first block of a search are whole ranges (one per row); interior rows of later rings contribute their two end
@@ -613,14 +739,26 @@ __global__ __launch_bounds__(256, OA_TRI_MIN_WAVES) void k_tri_search_grid(const
     int n_loop_trips = 0;
     if (STATS) cyc_t0 = cyc_mark = (long long)__builtin_readcyclecounter();
 #define OA_TRI_STAMP(acc) do { if (STATS) { const long long now_ = (long long)__builtin_readcyclecounter(); acc += now_ - cyc_mark; cyc_mark = now_; } } while (0)
-    const int vb = xcd_block_index();                                      // one contiguous part of the queries per XCD
+    // qlist (not with ACC): the queries are qlist[0 .. *qcount) -- what k_tri_accept left over --, in the dispatcher's own
+    // workgroup order (the list is short: an XCD's contiguous share of the launch would leave seven XCDs idle)
+    const bool listed = !ACC && qlist != nullptr;
+    const int vb = listed ? (int)blockIdx.x : xcd_block_index();          // one contiguous part of the queries per XCD
     const int gt = vb * (int)blockDim.x + threadIdx.x;
     int i = gt / L;
     const int sub = gt % L;                                         // the L lanes of a query are neighbours in a wave
+    if (listed) {
+        // The list's length is only known on the device, and it decides how many lanes a query should get (a short list leaves
+        // the chip's wave slots empty: then the rows of a ring are dealt out to 4 lanes): the host enqueues one launch per
+        // regime and each runs only when the length is in ITS range (qmin, qmax] -- an empty launch costs a few microseconds.
+        ns = *qcount;
+        if (ns <= qmin || ns > qmax) return;
+        if ((vb * (int)blockDim.x) / L >= ns) return;               // (the whole workgroup: before any barrier)
+    }
     // Lanes past the last query stay: phase 2 deals pool entries to ALL 64 lanes of the wave (entry e to lane e mod 64),
     // so a lane that left would take its share of the entries with it.  They repeat the last query without any say.
     const bool alive = i < ns;
     if (!alive) i = ns - 1;
+    if (listed) i = qlist[i];                                       // from here on: the query's slot
     const float4 p4 = src4[i];
     float pf[3];
     co_find(st, p4.x, p4.y, p4.z, pf[0], pf[1], pf[2]);          // co_find (general.py:287)
@@ -628,7 +766,51 @@ __global__ __launch_bounds__(256, OA_TRI_MIN_WAVES) void k_tri_search_grid(const
     float best = INFINITY;
     uint32_t bidx = IDX_NONE;
     const int s = prev ? prev[i] : -1;
-    if (s >= 0) tri_eval(pf, tri9, (uint32_t)s, best, bidx);
+    // Seed + neighbours (oa_tri_ring.hpp): a query within A(seed) of its seed is settled by the seed and the <= TRI_RING_MAX
+    // triangles listed beside it -- the minimum over ALL triangles is among them; no cell is listed, no record scanned.
+    bool accepted = false;
+    const float ring_scalef = (float)gp.scale * 1.000001f;
+    if (s >= 0) {
+        float a[3], b[3], c[3], r[3];
+        const float4 u = tri9[3ll * s], v = tri9[3ll * s + 1], w = tri9[3ll * s + 2];
+        a[0] = u.x; a[1] = u.y; a[2] = u.z; b[0] = u.w; b[1] = v.x; b[2] = v.y; c[0] = v.z; c[1] = v.w; c[2] = w.x;
+        closest_on_tri(pf, a, b, c, r);
+        const float d = tri_dist2(pf, r);
+        if (d < INFINITY) { best = d; bidx = (uint32_t)s; }
+        if (ring) {
+            // (delta of the search below, rounded up: 64 u (scale + |p|_1) + slack)
+            const float deltaf = (fabsf(pf[0]) + fabsf(pf[1]) + fabsf(pf[2]) + ring_scalef) * 3.8148e-6f + ring_scalef * 1.1e-10f;
+            accepted = d < INFINITY && tri_ring_accepts(d, w.y, deltaf);
+            if (accepted) accepted = tri_seed_certified(pf, a, b, c);
+        }
+    }
+    if (ring && __any(accepted)) {
+        const int4 *rp = (const int4 *)(ring + (size_t)TRI_RING_STRIDE * (size_t)(accepted ? s : 0));
+        const int cnt = accepted ? rp[3].w : 0;
+        int4 m = rp[0];
+        for (int k0 = 0; __any(k0 < cnt); k0 += 4) {
+            const int4 mn = rp[min((k0 >> 2) + 1, 3)];               // the next four, in flight during these
+            const int id[4] = { m.x, m.y, m.z, m.w };
+            float4 tu[4], tv[4], tw[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                            // (a lane that is through reads triangle 0 and drops it: no branch around the loads)
+                const long long tt = (k0 + j < cnt) ? (long long)id[j] : 0ll;
+                tu[j] = tri9[3 * tt]; tv[j] = tri9[3 * tt + 1]; tw[j] = tri9[3 * tt + 2];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (k0 + j < cnt) {
+                    const float a[3] = { tu[j].x, tu[j].y, tu[j].z }, b[3] = { tu[j].w, tv[j].x, tv[j].y }, c[3] = { tv[j].z, tv[j].w, tw[j].x };
+                    float r[3];
+                    closest_on_tri(pf, a, b, c, r);
+                    const float d = tri_dist2(pf, r);
+                    const uint32_t t = (uint32_t)id[j];
+                    if (d < best || (d == best && t < bidx && d < INFINITY)) { best = d; bidx = t; }
+                }
+            }
+            m = mn;
+        }
+    }
 
     double pabs = 0.0;
     const GridQuery q = grid_locate(gp, pf[0], pf[1], pf[2], &pabs);
@@ -652,7 +834,7 @@ __global__ __launch_bounds__(256, OA_TRI_MIN_WAVES) void k_tri_search_grid(const
     {
         const int last = (st->n + 4) % 5;
         const double moved = st->use_target && st->n > 0 ? (st->ring_t[last] + st->ring_r[last] * gp.scale) * st->local_per_world : 0.0;
-        if (st->n == 0 || moved > 0.25 * gp.h) budget = gp.budget_moving;
+        if (st->n == 0 || moved > gp.moving_h) budget = gp.budget_moving;
         if (L > 1) budget = budget / L + 8;
         budget_extra = budget - (L > 1 ? gp.budget / L + 8 : gp.budget);
     }
@@ -662,7 +844,8 @@ __global__ __launch_bounds__(256, OA_TRI_MIN_WAVES) void k_tri_search_grid(const
     // so phase 1 and phase 2 must be reached by all of its lanes at the same time -- hence no per-lane loops around
     // them: a lane's ring / batch counters are plain state, and the only loop condition is __any(busy).
     int r = r_start, b0 = 0;
-    bool busy = q.finite && alive;
+    bool busy = q.finite && alive && !accepted;
+    settled = accepted;
     OA_TRI_STAMP(cyc_prologue);
     while (__any(busy)) {
         bool ring_done = false;
@@ -751,6 +934,9 @@ __global__ __launch_bounds__(256, OA_TRI_MIN_WAVES) void k_tri_search_grid(const
             b0 += consumed * L;
             ring_done = b0 >= n_rows;
         }
+        // over its budget: the tree takes the query anyway -- with the seed's bound, which the records scanned so far rarely
+        // improve on -- so what this batch listed is not scanned (crowded cells: up to `budget` records per lane for nothing)
+        if (gp.drop_over && busy && budget < 0) n_seg = 0;
         OA_TRI_STAMP(cyc_list);
         // phase 1 and phase 2: the whole wave, every trip
         if (SHARE) tri_scan_shared(pf, cell_rec, tri9, S, gp.eps_plane, seg_j, seg_n, n_seg, chunk_tab[threadIdx.x >> 6], pool, delta, cutf,

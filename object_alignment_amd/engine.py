@@ -182,7 +182,8 @@ class IcpEngine:
     STATS = {"grid_cells": 1, "tri_grid_cells": 2, "tri_grid_entries": 3, "n_tris": 4, "surface": 5, "cache_bytes": 6,
              "brute_kernel": 7, "exchange": 8, "rccl_ranks": 9, "enqueue_us": 10, "host_threads": 11,
              "fast_iterations": 12, "handover_entries": 13, "handover_wave_max": 14, "enqueued_min": 15, "enqueued_max": 16,
-             "watchdog_aborts": 17, "nn_ms_min": 18, "nn_ms_max": 19, "safe_radii": 20}
+             "watchdog_aborts": 17, "nn_ms_min": 18, "nn_ms_max": 19, "safe_radii": 20,
+             "tri_ring": 21, "tri_ring_accepts": 22}
     EXCHANGE_NAMES = {-1: None, 0: "mailbox (pinned host memory)", 1: "rccl", 2: "mailbox (peer-mapped device memory)"}
 
     def exchange_info(self):

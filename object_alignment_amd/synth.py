@@ -94,6 +94,26 @@ def lattice_surface_mesh(nu: int, nv: int):
     return verts, tris
 
 
+def cubed_surface_mesh(n: int):
+    """The bunny surface over a cube-sphere: six n x n patches of two triangles per quad, no poles -- triangles of nearly uniform
+    size and aspect (the lat-long lattice_surface_mesh has fans of thin triangles at both poles).  Patches do not share vertex
+    indices along the cube's edges (the seams coincide geometrically).  (6 (n+1)^2 vertices, 12 n^2 triangles)."""
+    g = np.tan(np.linspace(-math.pi / 4, math.pi / 4, n + 1))          # equal-angle spacing
+    A, B = np.meshgrid(g, g, indexing="ij")
+    one = np.ones_like(A)
+    faces = [(one, A, B), (-one, B, A), (B, one, A), (A, -one, B), (A, B, one), (B, A, -one)]
+    verts, tris = [], []
+    i, j = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    a = (i * (n + 1) + j).ravel(); b = a + 1; c = a + (n + 1); d = c + 1
+    quad = np.concatenate([np.stack([a, c, b], 1), np.stack([b, c, d], 1)])
+    for k, (x, y, z) in enumerate(faces):
+        u = np.stack([x.ravel(), y.ravel(), z.ravel()], 1)
+        u /= np.linalg.norm(u, axis=1, keepdims=True)
+        verts.append(u * _bunny_radius(u)[:, None])
+        tris.append(quad + k * (n + 1) ** 2)
+    return np.concatenate(verts).astype(np.float32), np.concatenate(tris).astype(np.int32)
+
+
 def _bunny_radius(u: np.ndarray) -> np.ndarray:
     theta = np.arccos(np.clip(u[:, 2], -1.0, 1.0))
     phi = np.arctan2(u[:, 1], u[:, 0])

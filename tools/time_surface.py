@@ -11,7 +11,10 @@ nu = int(sys.argv[1]) if len(sys.argv) > 1 else 700
 nv = int(sys.argv[2]) if len(sys.argv) > 2 else 1400
 ns = int(sys.argv[3]) if len(sys.argv) > 3 else 1_000_000
 partial = os.environ.get("PARTIAL", "0") == "1"      # keep only the z > 0 half of the target: half the queries are far
-tgt, tris = synth.lattice_surface_mesh(nu, nv)
+if os.environ.get("MESH", "lattice") == "cubed":          # no poles: six patches of nu x nu quads
+    tgt, tris = synth.cubed_surface_mesh(nu)
+else:
+    tgt, tris = synth.lattice_surface_mesh(nu, nv)
 if partial:
     keep_v = tgt[:, 2] > 0.0
     keep_t = keep_v[tris].all(axis=1)
@@ -40,5 +43,6 @@ for mode, search in combos:
             r = e.run(iters=it, thresh=0.05, early_exit=False)
             wall = time.perf_counter() - t0
             print("%-8s %-5s upload+build %.1f ms; iters %d: wall %.3f ms/iter, device loop %.3f ms/iter, nn %.3f ms/iter, K %d, "
-                  "mean dist %.3e" % (mode, search, 1e3 * up, it, 1e3 * wall / it, r.loop_ms / it, r.nn_ms_total / it, r.last_K,
-                                      r.mean_dist), flush=True)
+                  "mean dist %.3e%s" % (mode, search, 1e3 * up, it, 1e3 * wall / it, r.loop_ms / it, r.nn_ms_total / it, r.last_K,
+                                      r.mean_dist, (", neighbour lists built, would settle %d queries now" % e.stat("tri_ring_accepts"))
+                                      if mode == "surface" and e.stat("tri_ring") else ""), flush=True)
