@@ -241,7 +241,7 @@ int oa_nn_search(oa_ctx *ctx, int64_t *idx, float *d2, double *kernel_ms);
 int oa_kabsch(oa_ctx *ctx, const double *A, const double *B, int64_t K, int64_t ld,
               int with_scale, double M[16]);
 /* The reference's full signature (functions/general.py:105): v0, v1 are ndims x K row-major doubles with leading
- * dimension ld (host), 2 <= ndims <= 8; shear != 0: the affine (Hartley & Zisserman) branch (:168-178, the signature's
+ * dimension ld (host), 2 <= ndims <= 64 (the reference takes any; 9 and more run through a device workspace); shear != 0: the affine (Hartley & Zisserman) branch (:168-178, the signature's
  * default), else rigid / similarity through the SVD of the covariance (:179-190, :208-212).  M: (ndims+1)^2 doubles,
  * row-major.  K < ndims or ndims < 2: OA_E_TOO_FEW_PAIRS, the reference's ValueError (:150-157). */
 int oa_affine_from_points(oa_ctx *ctx, const double *v0, const double *v1, int ndims, int64_t K, int64_t ld,

@@ -73,7 +73,18 @@ def load():
         import torch  # noqa: F401
     except ImportError:
         pass
-    path = os.environ.get("OA_ICP_LIB") or LIB_PATH                # (another BUILD of the same library: the sanitizer pass, A/B experiments)
+    # Another BUILD of the same library (the sanitizer pass, A/B experiments) -- only when OA_ICP_LIB_DEBUG=1 says that the
+    # override is meant, and never silently: an environment variable alone does not redirect what a production import loads.
+    path = LIB_PATH
+    override = os.environ.get("OA_ICP_LIB")
+    if override:
+        if os.environ.get("OA_ICP_LIB_DEBUG") == "1":
+            import sys
+            print("object_alignment_amd: loading %s instead of %s (OA_ICP_LIB, OA_ICP_LIB_DEBUG=1)" % (override, LIB_PATH), file=sys.stderr)
+            path = override
+        else:
+            import warnings
+            warnings.warn("OA_ICP_LIB is set but ignored: set OA_ICP_LIB_DEBUG=1 as well to load another build of liboa_icp.so")
     if not os.path.exists(path):
         raise RuntimeError(
             "object_alignment_amd: %s is missing -- build the HIP extension first "

@@ -34,25 +34,44 @@ def mat4_mul_vec3(m, v):
     return out
 
 
+def _det2(a, b, c, d):
+    return np.float32(np.float32(a * d) - np.float32(b * c))
+
+
+def _det3(a1, a2, a3, b1, b2, b3, c1, c2, c3):
+    t = np.float32(np.float32(a1 * _det2(b2, b3, c2, c3)) - np.float32(b1 * _det2(a2, a3, c2, c3)))
+    return np.float32(t + np.float32(c1 * _det2(a2, a3, b2, b3)))
+
+
 def mat4_inverted(m):
-    """Matrix.inverted(): adjugate / determinant in double in the fixed operation order of m4_inverted
-    (csrc/oa_kernels.hpp), rounded to float32.  Raises ValueError for a singular matrix, as mathutils does."""
-    a = [float(x) for x in np.asarray(m, dtype=np.float32).reshape(16)]
-    s0 = a[0] * a[5] - a[4] * a[1]; s1 = a[0] * a[6] - a[4] * a[2]; s2 = a[0] * a[7] - a[4] * a[3]
-    s3 = a[1] * a[6] - a[5] * a[2]; s4 = a[1] * a[7] - a[5] * a[3]; s5 = a[2] * a[7] - a[6] * a[3]
-    c5 = a[10] * a[15] - a[14] * a[11]; c4 = a[9] * a[15] - a[13] * a[11]; c3 = a[9] * a[14] - a[13] * a[10]
-    c2 = a[8] * a[15] - a[12] * a[11]; c1 = a[8] * a[14] - a[12] * a[10]; c0 = a[8] * a[13] - a[12] * a[9]
-    det = ((((s0 * c5 - s1 * c4) + s2 * c3) + s3 * c2) - s4 * c1) + s5 * c0
-    if det == 0.0:
-        raise ValueError("Matrix.invert(ed): matrix does not have an inverse")
-    b = [
-        ((a[5] * c5 - a[6] * c4) + a[7] * c3) / det, ((-a[1] * c5 + a[2] * c4) - a[3] * c3) / det,
-        ((a[13] * s5 - a[14] * s4) + a[15] * s3) / det, ((-a[9] * s5 + a[10] * s4) - a[11] * s3) / det,
-        ((-a[4] * c5 + a[6] * c2) - a[7] * c1) / det, ((a[0] * c5 - a[2] * c2) + a[3] * c1) / det,
-        ((-a[12] * s5 + a[14] * s2) - a[15] * s1) / det, ((a[8] * s5 - a[10] * s2) + a[11] * s1) / det,
-        ((a[4] * c4 - a[5] * c2) + a[7] * c0) / det, ((-a[0] * c4 + a[1] * c2) - a[3] * c0) / det,
-        ((a[12] * s4 - a[13] * s2) + a[15] * s0) / det, ((-a[8] * s4 + a[9] * s2) - a[11] * s0) / det,
-        ((-a[4] * c3 + a[5] * c1) - a[6] * c0) / det, ((a[0] * c3 - a[1] * c1) + a[2] * c0) / det,
-        ((-a[12] * s3 + a[13] * s1) - a[14] * s0) / det, ((a[8] * s3 - a[9] * s1) + a[10] * s0) / det,
-    ]
-    return np.array(b, dtype=np.float64).astype(np.float32).reshape(4, 4)
+    """Matrix.inverted() as Blender computes it (mathutils matrix_invert_internal: float determinant_m4, float adjoint_m4_m4,
+    element / det -- every operation rounded to float32, left to right), the rule of m4_inverted in csrc/oa_kernels.hpp and of
+    the oracle.  Raises ValueError for a singular matrix, as mathutils does."""
+    A = np.asarray(m, dtype=np.float32).reshape(4, 4)
+    with np.errstate(all="ignore"):
+        # Blender's column-major m[i][j] = element (row j, column i)
+        (a1, b1, c1, d1), (a2, b2, c2, d2), (a3, b3, c3, d3), (a4, b4, c4, d4) = (tuple(np.float32(A[j, i]) for j in range(4)) for i in range(4))
+        det = np.float32(np.float32(np.float32(np.float32(a1 * _det3(b2, b3, b4, c2, c3, c4, d2, d3, d4)) -
+                                               np.float32(b1 * _det3(a2, a3, a4, c2, c3, c4, d2, d3, d4))) +
+                                    np.float32(c1 * _det3(a2, a3, a4, b2, b3, b4, d2, d3, d4))) -
+                         np.float32(d1 * _det3(a2, a3, a4, b2, b3, b4, c2, c3, c4)))
+        if det == 0.0:
+            raise ValueError("Matrix.invert(ed): matrix does not have an inverse")
+        R = np.empty((4, 4), np.float32)
+        R[0, 0] = _det3(b2, b3, b4, c2, c3, c4, d2, d3, d4)
+        R[1, 0] = -_det3(a2, a3, a4, c2, c3, c4, d2, d3, d4)
+        R[2, 0] = _det3(a2, a3, a4, b2, b3, b4, d2, d3, d4)
+        R[3, 0] = -_det3(a2, a3, a4, b2, b3, b4, c2, c3, c4)
+        R[0, 1] = -_det3(b1, b3, b4, c1, c3, c4, d1, d3, d4)
+        R[1, 1] = _det3(a1, a3, a4, c1, c3, c4, d1, d3, d4)
+        R[2, 1] = -_det3(a1, a3, a4, b1, b3, b4, d1, d3, d4)
+        R[3, 1] = _det3(a1, a3, a4, b1, b3, b4, c1, c3, c4)
+        R[0, 2] = _det3(b1, b2, b4, c1, c2, c4, d1, d2, d4)
+        R[1, 2] = -_det3(a1, a2, a4, c1, c2, c4, d1, d2, d4)
+        R[2, 2] = _det3(a1, a2, a4, b1, b2, b4, d1, d2, d4)
+        R[3, 2] = -_det3(a1, a2, a4, b1, b2, b4, c1, c2, c4)
+        R[0, 3] = -_det3(b1, b2, b3, c1, c2, c3, d1, d2, d3)
+        R[1, 3] = _det3(a1, a2, a3, c1, c2, c3, d1, d2, d3)
+        R[2, 3] = -_det3(a1, a2, a3, b1, b2, b3, d1, d2, d3)
+        R[3, 3] = _det3(a1, a2, a3, b1, b2, b3, c1, c2, c3)
+        return (R / det).T.astype(np.float32).copy()          # out[row j][column i] = R[i][j] / det

@@ -1,5 +1,7 @@
-// oa_affine.hpp -- the general form of affine_matrix_from_points (functions/general.py:105-217): any ndims in 2..8,
-// and the shear=True (full affine, Hartley & Zisserman) branch the reference's signature defaults to.
+// oa_affine.hpp -- the general form of affine_matrix_from_points (functions/general.py:105-217): any ndims >= 2 (the
+// reference takes any, :149-150; 2..8 run on fixed-size registers / private arrays, 9..AFF_MAXD_HEAP on the same solve with
+// its matrices in a device workspace and one workgroup per row / per Gram entry for the sums), and the shear=True (full
+// affine, Hartley & Zisserman) branch the reference's signature defaults to.
 //
 // The ICP loop itself only ever asks for the 3-D rigid / similarity solve (k_solve_update, oa_kabsch: 24 running sums
 // and a 3x3 solve).  This is the rest of the contract, on the same accumulate-then-solve plan:
@@ -17,7 +19,8 @@
 
 namespace oa {
 
-constexpr int AFF_MAXD = 8;                 // largest ndims
+constexpr int AFF_MAXD = 8;                 // largest ndims of the fixed-size kernels
+constexpr int AFF_MAXD_HEAP = 64;           // largest ndims at all (k_affine_solve<16 / 32 / 64, true>: matrices in a workspace)
 constexpr int AFF_M2 = 2 * AFF_MAXD;        // rows of the stacked point matrix
 constexpr int AFF_TILE = 128;               // columns per LDS tile of k_affine_gram
 
@@ -92,7 +95,8 @@ __global__ __launch_bounds__(256) void k_affine_gram(const double *__restrict__ 
 
 // ---- small dense fp64 routines (one thread; sizes <= 16) ---------------------------------------------------------------
 // cyclic Jacobi on a symmetric m x m matrix: A -> diagonal (eigenvalues), V = eigenvectors in columns
-__device__ inline void aff_jacobi_eig(int m, double (*A)[AFF_M2], double (*V)[AFF_M2])
+template <int LD>
+__device__ inline void aff_jacobi_eig(int m, double (*A)[LD], double (*V)[LD])
 {
     for (int i = 0; i < m; ++i)
         for (int j = 0; j < m; ++j) V[i][j] = i == j ? 1.0 : 0.0;
@@ -119,7 +123,8 @@ __device__ inline void aff_jacobi_eig(int m, double (*A)[AFF_M2], double (*V)[AF
 
 // one-sided Jacobi SVD of an n x n matrix: on return G = H V (columns u_j s_j), V orthogonal, sg[j] = |column j of G|,
 // order[] = column indices by descending singular value
-__device__ inline void aff_svd(int n, double (*G)[AFF_MAXD], double (*V)[AFF_MAXD], double *sg, int *order)
+template <int LD>
+__device__ inline void aff_svd(int n, double (*G)[LD], double (*V)[LD], double *sg, int *order)
 {
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < n; ++j) V[i][j] = i == j ? 1.0 : 0.0;
@@ -156,9 +161,10 @@ __device__ inline void aff_svd(int n, double (*G)[AFF_MAXD], double (*V)[AFF_MAX
     }
 }
 
-__device__ inline double aff_det(int n, double (*R)[AFF_MAXD])
+// (a: n x n scratch, overwritten)
+template <int LD>
+__device__ inline double aff_det(int n, double (*R)[LD], double (*a)[LD])
 {
-    double a[AFF_MAXD][AFF_MAXD];
     for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) a[i][j] = R[i][j];
     double det = 1.0;
     for (int c = 0; c < n; ++c) {
@@ -176,19 +182,32 @@ __device__ inline double aff_det(int n, double (*R)[AFF_MAXD])
 }
 
 // out[0 .. (n+1)^2) = M (row-major), out[(n+1)^2] = 1 when K >= ndims (else 0: the reference's ValueError)
+// D = the capacity the arrays are laid out for (colsums: v1's sums start at D; n <= D).  HEAP: every matrix lives in `ws`
+// (aff_ws_doubles(D) doubles of device memory) instead of the thread's private arrays -- 64 dimensions would be 600 KB of
+// them.  The arithmetic is the same code either way.
+constexpr size_t aff_ws_doubles(int D) { return (size_t)2 * (2 * D) * (2 * D) + (size_t)10 * D * D + (size_t)8 * D + 64; }
+#define AFF_MAT(name, R, Cc) double name##_loc[HEAP ? 1 : (R)][HEAP ? 1 : (Cc)]; \
+                             double (*name)[Cc] = HEAP ? (double (*)[Cc])(ws_at += (size_t)(R) * (Cc), ws_at - (size_t)(R) * (Cc)) : (double (*)[Cc])&name##_loc[0][0]
+#define AFF_VEC(type, name, N) type name##_loc[HEAP ? 1 : (N)]; \
+                               type *name = HEAP ? (type *)(ws_at += (N), ws_at - (N)) : &name##_loc[0]
+template <int D, bool HEAP>
 __global__ void k_affine_solve(const double *__restrict__ colsums, const double *__restrict__ gram, int n, long long K,
-                               int shear, int with_scale, double *__restrict__ out)
+                               int shear, int with_scale, double *__restrict__ out, double *__restrict__ ws)
 {
+    constexpr int AFF_MAXD = D, AFF_M2 = 2 * D;                     // (shadow the fixed-size constants: the body below is written in them)
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double *ws_at = ws;
     const int m = 2 * n, w = n + 1;
     if (K < n) { out[w * w] = 0.0; return; }
-    double c0[AFF_MAXD], c1[AFF_MAXD], T[AFF_MAXD][AFF_MAXD];
+    AFF_VEC(double, c0, AFF_MAXD); AFF_VEC(double, c1, AFF_MAXD);
+    AFF_MAT(T, AFF_MAXD, AFF_MAXD); AFF_MAT(det_tmp, AFF_MAXD, AFF_MAXD);
     for (int i = 0; i < n; ++i) { c0[i] = colsums[i] / (double)K; c1[i] = colsums[AFF_MAXD + i] / (double)K; }
     if (shear) {
-        double A[AFF_M2][AFF_M2], V[AFF_M2][AFF_M2];
+        AFF_MAT(A, AFF_M2, AFF_M2); AFF_MAT(V, AFF_M2, AFF_M2);
         for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j) A[i][j] = 0.5 * (gram[i * m + j] + gram[j * m + i]);
         aff_jacobi_eig(m, A, V);
-        int ord[AFF_M2];
+        AFF_VEC(double, ord_d, AFF_M2);                             // (indices kept as doubles in the workspace: one element type)
+        int *ord = (int *)ord_d;
         for (int j = 0; j < m; ++j) ord[j] = j;
         for (int a = 1; a < m; ++a) {                               // eigenvalues descending
             const int oj = ord[a];
@@ -197,13 +216,14 @@ __global__ void k_affine_solve(const double *__restrict__ colsums, const double 
             ord[b + 1] = oj;
         }
         // B = rows 0..n-1, C = rows n..2n-1 of the n dominant eigenvectors (:172-173); t = C pinv(B) (:174)
-        double B[AFF_MAXD][AFF_MAXD], C[AFF_MAXD][AFF_MAXD], Gs[AFF_MAXD][AFF_MAXD], Vs[AFF_MAXD][AFF_MAXD], sg[AFF_MAXD];
-        int so[AFF_MAXD];
+        AFF_MAT(B, AFF_MAXD, AFF_MAXD); AFF_MAT(C, AFF_MAXD, AFF_MAXD); AFF_MAT(Gs, AFF_MAXD, AFF_MAXD); AFF_MAT(Vs, AFF_MAXD, AFF_MAXD);
+        AFF_VEC(double, sg, AFF_MAXD); AFF_VEC(double, so_d, AFF_MAXD);
+        int *so = (int *)so_d;
         for (int i = 0; i < n; ++i)
             for (int k = 0; k < n; ++k) { B[i][k] = V[i][ord[k]]; C[i][k] = V[n + i][ord[k]]; Gs[i][k] = B[i][k]; }
         aff_svd(n, Gs, Vs, sg, so);                                 // B Vs = U S  =>  pinv(B) = Vs S^+ U^T
         const double cut = 1e-15 * sg[so[0]];                       // numpy.linalg.pinv's default rcond
-        double P[AFF_MAXD][AFF_MAXD];
+        AFF_MAT(P, AFF_MAXD, AFF_MAXD);
         for (int i = 0; i < n; ++i)
             for (int j = 0; j < n; ++j) {
                 double acc = 0.0;
@@ -218,8 +238,9 @@ __global__ void k_affine_solve(const double *__restrict__ colsums, const double 
                 T[i][j] = acc;
             }
     } else {
-        double H[AFF_MAXD][AFF_MAXD], Vs[AFF_MAXD][AFF_MAXD], sg[AFF_MAXD], U[AFF_MAXD][AFF_MAXD];
-        int so[AFF_MAXD];
+        AFF_MAT(H, AFF_MAXD, AFF_MAXD); AFF_MAT(Vs, AFF_MAXD, AFF_MAXD); AFF_MAT(U, AFF_MAXD, AFF_MAXD);
+        AFF_VEC(double, sg, AFF_MAXD); AFF_VEC(double, so_d, AFF_MAXD);
+        int *so = (int *)so_d;
         for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) H[i][j] = gram[(n + i) * m + j];    // dot(v1c, v0c.T)  (:181)
         aff_svd(n, H, Vs, sg, so);
         // U columns in descending order; zero singular directions are completed to an orthonormal basis
@@ -249,7 +270,7 @@ __global__ void k_affine_solve(const double *__restrict__ colsums, const double 
                 for (int k = 0; k < n; ++k) acc += U[i][k] * Vs[j][so[k]];                           // R = u vh  (:183)
                 T[i][j] = acc;
             }
-        if (aff_det(n, T) < 0.0) {                                  // not a right-handed system (:184-187)
+        if (aff_det(n, T, det_tmp) < 0.0) {                                  // not a right-handed system (:184-187)
             const int last = so[n - 1];
             for (int i = 0; i < n; ++i)
                 for (int j = 0; j < n; ++j) T[i][j] -= 2.0 * U[i][n - 1] * Vs[j][last];
@@ -270,6 +291,43 @@ __global__ void k_affine_solve(const double *__restrict__ colsums, const double 
     for (int j = 0; j < n; ++j) out[n * w + j] = 0.0;
     out[n * w + n] = 1.0;
     out[w * w] = 1.0;
+}
+#undef AFF_MAT
+#undef AFF_VEC
+
+// ndims > 8: the same sums with one workgroup per row / per Gram entry (fixed order inside a workgroup: reproducible); the
+// layouts are those of the fixed-size kernels with D in place of AFF_MAXD.
+// colsums[r < n ? r : D + (r - n)] = sum over the columns of row r of [v0; v1]
+__global__ __launch_bounds__(256) void k_affine_rowsum_any(const double *__restrict__ v0, const double *__restrict__ v1, int n, int D,
+                                                           long long K, long long ld, double *__restrict__ colsums)
+{
+    __shared__ double red[4];
+    const int r = blockIdx.x;
+    const double *row = r < n ? v0 + (long long)r * ld : v1 + (long long)(r - n) * ld;
+    double acc = 0.0;
+    for (long long c = threadIdx.x; c < K; c += 256) acc += row[c];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) colsums[r < n ? r : D + (r - n)] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+// gram[i * 2n + j] = sum over the columns of x_i x_j, x = [v0 - c0; v1 - c1]; workgroup (i, j) = blockIdx.x / 2n, % 2n
+__global__ __launch_bounds__(256) void k_affine_gram_any(const double *__restrict__ v0, const double *__restrict__ v1, int n, int D,
+                                                         long long K, long long ld, const double *__restrict__ colsums,
+                                                         double *__restrict__ gram)
+{
+    __shared__ double red[4];
+    const int m = 2 * n, i = blockIdx.x / m, j = blockIdx.x % m;
+    const double *ri = i < n ? v0 + (long long)i * ld : v1 + (long long)(i - n) * ld;
+    const double *rj = j < n ? v0 + (long long)j * ld : v1 + (long long)(j - n) * ld;
+    const double mi = (i < n ? colsums[i] : colsums[D + (i - n)]) / (double)K, mj = (j < n ? colsums[j] : colsums[D + (j - n)]) / (double)K;
+    double acc = 0.0;
+    for (long long c = threadIdx.x; c < K; c += 256) acc += (ri[c] - mi) * (rj[c] - mj);
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) gram[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
 }
 
 #endif  // __HIPCC__

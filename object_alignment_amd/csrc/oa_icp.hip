@@ -394,7 +394,8 @@ struct oa_ctx {
     int *d_prev = nullptr;           // nearest index of the previous search (seed), -1 = none
     float4 *d_win = nullptr;         // vertex mode: per slot, the last winner's coordinates + index in .w (-1 = none)
     uint2 *d_wsafe = nullptr;        // vertex grid: per slot {index, safe2 bits} of a winner the grid scan found (k_grid_safe_radius); 0xFF.. = none
-    float *d_safe_by_idx = nullptr;  // vertex grid: safe2 per target vertex (original index)
+    float *d_safe_by_idx = nullptr;  // vertex grid: safe2 per target vertex (original index); allocated with the grid, filled by build_safe_radii
+    bool safe_ok = false;            // ... and filled
     int grid_safe = 1;               // OA_GRID_SAFE: 0 = the vertex searches (grid, whole-shard tree) never take a seed on its safe radius (A/B);
                                      // 1 = the radii are built once a target has seen SAFE_LAZY_ITERS accumulating searches (a 5-iteration
                                      // call at 1M vertices would pay 50-80 us to save 10); 2 = built with the grid
@@ -448,7 +449,7 @@ struct oa_ctx {
     std::vector<hipEvent_t> ev;
     int ev_used = 0;
     hipEvent_t ev_loop0 = nullptr, ev_loop1 = nullptr;
-    int32_t *h_poll = nullptr;          // pinned, device-mapped {halt, n, hand-over entries, most per wave}: the solve kernel mirrors them here for the enqueuing host
+    int32_t *h_poll = nullptr;          // pinned, device-mapped {halt, n, hand-over entries, most per wave, -, iteration whose exchange the stream has reached (k_reduce_partials), -, -}: the kernels mirror them here for the enqueuing host
     bool time_events = true;            // hipEvent pair around every search (brute force); else GPU-side stamps (see iter_fused)
     double wall_clock_khz = 100000.0;   // rate of wall_clock64()
     oa_settings settings;
@@ -525,8 +526,8 @@ int ensure_common(oa_ctx *c)
     if (!c->d_sums) HIPCHK(dev_malloc(&c->d_sums, sizeof(double) * oa::NSUMS));
     if (!c->d_solve) HIPCHK(dev_malloc(&c->d_solve, sizeof(double) * 32));
     if (!c->h_poll) {
-        HIPCHK(hipHostMalloc((void **)&c->h_poll, 4 * sizeof(int32_t), hipHostMallocMapped));
-        for (int k = 0; k < 4; ++k) c->h_poll[k] = 0;
+        HIPCHK(hipHostMalloc((void **)&c->h_poll, 8 * sizeof(int32_t), hipHostMallocMapped));
+        for (int k = 0; k < 8; ++k) c->h_poll[k] = 0;
     }
     if (!c->h_state_pin) HIPCHK(hipHostMalloc((void **)&c->h_state_pin, sizeof(oa::DevState), hipHostMallocDefault));
     return OA_OK;
@@ -644,17 +645,14 @@ int sort_pairs30(oa_ctx *c, const unsigned *k_in, unsigned *k_out, const int *v_
     return OA_OK;
 }
 constexpr long long SAFE_LAZY_ITERS = 8;   // OA_GRID_SAFE=1: loop iterations a target has to see before its safe radii are built
-// OA_GRID_SAFE=1: the radii are built once the target has seen SAFE_LAZY_ITERS accumulating searches.  counting: called for
-// an accumulating search that is about to be enqueued -- a context of its own builds right there, between two iterations
-// of its running loop (one launch on its stream, the searches queue behind it).  A CHILD of a multi-device group only
-// counts: inside a group's loop an allocation can wait -- for another child's stream, when the cache hands over a block
-// that stream released, or inside hipMalloc -- while that stream's gather kernel waits for the very post this thread has
-// not enqueued yet (the loop then ends with OA_E_RCCL after OA_EXCHANGE_TIMEOUT_S; seen with OA_FAULT_LAG_GROUP, where one
-// thread is always behind).  Children build at the start of their next loop (begin_loop: every stream is idle there).
-int safe_radii_lazy(oa_ctx *c, bool counting)
+// OA_GRID_SAFE=1: the radii are built once the target has seen SAFE_LAZY_ITERS iterations of a loop (counted once per iteration,
+// launch_search_accumulate).  The array is allocated with the grid; the build is ONE launch on the context's stream and no
+// allocation -- so it may sit between two iterations of a running loop, on the caller's stream or a multi-device child's
+// (round 4 allocated here: inside a group's loop an allocation can wait for another child's stream, whose gather kernel waits
+// for the post this thread has not enqueued yet -- children therefore built between loops only).
+int safe_radii_lazy(oa_ctx *c)
 {
-    if (c->grid_safe != 1 || c->d_safe_by_idx) return OA_OK;
-    if (counting) { ++c->target_iters; if (c->parent) return OA_OK; }
+    if (c->grid_safe != 1 || c->safe_ok || !c->d_safe_by_idx) return OA_OK;
     return c->target_iters > SAFE_LAZY_ITERS ? build_safe_radii(c) : OA_OK;
 }
 int build_tri_grid(oa_ctx *c, const double *diag_sum_known = nullptr);
@@ -698,8 +696,8 @@ int launch_bvh(oa_ctx *c, const int *list, const int *list_count, int turn = -1,
     const float *safe_by_idx = nullptr;
     uint2 *wsafe = nullptr;
     if (!TRI && !list && c->grid_safe) {
-        if (acc) { const int rcs = safe_radii_lazy(c, true); if (rcs) return rcs; }
-        if (c->d_safe_by_idx && c->d_wsafe) { safe_by_idx = c->d_safe_by_idx; wsafe = c->d_wsafe; }
+        if (acc) { const int rcs = safe_radii_lazy(c); if (rcs) return rcs; }
+        if (c->safe_ok && c->d_safe_by_idx && c->d_wsafe) { safe_by_idx = c->d_safe_by_idx; wsafe = c->d_wsafe; }
     }
 #define OA_BVH_ARGS c->d_state, c->d_src4, c->ns, TRI ? c->tbvh : c->bvh, TRI ? c->d_tbvh_box : c->d_bvh_box, TRI ? c->d_tbvh_prims : c->d_bvh_prims, \
                     c->d_tri9, c->d_prev, TRI ? (float4 *)nullptr : c->d_win, c->d_keys, list, list_count, turn
@@ -842,8 +840,8 @@ int launch_nn_impl(oa_ctx *c, bool acc)
 #define OA_GRID_ARGS c->d_state, c->d_src4, c->ns, c->gp, c->d_cell_start, c->d_sorted, c->d_win, c->d_keys, c->d_todo_list, c->d_todo_count, turn
 #define OA_GRID_ACC_ARGS OA_GRID_ARGS, c->bvh, (const float4 *)c->d_bvh_box, (const float4 *)c->d_bvh_prims, normal_test(c), c->d_partials
         // {index, safe2} per slot beside the winner records: both or neither (OA_GRID_SAFE=0)
-        if (acc) { const int rcs = safe_radii_lazy(c, true); if (rcs) return rcs; }
-        const float *safe_by_idx = c->grid_safe ? c->d_safe_by_idx : nullptr;
+        if (acc) { const int rcs = safe_radii_lazy(c); if (rcs) return rcs; }
+        const float *safe_by_idx = (c->grid_safe && c->safe_ok) ? c->d_safe_by_idx : nullptr;
         uint2 *wsafe = safe_by_idx ? c->d_wsafe : nullptr;
         if (!wsafe) safe_by_idx = nullptr;
 #define OA_GRID_SAFE_ARGS safe_by_idx, wsafe
@@ -982,6 +980,7 @@ int launch_search_accumulate(oa_ctx *c, bool timed, oa::RowSel &sel, bool &fused
     const SearchPlan plan = search_plan(c);
     fused = plan == PLAN_TREE || plan == PLAN_DUAL || (plan == PLAN_GRID && grid_fast_now(c));
     c->iter_enq++;
+    if (!c->surface && c->grid_ok && fused) ++c->target_iters;      // once per iteration, whatever the plan launches (the lazy safe radii)
     if (plan == PLAN_GRID && fused) c->fast_iters++;
     if (timed) {
         if ((rc = ensure_events(c, c->ev_used + 1))) return rc;
@@ -1101,13 +1100,13 @@ int begin_loop(oa_ctx *c, const oa_settings *st, int iters)
     c->settings = *st;
     c->iterate_mode = false;
     HIPCHK(hipStreamSynchronize(c->stream));                    // nothing of an earlier loop may still write the host flag
-    if (c->h_poll) { for (int k = 0; k < 4; ++k) c->h_poll[k] = 0; }
+    if (c->h_poll) { for (int k = 0; k < 8; ++k) c->h_poll[k] = 0; }
     init_loop_state(c, st, iters);
     *c->h_state_pin = c->h_state;                               // pinned staging copy (the stream is idle, see above)
     HIPCHK(hipMemcpyAsync(c->d_state, c->h_state_pin, sizeof(oa::DevState), hipMemcpyHostToDevice, c->stream));
     if (c->d_todo_count) HIPCHK(hipMemsetAsync(c->d_todo_count, 0, 4 * sizeof(int), c->stream));   // kept at zero by k_solve_update ([2], [3]: by k_tri_accept)
     c->u_slot = 0;
-    if (!c->surface && (rc = safe_radii_lazy(c, false))) return rc;   // a multi-device child's turn to build them (never inside its group's loop)
+    if (!c->surface && (rc = safe_radii_lazy(c))) return rc;
     hipLaunchKernelGGL(oa::k_stamp_start, dim3(1), dim3(64), 0, c->stream, c->d_state);
     HIPCHK(hipGetLastError());
     c->ev_used = 0;
@@ -1266,6 +1265,7 @@ struct oa_exchange {
     // RCCL
     void *lib = nullptr;
     std::vector<ncclComm_t> comms;
+    int rccl_fallbacks = 0;                        // loops that AUTO started on RCCL and finished through the mailboxes (multi_run)
     bool rccl_aborted = false;                     // a loop ran into the watchdog and the communicators were aborted: AUTO stays on the mailbox from here on
     long long watchdog_aborts = 0;                 // OA_STAT_WATCHDOG_ABORTS
     ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
@@ -1319,7 +1319,7 @@ void exchange_abort_rccl(oa_ctx *p, const char *why)
 // iteration for OA_EXCHANGE_TIMEOUT_S -- or RCCL reports an asynchronous error -- it aborts the communicators
 // (ncclCommAbort), gives the streams the same time again to drain, and the call fails with OA_E_RCCL.
 // abort_now: the caller knows the ranks' collective counts differ (a host thread failed mid-loop): no point in waiting.
-int multi_wait(oa_ctx *p, bool abort_now = false)
+int multi_wait(oa_ctx *p, bool abort_now = false, bool in_loop = true)
 {
     Exchange *x = p->xch;
     const size_t n = p->subs.size();
@@ -1342,7 +1342,10 @@ int multi_wait(oa_ctx *p, bool abort_now = false)
     if (abort_now) { exchange_abort_rccl(p, "a host thread failed while the loop was being enqueued"); aborted = true; why = "a host thread failed mid-loop"; }
     auto t_last = clk::now();
     for (;;) {
-        bool all = true, moved = false;
+        // The clock runs while SOME stream sits in its exchange (h_poll[5] > h_poll[1]: k_reduce_partials has run, the solve behind
+        // the collective has not) and nothing moves; a device that is still searching -- a 10M-point brute-force shard takes
+        // seconds per iteration -- is not a stalled collective.  in_loop = false: the handshake, which is nothing but a collective.
+        bool all = true, moved = false, waiting = !in_loop || aborted;
         for (size_t i = 0; i < n; ++i) {
             if (done[i]) continue;
             oa_ctx *c = p->subs[i];
@@ -1354,6 +1357,7 @@ int multi_wait(oa_ctx *p, bool abort_now = false)
             all = false;
             const int at = c->h_poll ? ((volatile int32_t *)c->h_poll)[1] : 0;
             if (at != seen[i]) { seen[i] = at; moved = true; }
+            if (!c->h_poll || ((volatile int32_t *)c->h_poll)[5] > at) waiting = true;
             if (!aborted && x->CommGetAsyncError && i < x->comms.size() && x->comms[i]) {
                 ncclResult_t ar = ncclSuccess;
                 if (x->CommGetAsyncError(x->comms[i], &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress) {
@@ -1364,7 +1368,7 @@ int multi_wait(oa_ctx *p, bool abort_now = false)
             }
         }
         if (all) break;
-        if (moved) t_last = clk::now();
+        if (moved || !waiting) t_last = clk::now();
         else if (clk::now() - t_last > limit) {
             if (aborted) return fail(OA_E_RCCL, "multi-device exchange: %s, and the streams did not drain within %.1f s of the abort", why.c_str(), x->timeout_s);
             why = "no device finished an iteration for " + std::to_string(x->timeout_s) + " s (OA_EXCHANGE_TIMEOUT_S)";
@@ -1409,7 +1413,7 @@ int exchange_handshake_rccl(oa_ctx *p)
     }
     if (!rc) {
         x->mode = OA_EXCHANGE_RCCL;                                     // (multi_wait's watchdog is the RCCL one)
-        rc = multi_wait(p);
+        rc = multi_wait(p, false, false);
         x->mode = keep_mode;
     }
     for (size_t i = 0; i < n && !rc; ++i) {
@@ -1482,7 +1486,8 @@ int exchange_resolve(oa_ctx *p)
         x->mode = OA_EXCHANGE_MAILBOX;
     } else {
         x->mode = OA_EXCHANGE_MAILBOX;
-        if (p->subs.size() < 2) x->auto_note = "one device: nothing to exchange";
+        const bool any = env_int("OA_AUTO_RCCL_ANY", 0) != 0;       // test hook: AUTO takes RCCL for a world of one too (the fallback of multi_run on a one-GPU box)
+        if (p->subs.size() < 2 && !any) x->auto_note = "one device: nothing to exchange";
         else if (!devices_distinct(p)) x->auto_note = "a device is listed more than once";
         else if (x->rccl_aborted) { /* auto_note says why: a communicator that hung once is not trusted again unasked */ }
         else {
@@ -1793,11 +1798,29 @@ int multi_group_loop(oa_ctx *p, size_t g, const oa_settings *st)
 
 int multi_run(oa_ctx *p, const oa_settings *st, oa_report *rep)
 {
-    int rc = multi_begin(p, st, st->iters);
-    if (rc) return rc;
-    rc = multi_for_groups(p, [p, st](size_t g) -> int { return multi_group_loop(p, g, st); });
-    if (rc) { const std::string keep = g_err; multi_abort(p, true); g_err = keep; return rc; }
-    return multi_end(p, rep);
+    for (int attempt = 0;; ++attempt) {
+        int rc = multi_begin(p, st, st->iters);
+        if (rc) return rc;
+        const bool was_rccl = p->xch && p->xch->mode == OA_EXCHANGE_RCCL;
+        rc = multi_for_groups(p, [p, st](size_t g) -> int { return multi_group_loop(p, g, st); });
+        const bool enqueued = rc == OA_OK;
+        if (enqueued) rc = multi_end(p, rep);                       // (waits: the watchdog's OA_E_RCCL comes out of here)
+        if (!rc) return OA_OK;
+        const std::string keep = g_err;
+        if (!enqueued) multi_abort(p, true);
+        // AUTO had picked RCCL and RCCL let the loop down (watchdog, asynchronous error: the communicators are aborted and AUTO
+        // resolves to the mailboxes from here on): the caller asked for an alignment, not for RCCL -- the same loop once more,
+        // through the mailboxes.  The children's host mirrors still hold the pose the loop started from (a loop's state comes
+        // back to the host in multi_end only); what the failed attempt left on the devices -- seeds -- changes no result.
+        // An explicit oa_set_exchange(RCCL) gets the error.  (the RCCL path has never run on distinct GPUs.)
+        if (rc == OA_E_RCCL && attempt == 0 && was_rccl && p->xch->requested == OA_EXCHANGE_AUTO && p->xch->rccl_aborted) {
+            p->xch->rccl_fallbacks++;
+            if (!p->subs.empty() && p->subs[0]->debug) fprintf(stderr, "[oa] RCCL failed (%s): the loop runs again through the mailboxes\n", keep.c_str());
+            continue;
+        }
+        g_err = keep;
+        return rc;
+    }
 }
 }  // namespace
 
@@ -2133,11 +2156,11 @@ int build_filter(oa_ctx *c)
 // launch on the context's stream, no wait: the searches that use the radii are enqueued behind it.
 int build_safe_radii(oa_ctx *c)
 {
-    if (!c->grid_ok || c->d_safe_by_idx || c->nt < 2) return OA_OK;
-    HIPCHK(dev_malloc(&c->d_safe_by_idx, sizeof(float) * (size_t)c->nt));
+    if (!c->grid_ok || c->safe_ok || !c->d_safe_by_idx || c->nt < 2) return OA_OK;
     hipLaunchKernelGGL(oa::k_grid_safe_radius, dim3((c->nt + 255) / 256), dim3(256), 0, c->stream, (const float4 *)c->d_sorted, c->nt, c->gp,
                        (const int *)c->d_cell_start, c->d_safe_by_idx);
     HIPCHK(hipGetLastError());
+    c->safe_ok = true;
     return OA_OK;
 }
 
@@ -2146,6 +2169,7 @@ int build_grid(oa_ctx *c)
 {
     c->grid_ok = false;
     dev_free(c->d_cell_start); dev_free(c->d_sorted); dev_free(c->d_safe_by_idx);
+    c->safe_ok = false;
     if (!c->filter_ok || c->grid_mode == 0 || c->nt < 2) return OA_OK;
     if ((long long)c->nt > oa::GRID_MAX_TARGETS) return OA_OK;       // k_nn_search_grid addresses `sorted` through 32-bit byte offsets; the tree takes over
     double ext[3], vol = 1.0, scale = 0.0;
@@ -2223,6 +2247,7 @@ int build_grid(oa_ctx *c)
     HIPCHK(hipStreamSynchronize(c->stream));
     c->gp = gp; c->n_cells = n_cells; c->grid_ok = true;
     c->target_iters = 0;
+    if (c->grid_safe) HIPCHK(dev_malloc(&c->d_safe_by_idx, sizeof(float) * (size_t)c->nt));
     if (c->grid_safe == 2) return build_safe_radii(c);
     return OA_OK;
 }
@@ -2255,6 +2280,9 @@ int set_target_common(oa_ctx *c, const float *xyz, int64_t n, int on_device, boo
     c->nt = (int)n;
     c->n_groups_pad = 0;
     c->seeded = false;
+    // {index, safe radius} per slot: only the vertex searches read it (8 bytes per source point)
+    if (!vertex_index || !c->grid_safe) dev_free(c->d_wsafe);
+    else if (c->d_prev && !c->d_wsafe) HIPCHK(dev_malloc(&c->d_wsafe, sizeof(uint2) * (size_t)c->ns_pad));
     if (c->d_prev) {   // seeds index the old target
         // (the safe radii beside the winner records belong to the old target's indices too)
         hipLaunchKernelGGL(oa::k_init_slots, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, c->d_prev, c->d_win, c->d_wsafe,
@@ -2454,15 +2482,23 @@ int sort_source_slots(oa_ctx *c, const float *d_xyz, long long n_verts)
     { const int rcs = sort_pairs30(c, k_in.p, k_out.p, v_in.p, c->d_perm, (size_t)c->ns); if (rcs) return rcs; }
     // d_src4 / d_sel become the sorted images: the packed buffers change names (they ARE the caller-order copy now) and
     // k_apply_perm fills new ones -- every slot up to ns_pad -- instead of two device-to-device copies in front of it
+    // (both new buffers first, the context's pointers only when both exist: a failed allocation leaves the unsorted source in
+    //  place -- d_perm without sorted images would send later launches through null pointers)
+    float4 *src_sorted = nullptr;
+    int *sel_sorted = nullptr;
+    {
+        const hipError_t e1 = dev_malloc(&src_sorted, sizeof(float4) * (size_t)c->ns_pad);
+        const hipError_t e2 = e1 == hipSuccess ? dev_malloc(&sel_sorted, sizeof(int) * (size_t)c->ns_pad) : e1;
+        if (e2 != hipSuccess) { dev_free(src_sorted); dev_free(sel_sorted); dev_free(c->d_perm); return fail(OA_E_HIP, "sort_source_slots: %s", hipGetErrorString(e2)); }
+    }
     dev_free(c->d_src4o);
-    c->d_src4o = c->d_src4; c->d_src4 = nullptr;
-    int *selo = c->d_sel; c->d_sel = nullptr;
-    HIPCHK(dev_malloc(&c->d_src4, sizeof(float4) * (size_t)c->ns_pad));
-    HIPCHK(dev_malloc(&c->d_sel, sizeof(int) * (size_t)c->ns_pad));
+    c->d_src4o = c->d_src4; c->d_src4 = src_sorted;
+    int *selo = c->d_sel; c->d_sel = sel_sorted;
     hipLaunchKernelGGL(oa::k_apply_perm, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, (const float4 *)c->d_src4o,
                        (const int *)selo, (const int *)c->d_perm, c->ns, c->ns_pad, c->d_src4, c->d_sel);
-    HIPCHK(hipGetLastError());
-    dev_free(selo);                                                // (stream ordered: behind the launch above)
+    const hipError_t el = hipGetLastError();
+    dev_free(selo);                                                // (stream ordered: behind the launch above; freed on every path)
+    if (el != hipSuccess) return fail(OA_E_HIP, "k_apply_perm: %s", hipGetErrorString(el));
     HIPCHK(hipStreamSynchronize(c->stream));
     return OA_OK;
 }
@@ -2798,7 +2834,7 @@ int source_reset(oa_ctx *c, long long count, long long begin, long long n_verts)
     HIPCHK(dev_malloc(&c->d_keys, sizeof(unsigned long long) * (size_t)c->ns_pad));
     HIPCHK(dev_malloc(&c->d_prev, sizeof(int) * (size_t)c->ns_pad));
     HIPCHK(dev_malloc(&c->d_win, sizeof(float4) * (size_t)c->ns_pad));
-    HIPCHK(dev_malloc(&c->d_wsafe, sizeof(uint2) * (size_t)c->ns_pad));
+    if (c->grid_safe && !c->surface) HIPCHK(dev_malloc(&c->d_wsafe, sizeof(uint2) * (size_t)c->ns_pad));   // (a vertex target set later allocates it: set_target_common)
     c->seeded = false;
     HIPCHK(dev_malloc(&c->d_sel, sizeof(int) * (size_t)c->ns_pad));
     dev_free(c->d_todo_list); dev_free(c->d_todo_count); dev_free(c->d_ulist);
@@ -3172,7 +3208,7 @@ OA_EXPORT int oa_get_stat(oa_ctx *c, int what, double *value)
     case OA_STAT_FAST_ITERATIONS: *value = (double)c->fast_iters; return OA_OK;
     case OA_STAT_HANDOVER_ENTRIES: *value = c->h_poll ? (double)c->h_poll[2] : 0.0; return OA_OK;
     case OA_STAT_HANDOVER_WAVE_MAX: *value = c->h_poll ? (double)c->h_poll[3] : 0.0; return OA_OK;
-    case OA_STAT_SAFE_RADII: *value = (c->grid_safe && c->d_safe_by_idx) ? 1.0 : 0.0; return OA_OK;
+    case OA_STAT_SAFE_RADII: *value = (c->grid_safe && c->safe_ok) ? 1.0 : 0.0; return OA_OK;
     case OA_STAT_TRI_RING: *value = (c->tri_ring && c->tri_ring_ok) ? 1.0 : 0.0; return OA_OK;
     default: return fail(OA_E_BAD_ARG, "oa_get_stat: unknown key %d", what);
     }
@@ -3458,19 +3494,47 @@ OA_EXPORT int oa_kabsch(oa_ctx *c, const double *A, const double *B, int64_t K, 
     return rc;
 }
 
-// the reference's full signature: any ndims in 2..8, shear (full affine) or rigid / similarity
+// the reference's full signature: any ndims (2..8 on the fixed-size kernels, up to 64 through a device workspace), shear (full
+// affine) or rigid / similarity
 OA_EXPORT int oa_affine_from_points(oa_ctx *c, const double *v0, const double *v1, int ndims, int64_t K, int64_t ld,
                                     int shear, int with_scale, double *M)
 {
     if (!c || !M) return fail(OA_E_BAD_ARG, "oa_affine_from_points: null argument");
     OA_ROUTE_FIRST(c, oa_affine_from_points(sub, v0, v1, ndims, K, ld, shear, with_scale, M));
     if (ndims < 2 || K < ndims) return fail(OA_E_TOO_FEW_PAIRS, "input arrays are of wrong shape or type");   // general.py:150-157
-    if (ndims > oa::AFF_MAXD) return fail(OA_E_BAD_ARG, "oa_affine_from_points: ndims %d > %d", ndims, oa::AFF_MAXD);
+    if (ndims > oa::AFF_MAXD_HEAP) return fail(OA_E_BAD_ARG, "oa_affine_from_points: ndims %d > %d", ndims, oa::AFF_MAXD_HEAP);
     if (!v0 || !v1 || ld < K) return fail(OA_E_BAD_ARG, "oa_affine_from_points: bad arrays");
     int rc = use_device(c);
     if (rc) return rc;
     if ((rc = ensure_common(c))) return rc;
     const int n = ndims, w = n + 1;
+    if (n > oa::AFF_MAXD) {
+        // more than 8 dimensions (no caller in the add-on; the reference's signature takes any): one workgroup per row and per
+        // Gram entry, the solve with its matrices in a device workspace
+        const int D = n <= 16 ? 16 : (n <= 32 ? 32 : 64), m = 2 * n;
+        DevTmp<double> d0, d1, d_cs, d_gram, d_out, d_ws;
+        HIPCHK(d0.alloc((size_t)n * K)); HIPCHK(d1.alloc((size_t)n * K));
+        HIPCHK(d_cs.alloc((size_t)2 * D)); HIPCHK(d_gram.alloc((size_t)m * m)); HIPCHK(d_out.alloc((size_t)w * w + 1));
+        HIPCHK(d_ws.alloc(oa::aff_ws_doubles(D)));
+        for (int a = 0; a < n; ++a) {
+            HIPCHK(hipMemcpyAsync(d0.p + (size_t)a * K, v0 + (size_t)a * ld, sizeof(double) * (size_t)K, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(hipMemcpyAsync(d1.p + (size_t)a * K, v1 + (size_t)a * ld, sizeof(double) * (size_t)K, hipMemcpyHostToDevice, c->stream));
+        }
+        hipLaunchKernelGGL(oa::k_affine_rowsum_any, dim3((unsigned)m), dim3(256), 0, c->stream, (const double *)d0.p, (const double *)d1.p, n, D,
+                           (long long)K, (long long)K, d_cs.p);
+        hipLaunchKernelGGL(oa::k_affine_gram_any, dim3((unsigned)(m * m)), dim3(256), 0, c->stream, (const double *)d0.p, (const double *)d1.p, n, D,
+                           (long long)K, (long long)K, (const double *)d_cs.p, d_gram.p);
+#define OA_AFF_SOLVE(DD) hipLaunchKernelGGL((oa::k_affine_solve<DD, true>), dim3(1), dim3(64), 0, c->stream, (const double *)d_cs.p, (const double *)d_gram.p, n, \
+                                            (long long)K, shear ? 1 : 0, with_scale ? 1 : 0, d_out.p, d_ws.p)
+        if (D == 16) OA_AFF_SOLVE(16); else if (D == 32) OA_AFF_SOLVE(32); else OA_AFF_SOLVE(64);
+#undef OA_AFF_SOLVE
+        HIPCHK(hipGetLastError());
+        std::vector<double> out((size_t)w * w + 1);
+        { int rcr = read_small(c, out.data(), d_out, sizeof(double) * out.size()); if (rcr) return rcr; }
+        if (out[(size_t)w * w] != 1.0) return fail(OA_E_TOO_FEW_PAIRS, "input arrays are of wrong shape or type");
+        memcpy(M, out.data(), sizeof(double) * (size_t)w * w);
+        return OA_OK;
+    }
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(512, (K + 1023) / 1024));
     const long long cols_per_block = ((K + blocks - 1) / blocks + oa::AFF_TILE - 1) / oa::AFF_TILE * oa::AFF_TILE;
     const int gblocks = (int)((K + cols_per_block - 1) / cols_per_block);
@@ -3488,8 +3552,8 @@ OA_EXPORT int oa_affine_from_points(oa_ctx *c, const double *v0, const double *v
     hipLaunchKernelGGL(oa::k_affine_gram, dim3(gblocks), dim3(256), 0, c->stream, (const double *)d0.p, (const double *)d1.p, n,
                        (long long)K, (long long)K, (const double *)d_cs.p, cols_per_block, p2.p);
     hipLaunchKernelGGL(oa::k_affine_reduce, dim3(1), dim3(256), 0, c->stream, (const double *)p2.p, gblocks, oa::AFF_M2 * oa::AFF_M2, d_gram.p);
-    hipLaunchKernelGGL(oa::k_affine_solve, dim3(1), dim3(64), 0, c->stream, (const double *)d_cs.p, (const double *)d_gram.p, n,
-                       (long long)K, shear ? 1 : 0, with_scale ? 1 : 0, d_out.p);
+    hipLaunchKernelGGL((oa::k_affine_solve<oa::AFF_MAXD, false>), dim3(1), dim3(64), 0, c->stream, (const double *)d_cs.p, (const double *)d_gram.p, n,
+                       (long long)K, shear ? 1 : 0, with_scale ? 1 : 0, d_out.p, (double *)nullptr);
     HIPCHK(hipGetLastError());
     std::vector<double> out((size_t)w * w + 1);
     { int rcr = read_small(c, out.data(), d_out, sizeof(double) * out.size()); if (rcr) return rcr; }

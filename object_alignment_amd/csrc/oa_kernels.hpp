@@ -147,35 +147,50 @@ __host__ __device__ inline double v3_length(float x, float y, float z)
     return sqrt(acc);
 }
 
-// adjugate / determinant in double, fixed operation order, rounded to float32.  false if singular.
+// Matrix.inverted() as Blender 3.2 computes it (mathutils_Matrix.c: matrix_invert_internal -> determinant_m4, adjoint_m4_m4,
+// element / det; blenlib math_matrix.c), ALL in float, left to right, no fused multiply-add (this translation unit is compiled
+// with -ffp-contract=off): bit-identical to oracle/oa_oracle.c: oo_mat4_inverted, which cites the routines.  mathutils stores a
+// matrix column-major; m[i][j] below is Blender's matrix[i][j] = element (row j, column i) of the row-major argument, so the
+// operand order inside every cofactor is Blender's.  false if the float determinant is exactly 0 (Blender raises ValueError).
+__host__ __device__ inline float bl_det_m2(float a, float b, float c, float d) { return a * d - b * c; }
+__host__ __device__ inline float bl_det_m3(float a1, float a2, float a3, float b1, float b2, float b3, float c1, float c2, float c3)
+{
+    return (a1 * bl_det_m2(b2, b3, c2, c3) - b1 * bl_det_m2(a2, a3, c2, c3)) + c1 * bl_det_m2(a2, a3, b2, b3);
+}
+// adjoint_m4_m4 + determinant_m4: R[i * 4 + j] = Blender's R[i][j]
+__host__ __device__ inline void m4_adjoint_det(const float *Af, float R[16], float &det)
+{
+    const float a1 = Af[0], b1 = Af[4], c1 = Af[8], d1 = Af[12];    // m[0][0..3]: column 0
+    const float a2 = Af[1], b2 = Af[5], c2 = Af[9], d2 = Af[13];
+    const float a3 = Af[2], b3 = Af[6], c3 = Af[10], d3 = Af[14];
+    const float a4 = Af[3], b4 = Af[7], c4 = Af[11], d4 = Af[15];
+    det = (((a1 * bl_det_m3(b2, b3, b4, c2, c3, c4, d2, d3, d4) - b1 * bl_det_m3(a2, a3, a4, c2, c3, c4, d2, d3, d4)) +
+            c1 * bl_det_m3(a2, a3, a4, b2, b3, b4, d2, d3, d4)) - d1 * bl_det_m3(a2, a3, a4, b2, b3, b4, c2, c3, c4));
+    R[0]  = bl_det_m3(b2, b3, b4, c2, c3, c4, d2, d3, d4);
+    R[4]  = -bl_det_m3(a2, a3, a4, c2, c3, c4, d2, d3, d4);
+    R[8]  = bl_det_m3(a2, a3, a4, b2, b3, b4, d2, d3, d4);
+    R[12] = -bl_det_m3(a2, a3, a4, b2, b3, b4, c2, c3, c4);
+    R[1]  = -bl_det_m3(b1, b3, b4, c1, c3, c4, d1, d3, d4);
+    R[5]  = bl_det_m3(a1, a3, a4, c1, c3, c4, d1, d3, d4);
+    R[9]  = -bl_det_m3(a1, a3, a4, b1, b3, b4, d1, d3, d4);
+    R[13] = bl_det_m3(a1, a3, a4, b1, b3, b4, c1, c3, c4);
+    R[2]  = bl_det_m3(b1, b2, b4, c1, c2, c4, d1, d2, d4);
+    R[6]  = -bl_det_m3(a1, a2, a4, c1, c2, c4, d1, d2, d4);
+    R[10] = bl_det_m3(a1, a2, a4, b1, b2, b4, d1, d2, d4);
+    R[14] = -bl_det_m3(a1, a2, a4, b1, b2, b4, c1, c2, c4);
+    R[3]  = -bl_det_m3(b1, b2, b3, c1, c2, c3, d1, d2, d3);
+    R[7]  = bl_det_m3(a1, a2, a3, c1, c2, c3, d1, d2, d3);
+    R[11] = -bl_det_m3(a1, a2, a3, b1, b2, b3, d1, d2, d3);
+    R[15] = bl_det_m3(a1, a2, a3, b1, b2, b3, c1, c2, c3);
+}
 __host__ __device__ inline bool m4_inverted(const float *Af, float *out)
 {
-    double a[16];
-    for (int i = 0; i < 16; ++i) a[i] = (double)Af[i];
-    const double s0 = a[0] * a[5] - a[4] * a[1], s1 = a[0] * a[6] - a[4] * a[2], s2 = a[0] * a[7] - a[4] * a[3];
-    const double s3 = a[1] * a[6] - a[5] * a[2], s4 = a[1] * a[7] - a[5] * a[3], s5 = a[2] * a[7] - a[6] * a[3];
-    const double c5 = a[10] * a[15] - a[14] * a[11], c4 = a[9] * a[15] - a[13] * a[11], c3 = a[9] * a[14] - a[13] * a[10];
-    const double c2 = a[8] * a[15] - a[12] * a[11], c1 = a[8] * a[14] - a[12] * a[10], c0 = a[8] * a[13] - a[12] * a[9];
-    const double det = ((((s0 * c5 - s1 * c4) + s2 * c3) + s3 * c2) - s4 * c1) + s5 * c0;
-    if (det == 0.0) return false;
-    double b[16];
-    b[0]  = (( a[5] * c5 - a[6] * c4) + a[7] * c3) / det;
-    b[1]  = ((-a[1] * c5 + a[2] * c4) - a[3] * c3) / det;
-    b[2]  = (( a[13] * s5 - a[14] * s4) + a[15] * s3) / det;
-    b[3]  = ((-a[9] * s5 + a[10] * s4) - a[11] * s3) / det;
-    b[4]  = ((-a[4] * c5 + a[6] * c2) - a[7] * c1) / det;
-    b[5]  = (( a[0] * c5 - a[2] * c2) + a[3] * c1) / det;
-    b[6]  = ((-a[12] * s5 + a[14] * s2) - a[15] * s1) / det;
-    b[7]  = (( a[8] * s5 - a[10] * s2) + a[11] * s1) / det;
-    b[8]  = (( a[4] * c4 - a[5] * c2) + a[7] * c0) / det;
-    b[9]  = ((-a[0] * c4 + a[1] * c2) - a[3] * c0) / det;
-    b[10] = (( a[12] * s4 - a[13] * s2) + a[15] * s0) / det;
-    b[11] = ((-a[8] * s4 + a[9] * s2) - a[11] * s0) / det;
-    b[12] = ((-a[4] * c3 + a[5] * c1) - a[6] * c0) / det;
-    b[13] = (( a[0] * c3 - a[1] * c1) + a[2] * c0) / det;
-    b[14] = ((-a[12] * s3 + a[13] * s1) - a[14] * s0) / det;
-    b[15] = (( a[8] * s3 - a[9] * s1) + a[10] * s0) / det;
-    for (int i = 0; i < 16; ++i) out[i] = (float)b[i];
+    float R[16], det;
+    m4_adjoint_det(Af, R, det);
+    if (det == 0.0f) return false;
+    // out (row-major) [j * 4 + i] = R[i][j] / det
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) out[j * 4 + i] = R[i * 4 + j] / det;
     return true;
 }
 
@@ -1475,6 +1490,10 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce_partials(const DevState 
 {
     if (stamp && threadIdx.x == 0) *stamp = wall_clock64();
     reduce_rows_block(partials, st ? rows_of(sel, st) : sel.n, sums_out);
+    // what follows this launch in the stream is the exchange of the sums (ncclAllReduce): the host's watchdog times THAT wait --
+    // "entered the collective of iteration n + 1" here, "iteration n + 1 done" (host_halt[1]) from the solve behind it -- not
+    // the search in front of it, which may take longer than any time limit without anything being wrong
+    if (st && st->host_halt && threadIdx.x == 0) st->host_halt[5] = st->n + 1;
 }
 
 // sums over explicit pairs (contract 2: oa_kabsch).  A, B: 3 x K row-major with leading dimension ld.
@@ -1523,33 +1542,15 @@ __global__ void k_solve_only(const double *__restrict__ sums, double pvx, double
 // post-solve chain).  Called by (at least) 16 lanes with the same Af; false if singular.
 __device__ __forceinline__ bool m4_inverted_lane(const float *Af, int lane, float &out)
 {
-    double a[16];
-    for (int i = 0; i < 16; ++i) a[i] = (double)Af[i];
-    const double s0 = a[0] * a[5] - a[4] * a[1], s1 = a[0] * a[6] - a[4] * a[2], s2 = a[0] * a[7] - a[4] * a[3];
-    const double s3 = a[1] * a[6] - a[5] * a[2], s4 = a[1] * a[7] - a[5] * a[3], s5 = a[2] * a[7] - a[6] * a[3];
-    const double c5 = a[10] * a[15] - a[14] * a[11], c4 = a[9] * a[15] - a[13] * a[11], c3 = a[9] * a[14] - a[13] * a[10];
-    const double c2 = a[8] * a[15] - a[12] * a[11], c1 = a[8] * a[14] - a[12] * a[10], c0 = a[8] * a[13] - a[12] * a[9];
-    const double det = ((((s0 * c5 - s1 * c4) + s2 * c3) + s3 * c2) - s4 * c1) + s5 * c0;
-    if (det == 0.0) return false;
-    double nk = (( a[5] * c5 - a[6] * c4) + a[7] * c3);
-#define OA_INV_PICK(k, expr) nk = (lane == (k)) ? (expr) : nk
-    OA_INV_PICK(1,  ((-a[1] * c5 + a[2] * c4) - a[3] * c3));
-    OA_INV_PICK(2,  (( a[13] * s5 - a[14] * s4) + a[15] * s3));
-    OA_INV_PICK(3,  ((-a[9] * s5 + a[10] * s4) - a[11] * s3));
-    OA_INV_PICK(4,  ((-a[4] * c5 + a[6] * c2) - a[7] * c1));
-    OA_INV_PICK(5,  (( a[0] * c5 - a[2] * c2) + a[3] * c1));
-    OA_INV_PICK(6,  ((-a[12] * s5 + a[14] * s2) - a[15] * s1));
-    OA_INV_PICK(7,  (( a[8] * s5 - a[10] * s2) + a[11] * s1));
-    OA_INV_PICK(8,  (( a[4] * c4 - a[5] * c2) + a[7] * c0));
-    OA_INV_PICK(9,  ((-a[0] * c4 + a[1] * c2) - a[3] * c0));
-    OA_INV_PICK(10, (( a[12] * s4 - a[13] * s2) + a[15] * s0));
-    OA_INV_PICK(11, ((-a[8] * s4 + a[9] * s2) - a[11] * s0));
-    OA_INV_PICK(12, ((-a[4] * c3 + a[5] * c1) - a[6] * c0));
-    OA_INV_PICK(13, (( a[0] * c3 - a[1] * c1) + a[2] * c0));
-    OA_INV_PICK(14, ((-a[12] * s3 + a[13] * s1) - a[14] * s0));
-    OA_INV_PICK(15, (( a[8] * s3 - a[9] * s1) + a[10] * s0));
-#undef OA_INV_PICK
-    out = (float)(nk / det);
+    float R[16], det;
+    m4_adjoint_det(Af, R, det);
+    if (det == 0.0f) return false;
+    // element `lane` = (row j, column i) of the inverse = R[i][j] / det: a select chain instead of a dynamic index (registers)
+    const int src = (lane & 3) * 4 + (lane >> 2);
+    float nk = R[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) nk = (src == k) ? R[k] : nk;
+    out = nk / det;
     return true;
 }
 

@@ -247,7 +247,7 @@ class IcpEngine:
         return M
 
     def affine_from_points(self, v0, v1, shear=True, scale=True) -> np.ndarray:
-        """affine_matrix_from_points in full: any ndims in 2..8, shear (affine) or rigid / similarity."""
+        """affine_matrix_from_points in full: any ndims in 2..64, shear (affine) or rigid / similarity."""
         v0 = np.ascontiguousarray(v0, np.float64)
         v1 = np.ascontiguousarray(v1, np.float64)
         n, K = v0.shape

@@ -247,8 +247,9 @@ def affine_matrix_from_points(v0, v1, shear=True, scale=True, usesvd=True):
     """Same contract as the reference's affine_matrix_from_points (functions/general.py:105-217), every branch:
     shear=True (the signature's default) is the affine estimate of Hartley & Zisserman (:168-178); shear=False the
     rigid (scale=False) or similarity (scale=True) transform through the SVD of the covariance (:179-190, :208-212).
-    v0, v1: (ndims, K) with 2 <= ndims <= 8.  The 3-D rigid / similarity case -- the one the ICP operators use -- takes
-    the 24-sum solve of the loop (oa_kabsch); everything else the general device path (oa_affine_from_points)."""
+    v0, v1: (ndims, K), ndims >= 2 (the device path is laid out for up to 64 dimensions; the reference takes any, no caller
+    passes anything but 3).  The 3-D rigid / similarity case -- the one the ICP operators use -- takes the 24-sum solve of
+    the loop (oa_kabsch); everything else the general device path (oa_affine_from_points)."""
     v0 = np.asarray(v0, dtype=np.float64)        # the reference copies (:146-147) because it centres in place; nothing
     v1 = np.asarray(v1, dtype=np.float64)        # is modified here
     if v0.ndim != 2 or v1.ndim != 2:
@@ -256,8 +257,8 @@ def affine_matrix_from_points(v0, v1, shear=True, scale=True, usesvd=True):
     ndims = v0.shape[0]
     if ndims < 2 or v0.shape[1] < ndims or v0.shape != v1.shape:       # :150
         raise ValueError(REF_VALUEERROR)                                # :157
-    if ndims > 8:
-        raise ValueError("affine_matrix_from_points: at most 8 dimensions on the device path (got %d)" % ndims)
+    if ndims > 64:
+        raise ValueError("affine_matrix_from_points: at most 64 dimensions on the device path (got %d)" % ndims)
     # usesvd=False (Horn's quaternion branch, :191-206, 3-D only) minimises the same objective and has the same
     # optimum; it is served by the same device solve.
     if ndims == 3 and not shear:

@@ -123,6 +123,22 @@ class IcpAlign:
                        with_scale=(s.align_meth == "1"), early_exit=early_exit)
 
 
+def report_lines(res: RunResult, settings, seconds=None):
+    """What the reference's execute prints when its loop ends (operators/icp_align.py:145-160), from the device's report: the
+    convergence line or 'Maxed out iterations', then the last translation, the last d_stats and the mean of the 5-slot
+    rotation ring -- same wording, same %f formats."""
+    lines = []
+    if settings.use_target and res.iters_done > 0:
+        lines.append('Converged in %s iterations' % str(res.iters_done) if res.converged else 'Maxed out iterations')   # :145 / :154
+        lines.append('Final Translation: %f ' % res.last_translation)                                                    # :146 / :155
+        lines.append('Final Avg Dist: %f' % res.mean_dist)                                                               # :147 / :156
+        lines.append('Final St Dev %f' % res.std_dist)                                                                   # :148 / :157
+        lines.append('Avg last 5 rotation angle: %f' % res.mean_rot_angle)                                               # :149 / :158
+    if seconds is not None:
+        lines.append('Aligned obj in %f sec' % seconds)                                                                  # :160
+    return lines
+
+
 def _assign_matrix(obj, new_np):
     old = obj.matrix_world
     if isinstance(old, np.ndarray):
@@ -153,6 +169,8 @@ class OBJECT_OT_icp_align(_OperatorBase):
             align_obj.rotation_mode = 'QUATERNION'
         except Exception:
             pass
+        import time
+        start = time.time()                                     # :51
         vlist = vlist_for_engine(align_obj)
         base_geo = evaluated_base(base_obj, context)            # BVHTree.FromObject(base_obj, depsgraph)  (:52-53)
         failure = None
@@ -184,6 +202,15 @@ class OBJECT_OT_icp_align(_OperatorBase):
         if hasattr(context, "view_layer") and hasattr(context.view_layer, "update"):
             context.view_layer.update()
         self.last_result = res
+        # the reference prints its summary (:145-160); here it also goes to Blender's info area
+        self.last_report = report_lines(res, settings, time.time() - start)
+        for line in self.last_report:
+            print(line)
+            if hasattr(self, "report"):
+                try:
+                    self.report({'INFO'}, line)
+                except Exception:
+                    pass
         if failure is not None:
             raise failure
         return {'FINISHED'}

@@ -26,8 +26,9 @@
  *               result cast to float            (mathutils column_vector_multiplication)
  *   M4 @ M4   : same per element, k = 0..3     (mathutils matrix_mul)
  *   v.length  : acc(double) += (double)(float)(v[i]*v[i]) for i = 2,1,0; sqrt (double)
- *   inverted  : adjugate / determinant evaluated in double in a fixed
- *               operation order, result cast to float
+ *   inverted  : Blender's float adjoint / float determinant, element by element
+ *               divided by the determinant (mathutils matrix_invert_internal,
+ *               blenlib adjoint_m4_m4 / determinant_m4)
  *   NN metric : dx=qx-px (float) ...; d2 = fmaf(dz,dz, fmaf(dy,dy, dx*dx));
  *               argmin over target vertices, lowest index wins ties.
  *
@@ -80,8 +81,28 @@ OO_API void oo_mat4_mul(const float *A, const float *B, float *out)
     memcpy(out, r, sizeof r);
 }
 
-/* functions/general.py:265-266  mx.inverted().  Returns 1 on success, 0 if singular. */
-OO_API int oo_mat4_inverted(const float *Af, float *out)
+/* functions/general.py:265-266  mx.inverted().  Returns 1 on success, 0 if singular.
+ *
+ * Blender 3.2 (bl_info, /root/reference/__init__.py:22), source/blender/python/mathutils/mathutils_Matrix.c: Matrix_inverted ->
+ * matrix_invert_internal: det = matrix_determinant_internal (4x4: determinant_m4), then matrix_invert_with_det_n_internal:
+ * adjoint_matrix_n (4x4: adjoint_m4_m4) and every element divided by det -- ALL in C float (blenlib math_matrix.c:
+ * determinant_m2 = a d - b c; determinant_m3 = a1 m2(b2,b3,c2,c3) - b1 m2(a2,a3,c2,c3) + c1 m2(a2,a3,b2,b3); determinant_m4 and
+ * adjoint_m4_m4 expand along the first index with alternating signs), evaluated left to right, every operation rounded to float
+ * (x86-64 build: no fused multiply-add; an arm64 build of Blender may contract a*b - c*d and differ in the last bit).  mathutils
+ * stores matrices column-major (matrix[col * 4 + row]); the routines below work on that layout, as Blender's do, so the operand
+ * ORDER inside every cofactor is Blender's.  Restated from the public source (Blender API knowledge); rounds 1-4
+ * used an adjugate in double rounded once to float (kept as rule 1 for the test that measures the difference). */
+static int g_inverse_rule = 0;       /* 0: Blender's float adjoint / float determinant; 1: rounds 1-4 (double, rounded once) */
+OO_API void oo_set_inverse_rule(int rule) { g_inverse_rule = rule; }
+
+static float bl_det_m2(float a, float b, float c, float d) { return a * d - b * c; }
+static float bl_det_m3(float a1, float a2, float a3, float b1, float b2, float b3, float c1, float c2, float c3)
+{
+    float ans = (a1 * bl_det_m2(b2, b3, c2, c3) - b1 * bl_det_m2(a2, a3, c2, c3) + c1 * bl_det_m2(a2, a3, b2, b3));
+    return ans;
+}
+
+static int mat4_inverted_double(const float *Af, float *out)
 {
     double a[16];
     for (int i = 0; i < 16; ++i) a[i] = (double)Af[i];
@@ -117,6 +138,45 @@ OO_API int oo_mat4_inverted(const float *Af, float *out)
     b[14] = ((-a[12] * s3 + a[13] * s1) - a[14] * s0) / det;
     b[15] = (( a[8] * s3 - a[9] * s1) + a[10] * s0) / det;
     for (int i = 0; i < 16; ++i) out[i] = (float)b[i];
+    return 1;
+}
+
+OO_API int oo_mat4_inverted(const float *Af, float *out)
+{
+    if (g_inverse_rule == 1) return mat4_inverted_double(Af, out);
+    /* m[i][j] = Blender's matrix[i][j] = element (row j, column i) of the row-major input */
+    float m[4][4];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) m[i][j] = Af[j * 4 + i];
+    const float a1 = m[0][0], b1 = m[0][1], c1 = m[0][2], d1 = m[0][3];
+    const float a2 = m[1][0], b2 = m[1][1], c2 = m[1][2], d2 = m[1][3];
+    const float a3 = m[2][0], b3 = m[2][1], c3 = m[2][2], d3 = m[2][3];
+    const float a4 = m[3][0], b4 = m[3][1], c4 = m[3][2], d4 = m[3][3];
+    /* determinant_m4 */
+    const float det = (a1 * bl_det_m3(b2, b3, b4, c2, c3, c4, d2, d3, d4) - b1 * bl_det_m3(a2, a3, a4, c2, c3, c4, d2, d3, d4) +
+                       c1 * bl_det_m3(a2, a3, a4, b2, b3, b4, d2, d3, d4) - d1 * bl_det_m3(a2, a3, a4, b2, b3, b4, c2, c3, c4));
+    if (det == 0.0f) return 0;
+    /* adjoint_m4_m4 */
+    float R[4][4];
+    R[0][0] = bl_det_m3(b2, b3, b4, c2, c3, c4, d2, d3, d4);
+    R[1][0] = -bl_det_m3(a2, a3, a4, c2, c3, c4, d2, d3, d4);
+    R[2][0] = bl_det_m3(a2, a3, a4, b2, b3, b4, d2, d3, d4);
+    R[3][0] = -bl_det_m3(a2, a3, a4, b2, b3, b4, c2, c3, c4);
+    R[0][1] = -bl_det_m3(b1, b3, b4, c1, c3, c4, d1, d3, d4);
+    R[1][1] = bl_det_m3(a1, a3, a4, c1, c3, c4, d1, d3, d4);
+    R[2][1] = -bl_det_m3(a1, a3, a4, b1, b3, b4, d1, d3, d4);
+    R[3][1] = bl_det_m3(a1, a3, a4, b1, b3, b4, c1, c3, c4);
+    R[0][2] = bl_det_m3(b1, b2, b4, c1, c2, c4, d1, d2, d4);
+    R[1][2] = -bl_det_m3(a1, a2, a4, c1, c2, c4, d1, d2, d4);
+    R[2][2] = bl_det_m3(a1, a2, a4, b1, b2, b4, d1, d2, d4);
+    R[3][2] = -bl_det_m3(a1, a2, a4, b1, b2, b4, c1, c2, c4);
+    R[0][3] = -bl_det_m3(b1, b2, b3, c1, c2, c3, d1, d2, d3);
+    R[1][3] = bl_det_m3(a1, a2, a3, c1, c2, c3, d1, d2, d3);
+    R[2][3] = -bl_det_m3(a1, a2, a3, b1, b2, b3, d1, d2, d3);
+    R[3][3] = bl_det_m3(a1, a2, a3, b1, b2, b3, c1, c2, c3);
+    /* matrix_invert_with_det_n_internal: element by element / det, same layout */
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) out[j * 4 + i] = R[i][j] / det;
     return 1;
 }
 

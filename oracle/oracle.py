@@ -118,6 +118,15 @@ def mat4_mul(a, b):
     return out
 
 
+def set_inverse_rule(rule: int):
+    """0 (default): Matrix.inverted() as Blender computes it -- float adjoint / float determinant; 1: the rule of rounds 1-4
+    (adjugate in double, rounded once).  Only tests/test_oracle_golden.py switches it, to measure what the choice moves."""
+    L = lib()
+    L.oo_set_inverse_rule.argtypes = [C.c_int]
+    L.oo_set_inverse_rule.restype = None
+    L.oo_set_inverse_rule(int(rule))
+
+
 def mat4_inverted(a):
     a = _f32(a, (4, 4))
     out = np.empty((4, 4), np.float32)

@@ -707,6 +707,32 @@ def test_rccl_watchdog_turns_a_stalled_collective_into_an_error(golden_dir, monk
     assert res.iters_done == int(g["iters_done"]) and np.abs(res.matrix_world - g["final_world"]).max() <= F32_ULP
 
 
+def test_auto_finishes_through_the_mailboxes_when_rccl_lets_the_loop_down(golden_dir, monkeypatch):
+    """AUTO resolves to RCCL on distinct devices, and that path has never run on distinct GPUs.  When a loop AUTO
+    started on RCCL ends in the watchdog, the library aborts the communicators and runs the SAME loop again through the
+    mailboxes: the caller gets the fixture's alignment, not OA_E_RCCL (an explicit request for RCCL still gets the error:
+    test_rccl_watchdog_turns_a_stalled_collective_into_an_error).  One GPU: OA_AUTO_RCCL_ANY lets AUTO take RCCL for a world of
+    one, OA_FAULT_STALL_RANK stalls its first loop's collective."""
+    import time
+    from object_alignment_amd.engine import IcpEngine
+    g = _load(golden_dir, "icp_loop_bumpy_converge")
+    monkeypatch.setenv("OA_EXCHANGE_TIMEOUT_S", "1.5")
+    monkeypatch.setenv("OA_FAULT_STALL_RANK", "0")
+    monkeypatch.setenv("OA_AUTO_RCCL_ANY", "1")
+    with IcpEngine(devices=[0]) as eng:                                  # exchange: AUTO
+        t0 = time.perf_counter()
+        res = _run_fixture(g, eng)
+        dt = time.perf_counter() - t0
+        assert 1.0 < dt < 15.0, dt
+        assert eng.stat("watchdog_aborts") == 1
+        info = eng.exchange_info()
+        assert info["rccl_ranks"] == 0 and "mailbox" in info["exchange"], info
+        res2 = _run_fixture(g, eng)                                      # and stays there: no second abort
+        assert eng.stat("watchdog_aborts") == 1
+    for r in (res, res2):
+        assert r.iters_done == int(g["iters_done"]) and np.abs(r.matrix_world - g["final_world"]).max() <= F32_ULP
+
+
 @pytest.mark.parametrize("exchange", ["mailbox", "rccl"])
 def test_a_failing_host_thread_ends_the_loop_everywhere(golden_dir, monkeypatch, exchange):
     """OA_FAULT_FAIL_GROUP: one host thread's enqueue fails at iteration 3.  The other threads stop committing to new

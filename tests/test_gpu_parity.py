@@ -456,6 +456,9 @@ def test_operator_execute_duck_typed(golden_dir, orc, name):
     assert op.execute(ctx) == {"FINISHED"}
     got = np.array([[align.matrix_world[r][c] for c in range(4)] for r in range(4)], np.float32)
     assert np.abs(got - g["final_world"]).max() <= F32_ULP
+    # the summary the reference printed at the end of its loop (operators/icp_align.py:145-158), line for line
+    assert [str(x) for x in g["report"]] == op.last_report[:-1], (list(g["report"]), op.last_report)
+    assert op.last_report[-1].startswith("Aligned obj in ")
     if g["m_final"].shape[0]:
         assert np.abs(np.asarray(m_obj.matrix_world) - g["m_final"][0]).max() <= 1e-6
     for k, v in icp_align.IcpSettings().__dict__.items():

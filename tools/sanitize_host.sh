@@ -40,7 +40,7 @@ driver)
 run)
   shift; shift
   mkdir -p "$REPO/gpurun_out"; rm -f "$REPO"/gpurun_out/san_$KIND.*
-  cd "$REPO" && OA_ICP_LIB="$SAN/liboa_icp_$KIND.so" LD_PRELOAD="$RT" \
+  cd "$REPO" && OA_ICP_LIB_DEBUG=1 OA_ICP_LIB="$SAN/liboa_icp_$KIND.so" LD_PRELOAD="$RT" \
     ASAN_OPTIONS="detect_leaks=0:protect_shadow_gap=0:verify_asan_link_order=0:halt_on_error=0:log_path=$REPO/gpurun_out/san_$KIND" \
     UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=0:log_path=$REPO/gpurun_out/san_$KIND" \
     TSAN_OPTIONS="halt_on_error=0:report_signal_unsafe=0:ignore_noninstrumented_modules=1:second_deadlock_stack=1:log_path=$REPO/gpurun_out/san_$KIND" \
