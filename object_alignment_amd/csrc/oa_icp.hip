@@ -980,7 +980,10 @@ int launch_search_accumulate(oa_ctx *c, bool timed, oa::RowSel &sel, bool &fused
     const SearchPlan plan = search_plan(c);
     fused = plan == PLAN_TREE || plan == PLAN_DUAL || (plan == PLAN_GRID && grid_fast_now(c));
     c->iter_enq++;
-    if (!c->surface && c->grid_ok && fused) ++c->target_iters;      // once per iteration, whatever the plan launches (the lazy safe radii)
+    // the lazy safe radii: counted once per iteration, whatever the plan launches (tree and grid in turns count once; shards too
+    // large for the fused path -- BASELINE config 5 on one GPU -- count too: their plain grid search takes seeds on their radii
+    // all the same); brute force never reads them
+    if (!c->surface && c->grid_ok && c->grid_mode != 0) { ++c->target_iters; if ((rc = safe_radii_lazy(c))) return rc; }
     if (plan == PLAN_GRID && fused) c->fast_iters++;
     if (timed) {
         if ((rc = ensure_events(c, c->ev_used + 1))) return rc;
