@@ -26,7 +26,10 @@ k_nn_search_filtered.  It is bound by fp32 vector-ALU issue (SURVEY.md 8d / DESI
     roofline.frac     = achieved / peak          (<= 1 by construction)
 
 with the instruction count from the committed PMC pass (profiles/hbm_traffic.json, stamped with the kernel name and
-the commit it was collected at) and the launch time measured live with hipEvents on the kernel's stream.  The
+the commit it was collected at) and the launch time measured live with hipEvents on the kernel's stream.  The chip does
+not hold 2.4 GHz under this load (1.8-2.1 GHz, box to box), so the line also carries every launch's time (`launch_ms`:
+min / median / max), what v_fma_f32 issues on THIS box right before and right after the timed loop
+(`measured_issue_ceiling`, with the shader clock under that load) and `frac_of_measured_ceiling`.  The
 SURVEY's algorithmic figure -- 8 flop per (source, target) pair -- is reported as `effective_tflops`: the kernel's
 conservative filter proves most pairs losers in ~3 instructions, so that figure can exceed what the chip executes and
 is NOT a roofline fraction.  `cpu_baseline` times the CPU oracle (KD-tree + Kabsch; OpenMP on all host cores) on a
@@ -162,14 +165,15 @@ def whole_call_leg(local_rank, src, tgt, mxa, mxb):
     from object_alignment_amd import synth
     from object_alignment_amd.engine import IcpEngine
     out = {"what": "host arrays -> aligned matrix: set_target + set_source + run(iters=50, early exit); PCIe-inclusive, "
-                   "AUTO search; best of 5 calls on a warm context", "unit": "ms"}
+                   "AUTO search; best (`ms`, with its parts), median and slowest of 5 calls on a warm context; the copies' own durations: "
+                   "profiles/r05*_whole_call_traces.txt (rocprofv3 --memory-copy-trace)", "unit": "ms"}
     cases = {"c3_1M_1M": (src, tgt, mxa, mxb)}
     s2, t2, a2, b2 = synth.c2_bunny_pair(100_000)
     cases["c2_100k_100k"] = (s2, t2, a2, b2)
     with IcpEngine(local_rank) as e:
         e.set_search_mode("auto")
         for name, (s_, t_, a_, b_) in cases.items():
-            best, parts, res = 1e9, None, None
+            best, parts, res, walls = 1e9, None, None, []
             for _ in range(5):
                 t0 = time.perf_counter()
                 e.set_target(t_)
@@ -179,9 +183,10 @@ def whole_call_leg(local_rank, src, tgt, mxa, mxb):
                 t2_ = time.perf_counter()
                 r = e.run(iters=50, thresh=0.5, target_d=0.01, use_target=True, early_exit=True)
                 t3 = time.perf_counter()
+                walls.append(t3 - t0)
                 if t3 - t0 < best:
                     best, parts, res = t3 - t0, (t1 - t0, t2_ - t1, t3 - t2_), r
-            out[name] = {"ms": 1e3 * best, "set_target_ms": 1e3 * parts[0], "set_source_ms": 1e3 * parts[1], "run_ms": 1e3 * parts[2],
+            out[name] = {"ms": 1e3 * best, "median_ms": 1e3 * float(np.median(walls)), "max_ms": 1e3 * max(walls), "set_target_ms": 1e3 * parts[0], "set_source_ms": 1e3 * parts[1], "run_ms": 1e3 * parts[2],
                          "iterations": int(res.iters_done), "converged": bool(res.converged), "last_K": int(res.last_K)}
     return out
 
@@ -242,6 +247,9 @@ def surface_leg(args, local_rank):
 # test, first 10 iterations; the 1-GPU figure is measured -- profiles/r03e_baseline_configs.txt --, the 8-GPU one predicted from
 # the per-shard search time + ~30 us of reduce / exchange / solve)
 C5_PREDICTED_MS_PER_ITERATION = {1: 2.06, 8: 0.35}
+# the headline workload (BASELINE config 4 at N = 8), brute-force kernel: one GPU measured (round 4: 52.7 ms), 8 GPUs PREDICTED
+# from the 125k-point shard's search time + reduce / exchange / solve
+C4_PREDICTED_MS_PER_ITERATION = {1: 52.7, 8: 6.49}
 
 
 def c5_leg(args, n_gpus, in_process, world, rank, local_rank, devices, dev, backend):
@@ -462,13 +470,34 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         ms = r.nn_ms_total / max(1, steps)
+        # per device: search time (fastest / slowest), the wait for the world's sums (GPU-side stamps), host enqueue time
+        diag = {"search_ms_per_device": {"min": ms, "max": ms}, "exchange_us_per_iteration": None, "host_enqueue_us_per_iteration": None}
+        try:
+            diag["exchange_us_per_iteration"] = eng.stat("exchange_us")
+            if in_process and n_gpus > 1:
+                diag["search_ms_per_device"] = {"min": eng.stat("nn_ms_min") / max(1, steps), "max": eng.stat("nn_ms_max") / max(1, steps)}
+                diag["host_enqueue_us_per_iteration"] = eng.stat("enqueue_us")
+        except Exception:
+            pass
         if world > 1:
-            t = torch.tensor([dt, ms], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt, ms, -ms, diag["exchange_us_per_iteration"] or 0.0], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt, ms = float(t[0]), float(t[1])
+            diag["search_ms_per_device"] = {"min": -float(t[2]), "max": ms}
+            diag["exchange_us_per_iteration"] = float(t[3])
+        timed.diag = diag
         return r, dt, ms
 
+    def ceiling():
+        """What the vector ALUs issue right now (5 ms of v_fma_f32 on every SIMD, oa_measure_valu_ceiling) and the shader clock
+        under that load: taken right before and right after the timed loop, it tells a throttling box from a slower kernel."""
+        try:
+            return eng.valu_ceiling(5.0)
+        except Exception as exc:                                  # never lose the headline line
+            return {"error": repr(exc)}
+
     exchange_note = None
+    ceil_before = ceiling()
     try:
         res, elapsed, nn_ms = timed(args.steps, args.warmup)
     except Exception as exc:
@@ -482,6 +511,17 @@ def main():
         xinfo = eng.exchange_info()
         exchange, rccl_ranks, host_threads = xinfo["exchange"], xinfo["rccl_ranks"], xinfo["host_threads"]
         res, elapsed, nn_ms = timed(args.steps, args.warmup)
+    ceil_after = ceiling()
+    try:
+        launch_ms = eng.search_ms()
+    except Exception:
+        launch_ms = np.zeros(0)
+    head_diag = dict(getattr(timed, "diag", {}))
+    xinfo_after = eng.exchange_info() if in_process else {}
+    if in_process and xinfo_after.get("rccl_fallbacks"):
+        # AUTO began on RCCL and the library finished the loop through the mailboxes (multi_run): say so, with RCCL's reason
+        exchange_note = "the library fell back to the mailbox exchange: %s" % xinfo_after.get("note")
+        exchange, rccl_ranks = xinfo_after["exchange"], xinfo_after["rccl_ranks"]
 
     # SURVEY 8f rank 2 ("next" row, reported beside the headline, never instead of it): the same run with the
     # uniform-grid exact search.  Correspondences are identical, so the final matrix must be bitwise the same.
@@ -548,6 +588,8 @@ def main():
         else:
             par = ("one process per GPU: source sharded x%d, target replicated, all-reduce of 24 f64 per iteration (%s)"
                    % (world, exchange))
+        ceil_t = [c["tlaneops"] for c in (ceil_before, ceil_after) if "tlaneops" in c and c["tlaneops"] > 0]
+        ceil_now = min(ceil_t) if ceil_t else None                           # the lower of the two: the conservative denominator
         out = {
             "metric": "ICP iterations/sec + ms/NN-search, 1M<->1M verts",
             "value": args.steps / elapsed,
@@ -565,11 +607,32 @@ def main():
                        "n_source": args.n_source, "n_target": args.n_target, "search": "brute force (north-star kernel)",
                        "parallelism": par, "exchange": exchange, "exchange_note": exchange_note, "rccl_ranks": rccl_ranks, "host_threads_per_process": host_threads,
                        "host_enqueue_us_per_iteration": (eng.stat("enqueue_us") if in_process else None)},
+            # a first run on real multi-GPU hardware should explain itself: per-device search times, the GPU-side wait for the
+            # world's sums, what the exchange resolved to and why, and DESIGN.md 4.7's prediction for this N beside the measurement
+            "multi_gpu": ({**head_diag,
+                           "exchange": exchange, "exchange_note": exchange_note or (xinfo_after.get("note") or None),
+                           "rccl_ranks": rccl_ranks,
+                           "rccl_ranks_of_the_last_communicator": (xinfo_after.get("rccl_ranks_last") if in_process else rccl_ranks),
+                           "rccl_fallbacks": xinfo_after.get("rccl_fallbacks", 0),
+                           "predicted_ms_per_step_design_4_7": C4_PREDICTED_MS_PER_ITERATION.get(n_gpus),
+                           "measured_over_predicted": ((1e3 * elapsed / args.steps) / C4_PREDICTED_MS_PER_ITERATION[n_gpus])
+                           if n_gpus in C4_PREDICTED_MS_PER_ITERATION and (args.n_source, args.n_target) == (1_000_000, 1_000_000) else None}
+                          if n_gpus > 1 else None),
             "roofline": {"bound": "valu", "achieved": laneops, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s",
                          "frac": laneops / VALU_PEAK_TLANEOPS, "traffic": traffic,
                          "kernel": KERNELS["brute"], "valu_instructions_per_pair": per_pair,
                          "valu_instructions_per_pair_source": per_pair_src, "pairs_per_launch": pairs,
                          "avg_launch_ms": nn_ms, "traffic_profile": stamp,
+                         # every launch of the timed loop (hipEvent pairs on the kernel's stream): a throttled box shows here
+                         "launch_ms": ({"min": float(launch_ms.min()), "median": float(np.median(launch_ms)), "max": float(launch_ms.max()),
+                                        "n": int(len(launch_ms))} if len(launch_ms) else None),
+                         # ... and here: what v_fma_f32 issues on this box right before / right after the timed loop, and the
+                         # shader clock under that load (nominal: 78.6 T lane-ops/s at 2400 MHz)
+                         "frac_of_nominal": laneops / VALU_PEAK_TLANEOPS,
+                         "measured_issue_ceiling": {"unit": "Tlane-op/s", "instruction": "v_add_f32 (two register sources: one wave-instruction per SIMD every two cycles = 32 lanes per clock), "
+                                                                   "16 independent chains, 8 waves per SIMD, ~2.5 ms; v_fma_f32 with three register sources beside it",
+                                                    "before_timed_loop": ceil_before, "after_timed_loop": ceil_after, "used": ceil_now},
+                         "frac_of_measured_ceiling": (laneops / ceil_now) if ceil_now else None,
                          "formula": "frac = valu_instructions_per_pair x pairs_per_launch / avg_launch_ms / 78.6e12 lane-ops/s "
                                     "(256 CU x 4 SIMD x 32 lanes x 2.4 GHz); valu_instructions_per_pair = SQ_INSTS_VALU x 64 / "
                                     "pairs from the committed PMC pass (profiles/), avg_launch_ms = hipEvent pairs around "

@@ -222,8 +222,15 @@ int oa_reset_seeds(oa_ctx *ctx);
                                        * seen 4 loop searches, OA_TRI_RING=2: with the grid; first device) */
 #define OA_STAT_TRI_RING_ACCEPTS  22   /* diagnostic (one extra launch + a wait): source points of this shard that the neighbour lists would settle at
                                        * the current pose with the current seeds; multi-device context: the sum over the shards */
+#define OA_STAT_EXCHANGE_US       23   /* multi-GPU: mean time per iteration of the last loop a device spent between "its sums are ready" and "the
+                                       * world's sums are in hand" (GPU-side stamps: the all-reduce, or the gather's wait), slowest device */
+#define OA_STAT_RCCL_FALLBACKS    24   /* loops that AUTO began on RCCL and finished through the mailboxes (the watchdog aborted the communicators) */
+#define OA_STAT_RCCL_RANKS_LAST   25   /* ranks of the last RCCL communicator that came up and passed its handshake -- still reported after a
+                                       * fallback, when OA_STAT_RCCL_RANKS is back to 0 */
 #define OA_STAT_ENQUEUED_CHILD  1000   /* + i: the same count for child i alone */
 int oa_get_stat(oa_ctx *ctx, int what, double *value);
+/* why the exchange is what it is (AUTO's reason for not taking RCCL, librccl's error, "RCCL was aborted: ..."), or "" */
+const char *oa_exchange_note(oa_ctx *ctx);
 int64_t oa_num_selected(oa_ctx *ctx);     /* selected source points held by this context (its shard) */
 
 /* ---- contract 1: make_pairs (functions/general.py:257-329) ------------------------------------ */
@@ -269,6 +276,15 @@ int oa_run(oa_ctx *ctx, const oa_settings *st, oa_report *rep);
  * step_K n, step_stats n x 2, step_trans n.  Returns the number of iterations recorded. */
 int oa_get_history(oa_ctx *ctx, int32_t max_n, double *step_M, float *step_new,
                    int64_t *step_K, double *step_stats, double *step_trans);
+
+/* search time (ms) of every iteration of the last oa_run / oa_run_end -- what oa_report::nn_ms_total sums; returns how many
+ * were written (<= max_n).  Multi-device context: its first device.  (bench.py: per-launch min / median / max) */
+int oa_get_search_ms(oa_ctx *ctx, int32_t max_n, double *ms);
+/* Diagnostic for bench.py's roofline (no counterpart in the reference): what the vector ALUs issue right now -- ~target_ms of
+ * independent v_add_f32 / v_fma_f32 chains on every SIMD, 8 waves each.  out[0] = T lane-ops/s of v_add_f32 (two register
+ * sources: the issue rate itself), out[1] = shader clock in MHz during that burn, out[2] = duration in ms, out[3] = T lane-ops/s
+ * of v_fma_f32 with three register sources.  The brute-force search is bound by exactly this rate. */
+int oa_measure_valu_ceiling(oa_ctx *ctx, double target_ms, double out[4]);
 
 /* ---- split-phase loop for one-process-per-GPU sharding ---------------------------------------- */
 /* oa_run_begin resets the loop state (ring buffer, counters) on the device. */

@@ -36,6 +36,7 @@ SYMBOLS = [
     "oa_reset_seeds", "oa_get_stat",
     "oa_make_pairs", "oa_nn_search", "oa_kabsch", "oa_affine_from_points", "oa_kabsch_from_sums", "oa_get_pivot",
     "oa_iterate", "oa_run", "oa_get_history", "oa_run_begin", "oa_iter_partial", "oa_iter_finish", "oa_run_end",
+    "oa_get_search_ms", "oa_measure_valu_ceiling", "oa_exchange_note",
 ]
 
 
@@ -122,6 +123,10 @@ def load():
     L.oa_iterate.argtypes = [vp, C.POINTER(Settings), dp, dp]
     L.oa_run.argtypes = [vp, C.POINTER(Settings), C.POINTER(Report)]
     L.oa_get_history.argtypes = [vp, C.c_int32, dp, fp, ip, dp, dp]
+    L.oa_exchange_note.argtypes = [vp]
+    L.oa_exchange_note.restype = C.c_char_p
+    L.oa_get_search_ms.argtypes = [vp, C.c_int32, dp]
+    L.oa_measure_valu_ceiling.argtypes = [vp, C.c_double, dp]
     L.oa_run_begin.argtypes = [vp, C.POINTER(Settings)]
     L.oa_iter_partial.argtypes = [vp, vp]
     L.oa_iter_finish.argtypes = [vp, vp]

@@ -425,6 +425,8 @@ struct oa_ctx {
     char *h_scratch = nullptr;              // pinned scratch for small read-backs (read_small)
     char *h_result = nullptr;               // pinned, device-mapped: kernels store small results here (result_buffer)
     void *d_result_view = nullptr;
+    double last_exchange_us = 0.0;        // mean exchange wait per iteration of the last loop (fill_report; OA_STAT_EXCHANGE_US)
+    std::vector<double> h_search_ms;      // search time of every iteration of the last loop (fill_report; oa_get_search_ms)
     std::vector<oa::StepRecord> h_hist;   // host copy of the executed iterations' records, filled by fill_report
     bool h_hist_valid = false;
     int max_records = 0;
@@ -1199,17 +1201,25 @@ int fill_report(oa_ctx *c, oa_report *rep)
     // search time: hipEvent pairs around every launch (brute force), else the GPU-side stamps the loop left in the
     // step records (end of the previous iteration -> start of k_pair_accumulate)
     double nn_ms = 0.0;
+    c->h_search_ms.clear();                                       // per launch, for oa_get_search_ms
     if (c->time_events) {
         for (int k = 0; k < c->ev_used; ++k) {
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, c->ev[2 * k], c->ev[2 * k + 1]) == hipSuccess) nn_ms += ms;
+            if (hipEventElapsedTime(&ms, c->ev[2 * k], c->ev[2 * k + 1]) == hipSuccess) { nn_ms += ms; c->h_search_ms.push_back((double)ms); }
         }
     } else if (m > 0) {
         double ticks = 0.0;
-        for (int k = 0; k < m; ++k) ticks += c->h_hist[(size_t)k].search_ticks;
+        for (int k = 0; k < m; ++k) { ticks += c->h_hist[(size_t)k].search_ticks; c->h_search_ms.push_back(c->h_hist[(size_t)k].search_ticks / c->wall_clock_khz); }
         nn_ms = ticks / c->wall_clock_khz * ((double)s.n / (double)m);
     }
     rep->nn_ms_total = nn_ms;
+    // multi-GPU: how long the device waited for the world's sums, per iteration (StepRecord::exchange_ticks)
+    c->last_exchange_us = 0.0;
+    if (m > 0) {
+        double ticks = 0.0;
+        for (int k = 0; k < m; ++k) ticks += c->h_hist[(size_t)k].exchange_ticks;
+        c->last_exchange_us = ticks / c->wall_clock_khz * 1e3 / (double)m;
+    }
     return OA_OK;
 }
 
@@ -1268,6 +1278,7 @@ struct oa_exchange {
     // RCCL
     void *lib = nullptr;
     std::vector<ncclComm_t> comms;
+    int rccl_ranks_last = 0;                       // ranks of the last communicator that came up and passed its handshake (it may have been aborted since)
     int rccl_fallbacks = 0;                        // loops that AUTO started on RCCL and finished through the mailboxes (multi_run)
     bool rccl_aborted = false;                     // a loop ran into the watchdog and the communicators were aborted: AUTO stays on the mailbox from here on
     long long watchdog_aborts = 0;                 // OA_STAT_WATCHDOG_ABORTS
@@ -1427,7 +1438,7 @@ int exchange_handshake_rccl(oa_ctx *p)
     }
     for (size_t i = 0; i < n; ++i) if (bufs[i]) { (void)hipSetDevice(p->subs[i]->device); (void)hipFree(bufs[i]); }
     if (rc && !x->comms.empty()) { const std::string keep = g_err; exchange_abort_rccl(p, "handshake failed"); g_err = keep; }
-    if (!rc) x->rccl_aborted = false;
+    if (!rc) { x->rccl_aborted = false; x->rccl_ranks_last = (int)n; }
     return rc;
 }
 
@@ -1998,6 +2009,15 @@ OA_EXPORT int oa_set_exchange(oa_ctx *c, int mode)
     c->xch->requested = mode;
     c->xch->resolved = false;
     return exchange_resolve(c);                                         // RCCL fails now rather than in the first iteration
+}
+
+// why the exchange is what it is: the reason AUTO did not take (or no longer takes) RCCL -- "a device is listed more than once",
+// librccl's load error, "RCCL was aborted: ..." after a watchdog abort -- or "" when there is nothing to say
+OA_EXPORT const char *oa_exchange_note(oa_ctx *c)
+{
+    static thread_local std::string note;
+    note = (c && c->xch) ? c->xch->auto_note : std::string();
+    return note.c_str();
 }
 
 OA_EXPORT int oa_num_devices(oa_ctx *c) { return !c ? 0 : (c->subs.empty() ? 1 : (int)c->subs.size()); }
@@ -3182,6 +3202,13 @@ OA_EXPORT int oa_get_stat(oa_ctx *c, int what, double *value)
                     n[0], c->ns, n[1], n[2], n[3], n[4], n[5], n[6], n[7], n[8]);
         return OA_OK;
     }
+    if (what == OA_STAT_EXCHANGE_US) {                                  // the slowest device's mean wait for the world's sums (one GPU: 0)
+        *value = c->last_exchange_us;
+        for (oa_ctx *sub : c->subs) *value = std::max(*value, sub->last_exchange_us);
+        return OA_OK;
+    }
+    if (what == OA_STAT_RCCL_FALLBACKS) { *value = c->xch && !c->parent ? (double)c->xch->rccl_fallbacks : 0.0; return OA_OK; }
+    if (what == OA_STAT_RCCL_RANKS_LAST) { *value = c->xch && !c->parent ? (double)c->xch->rccl_ranks_last : 0.0; return OA_OK; }
     if (what == OA_STAT_WATCHDOG_ABORTS) { *value = c->xch && !c->parent ? (double)c->xch->watchdog_aborts : 0.0; return OA_OK; }
     if (what == OA_STAT_EXCHANGE || what == OA_STAT_RCCL_RANKS || what == OA_STAT_ENQUEUE_US || what == OA_STAT_HOST_THREADS) {
         if (c->subs.empty()) { *value = what == OA_STAT_EXCHANGE ? -1.0 : (what == OA_STAT_HOST_THREADS ? 1.0 : 0.0); return OA_OK; }
@@ -3240,6 +3267,63 @@ OA_EXPORT int oa_get_pivot(oa_ctx *c, double pivot[3])
     if (!c || !pivot) return fail(OA_E_BAD_ARG, "null argument");
     OA_ROUTE_FIRST(c, oa_get_pivot(sub, pivot));
     for (int k = 0; k < 3; ++k) pivot[k] = c->pivot[k];
+    return OA_OK;
+}
+
+// search time of every iteration of the last oa_run / oa_run_end, in ms (hipEvent pairs around the brute-force launches, GPU-side
+// stamps otherwise): what oa_report::nn_ms_total sums.  A multi-device context answers for its first device.
+OA_EXPORT int oa_get_search_ms(oa_ctx *c, int32_t max_n, double *ms)
+{
+    if (!c) return fail(OA_E_BAD_ARG, "null context");
+    OA_ROUTE_FIRST(c, oa_get_search_ms(sub, max_n, ms));
+    const int n = std::min((int)c->h_search_ms.size(), (int)std::max(0, max_n));
+    for (int i = 0; i < n && ms; ++i) ms[i] = c->h_search_ms[(size_t)i];
+    return n;
+}
+
+// What the chip's vector ALUs issue RIGHT NOW: a burn of dependent-free v_fma_f32 chains on every SIMD for ~target_ms, timed
+// with hipEvents and with the shader clock / the constant-rate clock read by the same wave at both ends.  bench.py runs it next to
+// the headline's timed loop: the brute-force search is bound by VALU issue, the clock under that load is 1.8-2.1 GHz rather
+// than the nominal 2.4 and moves from box to box -- with this figure beside it a 50 vs 58 ms launch explains itself.
+// out[0] = T lane-ops/s of v_add_f32 (two register sources: the issue rate -- 32 lanes per SIMD and clock), out[1] = shader clock
+// (MHz) during that burn, out[2] = duration of both burns (ms), out[3] = T lane-ops/s of v_fma_f32 with three register sources
+// (0.89 of the issue rate: operand reads)
+OA_EXPORT int oa_measure_valu_ceiling(oa_ctx *c, double target_ms, double out[4])
+{
+    if (!c || !out) return fail(OA_E_BAD_ARG, "oa_measure_valu_ceiling: null argument");
+    OA_ROUTE_FIRST(c, oa_measure_valu_ceiling(sub, target_ms, out));
+    int rc = use_device(c);
+    if (rc) return rc;
+    const int wgs_per_cu = 8;                                        // 8 workgroups of 4 waves per CU: 8 waves per SIMD
+    const unsigned blocks = (unsigned)(c->n_cu * wgs_per_cu);
+    // ~2.7 cycles per wave-instruction and SIMD measured (tools/valu_microbench.hip): iterations for the time asked for
+    const double per_iter_s = 8.0 * oa::VALU_BURN_CHAINS * 2.7 / 2.0e9;
+    const int iters = ((int)std::max(64.0, std::min(4.0e6, std::max(0.05, std::min(target_ms, 200.0)) * 1e-3 / per_iter_s)) + 7) & ~7;   // (halves are multiples of 4)
+    DevTmp<float> d_sink;
+    DevTmp<unsigned long long> d_clk;
+    HIPCHK(d_sink.alloc((size_t)blocks * 256));
+    HIPCHK(d_clk.alloc(4));
+    HIPCHK(hipMemsetAsync(d_clk, 0, 4 * sizeof(unsigned long long), c->stream));
+    if ((rc = ensure_events(c, 2))) return rc;
+    // (a short first launch loads the code object and wakes the clocks; then half the time on each instruction)
+    hipLaunchKernelGGL(oa::k_valu_burn<1>, dim3(blocks), dim3(256), 0, c->stream, d_sink.p, 1.0000001f, 1e-9f, std::max(64, (iters / 8) & ~3), d_clk.p);
+    HIPCHK(hipEventRecord(c->ev[0], c->stream));
+    hipLaunchKernelGGL(oa::k_valu_burn<0>, dim3(blocks), dim3(256), 0, c->stream, d_sink.p, 1.0000001f, 1e-9f, iters / 2, d_clk.p);
+    HIPCHK(hipEventRecord(c->ev[1], c->stream));
+    HIPCHK(hipEventRecord(c->ev[2], c->stream));
+    hipLaunchKernelGGL(oa::k_valu_burn<1>, dim3(blocks), dim3(256), 0, c->stream, d_sink.p, 1.0000001f, 1e-9f, iters / 2, d_clk.p + 2);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->ev[3], c->stream));
+    unsigned long long clk[4];
+    if ((rc = read_small(c, clk, d_clk, sizeof(clk)))) return rc;
+    float ms_fma = 0.f, ms_add = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms_fma, c->ev[0], c->ev[1]));
+    HIPCHK(hipEventElapsedTime(&ms_add, c->ev[2], c->ev[3]));
+    const double laneops = (double)blocks * 256.0 * (double)oa::VALU_BURN_CHAINS * (double)(iters / 2);
+    out[0] = ms_add > 0.f ? laneops / ((double)ms_add * 1e-3) / 1e12 : 0.0;       // v_add_f32: the issue rate
+    out[1] = clk[3] > 0 ? (double)clk[2] / (double)clk[3] * c->wall_clock_khz * 1e-3 : 0.0;
+    out[2] = (double)(ms_fma + ms_add);
+    out[3] = ms_fma > 0.f ? laneops / ((double)ms_fma * 1e-3) / 1e12 : 0.0;       // v_fma_f32, three register sources
     return OA_OK;
 }
 

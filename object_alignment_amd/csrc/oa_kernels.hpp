@@ -42,6 +42,8 @@ struct StepRecord {
     float  new_mat[16];
     double K, mean_d, std_d, trans, angle;
     double search_ticks;      // wall_clock64 ticks from the end of the previous iteration to the start of k_pair_accumulate
+    double exchange_ticks;    // ... from "this device's sums are ready" (end of k_reduce_post / k_reduce_partials) to "the world's sums are in
+                              // hand" (the gather's wait is over / the solve behind the all-reduce starts); 0 on one GPU
 };
 
 struct DevState {
@@ -67,6 +69,7 @@ struct DevState {
     // GPU-side timing of the search (no hipEvents in the stream: they cost ~3 us each): k_stamp_start / the solve
     // kernel leave the end of the previous iteration in t_prev_end, k_pair_accumulate its own start in t_acc_start
     unsigned long long t_prev_end, t_acc_start;
+    unsigned long long t_xchg_start;  // multi-GPU: when this device's sums of the iteration were ready for the exchange (StepRecord::exchange_ticks)
     // Shards in the zone where the tree search wins while the pose still moves (stale seeds, long reach) and the grid
     // search once it has settled: both are enqueued every iteration and `tree_turn` says whose turn it is.  Set by the
     // host for the first search (no seeds: tree) and by the solve kernel afterwards, from the same quantity the grid
@@ -1494,6 +1497,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce_partials(const DevState 
     // "entered the collective of iteration n + 1" here, "iteration n + 1 done" (host_halt[1]) from the solve behind it -- not
     // the search in front of it, which may take longer than any time limit without anything being wrong
     if (st && st->host_halt && threadIdx.x == 0) st->host_halt[5] = st->n + 1;
+    if (st && threadIdx.x == 0) const_cast<DevState *>(st)->t_xchg_start = wall_clock64();
 }
 
 // sums over explicit pairs (contract 2: oa_kabsch).  A, B: 3 x K row-major with leading dimension ld.
@@ -1574,7 +1578,8 @@ __device__ __forceinline__ void snapshot_state(const DevState *__restrict__ st, 
 }
 
 __device__ __forceinline__ void solve_update_block(DevState *__restrict__ st, const DevState *cs, const double *sums,
-                                                   StepRecord *__restrict__ hist, int *__restrict__ todo_count)
+                                                   StepRecord *__restrict__ hist, int *__restrict__ todo_count,
+                                                   unsigned long long t_sums_in_hand = 0ull)
 {
     // st: the loop state in global memory (written); cs: its snapshot from the start of this launch (read)
     __shared__ double sh_M[16];
@@ -1667,6 +1672,7 @@ __device__ __forceinline__ void solve_update_block(DevState *__restrict__ st, co
             if (lane == 0) {
                 r.K = K; r.mean_d = mean_d; r.std_d = sqrt(var); r.trans = trans; r.angle = angle;
                 r.search_ticks = (cs->t_acc_start > cs->t_prev_end) ? (double)(cs->t_acc_start - cs->t_prev_end) : 0.0;
+                r.exchange_ticks = (t_sums_in_hand > cs->t_xchg_start && cs->t_xchg_start) ? (double)(t_sums_in_hand - cs->t_xchg_start) : 0.0;
             }
         }
         if (lane == 0) {
@@ -1690,9 +1696,10 @@ __global__ __launch_bounds__(128) void k_solve_update(DevState *__restrict__ st,
                                int *__restrict__ todo_count)
 {
     __shared__ DevState cs;
+    const unsigned long long t_in_hand = wall_clock64();            // behind the all-reduce in the stream: the world's sums are here
     snapshot_state(st, &cs);
     __syncthreads();
-    solve_update_block(st, &cs, sums, hist, todo_count);
+    solve_update_block(st, &cs, sums, hist, todo_count, t_in_hand);
 }
 
 // single-GPU form: the fixed-order reduction and the solve in one launch (same arithmetic, one boundary less)
@@ -1731,6 +1738,36 @@ constexpr int STATUS_EXCHANGE = -9;  // OA_E_RCCL: a rank's post did not arrive 
 
 // test hook (OA_FAULT_STALL_RANK): the stream stops here until the host releases it -- or for max_ticks of wall_clock64 at
 // most, so that no test can hang a GPU
+// oa_measure_valu_ceiling: VALU_BURN_CHAINS independent v_fma_f32 chains per lane, `iters` times; workgroup 0's first wave reads
+// the shader clock and the constant-rate clock at both ends (clk[0] += shader cycles, clk[1] += wall_clock64 ticks)
+constexpr int VALU_BURN_CHAINS = 16;
+// OP 0: v_fma_f32 with three vector-register sources (0.89 of the issue rate on gfx950: operand reads); OP 1: v_add_f32, two
+// sources -- one wave-instruction per SIMD every two cycles, the issue rate itself
+template <int OP>
+__global__ __launch_bounds__(256) void k_valu_burn(float *__restrict__ sink, float a, float b, int iters, unsigned long long *__restrict__ clk)
+{
+    float acc[VALU_BURN_CHAINS];
+#pragma unroll
+    for (int i = 0; i < VALU_BURN_CHAINS; ++i) acc[i] = (float)threadIdx.x + (float)i;
+    const unsigned long long c0 = (unsigned long long)__builtin_readcyclecounter(), w0 = wall_clock64();
+    for (int it = 0; it < iters; it += 4) {                          // (64 instructions per trip: the loop's own scalar work stays below 3 %)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int i = 0; i < VALU_BURN_CHAINS; ++i) {
+                if (OP == 0) asm volatile("v_fma_f32 %0, %1, %0, %2" : "+v"(acc[i]) : "v"(a), "v"(b));
+                else asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc[i]) : "v"(b));
+            }
+        }
+    }
+    const unsigned long long c1 = (unsigned long long)__builtin_readcyclecounter(), w1 = wall_clock64();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < VALU_BURN_CHAINS; ++i) t += acc[i];
+    sink[(size_t)blockIdx.x * 256 + threadIdx.x] = t;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = c1 - c0; clk[1] = w1 - w0; }
+}
+
 __global__ void k_fault_stall(const int32_t *release, unsigned long long max_ticks)
 {
     if (threadIdx.x != 0) return;
@@ -1765,6 +1802,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce_post(const DevState *__r
     __syncthreads();
     for (int d = threadIdx.x; d < n_dest; d += RED_THREADS)
         __hip_atomic_store(&dests[d][slot_ix].seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) const_cast<DevState *>(st)->t_xchg_start = wall_clock64();
 }
 
 // step 2 on every device: wait for the world's posts of this iteration (in this rank's mailbox), add them in rank
@@ -1811,7 +1849,7 @@ __global__ __launch_bounds__(128) void k_gather_solve_update(DevState *__restric
         }
         return;
     }
-    solve_update_block(st, &cs, sums, hist, todo_count);
+    solve_update_block(st, &cs, sums, hist, todo_count, live ? wall_clock64() : 0ull);   // (the wait above is over: the world's sums are in hand)
 }
 
 // ------------------------------------------------------------------------------------------------

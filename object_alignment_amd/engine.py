@@ -183,18 +183,34 @@ class IcpEngine:
              "brute_kernel": 7, "exchange": 8, "rccl_ranks": 9, "enqueue_us": 10, "host_threads": 11,
              "fast_iterations": 12, "handover_entries": 13, "handover_wave_max": 14, "enqueued_min": 15, "enqueued_max": 16,
              "watchdog_aborts": 17, "nn_ms_min": 18, "nn_ms_max": 19, "safe_radii": 20,
-             "tri_ring": 21, "tri_ring_accepts": 22}
+             "tri_ring": 21, "tri_ring_accepts": 22, "exchange_us": 23, "rccl_fallbacks": 24, "rccl_ranks_last": 25}
     EXCHANGE_NAMES = {-1: None, 0: "mailbox (pinned host memory)", 1: "rccl", 2: "mailbox (peer-mapped device memory)"}
 
     def exchange_info(self):
         """What a multi-device engine's loops exchange their sums through: {"exchange": name, "rccl_ranks": n}."""
+        note = self._L.oa_exchange_note(self._h)
         return {"exchange": self.EXCHANGE_NAMES.get(int(self.stat("exchange"))), "rccl_ranks": int(self.stat("rccl_ranks")),
-                "host_threads": int(self.stat("host_threads"))}
+                "host_threads": int(self.stat("host_threads")), "note": note.decode("utf-8", "replace") if note else "",
+                "rccl_ranks_last": int(self.stat("rccl_ranks_last")), "rccl_fallbacks": int(self.stat("rccl_fallbacks"))}
 
     def stat(self, name) -> float:
         v = C.c_double(0.0)
         capi.check(self._L.oa_get_stat(self._h, self.STATS[name] if isinstance(name, str) else int(name), C.byref(v)))
         return float(v.value)
+
+    def search_ms(self, max_n=1 << 16) -> np.ndarray:
+        """Search time (ms) of every iteration of the last run (oa_get_search_ms)."""
+        out = np.zeros(int(max_n), np.float64)
+        n = self._L.oa_get_search_ms(self._h, int(max_n), capi.dptr(out))
+        if n < 0:
+            capi.check(n)
+        return out[:n].copy()
+
+    def valu_ceiling(self, target_ms=5.0) -> dict:
+        """What the vector ALUs issue right now (oa_measure_valu_ceiling): v_add_f32 (the issue rate) and v_fma_f32 on every SIMD."""
+        out = np.zeros(4, np.float64)
+        capi.check(self._L.oa_measure_valu_ceiling(self._h, float(target_ms), capi.dptr(out)))
+        return {"tlaneops": float(out[0]), "shader_clock_mhz": float(out[1]), "ms": float(out[2]), "tlaneops_fma_3_sources": float(out[3])}
 
     def enqueued_iterations(self):
         """Iterations the host enqueued for every child in the last run() (OA_STAT_ENQUEUED_CHILD + i): all equal, whatever

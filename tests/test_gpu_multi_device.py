@@ -605,6 +605,20 @@ def test_bench_two_shards_reports_its_exchange(monkeypatch):
     cfg = d["config"]
     assert cfg["exchange"].startswith("mailbox") and cfg["rccl_ranks"] == 0
     assert cfg["host_enqueue_us_per_iteration"] > 0
+    # what makes a first run on real multi-GPU hardware explain itself
+    mg = d["multi_gpu"]
+    assert 0 < mg["search_ms_per_device"]["min"] <= mg["search_ms_per_device"]["max"]
+    assert mg["exchange_us_per_iteration"] > 0                        # GPU-side stamps: own sums ready -> the world's sums in hand
+    assert mg["host_enqueue_us_per_iteration"] > 0
+    assert mg["exchange"].startswith("mailbox") and mg["rccl_ranks"] == 0 and mg["rccl_fallbacks"] == 0
+    assert "more than once" in mg["exchange_note"]                     # why AUTO did not take RCCL here
+    assert mg["predicted_ms_per_step_design_4_7"] is None             # (predictions exist for 1 and 8 GPUs at full size)
+    # ... and the headline's own diagnostics
+    r = d["roofline"]
+    assert r["launch_ms"]["n"] == 3 and r["launch_ms"]["min"] <= r["launch_ms"]["median"] <= r["launch_ms"]["max"]
+    c = r["measured_issue_ceiling"]
+    assert 20.0 < c["used"] < 90.0 and 800.0 < c["after_timed_loop"]["shader_clock_mhz"] < 3000.0, c
+    assert 0.0 < r["frac_of_measured_ceiling"] < 1.2
 
 
 # ---------------------------------------------------------------------------------------------------------------------

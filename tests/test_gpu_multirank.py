@@ -35,6 +35,11 @@ def test_bench_two_ranks_gloo_same_gpu():
     for d in (one, two):
         assert d["metric"].startswith("ICP iterations/sec") and d["unit"] == "iterations/s" and d["steps"] == 4
         assert d["roofline"]["frac"] > 0 and d["grid_path"]["final_matrix_bitwise_equal_to_brute_force"] is True
+    # one process per GPU: every rank's search time and its GPU-side wait for the all-reduced sums are on rank 0's line
+    mg = two["multi_gpu"]
+    assert one["multi_gpu"] is None
+    assert 0 < mg["search_ms_per_device"]["min"] <= mg["search_ms_per_device"]["max"]
+    assert mg["exchange_us_per_iteration"] > 0 and "torch.distributed" in mg["exchange"]
     # same job, different sharding: the per-iteration sums differ only by fp64 summation order
     assert one["result"]["last_K"] == two["result"]["last_K"]
     assert abs(one["result"]["final_translation"] - two["result"]["final_translation"]) < 1e-12

@@ -23,7 +23,7 @@ if only:
     cases = {k: v for k, v in cases.items() if only in k}
 with IcpEngine(0) as e:
     for name, (src, tgt, tris, mxa, mxb, thresh) in cases.items():
-        best, parts, res = 1e9, None, None
+        best, parts, res, walls = 1e9, None, None, []
         for rep in range(int(os.environ.get("REPS", "8"))):
             t0 = time.perf_counter()
             if tris is None:
@@ -36,7 +36,11 @@ with IcpEngine(0) as e:
             t2 = time.perf_counter()
             r = e.run(iters=50, thresh=thresh, target_d=0.01, use_target=True, early_exit=True)
             t3 = time.perf_counter()
+            walls.append(t3 - t0)
             if t3 - t0 < best:
                 best, parts, res = t3 - t0, (t1 - t0, t2 - t1, t3 - t2), r
-        print("%-48s %7.2f ms  (target %.2f, source %.2f, run %.2f: %d iterations, converged %s, K %d)" % (
-            name, 1e3 * best, 1e3 * parts[0], 1e3 * parts[1], 1e3 * parts[2], res.iters_done, res.converged, res.last_K), flush=True)
+        # (uploads: the target's and the source's coordinates, and the triangle indices of a mesh -- for tools/trace_whole_call.py)
+        up = [tgt.nbytes, src.nbytes] + ([np.asarray(tris, np.int32).nbytes] if tris is not None else [])
+        print("%-48s best %7.2f ms, median %7.2f  (target %.2f, source %.2f, run %.2f: %d iterations, converged %s, K %d) uploads_bytes=%s" % (
+            name, 1e3 * best, 1e3 * float(np.median(walls)), 1e3 * parts[0], 1e3 * parts[1], 1e3 * parts[2], res.iters_done, res.converged,
+            res.last_K, ",".join(str(int(x)) for x in up)), flush=True)
