@@ -19,7 +19,7 @@ N > 1: BASELINE config "1M <-> 1M, source sharded across N GPUs with ... covaria
        rank holds one context and the 24 sums go through torch.distributed's all_reduce (backend "nccl" = RCCL).
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel of the headline, the brute-force search
-k_nn_search_filtered.  It is bound by fp32 vector-ALU issue (SURVEY.md 8d / DESIGN.md 4.1), so
+k_nn_search_filtered.  It is bound by fp32 vector-ALU issue (SURVEY.md 8d / docs/HISTORY.md 4.1), so
 
     roofline.achieved = executed VALU lane-ops/s = (SQ_INSTS_VALU per launch x 64 lanes) / average launch time
     roofline.peak     = 78.6e12 lane-ops/s       = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
@@ -243,12 +243,12 @@ def surface_leg(args, local_rank):
                          "cell_list_entries": entries, "cells": cells}}
 
 
-# DESIGN.md 4.7's table, for the line that sits next to the measurement (ms per iteration, AUTO search, masked + normal-angle
+# DESIGN.md 4 (derivation: docs/HISTORY.md 4.7)'s table, for the line that sits next to the measurement (ms per iteration, AUTO search, masked + normal-angle
 # test, first 10 iterations; the 1-GPU figure is measured -- profiles/r03e_baseline_configs.txt --, the 8-GPU one predicted from
 # the per-shard search time + ~30 us of reduce / exchange / solve)
 C5_PREDICTED_MS_PER_ITERATION = {1: 2.06, 8: 0.35}
 # the headline workload (BASELINE config 4 at N = 8), brute-force kernel: one GPU measured (round 4: 52.7 ms), 8 GPUs PREDICTED
-# from the 125k-point shard's search time + reduce / exchange / solve
+# from the 125k-point shard's search time + reduce / exchange / solve (DESIGN.md 4 (derivation: docs/HISTORY.md 4.7))
 C4_PREDICTED_MS_PER_ITERATION = {1: 52.7, 8: 6.49}
 
 
@@ -337,7 +337,7 @@ def c5_leg(args, n_gpus, in_process, world, rank, local_rank, devices, dev, back
                 "upload_ms": 1e3 * upload_s,
                 "predicted_ms_per_step_design_4_7": pred,
                 "measured_over_predicted": (ms / pred) if pred else None,
-                "prediction_note": "DESIGN.md 4.7: 1 GPU measured in round 3 (2.06 ms), 8 GPUs PREDICTED (0.35 ms = shard search "
+                "prediction_note": "DESIGN.md 4 (derivation: docs/HISTORY.md 4.7): 1 GPU measured in round 3 (2.06 ms), 8 GPUs PREDICTED (0.35 ms = shard search "
                                    "0.32 + ~0.03 reduce / exchange / solve); no figure for 2 and 4 GPUs"}
     finally:
         eng.close()
@@ -608,7 +608,7 @@ def main():
                        "parallelism": par, "exchange": exchange, "exchange_note": exchange_note, "rccl_ranks": rccl_ranks, "host_threads_per_process": host_threads,
                        "host_enqueue_us_per_iteration": (eng.stat("enqueue_us") if in_process else None)},
             # a first run on real multi-GPU hardware should explain itself: per-device search times, the GPU-side wait for the
-            # world's sums, what the exchange resolved to and why, and DESIGN.md 4.7's prediction for this N beside the measurement
+            # world's sums, what the exchange resolved to and why, and DESIGN.md 4 (derivation: docs/HISTORY.md 4.7)'s prediction for this N beside the measurement
             "multi_gpu": ({**head_diag,
                            "exchange": exchange, "exchange_note": exchange_note or (xinfo_after.get("note") or None),
                            "rccl_ranks": rccl_ranks,
@@ -658,7 +658,7 @@ def main():
                 "value": g_steps / g_elapsed, "unit": "iterations/s", "steps": g_steps,
                 "ms_per_step": 1e3 * g_elapsed / g_steps, "ms_per_nn_search": g_nn_ms,
                 "final_matrix_bitwise_equal_to_brute_force": same,
-                "safe_radii": safe_radii,                              # seeds inside their safe radius settle their query without a scan
+                "safe_radii": safe_radii,                              # docs/HISTORY.md 4.4: seeds inside their safe radius settle their query without a scan
                 "roofline": {"bound": "hbm", "achieved": g_bytes / (g_nn_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": g_bytes / (g_nn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                              "algorithmic_bytes_per_launch": g_bytes, "traffic": ge["bytes_per_launch"] if ge else None,

@@ -27,7 +27,7 @@
  *     OA_E_NO_DEVICE / OA_E_HIP when no gfx950 device is usable.
  *
  * Correspondence rule: nearest target VERTEX (fp32, d2 = fma(dz,dz,fma(dy,dy,dx*dx)),
- * lowest index wins ties) -- see DESIGN.md "D2".
+ * lowest index wins ties) -- see docs/HISTORY.md 5.3 "D2".
  */
 #ifndef OA_ICP_H
 #define OA_ICP_H
@@ -206,19 +206,19 @@ int oa_reset_seeds(oa_ctx *ctx);
                                        * last oa_run (mean over iterations, max over devices), microseconds */
 #define OA_STAT_HOST_THREADS     11   /* multi-device context: host threads that drive its devices (1 = the caller alone) */
 #define OA_STAT_FAST_ITERATIONS  12   /* iterations of the last / current loop in which the grid search finished its own leftovers and
-                                       * accumulated in its epilogue (the adaptive choice of DESIGN.md 4.4; first device) */
+                                       * accumulated in its epilogue (the adaptive choice of docs/HISTORY.md 4.4; first device) */
 #define OA_STAT_HANDOVER_ENTRIES 13   /* what the last grid search handed to the tree: queries ... */
 #define OA_STAT_HANDOVER_WAVE_MAX 14  /* ... and the most any ONE wavefront handed over (what the adaptive choice looks at) */
 #define OA_STAT_ENQUEUED_MIN      15   /* multi-device context: iterations the host enqueued for its children in the last oa_run, the */
-#define OA_STAT_ENQUEUED_MAX      16   /* least and the most over the children.  Equal by construction ("the invariant"):
+#define OA_STAT_ENQUEUED_MAX      16   /* least and the most over the children.  Equal by construction (docs/HISTORY.md 4.7, "the invariant"):
                                        * in RCCL mode every enqueued iteration holds a collective every rank has to enter */
 #define OA_STAT_WATCHDOG_ABORTS   17   /* times this context's RCCL communicators were aborted (watchdog / asynchronous error) */
 #define OA_STAT_NN_MS_MIN         18   /* multi-device context: search time of the last oa_run (sum over its iterations, ms) on the */
 #define OA_STAT_NN_MS_MAX         19   /* fastest / the slowest device: how evenly the shards load the GPUs */
 #define OA_STAT_SAFE_RADII        20   /* 1 = the vertex grid's safe radii are built for the current target (a seed inside its own settles the
-                                       * query without a scan or a descent; built once the target has seen 8 loop iterations; first device) */
+                                       * query without a scan or a descent, docs/HISTORY.md 4.4; built once the target has seen 8 loop iterations; first device) */
 #define OA_STAT_TRI_RING          21   /* 1 = the triangle neighbour lists are built for the current mesh (a query within its seed triangle's accept
-                                       * radius is settled by the seed and the triangles that touch it; built once the mesh has
+                                       * radius is settled by the seed and the triangles that touch it, docs/HISTORY.md 4.5; built once the mesh has
                                        * seen 4 loop searches, OA_TRI_RING=2: with the grid; first device) */
 #define OA_STAT_TRI_RING_ACCEPTS  22   /* diagnostic (one extra launch + a wait): source points of this shard that the neighbour lists would settle at
                                        * the current pose with the current seeds; multi-device context: the sum over the shards */
@@ -253,7 +253,7 @@ int oa_kabsch(oa_ctx *ctx, const double *A, const double *B, int64_t K, int64_t 
  * row-major.  K < ndims or ndims < 2: OA_E_TOO_FEW_PAIRS, the reference's ValueError (:150-157). */
 int oa_affine_from_points(oa_ctx *ctx, const double *v0, const double *v1, int ndims, int64_t K, int64_t ld,
                           int shear, int with_scale, double *M);
-/* same solve from the OA_NSUMS accumulated sums (host array; layout in DESIGN.md).  The sums are taken
+/* same solve from the OA_NSUMS accumulated sums (host array; layout: S_A .. S_DD in csrc/oa_kernels.hpp).  The sums are taken
  * relative to `pivot` (a' = a - pivot, b' = b - pivot); pivot == NULL means the origin. */
 int oa_kabsch_from_sums(oa_ctx *ctx, const double sums[OA_NSUMS], const double pivot[3], int with_scale,
                         double M[16]);

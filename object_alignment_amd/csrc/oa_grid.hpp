@@ -410,7 +410,7 @@ constexpr int GRID_SEGS = 10;      // ranges of one batch: 9 rows of the first b
 // (k_pair_accumulate, 16 us at 1M points and its own launch).  One row of `partials` per workgroup, fixed order.
 // keys[] is not written then: nothing reads it inside the loop.
 // BT = threads per workgroup: 256, or 512 for the accumulating variant on large shards -- half as many rows of partials for
-// the reduction behind it (1M points 63.6 -> 60.3 us per iteration), the same six waves per SIMD (three
+// the reduction behind it (docs/HISTORY.md 4.3: 1M points 63.6 -> 60.3 us per iteration), the same six waves per SIMD (three
 // workgroups of eight waves per CU instead of six of four); small shards lose with the coarser workgroups (100k: +1.5 us).
 // STATS (instrumented build of the accumulating variant, OA_GRID_STATS=1): shader-clock stamps at the phase boundaries and
 // candidate counts, one row of GRID_STAT_N counters per wave in `stats`

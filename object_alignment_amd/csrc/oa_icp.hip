@@ -357,7 +357,7 @@ struct oa_ctx {
     // seed + neighbours settle a query (oa_tri_ring.hpp): per triangle its neighbours' indices; the accept radius lives in d_tri9
     int *d_tri_ring = nullptr;
     bool tri_ring_ok = false;        // built for the current mesh
-    int tri_ring = 0;                // OA_TRI_RING (EXPERIMENT, off: exact, measured, not faster -- DESIGN.md 4.5): 0 = never; 1 = built once a mesh has seen TRI_RING_LAZY_ITERS searches of a loop; 2 = built with the grid
+    int tri_ring = 0;                // OA_TRI_RING (EXPERIMENT, off: exact, measured, not faster -- docs/HISTORY.md 4.5): 0 = never; 1 = built once a mesh has seen TRI_RING_LAZY_ITERS searches of a loop; 2 = built with the grid
     double tri_ring_cap = 0.25;      // OA_TRI_RING_CAP: clearances are looked for up to this fraction of a cell edge
     bool tri_split_lanes = true;     // OA_TRI_SPLIT_LANES=0 (A/B): the list is always searched with the shard's own lanes per query
     bool tri_split = true;           // OA_TRI_SPLIT=0 (A/B): the seed + neighbours test stays in the grid search's prologue (no k_tri_accept launch)
@@ -694,7 +694,7 @@ template <bool TRI>
 int launch_bvh(oa_ctx *c, const int *list, const int *list_count, int turn = -1, bool acc = false)
 {
     const unsigned blocks = bvh_blocks(c, list != nullptr, acc);
-    // whole-shard vertex searches take seeds on their safe radii: both arrays or neither
+    // whole-shard vertex searches take seeds on their safe radii (docs/HISTORY.md 4.4 / 4.8): both arrays or neither
     const float *safe_by_idx = nullptr;
     uint2 *wsafe = nullptr;
     if (!TRI && !list && c->grid_safe) {
@@ -1262,7 +1262,7 @@ struct oa_exchange {
     // the first thread that hears of the halt -- or fails -- freezes agree_stop_at = agree_committed; from then on every
     // thread enqueues exactly agree_stop_at iterations, no more (it stops there) and no fewer (it tops up to it: iterations
     // after the halt are empty but for the collective).  The count is a function of the lock order alone, never of what a
-    // thread happened to read from its device afterwards.  (multi_group_loop; DESIGN.md 4.7 "the invariant")
+    // thread happened to read from its device afterwards.  (multi_group_loop; docs/HISTORY.md 4.7 "the invariant")
     std::mutex agree_mu;
     int agree_committed = 0;
     std::atomic<int> agree_stop_at{ -1 };          // -1: not frozen yet
@@ -3156,7 +3156,7 @@ OA_EXPORT int oa_get_stat(oa_ctx *c, int what, double *value)
     if (!c || !value) return fail(OA_E_BAD_ARG, "oa_get_stat: null argument");
     if (what == OA_STAT_CACHE_BYTES) { *value = (double)dev_cache().cached_bytes; return OA_OK; }
     if (what == OA_STAT_ENQUEUED_MIN || what == OA_STAT_ENQUEUED_MAX || what >= OA_STAT_ENQUEUED_CHILD) {
-        // iterations the host enqueued for the children in the last oa_run (the agreement of DESIGN.md 4.7: all equal)
+        // iterations the host enqueued for the children in the last oa_run (the agreement of docs/HISTORY.md 4.7: all equal)
         if (c->subs.empty()) { *value = (double)c->iter_enq; return OA_OK; }
         if (what >= OA_STAT_ENQUEUED_CHILD) {
             const size_t i = (size_t)(what - OA_STAT_ENQUEUED_CHILD);

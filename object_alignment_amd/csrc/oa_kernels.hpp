@@ -11,7 +11,7 @@
 //                         or k_reduce_partials -> ncclAllReduce -> k_solve_update
 // This file: the state (DevState), the float32 "mathutils" arithmetic, the brute-force searches
 //   k_nn_search / k_nn_search_filtered   nearest target vertex per source point; target tiles staged through LDS and read
-//                         back as wave-uniform (broadcast) ds_read_b128; fp32 VALU bound
+//                         back as wave-uniform (broadcast) ds_read_b128; fp32 VALU bound (docs/HISTORY.md 4.1)
 // the pair test and the accumulation helpers (pair_eval, block_store_pair), the row reduction and the solve.
 //
 // Arithmetic conventions are spelled out in DESIGN.md ("float32 semantics") and are shared bit-for-bit with the
@@ -731,7 +731,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn_search(const DevState *__rest
 //   threshold             T = round_up( best*(1+16u) + 16u*G^2 - |ph|^2 + 1e-30 ),  G = |ph| + max_j |qh_j|,  u = 2^-24
 // Claim: s_j > T  implies  d2_metric(p, q_j) > best  (strictly), so a group of 4 targets whose smallest score exceeds
 // T is skipped; every other group takes the exact path (difference-form d2, lexicographic (d2, index) update).
-// Proof sketch (full derivation in DESIGN.md): |s_j - S_j| <= 4.01u G^2 (three fma roundings + the rounding of w_j);
+// Proof sketch (full derivation in docs/HISTORY.md 4.1): |s_j - S_j| <= 4.01u G^2 (three fma roundings + the rounding of w_j);
 // centring moves |ph-qh_j| by at most 1.01u G; the exact metric is within a factor (1 +- 5.01u) of the real squared
 // distance.  8u would already suffice for both terms; 16u is used.  T is rounded towards +inf.
 // Targets/queries with non-finite or astronomically large coordinates disable the filter on the host side
@@ -864,7 +864,7 @@ __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_filt
                                                                    int n_groups_pad,
                                                                    unsigned long long *__restrict__ keys)
 {
-    // scalar v_fma_f32 throughout: the packed form (v_pk_fma_f32) measured 3-5 % slower in this loop
+    // scalar v_fma_f32 throughout: the packed form (v_pk_fma_f32) measured 3-5 % slower in this loop (docs/HISTORY.md 5)
     if (st->halt) return;
     // TG = groups of 4 targets per LDS tile: 256 for large targets, 64 for small ones (more, shorter workgroups)
     constexpr int TILE_F4 = TG * 3, LOADS = (TILE_F4 + NN_THREADS - 1) / NN_THREADS;

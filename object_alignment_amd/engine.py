@@ -214,7 +214,7 @@ class IcpEngine:
 
     def enqueued_iterations(self):
         """Iterations the host enqueued for every child in the last run() (OA_STAT_ENQUEUED_CHILD + i): all equal, whatever
-        the host threads saw of their devices while they enqueued."""
+        the host threads saw of their devices while they enqueued (docs/HISTORY.md 4.7)."""
         return [int(self.stat(1000 + i)) for i in range(len(self.devices))] if self.multi else [int(self.stat("enqueued_max"))]
 
     def matrix_world(self) -> np.ndarray:

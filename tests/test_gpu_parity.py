@@ -966,7 +966,7 @@ def test_surface_winner_is_the_exact_nearest_triangle(case):
         D = _exact_point_triangle_distance(Q[s0:s0 + 64], a, b, c)              # (64, n_tris)
         rows = np.arange(D.shape[0])
         won = D[rows, idx[s0:s0 + 64]]
-        delta = 64.0 * 2.0 ** -24 * (scale + np.abs(Q[s0:s0 + 64]).sum(axis=1))   # float32 evaluation error
+        delta = 64.0 * 2.0 ** -24 * (scale + np.abs(Q[s0:s0 + 64]).sum(axis=1))   # docs/HISTORY.md 4.5: float32 evaluation error
         gap = won - D.min(axis=1)
         assert np.all(gap <= 2.0 * delta), float((gap / delta).max())
         err = np.abs(np.sqrt(d2[s0:s0 + 64].astype(np.float64)) - won)
@@ -1582,7 +1582,7 @@ def test_make_pairs_sees_in_place_edits_of_the_source():
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", ["settled", "far_start", "half_target", "lanes4"])
 def test_grid_paths_give_the_same_bits(orc, case, monkeypatch):
-    """The loop's grid search has two forms: FAST -- it finishes the queries its rings did not settle through
+    """The loop's grid search has two forms (docs/HISTORY.md 4.4): FAST -- it finishes the queries its rings did not settle through
     the tree itself and accumulates in its epilogue -- and SAFE -- grid search, tree search of the hand-over list,
     k_pair_accumulate_canon.  The host picks per iteration from what the device last reported, i.e. timing dependent, so
     the two must leave the same bits: forced fast, forced safe and adaptive runs are compared bitwise, and against the

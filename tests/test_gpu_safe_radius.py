@@ -1,4 +1,4 @@
-"""The vertex grid search takes a seed on its SAFE RADIUS (oa_grid.hpp: k_grid_safe_radius, DESIGN 4.4 "safe radii"): a
+"""The vertex grid search takes a seed on its SAFE RADIUS (oa_grid.hpp: k_grid_safe_radius, docs/HISTORY.md 4.4 "safe radii"): a
 query closer to its seed than half the seed's distance to its nearest other target needs no scan.  The answers must stay
 those of the exhaustive search (/root/reference/functions/general.py:297, SURVEY D2's vertex rule): index and float32 d2
 bit for bit -- also for queries placed ON the rule's edge, next to duplicates, and in crowded cells."""

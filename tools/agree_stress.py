@@ -1,5 +1,5 @@
 """Early-exit loops on a multi-device context with one host thread per child (OA_MULTI_THREADS=1 + OA_MULTI_OWN_STREAMS=1):
-do the threads enqueue the same number of iterations?  ("the invariant")
+do the threads enqueue the same number of iterations?  (docs/HISTORY.md 4.7, "the invariant")
 
 One GPU, the device listed `--children` times; every child gets its own stream and host thread, as children on distinct
 GPUs do.  GPU_MAX_HW_QUEUES is raised so that every child's stream has a hardware queue of its own (HIP multiplexes

@@ -56,7 +56,7 @@ def rand_matrix(rng, scaled):
 
 
 def well_posed(A, B):
-    """The rotation is only defined when the covariance has rank >= 2 (DESIGN.md 6.3): skip the loop comparison when
+    """The rotation is only defined when the covariance has rank >= 2 (DESIGN.md 3.2): skip the loop comparison when
     the pairs are degenerate (e.g. a tiny source cloud whose points all find the same target vertex)."""
     Ac, Bc = A - A.mean(axis=1, keepdims=True), B - B.mean(axis=1, keepdims=True)
     sv = np.linalg.svd(Bc @ Ac.T, compute_uv=False)
