@@ -19,7 +19,8 @@ N > 1: BASELINE config "1M <-> 1M, source sharded across N GPUs with ... covaria
        rank holds one context and the 24 sums go through torch.distributed's all_reduce (backend "nccl" = RCCL).
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel of the headline, the brute-force search
-k_nn_search_filtered.  It is bound by fp32 vector-ALU issue (SURVEY.md 8d / docs/HISTORY.md 4.1), so
+k_nn_search_sorted (OA_NN_SORT=0: its predecessor k_nn_search_filtered).  It is bound by fp32 vector-ALU issue (SURVEY.md
+8d / docs/HISTORY.md 4.1), so
 
     roofline.achieved = executed VALU lane-ops/s = (SQ_INSTS_VALU per launch x 64 lanes) / average launch time
     roofline.peak     = 78.6e12 lane-ops/s       = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
@@ -31,7 +32,7 @@ not hold 2.4 GHz under this load (1.8-2.1 GHz, box to box), so the line also car
 min / median / max), what v_fma_f32 issues on THIS box right before and right after the timed loop
 (`measured_issue_ceiling`, with the shader clock under that load) and `frac_of_measured_ceiling`.  The
 SURVEY's algorithmic figure -- 8 flop per (source, target) pair -- is reported as `effective_tflops`: the kernel's
-conservative filter proves most pairs losers in ~3 instructions, so that figure can exceed what the chip executes and
+conservative filter proves most pairs losers in ~2 instructions, so that figure can exceed what the chip executes and
 is NOT a roofline fraction.  `cpu_baseline` times the CPU oracle (KD-tree + Kabsch; OpenMP on all host cores) on a
 bounded sample of the same workload, rank 0, N = 1 only.
 """
@@ -55,8 +56,12 @@ FP32_VECTOR_PEAK_TFLOPS = 157.3      # the same peak counting an FMA as 2 flop
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F16_PEAK_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense f16 / bf16 MFMA (the experiment leg only)
 FLOP_PER_PAIR = 8                    # 3 sub, 3 mul, 2 add (difference-form squared distance), SURVEY.md 8d
-VALU_PER_PAIR_ISA = 3.0              # hot loop of k_nn_search_filtered: (64 FMA + 16 min3 [2 slots] + 4 cmp) / 32 pairs
-KERNELS = {"brute": "k_nn_search_filtered", "grid": "k_nn_search_grid", "surface_grid": "k_tri_search_grid",
+# hot loops, instructions per pair (the fallback when profiles/ holds no PMC pass for the kernel that ran):
+#   k_nn_search_sorted   (32 sub + 12 min + 8 min3 + 4 cmp) / 32 pairs = 1.75, + ~7 % of the blocks going on to level 1
+#   k_nn_search_filtered (64 fma + 16 min3 + 4 cmp) / 32 pairs
+VALU_PER_PAIR_ISA = {"k_nn_search_sorted": 1.95, "k_nn_search_filtered": 2.7}
+BRUTE_KERNELS = {3.0: "k_nn_search_sorted", 1.0: "k_nn_search_filtered", 2.0: "k_nn_search_mfma", 0.0: "k_nn_search"}
+KERNELS = {"brute": "k_nn_search_sorted", "grid": "k_nn_search_grid", "surface_grid": "k_tri_search_grid",
            "surface_tree": "k_bvh_search"}
 
 
@@ -513,6 +518,10 @@ def main():
         res, elapsed, nn_ms = timed(args.steps, args.warmup)
     ceil_after = ceiling()
     try:
+        brute_kind = eng.stat("brute_kernel")                     # which brute-force kernel the timed loop launched
+    except Exception:
+        brute_kind = 3.0
+    try:
         launch_ms = eng.search_ms()
     except Exception:
         launch_ms = np.zeros(0)
@@ -569,13 +578,19 @@ def main():
     if rank == 0:
         assert res.iters_done == args.steps, (res.iters_done, args.steps)
         ns_local = -(-args.n_source // n_gpus)                              # points per GPU (the largest shard)
-        pairs = float(ns_local) * float(args.n_target)                      # per launch of k_nn_search_filtered on one GPU
+        pairs = float(ns_local) * float(args.n_target)                      # per launch of the search kernel on one GPU
         key = "%dx%d_n%d" % (args.n_source, args.n_target, n_gpus)
-        e, stamp = pmc_entry(key, KERNELS["brute"])
+        brute_kernel = BRUTE_KERNELS.get(float(brute_kind), KERNELS["brute"])   # the kernel that RAN (OA_STAT_BRUTE_KERNEL)
+        e, stamp = pmc_entry(key, brute_kernel)
         per_pair = e.get("valu_instructions_per_pair") if e else None
         per_pair_src = "pmc" if per_pair else "isa-count"
+        if e and e.get("valu_instructions_per_pair_cold") and e.get("valu_instructions_per_pair_seeded") and args.steps >= 1:
+            # the first launch of a loop searches without seeds and executes more; the PMC pass holds both kinds: weigh them
+            # as THIS run's K launches are (1 cold, K - 1 seeded)
+            per_pair = (e["valu_instructions_per_pair_cold"] + (args.steps - 1) * e["valu_instructions_per_pair_seeded"]) / args.steps
+            per_pair_src = "pmc (1 unseeded + %d seeded launches)" % (args.steps - 1)
         if not per_pair:
-            per_pair = VALU_PER_PAIR_ISA
+            per_pair = VALU_PER_PAIR_ISA.get(brute_kernel, 3.0)
         laneops = per_pair * pairs / (nn_ms * 1e-3) / 1e12                  # T lane-ops/s actually executed
         eff_tflops = FLOP_PER_PAIR * pairs / (nn_ms * 1e-3) / 1e12
         algo_bytes = 16.0 * ns_local + 12.0 * args.n_target + 8.0 * ns_local  # source float4 + target SoA + keys
@@ -620,7 +635,7 @@ def main():
                           if n_gpus > 1 else None),
             "roofline": {"bound": "valu", "achieved": laneops, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s",
                          "frac": laneops / VALU_PEAK_TLANEOPS, "traffic": traffic,
-                         "kernel": KERNELS["brute"], "valu_instructions_per_pair": per_pair,
+                         "kernel": brute_kernel, "valu_instructions_per_pair": per_pair,
                          "valu_instructions_per_pair_source": per_pair_src, "pairs_per_launch": pairs,
                          "avg_launch_ms": nn_ms, "traffic_profile": stamp,
                          # every launch of the timed loop (hipEvent pairs on the kernel's stream): a throttled box shows here

@@ -198,7 +198,8 @@ int oa_reset_seeds(oa_ctx *ctx);
 #define OA_STAT_SURFACE           5   /* 1 = surface mode (oa_set_target_mesh) */
 #define OA_STAT_CACHE_BYTES       6   /* device bytes currently held by the process-wide allocation cache */
 #define OA_STAT_BRUTE_KERNEL      7   /* what OA_SEARCH_BRUTE launches for the current shard: 0 = k_nn_search (exact only), 1 =
-                                       * k_nn_search_filtered (default), 2 = k_nn_search_mfma (experiment, env OA_NN_MFMA=1) */
+                                       * k_nn_search_filtered (rounds 1-4; OA_NN_SORT=0), 2 = k_nn_search_mfma (experiment, env OA_NN_MFMA=1),
+                                       * 3 = k_nn_search_sorted (default: the filtered search over the target sorted along its longest axis) */
 #define OA_STAT_EXCHANGE          8   /* multi-device context: what its loops exchange through (resolves AUTO): 0 = mailbox in pinned
                                        * host memory, 1 = RCCL, 2 = mailboxes in peer-mapped device memory; -1 = not a multi context */
 #define OA_STAT_RCCL_RANKS        9   /* ranks of the RCCL communicator the loops use (0 = RCCL not in use) */

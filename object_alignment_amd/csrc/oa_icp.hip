@@ -334,6 +334,11 @@ struct oa_ctx {
     float4 *d_tg = nullptr;
     float4 *d_tf = nullptr;          // filter image, level 1: 3 float4 per group (k_nn_search_filtered)
     float4 *d_tf3 = nullptr;         // filter image, level 2: 2 float4 per group
+    // the same images in the order of the coordinate along the cloud's longest axis (k_nn_search_sorted, round 5)
+    float4 *d_tfs = nullptr, *d_tf3s = nullptr, *d_tgs = nullptr;   // 3 / 2 / 3 float4 per group of 4 sorted positions
+    int4 *d_tidx = nullptr;          // original index of every sorted position
+    int sax[3] = { 0, 1, 2 };        // its axes: longest (sorted along), second, thinnest
+    bool nn_sort = true;             // OA_NN_SORT=0 (A/B): the brute-force search stays k_nn_search_filtered (rounds 1-4)
     int fax[3] = { 0, 1, 2 };
     double bb_lo[3] = { 0, 0, 0 }, bb_hi[3] = { 0, 0, 0 };
     // uniform grid (k_nn_search_grid)
@@ -901,6 +906,23 @@ int launch_nn_impl(oa_ctx *c, bool acc)
         else if (c->mfma_wps == 3) hipLaunchKernelGGL(oa::k_nn_search_mfma<3>, grid, block, 0, c->stream, OA_MFMA_ARGS);
         else hipLaunchKernelGGL(oa::k_nn_search_mfma<4>, grid, block, 0, c->stream, OA_MFMA_ARGS);
 #undef OA_MFMA_ARGS
+    } else if (c->filter_ok && c->use_filter && c->nn_sort && c->d_tfs) {
+        const bool small = (c->tile_groups == 64);
+#define OA_NNS_ARGS c->d_state, c->d_src4, (const float4 *)c->d_tgs, (const float4 *)c->d_tfs, (const float4 *)c->d_tf3s, (const int4 *)c->d_tidx, \
+                    (const float4 *)c->d_win, c->n_groups_pad, c->sax[0], c->sax[1], c->d_keys
+#define OA_LAUNCH_S(RR)                                                                                              \
+        do {                                                                                                         \
+            if (small) hipLaunchKernelGGL((oa::k_nn_search_sorted<RR, 64>), grid, block, 0, c->stream, OA_NNS_ARGS);  \
+            else hipLaunchKernelGGL((oa::k_nn_search_sorted<RR, oa::FTILE_GROUPS>), grid, block, 0, c->stream, OA_NNS_ARGS); \
+        } while (0)
+        switch (c->R) {
+        case 1: OA_LAUNCH_S(1); break;
+        case 2: OA_LAUNCH_S(2); break;
+        case 8: OA_LAUNCH_S(8); break;
+        default: OA_LAUNCH_S(4); break;
+        }
+#undef OA_LAUNCH_S
+#undef OA_NNS_ARGS
     } else if (c->filter_ok && c->use_filter) {
         const bool small = (c->tile_groups == 64);
 #define OA_LAUNCH_F(RR)                                                                                              \
@@ -1896,6 +1918,7 @@ OA_EXPORT int oa_create(oa_ctx **out, int device)
     c->tri_acc = env_int("OA_TRI_ACC", 1) != 0;
     c->turn_frac = env_double("OA_TURN_FRAC", 0.1);
     c->use_filter = env_int("OA_NN_FILTER", 1) != 0;
+    c->nn_sort = env_int("OA_NN_SORT", 1) != 0;
     c->nn_mfma = env_int("OA_NN_MFMA", 0);
     c->mfma_wps = env_int("OA_MFMA_WPS", 4);
     c->grid_mode = env_int("OA_NN_GRID", -1);
@@ -2042,7 +2065,7 @@ OA_EXPORT void oa_destroy(oa_ctx *c)
     (void)hipDeviceSynchronize();
     tl_stream_known = false;                                        // the stream below is about to go away
 #define OA_FREE(x) dev_free(c->x, true)
-    OA_FREE(d_tgt_xyz); OA_FREE(d_tg); OA_FREE(d_tf); OA_FREE(d_tf3); OA_FREE(d_tfm); OA_FREE(d_members); OA_FREE(d_pos); OA_FREE(d_prev); OA_FREE(d_win); OA_FREE(d_wsafe); OA_FREE(d_safe_by_idx); OA_FREE(d_cell_start);
+    OA_FREE(d_tgt_xyz); OA_FREE(d_tg); OA_FREE(d_tf); OA_FREE(d_tf3); OA_FREE(d_tfs); OA_FREE(d_tf3s); OA_FREE(d_tgs); OA_FREE(d_tidx); OA_FREE(d_tfm); OA_FREE(d_members); OA_FREE(d_pos); OA_FREE(d_prev); OA_FREE(d_win); OA_FREE(d_wsafe); OA_FREE(d_safe_by_idx); OA_FREE(d_cell_start);
     OA_FREE(d_sorted); OA_FREE(d_todo_list); OA_FREE(d_todo_count); OA_FREE(d_ulist); OA_FREE(d_src4); OA_FREE(d_keys); OA_FREE(d_state);
     OA_FREE(d_partials); OA_FREE(d_sums); OA_FREE(d_solve);
     OA_FREE(d_valid); OA_FREE(d_b); OA_FREE(d_dist); OA_FREE(d_counts); OA_FREE(d_offsets); OA_FREE(d_A); OA_FREE(d_B);
@@ -2161,6 +2184,31 @@ int build_filter(oa_ctx *c)
     for (double v : mx) if (v > m) m = v;
     c->qmax = sqrt(m) * (1.0 + 1e-6);
     c->filter_ok = (c->qmax < 1e18);
+    dev_free(c->d_tfs); dev_free(c->d_tf3s); dev_free(c->d_tgs); dev_free(c->d_tidx);
+    if (c->filter_ok && c->nn_sort && c->nt >= 2) {
+        // k_nn_search_sorted's images: the target in the order of its coordinate along the longest axis (30-bit quantised key
+        // through the library's stable argsort -- the order is for speed only, any permutation gives the same answers)
+        int su = 0;
+        for (int a = 1; a < 3; ++a) if (hi[a] - lo[a] > hi[su] - lo[su]) su = a;
+        const int sd = ad != su ? ad : (su + 1) % 3;               // (all extents equal: any other axis)
+        c->sax[0] = su; c->sax[2] = sd; c->sax[1] = 3 - su - sd;
+        const double ext = hi[su] - lo[su];
+        DevTmp<unsigned> k_in, k_out;
+        DevTmp<int> v_in, v_out;
+        HIPCHK(k_in.alloc((size_t)c->nt)); HIPCHK(k_out.alloc((size_t)c->nt)); HIPCHK(v_in.alloc((size_t)c->nt)); HIPCHK(v_out.alloc((size_t)c->nt));
+        hipLaunchKernelGGL(oa::k_sort_keys_axis, dim3((c->nt + 255) / 256), dim3(256), 0, c->stream, (const float *)c->d_tgt_xyz, c->nt, su, lo[su],
+                           ext > 0.0 ? 1073741823.0 / ext : 0.0, k_in.p, v_in.p);
+        HIPCHK(hipGetLastError());
+        { const int rcs = sort_pairs30(c, k_in.p, k_out.p, v_in.p, v_out.p, (size_t)c->nt); if (rcs) return rcs; }
+        HIPCHK(dev_malloc(&c->d_tfs, sizeof(float4) * 3 * (size_t)c->n_groups_pad));
+        HIPCHK(dev_malloc(&c->d_tf3s, sizeof(float4) * 2 * (size_t)c->n_groups_pad));
+        HIPCHK(dev_malloc(&c->d_tgs, sizeof(float4) * 3 * (size_t)c->n_groups_pad));
+        HIPCHK(dev_malloc(&c->d_tidx, sizeof(int4) * (size_t)c->n_groups_pad));
+        hipLaunchKernelGGL(oa::k_pack_sorted, dim3((unsigned)blocks), dim3(256), 0, c->stream, (const float *)c->d_tgt_xyz, c->nt, c->n_groups_pad,
+                           (const int *)v_out.p, c->tc[0], c->tc[1], c->tc[2], c->sax[0], c->sax[1], c->sax[2], c->d_tfs, c->d_tf3s, c->d_tgs, c->d_tidx);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(c->stream));                  // (the temporaries are released on return)
+    }
     dev_free(c->d_tfm);
     if (c->filter_ok && c->nn_mfma) {                            // experiment: the MFMA image (32 B per target)
         int e = 0;
@@ -2293,6 +2341,7 @@ int set_target_common(oa_ctx *c, const float *xyz, int64_t n, int on_device, boo
     HIPCHK(hipStreamSynchronize(c->stream));
     c->loop_active = false;                                         // an open oa_iterate sequence ends with the old target
     dev_free(c->d_tgt_xyz); dev_free(c->d_tg); dev_free(c->d_tf); dev_free(c->d_tf3); dev_free(c->d_tfm);
+    dev_free(c->d_tfs); dev_free(c->d_tf3s); dev_free(c->d_tgs); dev_free(c->d_tidx);
     dev_free(c->d_tri9); dev_free(c->d_tcell_start); dev_free(c->d_tcell_rec); dev_free(c->d_tri_ring);
     c->tri_ring_ok = false;
     dev_free(c->d_bvh_box); dev_free(c->d_bvh_prims); dev_free(c->d_tbvh_box); dev_free(c->d_tbvh_prims);
@@ -3233,7 +3282,7 @@ OA_EXPORT int oa_get_stat(oa_ctx *c, int what, double *value)
     case OA_STAT_SURFACE: *value = c->surface ? 1.0 : 0.0; return OA_OK;
     case OA_STAT_BRUTE_KERNEL:
         *value = !(c->filter_ok && c->use_filter) ? 0.0
-                 : ((c->nn_mfma && c->d_tfm && c->R == 4 && c->tile_groups == oa::FTILE_GROUPS) ? 2.0 : 1.0);
+                 : ((c->nn_mfma && c->d_tfm && c->R == 4 && c->tile_groups == oa::FTILE_GROUPS) ? 2.0 : ((c->nn_sort && c->d_tfs) ? 3.0 : 1.0));
         return OA_OK;
     case OA_STAT_FAST_ITERATIONS: *value = (double)c->fast_iters; return OA_OK;
     case OA_STAT_HANDOVER_ENTRIES: *value = c->h_poll ? (double)c->h_poll[2] : 0.0; return OA_OK;

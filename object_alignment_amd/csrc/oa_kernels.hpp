@@ -1023,6 +1023,299 @@ __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_filt
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_nn_search_sorted : k_nn_search_filtered with one more level in front (round 5) -- ~2 full-rate VALU ops per pair instead of ~3.1
+// ------------------------------------------------------------------------------------------------
+// Still every (source, target) pair gets its own arithmetic; what changes is the ORDER of the target and a cheaper first test.
+//   The target's images are laid out in the order of the coordinate u along the cloud's longest axis (a 30-bit quantised key,
+//   stable sort; the order only matters for speed -- any permutation gives the same answers), so an LDS tile of 1024 vertices is
+//   a thin slab in u; the source points a wave owns are neighbours in space (Morton order).
+//   level 0 (hot loop)  the 1-D gap  a_j = |fl32(qu_j - hu)|:  ONE two-operand subtract + the min tree per pair (the |.| rides on
+//                       the min's source modifier).  With base the right-hand side of filter_thresholds (best inflated by every
+//                       rounding allowance of the 2-D / 3-D scores), a pair is a proven loser when its REAL gap t = |qu_j - hu|
+//                       has t^2 > base (the distance along one axis never exceeds the 3-D distance; no rounding at all on this
+//                       side of the inequality).  fl32(qu_j - hu) = (qu_j - hu)(1 + e), |e| <= 2^-24, so
+//                       a_j > T1 = round_up(sqrt(base) (1 + 2^-22))  =>  t >= a_j / (1 + 2^-24) > sqrt(base).
+//                       For all slabs but the few around the wave's own u range every pair fails here.
+//   levels 1, 2, 3      as k_nn_search_filtered (2-D score, 3-D score, exact metric), reached by ~6 % of the blocks at 1M <-> 1M.
+// Indices: position j of the sorted images holds original vertex tidx[j]; the exact path compares and reports ORIGINAL indices
+// (lowest index on ties, as everywhere).  A split owns a seed when seed index mod splits = split (no position lookup).
+// Tiles are visited middle-out from the slab nearest to the workgroup's first point: an unseeded search (the first iteration of a
+// loop) then finds a tight best at once instead of sweeping towards it; with seeds the order is immaterial.
+__global__ void k_sort_keys_axis(const float *__restrict__ xyz, int nt, int axis, double lo, double scale, unsigned *__restrict__ keys,
+                                 int *__restrict__ ids)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nt) return;
+    double t = ((double)xyz[3ll * i + axis] - lo) * scale;
+    t = t < 0.0 ? 0.0 : (t > 1073741823.0 ? 1073741823.0 : t);
+    keys[i] = (unsigned)t;
+    ids[i] = i;
+}
+
+// images in sorted order, per group of 4 positions: tfs [qu][-2qv][qu^2+qv^2] (LDS tiles; -2qu is exact from qu), tf3s [-2qd][|q|^2],
+// tgs [x][y][z] (exact), tidx original indices.  Same centring and roundings as k_pack_filter / k_pack_target.
+__global__ void k_pack_sorted(const float *__restrict__ xyz, int nt, int n_groups_pad, const int *__restrict__ order, float cx, float cy,
+                              float cz, int au, int av, int ad, float4 *__restrict__ tfs, float4 *__restrict__ tf3s,
+                              float4 *__restrict__ tgs, int4 *__restrict__ tidx)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_groups_pad) return;
+    float a[3][4], qu[4], w2[4], w3[4], e[3][4];
+    int id[4];
+    for (int k = 0; k < 4; ++k) {
+        const long long j = 4ll * g + k;
+        if (j < nt) {
+            const int v = order[j];
+            id[k] = v;
+            float q[3];
+            e[0][k] = xyz[3ll * v]; e[1][k] = xyz[3ll * v + 1]; e[2][k] = xyz[3ll * v + 2];
+            q[0] = (float)((double)e[0][k] - (double)cx);
+            q[1] = (float)((double)e[1][k] - (double)cy);
+            q[2] = (float)((double)e[2][k] - (double)cz);
+            const double p1 = (double)q[au] * (double)q[au];
+            const double p2 = p1 + (double)q[av] * (double)q[av];
+            const double q2 = p2 + (double)q[ad] * (double)q[ad];
+            a[0][k] = -2.0f * q[au]; a[1][k] = -2.0f * q[av]; a[2][k] = -2.0f * q[ad];
+            qu[k] = q[au]; w2[k] = (float)p2; w3[k] = (float)q2;
+        } else {                                                  // padding can never pass a level, nor win
+            id[k] = -1;
+            e[0][k] = e[1][k] = e[2][k] = INFINITY;
+            a[0][k] = a[1][k] = a[2][k] = 0.f;
+            qu[k] = 1.0e18f;                                      // (far, and -2 qu stays finite; the tail of the order -- keys clamp)
+            w2[k] = w3[k] = 3.0e38f;
+        }
+    }
+    tfs[3ll * g] = make_float4(qu[0], qu[1], qu[2], qu[3]);
+    tfs[3ll * g + 1] = make_float4(a[1][0], a[1][1], a[1][2], a[1][3]);
+    tfs[3ll * g + 2] = make_float4(w2[0], w2[1], w2[2], w2[3]);
+    tf3s[2ll * g] = make_float4(a[2][0], a[2][1], a[2][2], a[2][3]);
+    tf3s[2ll * g + 1] = make_float4(w3[0], w3[1], w3[2], w3[3]);
+    tgs[3ll * g] = make_float4(e[0][0], e[0][1], e[0][2], e[0][3]);
+    tgs[3ll * g + 1] = make_float4(e[1][0], e[1][1], e[1][2], e[1][3]);
+    tgs[3ll * g + 2] = make_float4(e[2][0], e[2][1], e[2][2], e[2][3]);
+    tidx[g] = make_int4(id[0], id[1], id[2], id[3]);
+}
+
+// thr1: the 1-D gap's threshold (header above); thr2: the 2-D score's (filter_thresholds).  The 3-D score's is derived from thr2
+// where it is needed.
+__device__ __forceinline__ void sorted_thresholds(float best, float hu, float hv, float hd, double qmax, float &thr1, float &thr2)
+{
+    if (!(best < INFINITY)) { thr1 = INFINITY; thr2 = INFINITY; return; }
+    const double P2 = (double)hu * (double)hu + (double)hv * (double)hv;
+    const double P3 = P2 + (double)hd * (double)hd;
+    const double G = sqrt(P3) * (1.0 + 1e-12) + qmax;
+    const double base = (double)best * (1.0 + FILTER_K) + FILTER_K * G * G + FILTER_ABS;
+    thr1 = round_up_to_float(sqrt(base) * (1.0 + 0x1p-22));
+    thr2 = round_up_to_float(base - P2);
+}
+
+constexpr int SORT_ORDER_MAX = 1024;      // tiles of one split whose middle-out order fits the LDS table (more: ascending)
+
+template <int R, int TG = FTILE_GROUPS>
+__global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_sorted(const DevState *__restrict__ st,
+                                                                 const float4 *__restrict__ src4,
+                                                                 const float4 *__restrict__ tgs,
+                                                                 const float4 *__restrict__ tfs,
+                                                                 const float4 *__restrict__ tf3s,
+                                                                 const int4 *__restrict__ tidx,
+                                                                 const float4 *__restrict__ win,
+                                                                 int n_groups_pad, int au, int av,
+                                                                 unsigned long long *__restrict__ keys)
+{
+    if (st->halt) return;
+    constexpr int TILE_F4 = TG * 3, LOADS = (TILE_F4 + NN_THREADS - 1) / NN_THREADS;   // TG = 256: 3 whole rounds; TG = 64: 192 of 256 threads
+    constexpr bool WHOLE = TILE_F4 % NN_THREADS == 0;
+    static_assert(LOADS >= 1 && LOADS <= 3, "k_nn_search_sorted: 1 .. 3 float4 per thread and tile");
+    __shared__ float4 tile[2][TILE_F4];
+    __shared__ short ord[SORT_ORDER_MAX];
+    const int tid = threadIdx.x;
+    const double qmax = st->qmax;
+    const float cx = st->tc[0], cy = st->tc[1], cz = st->tc[2];
+    const int base = blockIdx.y * (NN_THREADS * R);
+    // a wave owns R x 64 CONSECUTIVE slots (neighbours in space: the smallest extent in u, the fewest slabs it must look into);
+    // point r of a lane is slot base + slot_of(r)
+    const int wave_base = (tid >> 6) * (64 * R) + (tid & 63);
+#define OA_SLOT(r) (base + wave_base + (r) * 64)
+    float px[R], py[R], pz[R], hu[R], hv[R], hd[R], best[R], thr1[R], thr2[R];
+    uint32_t bidx[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = OA_SLOT(r);
+        const float4 p = src4[i];
+        co_find(st, p.x, p.y, p.z, px[r], py[r], pz[r]);    // co_find (general.py:287)
+        const float h0 = (float)((double)px[r] - (double)cx);
+        const float h1 = (float)((double)py[r] - (double)cy);
+        const float h2 = (float)((double)pz[r] - (double)cz);
+        hu[r] = au == 0 ? h0 : (au == 1 ? h1 : h2);
+        hv[r] = av == 0 ? h0 : (av == 1 ? h1 : h2);
+        hd[r] = (au + av == 1) ? h2 : ((au + av == 2) ? h1 : h0);
+        best[r] = INFINITY;
+        bidx[r] = IDX_NONE;
+        const float4 sw = win ? win[i] : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+        if (__float_as_int(sw.w) >= 0) {
+            const float d = d2_metric(px[r], py[r], pz[r], sw.x, sw.y, sw.z);
+            if (d < INFINITY) { best[r] = d; bidx[r] = (uint32_t)__float_as_int(sw.w); }
+        }
+        sorted_thresholds(best[r], hu[r], hv[r], hd[r], qmax, thr1[r], thr2[r]);
+    }
+
+    int g_begin, g_end;
+    split_range(n_groups_pad, TG, g_begin, g_end);
+    const int n_tiles = (g_end - g_begin) / TG;
+    const float4 *tsrc = tfs + 3ll * g_begin;
+
+    // visiting order of this split's tiles: middle-out from the slab nearest (in u) to the workgroup's first point
+    const bool ordered = n_tiles <= SORT_ORDER_MAX;
+    if (ordered && tid == 0) {
+        // the first vertex of tile t has u = tsrc[3 TG t].x, rising with t (the images are sorted by u): binary search for
+        // the first tile that starts beyond the point -- the slab before it holds the point's u (an approximate start is fine)
+        int a = 0, b = n_tiles;                                    // tiles [0, a) start at or before the point
+        while (a < b) {
+            const int mid = (a + b) >> 1;
+            if (tsrc[3ll * TG * mid].x <= hu[0]) a = mid + 1; else b = mid;
+        }
+        const int s = a > 0 ? a - 1 : 0;
+        int lo = s - 1, hi = s + 1, n = 0;
+        ord[n++] = (short)s;
+        while (n < n_tiles) {
+            if (hi < n_tiles) ord[n++] = (short)hi++;
+            if (lo >= 0 && n < n_tiles) ord[n++] = (short)lo--;
+        }
+    }
+    __syncthreads();
+#define OA_TILE_AT(k) (ordered ? (int)ord[(k)] : (k))
+
+    float4 stg0 = make_float4(0.f, 0.f, 0.f, 0.f), stg1 = stg0, stg2 = stg0;
+#define OA_STG_ON(k) (WHOLE || (k) * NN_THREADS + tid < TILE_F4)
+#define OA_STG_EACH(OP)                                       \
+    do {                                                      \
+        if (LOADS > 0 && OA_STG_ON(0)) { OP(0, stg0); }       \
+        if (LOADS > 1 && OA_STG_ON(1)) { OP(1, stg1); }       \
+        if (LOADS > 2 && OA_STG_ON(2)) { OP(2, stg2); }       \
+    } while (0)
+    {
+        const float4 *fsrc = tsrc + 3ll * TG * OA_TILE_AT(0);
+#define OA_STG_FIRST(k, reg) reg = fsrc[(k) * NN_THREADS + tid]; tile[0][(k) * NN_THREADS + tid] = reg
+        OA_STG_EACH(OA_STG_FIRST);
+#undef OA_STG_FIRST
+    }
+    __syncthreads();
+
+    for (int t = 0; t < n_tiles; ++t) {
+        const int cur = t & 1;
+        const bool more = (t + 1 < n_tiles);
+        if (more) {                                               // next tile: global -> registers, hidden under compute
+            const float4 *nsrc = tsrc + 3ll * TG * OA_TILE_AT(t + 1);
+#define OA_STG_LOAD(k, reg) reg = nsrc[(k) * NN_THREADS + tid]
+            OA_STG_EACH(OA_STG_LOAD);
+#undef OA_STG_LOAD
+        }
+        const int gbase = g_begin + OA_TILE_AT(t) * TG;
+        // 16 targets x R points per skip test.  On gfx950 v_sub_f32 issues at full rate, v_min_f32, v_min3_f32 and v_cmp_*_f32 at
+        // half rate (tools/_exp/burn.hip): the tree is all min3 (two comparisons per instruction), one compare per 16 targets.
+        constexpr int GW = 4;
+        for (int g = 0; g < TG; g += GW) {
+            float4 QU[GW];
+#pragma unroll
+            for (int k = 0; k < GW; ++k) QU[k] = tile[cur][3 * (g + k)];
+            bool hit0 = false, hit[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {                          // level 0: one subtract + half a min3 per pair, no branch inside
+                float a[4 * GW];
+#pragma unroll
+                for (int k = 0; k < GW; ++k) {
+                    a[4 * k] = __builtin_fabsf(QU[k].x - hu[r]); a[4 * k + 1] = __builtin_fabsf(QU[k].y - hu[r]);
+                    a[4 * k + 2] = __builtin_fabsf(QU[k].z - hu[r]); a[4 * k + 3] = __builtin_fabsf(QU[k].w - hu[r]);
+                }
+                float m = a[0];
+#pragma unroll
+                for (int k = 1; k + 1 < 4 * GW; k += 2) m = __builtin_fminf(__builtin_fminf(m, a[k]), a[k + 1]);   // v_min3_f32
+                m = __builtin_fminf(m, a[4 * GW - 1]);
+                hit[r] = !(m > thr1[r]);
+                hit0 |= hit[r];
+            }
+            if (!hit0) continue;
+#pragma unroll 1
+            for (int k = 0; k < GW; ++k) {                         // rare from here on: one group of 4 targets at a time
+                const float4 Q = tile[cur][3 * (g + k)], AV = tile[cur][3 * (g + k) + 1], W2 = tile[cur][3 * (g + k) + 2];
+                const float4 AU = make_float4(-2.0f * Q.x, -2.0f * Q.y, -2.0f * Q.z, -2.0f * Q.w);   // exact
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if (!hit[r]) continue;                         // (a point's run of 64 slots is a quarter of the wave's extent)
+                    // level 1: the 2-D score
+                    const float c0 = __builtin_fmaf(hu[r], AU.x, __builtin_fmaf(hv[r], AV.x, W2.x));
+                    const float c1 = __builtin_fmaf(hu[r], AU.y, __builtin_fmaf(hv[r], AV.y, W2.y));
+                    const float c2 = __builtin_fmaf(hu[r], AU.z, __builtin_fmaf(hv[r], AV.z, W2.z));
+                    const float c3 = __builtin_fmaf(hu[r], AU.w, __builtin_fmaf(hv[r], AV.w, W2.w));
+                    if (__builtin_fminf(__builtin_fminf(c0, c1), __builtin_fminf(c2, c3)) > thr2[r]) continue;
+                    // level 2: the 3-D score
+                    const float4 AD = tf3s[2ll * (gbase + g + k)], W3 = tf3s[2ll * (gbase + g + k) + 1];
+                    const float e0s = __builtin_fmaf(hu[r], AU.x, __builtin_fmaf(hv[r], AV.x, __builtin_fmaf(hd[r], AD.x, W3.x)));
+                    const float e1s = __builtin_fmaf(hu[r], AU.y, __builtin_fmaf(hv[r], AV.y, __builtin_fmaf(hd[r], AD.y, W3.y)));
+                    const float e2s = __builtin_fmaf(hu[r], AU.z, __builtin_fmaf(hv[r], AV.z, __builtin_fmaf(hd[r], AD.z, W3.z)));
+                    const float e3s = __builtin_fmaf(hu[r], AU.w, __builtin_fmaf(hv[r], AV.w, __builtin_fmaf(hd[r], AD.w, W3.w)));
+                    // (the 3-D threshold from the 2-D one: base - P3 <= thr2 - hd^2, rounded up -- a register per point less than
+                    //  keeping it; a threshold that is too high only prunes less)
+                    if (__builtin_fminf(__builtin_fminf(e0s, e1s), __builtin_fminf(e2s, e3s))
+                        > round_up_to_float((double)thr2[r] - (double)hd[r] * (double)hd[r])) continue;
+                    // level 3: cannot be ruled out, exact metric, original indices
+                    float b = best[r];
+                    uint32_t bi = bidx[r];
+                    const float4 *eg = tgs + 3ll * (gbase + g + k);
+                    const float4 X = eg[0], Y = eg[1], Z = eg[2];
+                    const int4 J = tidx[gbase + g + k];
+                    const float e0 = d2_metric(px[r], py[r], pz[r], X.x, Y.x, Z.x);
+                    const float e1 = d2_metric(px[r], py[r], pz[r], X.y, Y.y, Z.y);
+                    const float e2 = d2_metric(px[r], py[r], pz[r], X.z, Y.z, Z.z);
+                    const float e3 = d2_metric(px[r], py[r], pz[r], X.w, Y.w, Z.w);
+                    if (e0 < b || (e0 == b && (uint32_t)J.x < bi)) { b = e0; bi = (uint32_t)J.x; }
+                    if (e1 < b || (e1 == b && (uint32_t)J.y < bi)) { b = e1; bi = (uint32_t)J.y; }
+                    if (e2 < b || (e2 == b && (uint32_t)J.z < bi)) { b = e2; bi = (uint32_t)J.z; }
+                    if (e3 < b || (e3 == b && (uint32_t)J.w < bi)) { b = e3; bi = (uint32_t)J.w; }
+                    if (b < best[r]) sorted_thresholds(b, hu[r], hv[r], hd[r], qmax, thr1[r], thr2[r]);
+                    best[r] = b;
+                    bidx[r] = (b < INFINITY) ? bi : IDX_NONE;      // overflowed distances (+inf) never win
+                }
+            }
+        }
+        if (more) {
+#define OA_STG_STORE(k, reg) tile[cur ^ 1][(k) * NN_THREADS + tid] = reg
+            OA_STG_EACH(OA_STG_STORE);
+#undef OA_STG_STORE
+        }
+        __syncthreads();
+    }
+#undef OA_STG_EACH
+#undef OA_STG_ON
+#undef OA_TILE_AT
+
+    // a split reports when it has something to say (k_nn_search_filtered); the seed's owner: seed index mod splits
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const unsigned long long key = ((unsigned long long)__float_as_uint(best[r]) << 32) | bidx[r];
+        unsigned long long *dst = keys + OA_SLOT(r);
+        if (gridDim.x == 1) *dst = key;
+        else {
+            // (the seed again, from the slot's record -- the same arithmetic as at the start -- instead of two registers per point
+            //  held through the scan)
+            uint32_t seed_idx = IDX_NONE;
+            float seed_d = INFINITY;
+            const float4 sw = win ? win[OA_SLOT(r)] : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+            if (__float_as_int(sw.w) >= 0) {
+                const float d = d2_metric(px[r], py[r], pz[r], sw.x, sw.y, sw.z);
+                if (d < INFINITY) { seed_d = d; seed_idx = (uint32_t)__float_as_int(sw.w); }
+            }
+            const bool seeded = seed_idx != IDX_NONE;
+            const bool improved = bidx[r] != seed_idx || best[r] != seed_d;
+            const bool owner = seeded && (seed_idx % gridDim.x) == blockIdx.x;
+            if (!seeded || improved || owner) atomicMin(dst, key);
+        }
+    }
+}
+
+#undef OA_SLOT
+
+// ------------------------------------------------------------------------------------------------
 // k_pair_accumulate
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double wave_sum(double v)

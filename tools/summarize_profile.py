@@ -25,6 +25,18 @@ OUT = os.path.join(ROOT, "gpurun_out")
 PROF = os.path.join(ROOT, "profiles")
 
 
+BRUTE = ("k_nn_search_sorted", "k_nn_search_filtered")       # the headline's kernel (OA_NN_SORT=0: its predecessor)
+
+
+def brute_of(traffic):
+    """the brute-force search kernel of a pass: the sorted kernel when it ran, else the filtered one"""
+    for name in BRUTE:
+        ks = [k for k in traffic if k.startswith(name)]
+        if ks:
+            return ks
+    return []
+
+
 def newest(pattern):
     files = glob.glob(pattern)
     return max(files, key=os.path.getmtime) if files else None
@@ -93,7 +105,7 @@ def main():
              "# rocprofv3 PMC passes of `python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-surface` (tools/profile.sh); per-dispatch means",
              "# commit %s, kernel sources sha16 %s" % (commit, stamp["csrc_sha16"]), ""]
     mean, traffic = table(agg, lines)
-    brute = [k for k in traffic if k.startswith("k_nn_search_filtered")]
+    brute = brute_of(traffic)
     per_pair = None
     if brute and (brute[0], "SQ_INSTS_VALU") in mean:
         per_pair = mean[(brute[0], "SQ_INSTS_VALU")] * 64.0 / 1e12
@@ -107,25 +119,39 @@ def main():
                                         write_size_kb=mean[(k, "WRITE_SIZE")], source=rel)
         if per_pair is not None:
             tr["1000000x1000000_n1"]["valu_instructions_per_pair"] = per_pair
+        # the profiled command runs `--warmup 1` and a timed loop, each from a cold start: launches 0 and 1 search without seeds
+        # (more pairs reach the later filter levels), the others with.  bench.py weighs the two by its own step count.
+        series = agg.get((k, "SQ_INSTS_VALU"), [])
+        if len(series) >= 3:
+            cold = sum(series[:2]) / 2.0 * 64.0 / 1e12
+            seeded = sum(series[2:]) / len(series[2:]) * 64.0 / 1e12
+            tr["1000000x1000000_n1"]["valu_instructions_per_pair_cold"] = cold
+            tr["1000000x1000000_n1"]["valu_instructions_per_pair_seeded"] = seeded
+            lines.append("%s: launches without seeds (the first of a loop) %.4g, with seeds %.4g VALU instructions per pair" % (k, cold, seeded))
+            open(summ, "w").write("\n".join(lines) + "\n")
     gk = sorted((k for k in traffic if k.startswith("k_nn_search_grid")), key=lambda k: "true" not in k)   # the loop's kernel first: k_nn_search_grid<1, true>
     if gk:
         tr["grid_1000000x1000000_n1"] = dict(stamp, kernel=gk[0], bytes_per_launch=traffic[gk[0]], source=rel)
     # ---- N shards on this GPU (python bench.py --gpus N with OA_BENCH_SAME_DEVICE=1): the figures an N > 1 line reports
     for n in (2, 4, 8):
-        aggn = collect(("prof_n%d_FETCH_SIZE" % n, "prof_n%d_WRITE_SIZE" % n, "prof_n%d_SQ" % n), lambda k: k.startswith("k_nn_search_filtered"))
+        aggn = collect(("prof_n%d_FETCH_SIZE" % n, "prof_n%d_WRITE_SIZE" % n, "prof_n%d_SQ" % n), lambda k: k.startswith(BRUTE))
         if not aggn:
             continue
         shard = -(-1000000 // n)
         lines.append("")
         lines.append("# %d shards of %d points on this GPU (OA_BENCH_SAME_DEVICE=1 python bench.py --gpus %d ...): per-dispatch means" % (n, shard, n))
         meann, trafficn = table(aggn, lines)
-        bn = [k for k in trafficn if k.startswith("k_nn_search_filtered")]
+        bn = brute_of(trafficn)
         if bn:
             en = dict(stamp, kernel=bn[0], bytes_per_launch=trafficn[bn[0]], fetch_size_kb=meann[(bn[0], "FETCH_SIZE")],
                       write_size_kb=meann[(bn[0], "WRITE_SIZE")], source=rel,
                       note="measured with all %d shards on ONE GPU (OA_BENCH_SAME_DEVICE=1); per launch of one %d-point shard" % (n, shard))
             if (bn[0], "SQ_INSTS_VALU") in meann:
                 en["valu_instructions_per_pair"] = meann[(bn[0], "SQ_INSTS_VALU")] * 64.0 / (shard * 1e6)
+                sn = aggn.get((bn[0], "SQ_INSTS_VALU"), [])       # n shards per iteration: the first 2 n launches are unseeded
+                if len(sn) >= 3 * n:
+                    en["valu_instructions_per_pair_cold"] = sum(sn[:2 * n]) / (2.0 * n) * 64.0 / (shard * 1e6)
+                    en["valu_instructions_per_pair_seeded"] = sum(sn[2 * n:]) / len(sn[2 * n:]) * 64.0 / (shard * 1e6)
                 lines.append("%s (%d-point shard): SQ_INSTS_VALU*64 / pairs = %.4g VALU instructions per pair" % (bn[0], shard, en["valu_instructions_per_pair"]))
             tr["1000000x1000000_n%d" % n] = en
     open(summ, "w").write("\n".join(lines) + "\n")
