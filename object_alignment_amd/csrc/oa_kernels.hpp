@@ -1109,6 +1109,50 @@ __device__ __forceinline__ void sorted_thresholds(float best, float hu, float hv
     thr2 = round_up_to_float(base - P2);
 }
 
+// Levels 1 .. 3 of the sorted kernels for ONE point and ONE group of 4 sorted positions (AU / AV / W2: the group's -2qu, -2qv,
+// qu^2+qv^2).  Returns true when the point's best improved (its thresholds are then already renewed).
+__device__ __forceinline__ bool sorted_finish_group(const float4 AU, const float4 AV, const float4 W2, long long group,
+                                                    const float4 *__restrict__ tf3s, const float4 *__restrict__ tgs,
+                                                    const int4 *__restrict__ tidx, float px, float py, float pz, float hu, float hv,
+                                                    float hd, double qmax, float &best, uint32_t &bidx, float &thr1, float &thr2)
+{
+    // level 1: the 2-D score
+    const float c0 = __builtin_fmaf(hu, AU.x, __builtin_fmaf(hv, AV.x, W2.x));
+    const float c1 = __builtin_fmaf(hu, AU.y, __builtin_fmaf(hv, AV.y, W2.y));
+    const float c2 = __builtin_fmaf(hu, AU.z, __builtin_fmaf(hv, AV.z, W2.z));
+    const float c3 = __builtin_fmaf(hu, AU.w, __builtin_fmaf(hv, AV.w, W2.w));
+    if (__builtin_fminf(__builtin_fminf(c0, c1), __builtin_fminf(c2, c3)) > thr2) return false;
+    // level 2: the 3-D score
+    const float4 AD = tf3s[2ll * group], W3 = tf3s[2ll * group + 1];
+    const float e0s = __builtin_fmaf(hu, AU.x, __builtin_fmaf(hv, AV.x, __builtin_fmaf(hd, AD.x, W3.x)));
+    const float e1s = __builtin_fmaf(hu, AU.y, __builtin_fmaf(hv, AV.y, __builtin_fmaf(hd, AD.y, W3.y)));
+    const float e2s = __builtin_fmaf(hu, AU.z, __builtin_fmaf(hv, AV.z, __builtin_fmaf(hd, AD.z, W3.z)));
+    const float e3s = __builtin_fmaf(hu, AU.w, __builtin_fmaf(hv, AV.w, __builtin_fmaf(hd, AD.w, W3.w)));
+    // (the 3-D threshold from the 2-D one: base - P3 <= thr2 - hd^2, rounded up -- a register per point less than keeping it; a
+    //  threshold that is too high only prunes less)
+    if (__builtin_fminf(__builtin_fminf(e0s, e1s), __builtin_fminf(e2s, e3s)) > round_up_to_float((double)thr2 - (double)hd * (double)hd))
+        return false;
+    // level 3: cannot be ruled out, exact metric, original indices
+    float b = best;
+    uint32_t bi = bidx;
+    const float4 *eg = tgs + 3ll * group;
+    const float4 X = eg[0], Y = eg[1], Z = eg[2];
+    const int4 J = tidx[group];
+    const float e0 = d2_metric(px, py, pz, X.x, Y.x, Z.x);
+    const float e1 = d2_metric(px, py, pz, X.y, Y.y, Z.y);
+    const float e2 = d2_metric(px, py, pz, X.z, Y.z, Z.z);
+    const float e3 = d2_metric(px, py, pz, X.w, Y.w, Z.w);
+    if (e0 < b || (e0 == b && (uint32_t)J.x < bi)) { b = e0; bi = (uint32_t)J.x; }
+    if (e1 < b || (e1 == b && (uint32_t)J.y < bi)) { b = e1; bi = (uint32_t)J.y; }
+    if (e2 < b || (e2 == b && (uint32_t)J.z < bi)) { b = e2; bi = (uint32_t)J.z; }
+    if (e3 < b || (e3 == b && (uint32_t)J.w < bi)) { b = e3; bi = (uint32_t)J.w; }
+    const bool improved = b < best;
+    if (improved) sorted_thresholds(b, hu, hv, hd, qmax, thr1, thr2);
+    best = b;
+    bidx = (b < INFINITY) ? bi : IDX_NONE;                        // overflowed distances (+inf) never win
+    return improved;
+}
+
 constexpr int SORT_ORDER_MAX = 1024;      // tiles of one split whose middle-out order fits the LDS table (more: ascending)
 
 template <int R, int TG = FTILE_GROUPS>
@@ -1242,39 +1286,8 @@ __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_sort
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     if (!hit[r]) continue;                         // (a point's run of 64 slots is a quarter of the wave's extent)
-                    // level 1: the 2-D score
-                    const float c0 = __builtin_fmaf(hu[r], AU.x, __builtin_fmaf(hv[r], AV.x, W2.x));
-                    const float c1 = __builtin_fmaf(hu[r], AU.y, __builtin_fmaf(hv[r], AV.y, W2.y));
-                    const float c2 = __builtin_fmaf(hu[r], AU.z, __builtin_fmaf(hv[r], AV.z, W2.z));
-                    const float c3 = __builtin_fmaf(hu[r], AU.w, __builtin_fmaf(hv[r], AV.w, W2.w));
-                    if (__builtin_fminf(__builtin_fminf(c0, c1), __builtin_fminf(c2, c3)) > thr2[r]) continue;
-                    // level 2: the 3-D score
-                    const float4 AD = tf3s[2ll * (gbase + g + k)], W3 = tf3s[2ll * (gbase + g + k) + 1];
-                    const float e0s = __builtin_fmaf(hu[r], AU.x, __builtin_fmaf(hv[r], AV.x, __builtin_fmaf(hd[r], AD.x, W3.x)));
-                    const float e1s = __builtin_fmaf(hu[r], AU.y, __builtin_fmaf(hv[r], AV.y, __builtin_fmaf(hd[r], AD.y, W3.y)));
-                    const float e2s = __builtin_fmaf(hu[r], AU.z, __builtin_fmaf(hv[r], AV.z, __builtin_fmaf(hd[r], AD.z, W3.z)));
-                    const float e3s = __builtin_fmaf(hu[r], AU.w, __builtin_fmaf(hv[r], AV.w, __builtin_fmaf(hd[r], AD.w, W3.w)));
-                    // (the 3-D threshold from the 2-D one: base - P3 <= thr2 - hd^2, rounded up -- a register per point less than
-                    //  keeping it; a threshold that is too high only prunes less)
-                    if (__builtin_fminf(__builtin_fminf(e0s, e1s), __builtin_fminf(e2s, e3s))
-                        > round_up_to_float((double)thr2[r] - (double)hd[r] * (double)hd[r])) continue;
-                    // level 3: cannot be ruled out, exact metric, original indices
-                    float b = best[r];
-                    uint32_t bi = bidx[r];
-                    const float4 *eg = tgs + 3ll * (gbase + g + k);
-                    const float4 X = eg[0], Y = eg[1], Z = eg[2];
-                    const int4 J = tidx[gbase + g + k];
-                    const float e0 = d2_metric(px[r], py[r], pz[r], X.x, Y.x, Z.x);
-                    const float e1 = d2_metric(px[r], py[r], pz[r], X.y, Y.y, Z.y);
-                    const float e2 = d2_metric(px[r], py[r], pz[r], X.z, Y.z, Z.z);
-                    const float e3 = d2_metric(px[r], py[r], pz[r], X.w, Y.w, Z.w);
-                    if (e0 < b || (e0 == b && (uint32_t)J.x < bi)) { b = e0; bi = (uint32_t)J.x; }
-                    if (e1 < b || (e1 == b && (uint32_t)J.y < bi)) { b = e1; bi = (uint32_t)J.y; }
-                    if (e2 < b || (e2 == b && (uint32_t)J.z < bi)) { b = e2; bi = (uint32_t)J.z; }
-                    if (e3 < b || (e3 == b && (uint32_t)J.w < bi)) { b = e3; bi = (uint32_t)J.w; }
-                    if (b < best[r]) sorted_thresholds(b, hu[r], hv[r], hd[r], qmax, thr1[r], thr2[r]);
-                    best[r] = b;
-                    bidx[r] = (b < INFINITY) ? bi : IDX_NONE;      // overflowed distances (+inf) never win
+                    sorted_finish_group(AU, AV, W2, gbase + g + k, tf3s, tgs, tidx, px[r], py[r], pz[r], hu[r], hv[r], hd[r], qmax,
+                                        best[r], bidx[r], thr1[r], thr2[r]);
                 }
             }
         }

@@ -2,7 +2,8 @@
 
 The order of the target and the filter levels may only change the SPEED: every answer must be bit-identical to the
 oracle's brute force and to the kernel it replaced (OA_NN_SORT=0: k_nn_search_filtered).  The cases are chosen for
-what is new -- slabs of the sorted order, the tile-local arithmetic of level 0, original indices behind the order."""
+what is new -- slabs of the sorted order (wide, degenerate, of very different scales), radii far above and below the
+slab width, huge offsets, original indices behind the order.  Both LDS tile sizes run (OA_NN_BIGTILE)."""
 import zlib
 
 import numpy as np
@@ -12,7 +13,8 @@ pytestmark = pytest.mark.gpu
 
 KERNEL_OF = {"0": 1.0, "1": 3.0}        # OA_NN_SORT -> OA_STAT_BRUTE_KERNEL
 CASES = ["uniform", "outlier_slabs", "equal_u", "two_blobs", "duplicates", "lattice_ties", "dynamic_range",
-         "line_along_u", "query_far_along_u", "tiny_cluster_in_big_box", "nt_1", "nt_5", "nt_1025", "denormal_u"]
+         "line_along_u", "query_far_along_u", "tiny_cluster_in_big_box", "nt_1", "nt_5", "nt_1025", "denormal_u",
+         "exact_copies", "far_offset", "planes_along_u", "two_scales", "radius_above_half_range"]
 
 
 def _case(case):
@@ -60,6 +62,25 @@ def _case(case):
         n = int(case[3:])
         tgt = rng.uniform(-1, 1, size=(n, 3))
         src = rng.uniform(-1, 1, size=(ns, 3))
+    elif case == "exact_copies":             # best = 0 for most points: the smallest radii the filter ever sees
+        tgt = rng.uniform(-1, 1, size=(nt, 3))
+        src = tgt[rng.permutation(nt)[:ns]].copy()
+        src[::5] += rng.normal(0, 1e-7, size=src[::5].shape)
+    elif case == "far_offset":               # extent 1 at distance 1e3 .. 2e3 from the origin
+        tgt = rng.uniform(-0.5, 0.5, size=(nt, 3)) + [1000.0, -2000.0, 500.0]
+        src = rng.uniform(-0.5, 0.5, size=(ns, 3)) + [1000.0, -2000.0, 500.0]
+    elif case == "planes_along_u":           # 7 planes of constant u: every tile is a slab of zero width
+        tgt = rng.uniform(-1, 1, size=(nt, 3))
+        tgt[:, 0] = rng.integers(-3, 4, size=nt) * 0.75
+        src = rng.uniform(-1, 1, size=(ns, 3)) * [3.0, 1.0, 1.0]
+    elif case == "two_scales":               # the same shape at scale 1 and at scale 1e-3, interleaved along u
+        a = rng.uniform(-1, 1, size=(nt // 2, 3))
+        tgt = np.concatenate([a, a[: nt - nt // 2] * 1e-3 + [0.25, 0.0, 0.0]])
+        s = rng.uniform(-1, 1, size=(ns // 2, 3))
+        src = np.concatenate([s, s[: ns - ns // 2] * 1e-3 + [0.25, 0.0, 0.0]])
+    elif case == "radius_above_half_range":  # seeds so bad that the scaled radius leaves the half-precision range
+        tgt = rng.uniform(-1, 1, size=(nt, 3)) * [1.0, 1e-3, 1e-3]
+        src = rng.uniform(-1, 1, size=(ns, 3)) * [1.0, 300.0, 300.0]
     elif case == "denormal_u":
         tgt = rng.uniform(-1, 1, size=(nt, 3)) * [1e-40, 1e-42, 1e-44]
         src = rng.uniform(-1, 1, size=(ns, 3)) * [1e-40, 1e-42, 1e-44]
@@ -68,11 +89,12 @@ def _case(case):
     return tgt.astype(np.float32), src.astype(np.float32)
 
 
-@pytest.mark.parametrize("sort", sorted(KERNEL_OF))
+@pytest.mark.parametrize("sort,bigtile", [("0", "0"), ("1", "0"), ("1", "1")])
 @pytest.mark.parametrize("case", CASES)
-def test_sorted_kernel_answers_are_the_oracles(orc, case, sort, monkeypatch):
+def test_sorted_kernel_answers_are_the_oracles(orc, case, sort, bigtile, monkeypatch):
     from object_alignment_amd.engine import IcpEngine
     monkeypatch.setenv("OA_NN_SORT", sort)
+    monkeypatch.setenv("OA_NN_BIGTILE", bigtile)         # 1: the 1024-vertex LDS tile of large targets, also for these small ones
     tgt, src = _case(case)
     eye = np.identity(4, dtype=np.float32)
     with IcpEngine(0) as e:
