@@ -662,6 +662,7 @@ int safe_radii_lazy(oa_ctx *c)
     if (c->grid_safe != 1 || c->safe_ok || !c->d_safe_by_idx) return OA_OK;
     return c->target_iters > SAFE_LAZY_ITERS ? build_safe_radii(c) : OA_OK;
 }
+int build_sorted_images(oa_ctx *c);
 int build_tri_grid(oa_ctx *c, const double *diag_sum_known = nullptr);
 int build_tri_ring(oa_ctx *c);
 // OA_TRI_RING=1: the neighbour lists are built once the mesh has served TRI_RING_LAZY_ITERS searches of a loop -- while the pose
@@ -2092,7 +2093,13 @@ OA_EXPORT int oa_set_search_mode(oa_ctx *c, int mode)
     if (mode < -1 || mode > 2) return fail(OA_E_BAD_ARG, "search mode %d (use OA_SEARCH_AUTO/BRUTE/GRID/BVH)", mode);
     OA_ROUTE_ALL(c, oa_set_search_mode(sub, mode));
     const bool rebuild = (c->grid_mode == 0 && mode != 0 && c->nt > 0);
+    const bool sorted_now = (mode == 0 && c->nt > 0 && !c->surface && !c->d_tfs);   // (skipped when the target was uploaded)
     c->grid_mode = mode;
+    if (sorted_now) {
+        int rc = use_device(c);
+        if (rc) return rc;
+        if ((rc = build_sorted_images(c))) return rc;
+    }
     if (rebuild) {                                   // the grids were skipped when the target was uploaded
         int rc = use_device(c);
         if (rc) return rc;
@@ -2141,6 +2148,40 @@ int bbox_partials(oa_ctx *c, const float *d_xyz, long long n, int nb, float *out
 }
 
 // filter image for k_nn_search_filtered: bbox centre, centred -2q / |q|^2 arrays, max |q - centre|
+// k_nn_search_sorted's images: the target in the order of its coordinate along the longest axis (30-bit quantised key through
+// the library's stable argsort -- the order is for speed only, any permutation gives the same answers).  Needs build_filter's
+// results (bounding box, centre, axes, filter_ok); allocates, so it runs with the upload or from oa_set_search_mode, never
+// inside a loop.
+int build_sorted_images(oa_ctx *c)
+{
+    dev_free(c->d_tfs); dev_free(c->d_tf3s); dev_free(c->d_tgs); dev_free(c->d_tidx);
+    if (!(c->filter_ok && c->nn_sort && c->nt >= 2)) return OA_OK;
+    const double *lo = c->bb_lo, *hi = c->bb_hi;
+    const int ad = c->fax[2];
+    int su = 0;
+    for (int a = 1; a < 3; ++a) if (hi[a] - lo[a] > hi[su] - lo[su]) su = a;
+    const int sd = ad != su ? ad : (su + 1) % 3;                   // (all extents equal: any other axis)
+    c->sax[0] = su; c->sax[2] = sd; c->sax[1] = 3 - su - sd;
+    const double ext = hi[su] - lo[su];
+    const int blocks = (c->n_groups_pad + 255) / 256;
+    DevTmp<unsigned> k_in, k_out;
+    DevTmp<int> v_in, v_out;
+    HIPCHK(k_in.alloc((size_t)c->nt)); HIPCHK(k_out.alloc((size_t)c->nt)); HIPCHK(v_in.alloc((size_t)c->nt)); HIPCHK(v_out.alloc((size_t)c->nt));
+    hipLaunchKernelGGL(oa::k_sort_keys_axis, dim3((c->nt + 255) / 256), dim3(256), 0, c->stream, (const float *)c->d_tgt_xyz, c->nt, su, lo[su],
+                       ext > 0.0 ? 1073741823.0 / ext : 0.0, k_in.p, v_in.p);
+    HIPCHK(hipGetLastError());
+    { const int rcs = sort_pairs30(c, k_in.p, k_out.p, v_in.p, v_out.p, (size_t)c->nt); if (rcs) return rcs; }
+    HIPCHK(dev_malloc(&c->d_tfs, sizeof(float4) * 3 * (size_t)c->n_groups_pad));
+    HIPCHK(dev_malloc(&c->d_tf3s, sizeof(float4) * 2 * (size_t)c->n_groups_pad));
+    HIPCHK(dev_malloc(&c->d_tgs, sizeof(float4) * 3 * (size_t)c->n_groups_pad));
+    HIPCHK(dev_malloc(&c->d_tidx, sizeof(int4) * (size_t)c->n_groups_pad));
+    hipLaunchKernelGGL(oa::k_pack_sorted, dim3((unsigned)blocks), dim3(256), 0, c->stream, (const float *)c->d_tgt_xyz, c->nt, c->n_groups_pad,
+                       (const int *)v_out.p, c->tc[0], c->tc[1], c->tc[2], c->sax[0], c->sax[1], c->sax[2], c->d_tfs, c->d_tf3s, c->d_tgs, c->d_tidx);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));                      // (the temporaries are released on return)
+    return OA_OK;
+}
+
 int build_filter(oa_ctx *c)
 {
     c->filter_ok = false;
@@ -2185,30 +2226,9 @@ int build_filter(oa_ctx *c)
     c->qmax = sqrt(m) * (1.0 + 1e-6);
     c->filter_ok = (c->qmax < 1e18);
     dev_free(c->d_tfs); dev_free(c->d_tf3s); dev_free(c->d_tgs); dev_free(c->d_tidx);
-    if (c->filter_ok && c->nn_sort && c->nt >= 2) {
-        // k_nn_search_sorted's images: the target in the order of its coordinate along the longest axis (30-bit quantised key
-        // through the library's stable argsort -- the order is for speed only, any permutation gives the same answers)
-        int su = 0;
-        for (int a = 1; a < 3; ++a) if (hi[a] - lo[a] > hi[su] - lo[su]) su = a;
-        const int sd = ad != su ? ad : (su + 1) % 3;               // (all extents equal: any other axis)
-        c->sax[0] = su; c->sax[2] = sd; c->sax[1] = 3 - su - sd;
-        const double ext = hi[su] - lo[su];
-        DevTmp<unsigned> k_in, k_out;
-        DevTmp<int> v_in, v_out;
-        HIPCHK(k_in.alloc((size_t)c->nt)); HIPCHK(k_out.alloc((size_t)c->nt)); HIPCHK(v_in.alloc((size_t)c->nt)); HIPCHK(v_out.alloc((size_t)c->nt));
-        hipLaunchKernelGGL(oa::k_sort_keys_axis, dim3((c->nt + 255) / 256), dim3(256), 0, c->stream, (const float *)c->d_tgt_xyz, c->nt, su, lo[su],
-                           ext > 0.0 ? 1073741823.0 / ext : 0.0, k_in.p, v_in.p);
-        HIPCHK(hipGetLastError());
-        { const int rcs = sort_pairs30(c, k_in.p, k_out.p, v_in.p, v_out.p, (size_t)c->nt); if (rcs) return rcs; }
-        HIPCHK(dev_malloc(&c->d_tfs, sizeof(float4) * 3 * (size_t)c->n_groups_pad));
-        HIPCHK(dev_malloc(&c->d_tf3s, sizeof(float4) * 2 * (size_t)c->n_groups_pad));
-        HIPCHK(dev_malloc(&c->d_tgs, sizeof(float4) * 3 * (size_t)c->n_groups_pad));
-        HIPCHK(dev_malloc(&c->d_tidx, sizeof(int4) * (size_t)c->n_groups_pad));
-        hipLaunchKernelGGL(oa::k_pack_sorted, dim3((unsigned)blocks), dim3(256), 0, c->stream, (const float *)c->d_tgt_xyz, c->nt, c->n_groups_pad,
-                           (const int *)v_out.p, c->tc[0], c->tc[1], c->tc[2], c->sax[0], c->sax[1], c->sax[2], c->d_tfs, c->d_tf3s, c->d_tgs, c->d_tidx);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(c->stream));                  // (the temporaries are released on return)
-    }
+    // k_nn_search_sorted's images are built for the search mode that uses them: a target uploaded for the grid / tree searches
+    // (OA_SEARCH_AUTO, the default) does not pay for them; oa_set_search_mode(OA_SEARCH_BRUTE) builds them when it finds none
+    if (c->grid_mode == 0) { const int rcs = build_sorted_images(c); if (rcs) return rcs; }
     dev_free(c->d_tfm);
     if (c->filter_ok && c->nn_mfma) {                            // experiment: the MFMA image (32 B per target)
         int e = 0;

@@ -161,3 +161,30 @@ def test_sorted_and_filtered_loops_agree_bitwise(monkeypatch):
     assert out["1"][2] == 3.0 and out["0"][2] == 1.0
     assert out["1"][1] == out["0"][1] == 12
     assert np.array_equal(out["1"][0], out["0"][0])
+
+
+def test_sorted_images_are_built_for_the_mode_that_uses_them(orc):
+    """A target uploaded under AUTO (grid / tree searches) does not pay for the sorted images; switching to brute force builds
+    them, and the answers are the oracle's either way."""
+    from object_alignment_amd.engine import IcpEngine
+    rng = np.random.default_rng(5)
+    tgt = rng.uniform(-1, 1, size=(20000, 3)).astype(np.float32)
+    src = rng.uniform(-1, 1, size=(3000, 3)).astype(np.float32)
+    eye = np.identity(4, dtype=np.float32)
+    ridx, rd2 = orc.nn_brute(src, tgt)
+    with IcpEngine(0) as e:
+        e.set_target(tgt)                            # AUTO
+        e.set_source(src)
+        e.set_matrices(eye, eye)
+        assert e.stat("brute_kernel") == 1.0         # no sorted images yet: brute force would be k_nn_search_filtered
+        idx, d2, _ = e.nn_search()
+        assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2)
+        e.set_search_mode("brute")
+        assert e.stat("brute_kernel") == 3.0
+        idx, d2, _ = e.nn_search()
+        assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2)
+        e.set_target(tgt[::-1].copy())               # a new target under brute: built with the upload
+        assert e.stat("brute_kernel") == 3.0
+        idx, d2, _ = e.nn_search()
+    r2, rd22 = orc.nn_brute(src, tgt[::-1].copy())
+    assert np.array_equal(idx, r2) and np.array_equal(d2, rd22)
