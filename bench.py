@@ -29,8 +29,9 @@ k_nn_search_sorted (OA_NN_SORT=0: its predecessor k_nn_search_filtered).  It is 
 with the instruction count from the committed PMC pass (profiles/hbm_traffic.json, stamped with the kernel name and
 the commit it was collected at) and the launch time measured live with hipEvents on the kernel's stream.  The chip does
 not hold 2.4 GHz under this load (1.8-2.1 GHz, box to box), so the line also carries every launch's time (`launch_ms`:
-min / median / max), what v_fma_f32 issues on THIS box right before and right after the timed loop
-(`measured_issue_ceiling`, with the shader clock under that load) and `frac_of_measured_ceiling`.  The
+min / median / max), what v_add_f32 (full rate) and v_min3_f32 (half rate) issue on THIS box right before and right after
+the timed loop (`measured_issue_ceiling`, with the shader clock under that load), `frac_of_measured_ceiling` (instructions
+counted alike) and `frac_of_measured_mix_ceiling` (the hot loop's share of half-rate instructions priced at their own rate).  The
 SURVEY's algorithmic figure -- 8 flop per (source, target) pair -- is reported as `effective_tflops`: the kernel's
 conservative filter proves most pairs losers in ~2 instructions, so that figure can exceed what the chip executes and
 is NOT a roofline fraction.  `cpu_baseline` times the CPU oracle (KD-tree + Kabsch; OpenMP on all host cores) on a
@@ -60,6 +61,10 @@ FLOP_PER_PAIR = 8                    # 3 sub, 3 mul, 2 add (difference-form squa
 #   k_nn_search_sorted   (32 sub + 12 min + 8 min3 + 4 cmp) / 32 pairs = 1.75, + ~7 % of the blocks going on to level 1
 #   k_nn_search_filtered (64 fma + 16 min3 + 4 cmp) / 32 pairs
 VALU_PER_PAIR_ISA = {"k_nn_search_sorted": 1.95, "k_nn_search_filtered": 2.7}
+# share of half-rate instructions (v_min_f32 / v_min3_f32 / v_cmp_*_f32, tools/valu_rates.hip) in the hot loop, from the ISA:
+#   k_nn_search_sorted   36 of 102 per 64 pairs (64 v_sub + v_mov | 28 v_min3 + 4 v_min + 4 v_cmp)
+#   k_nn_search_filtered 20 of 84 per 32 pairs (64 v_fma | 16 v_min3 + 4 v_cmp)
+HALF_RATE_SHARE = {"k_nn_search_sorted": 36.0 / 102.0, "k_nn_search_filtered": 20.0 / 84.0}
 BRUTE_KERNELS = {3.0: "k_nn_search_sorted", 1.0: "k_nn_search_filtered", 2.0: "k_nn_search_mfma", 0.0: "k_nn_search"}
 KERNELS = {"brute": "k_nn_search_sorted", "grid": "k_nn_search_grid", "surface_grid": "k_tri_search_grid",
            "surface_tree": "k_bvh_search"}
@@ -253,7 +258,7 @@ def surface_leg(args, local_rank):
 # the per-shard search time + ~30 us of reduce / exchange / solve)
 C5_PREDICTED_MS_PER_ITERATION = {1: 2.06, 8: 0.35}
 # the headline workload (BASELINE config 4 at N = 8), brute-force kernel: one GPU measured (round 5, k_nn_search_sorted: 35.9 ms),
-# 8 GPUs PREDICTED from the 125k-point shard's iteration time on one GPU (4.98 ms, profiles/r05t_baseline_configs.txt) + the
+# 8 GPUs PREDICTED from the 125k-point shard's iteration time on one GPU (4.98 ms, profiles/r05w_baseline_configs.txt) + the
 # exchange (derivation: docs/HISTORY.md 4.7)
 C4_PREDICTED_MS_PER_ITERATION = {1: 35.9, 8: 5.02}
 
@@ -495,7 +500,7 @@ def main():
         return r, dt, ms
 
     def ceiling():
-        """What the vector ALUs issue right now (5 ms of v_fma_f32 on every SIMD, oa_measure_valu_ceiling) and the shader clock
+        """What the vector ALUs issue right now (5 ms of v_add_f32 / v_min3_f32 on every SIMD, oa_measure_valu_ceiling) and the shader clock
         under that load: taken right before and right after the timed loop, it tells a throttling box from a slower kernel."""
         try:
             return eng.valu_ceiling(5.0)
@@ -606,6 +611,17 @@ def main():
                    % (world, exchange))
         ceil_t = [c["tlaneops"] for c in (ceil_before, ceil_after) if "tlaneops" in c and c["tlaneops"] > 0]
         ceil_now = min(ceil_t) if ceil_t else None                           # the lower of the two: the conservative denominator
+        half_share = HALF_RATE_SHARE.get(brute_kernel)
+        mix_frac = None
+        if half_share is not None:
+            # the time the executed instructions need at the rates measured before / after the timed loop, over the time the
+            # launch took: both are given (the clock inside a 2 s loop lies between the two burns')
+            mix_frac = {}
+            for when, cm in (("before_timed_loop", ceil_before), ("after_timed_loop", ceil_after)):
+                if cm.get("tlaneops", 0) > 0 and cm.get("tlaneops_min3", 0) > 0:
+                    need_s = per_pair * pairs * ((1.0 - half_share) / (cm["tlaneops"] * 1e12) + half_share / (cm["tlaneops_min3"] * 1e12))
+                    mix_frac[when] = need_s / (nn_ms * 1e-3)
+            mix_frac = mix_frac or None
         out = {
             "metric": "ICP iterations/sec + ms/NN-search, 1M<->1M verts",
             "value": args.steps / elapsed,
@@ -646,9 +662,13 @@ def main():
                          # shader clock under that load (nominal: 78.6 T lane-ops/s at 2400 MHz)
                          "frac_of_nominal": laneops / VALU_PEAK_TLANEOPS,
                          "measured_issue_ceiling": {"unit": "Tlane-op/s", "instruction": "v_add_f32 (two register sources: one wave-instruction per SIMD every two cycles = 32 lanes per clock), "
-                                                                   "16 independent chains, 8 waves per SIMD, ~2.5 ms; v_fma_f32 with three register sources beside it",
+                                                                   "16 independent chains, 8 waves per SIMD, ~2.5 ms; v_min3_f32 (`tlaneops_min3`: the half-rate class) beside it",
                                                     "before_timed_loop": ceil_before, "after_timed_loop": ceil_after, "used": ceil_now},
                          "frac_of_measured_ceiling": (laneops / ceil_now) if ceil_now else None,
+                         # the same with the half-rate instructions of the hot loop priced at their own measured rate: the time
+                         # the executed instructions need at this box's rates / the time the launch took
+                         "half_rate_instruction_share": half_share,
+                         "frac_of_measured_mix_ceiling": mix_frac,
                          "formula": "frac = valu_instructions_per_pair x pairs_per_launch / avg_launch_ms / 78.6e12 lane-ops/s "
                                     "(256 CU x 4 SIMD x 32 lanes x 2.4 GHz); valu_instructions_per_pair = SQ_INSTS_VALU x 64 / "
                                     "pairs from the committed PMC pass (profiles/), avg_launch_ms = hipEvent pairs around "

@@ -282,9 +282,10 @@ int oa_get_history(oa_ctx *ctx, int32_t max_n, double *step_M, float *step_new,
  * were written (<= max_n).  Multi-device context: its first device.  (bench.py: per-launch min / median / max) */
 int oa_get_search_ms(oa_ctx *ctx, int32_t max_n, double *ms);
 /* Diagnostic for bench.py's roofline (no counterpart in the reference): what the vector ALUs issue right now -- ~target_ms of
- * independent v_add_f32 / v_fma_f32 chains on every SIMD, 8 waves each.  out[0] = T lane-ops/s of v_add_f32 (two register
+ * independent v_add_f32 / v_min3_f32 chains on every SIMD, 8 waves each.  out[0] = T lane-ops/s of v_add_f32 (two register
  * sources: the issue rate itself), out[1] = shader clock in MHz during that burn, out[2] = duration in ms, out[3] = T lane-ops/s
- * of v_fma_f32 with three register sources.  The brute-force search is bound by exactly this rate. */
+ * of v_min3_f32 (the half-rate class: v_min_f32, v_min3_f32, v_cmp_*_f32).  The brute-force search is bound by exactly these
+ * rates, weighted by its instruction mix. */
 int oa_measure_valu_ceiling(oa_ctx *ctx, double target_ms, double out[4]);
 
 /* ---- split-phase loop for one-process-per-GPU sharding ---------------------------------------- */

@@ -3385,14 +3385,14 @@ OA_EXPORT int oa_measure_valu_ceiling(oa_ctx *c, double target_ms, double out[4]
     HIPCHK(hipEventRecord(c->ev[3], c->stream));
     unsigned long long clk[4];
     if ((rc = read_small(c, clk, d_clk, sizeof(clk)))) return rc;
-    float ms_fma = 0.f, ms_add = 0.f;
-    HIPCHK(hipEventElapsedTime(&ms_fma, c->ev[0], c->ev[1]));
+    float ms_min3 = 0.f, ms_add = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms_min3, c->ev[0], c->ev[1]));
     HIPCHK(hipEventElapsedTime(&ms_add, c->ev[2], c->ev[3]));
     const double laneops = (double)blocks * 256.0 * (double)oa::VALU_BURN_CHAINS * (double)(iters / 2);
     out[0] = ms_add > 0.f ? laneops / ((double)ms_add * 1e-3) / 1e12 : 0.0;       // v_add_f32: the issue rate
     out[1] = clk[3] > 0 ? (double)clk[2] / (double)clk[3] * c->wall_clock_khz * 1e-3 : 0.0;
-    out[2] = (double)(ms_fma + ms_add);
-    out[3] = ms_fma > 0.f ? laneops / ((double)ms_fma * 1e-3) / 1e12 : 0.0;       // v_fma_f32, three register sources
+    out[2] = (double)(ms_min3 + ms_add);
+    out[3] = ms_min3 > 0.f ? laneops / ((double)ms_min3 * 1e-3) / 1e12 : 0.0;     // v_min3_f32: the half-rate class
     return OA_OK;
 }
 

@@ -2047,8 +2047,9 @@ constexpr int STATUS_EXCHANGE = -9;  // OA_E_RCCL: a rank's post did not arrive 
 // oa_measure_valu_ceiling: VALU_BURN_CHAINS independent v_fma_f32 chains per lane, `iters` times; workgroup 0's first wave reads
 // the shader clock and the constant-rate clock at both ends (clk[0] += shader cycles, clk[1] += wall_clock64 ticks)
 constexpr int VALU_BURN_CHAINS = 16;
-// OP 0: v_fma_f32 with three vector-register sources (0.89 of the issue rate on gfx950: operand reads); OP 1: v_add_f32, two
-// sources -- one wave-instruction per SIMD every two cycles, the issue rate itself
+// OP 0: v_min3_f32, the half-rate class of gfx950 (v_min_f32, v_min3_f32, v_cmp_*_f32: tools/valu_rates.hip) that a third of
+// k_nn_search_sorted's instructions belong to; OP 1: v_add_f32, two sources -- one wave-instruction per SIMD every two cycles,
+// the issue rate itself
 template <int OP>
 __global__ __launch_bounds__(256) void k_valu_burn(float *__restrict__ sink, float a, float b, int iters, unsigned long long *__restrict__ clk)
 {
@@ -2061,7 +2062,7 @@ __global__ __launch_bounds__(256) void k_valu_burn(float *__restrict__ sink, flo
         for (int u = 0; u < 4; ++u) {
 #pragma unroll
             for (int i = 0; i < VALU_BURN_CHAINS; ++i) {
-                if (OP == 0) asm volatile("v_fma_f32 %0, %1, %0, %2" : "+v"(acc[i]) : "v"(a), "v"(b));
+                if (OP == 0) asm volatile("v_min3_f32 %0, %0, %1, %2" : "+v"(acc[i]) : "v"(a), "v"(b));
                 else asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc[i]) : "v"(b));
             }
         }

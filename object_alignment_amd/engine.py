@@ -207,10 +207,10 @@ class IcpEngine:
         return out[:n].copy()
 
     def valu_ceiling(self, target_ms=5.0) -> dict:
-        """What the vector ALUs issue right now (oa_measure_valu_ceiling): v_add_f32 (the issue rate) and v_fma_f32 on every SIMD."""
+        """What the vector ALUs issue right now (oa_measure_valu_ceiling): v_add_f32 (the issue rate) and v_min3_f32 (the half-rate class) on every SIMD."""
         out = np.zeros(4, np.float64)
         capi.check(self._L.oa_measure_valu_ceiling(self._h, float(target_ms), capi.dptr(out)))
-        return {"tlaneops": float(out[0]), "shader_clock_mhz": float(out[1]), "ms": float(out[2]), "tlaneops_fma_3_sources": float(out[3])}
+        return {"tlaneops": float(out[0]), "shader_clock_mhz": float(out[1]), "ms": float(out[2]), "tlaneops_min3": float(out[3])}
 
     def enqueued_iterations(self):
         """Iterations the host enqueued for every child in the last run() (OA_STAT_ENQUEUED_CHILD + i): all equal, whatever

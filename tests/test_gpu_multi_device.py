@@ -619,6 +619,9 @@ def test_bench_two_shards_reports_its_exchange(monkeypatch):
     c = r["measured_issue_ceiling"]
     assert 20.0 < c["used"] < 90.0 and 800.0 < c["after_timed_loop"]["shader_clock_mhz"] < 3000.0, c
     assert 0.0 < r["frac_of_measured_ceiling"] < 1.2
+    assert 10.0 < c["after_timed_loop"]["tlaneops_min3"] < c["after_timed_loop"]["tlaneops"]     # the half-rate class, measured
+    assert r["kernel"] == "k_nn_search_sorted" and 0.2 < r["half_rate_instruction_share"] < 0.5
+    assert all(0.0 < v < 1.5 for v in r["frac_of_measured_mix_ceiling"].values()) and len(r["frac_of_measured_mix_ceiling"]) == 2
 
 
 # ---------------------------------------------------------------------------------------------------------------------
