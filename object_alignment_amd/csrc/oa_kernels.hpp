@@ -1023,7 +1023,7 @@ __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_filt
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_nn_search_sorted : k_nn_search_filtered with one more level in front (round 5) -- ~2 full-rate VALU ops per pair instead of ~3.1
+// k_nn_search_sorted : k_nn_search_filtered with one more level in front (round 5) -- 1.84 VALU instructions per pair instead of 3.0
 // ------------------------------------------------------------------------------------------------
 // Still every (source, target) pair gets its own arithmetic; what changes is the ORDER of the target and a cheaper first test.
 //   The target's images are laid out in the order of the coordinate u along the cloud's longest axis (a 30-bit quantised key,
@@ -1035,6 +1035,7 @@ __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_filt
 //                       has t^2 > base (the distance along one axis never exceeds the 3-D distance; no rounding at all on this
 //                       side of the inequality).  fl32(qu_j - hu) = (qu_j - hu)(1 + e), |e| <= 2^-24, so
 //                       a_j > T1 = round_up(sqrt(base) (1 + 2^-22))  =>  t >= a_j / (1 + 2^-24) > sqrt(base).
+//                       (Flushed denormals only ever make a_j smaller: fewer pairs skipped, never a wrong one.)
 //                       For all slabs but the few around the wave's own u range every pair fails here.
 //   levels 1, 2, 3      as k_nn_search_filtered (2-D score, 3-D score, exact metric), reached by ~6 % of the blocks at 1M <-> 1M.
 // Indices: position j of the sorted images holds original vertex tidx[j]; the exact path compares and reports ORIGINAL indices
@@ -1256,7 +1257,7 @@ __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_sort
         }
         const int gbase = g_begin + OA_TILE_AT(t) * TG;
         // 16 targets x R points per skip test.  On gfx950 v_sub_f32 issues at full rate, v_min_f32, v_min3_f32 and v_cmp_*_f32 at
-        // half rate (tools/_exp/burn.hip): the tree is all min3 (two comparisons per instruction), one compare per 16 targets.
+        // half rate (tools/valu_rates.hip): the tree is all min3 (two comparisons per instruction), one compare per 16 targets.
         constexpr int GW = 4;
         for (int g = 0; g < TG; g += GW) {
             float4 QU[GW];
