@@ -132,7 +132,9 @@ const char *oa_version(void);
 int         oa_set_stream(oa_ctx *ctx, void *stream);
 
 /* Correspondence-search strategy.  Every mode returns the same (index, d2) per source point, bit for bit:
- *   OA_SEARCH_BRUTE  k_nn_search_filtered: LDS-tiled brute force over all target vertices (the north-star kernel)
+ *   OA_SEARCH_BRUTE  k_nn_search_sorted: LDS-tiled brute force over all target vertices (the north-star kernel); its images of
+ *                    the target, in the order of the longest axis, are built with the upload when this mode is set, else by
+ *                    the call that sets it (a target uploaded for the other modes does not pay for them)
  *   OA_SEARCH_GRID   k_nn_search_grid: exact search through a uniform grid; points it cannot settle within a few
  *                    rings (far from the target: partial overlaps, holes) are finished by the tree search
  *   OA_SEARCH_BVH    k_bvh_search: every query through the 64-ary bounding-box tree, one wavefront per query
