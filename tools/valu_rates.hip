@@ -60,17 +60,17 @@ template <int OP> __global__ __launch_bounds__(256) void burn(float *out, int tr
 }
 template <int OP> void run(const char *name)
 {
-    float *d; hipMalloc(&d, 4);
-    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float *d; (void)hipMalloc(&d, 4);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     const int trips = 20000, blocks = 256 * 8;     // 8 waves / SIMD
     burn<OP><<<blocks, 256>>>(d, 100, 1.0f);
-    hipDeviceSynchronize();
-    hipEventRecord(e0); burn<OP><<<blocks, 256>>>(d, trips, 1.0f); hipEventRecord(e1); hipEventSynchronize(e1);
-    float ms; hipEventElapsedTime(&ms, e0, e1);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0); burn<OP><<<blocks, 256>>>(d, trips, 1.0f); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     const double winst = (double)blocks * 4 * trips * 64;            // wave-instructions
     const double per_simd = winst / 1024.0;
     printf("%-34s %8.3f ms  %7.2f G wave-instr/s/SIMD  (%.3f ns per instr per SIMD)\n", name, ms, per_simd / ms / 1e6, ms * 1e6 / per_simd);
-    hipFree(d);
+    (void)hipFree(d);
 }
 int main()
 {
