@@ -257,10 +257,10 @@ def surface_leg(args, local_rank):
 # test, first 10 iterations; the 1-GPU figure is measured -- profiles/r03e_baseline_configs.txt --, the 8-GPU one predicted from
 # the per-shard search time + ~30 us of reduce / exchange / solve)
 C5_PREDICTED_MS_PER_ITERATION = {1: 2.06, 8: 0.35}
-# the headline workload (BASELINE config 4 at N = 8), brute-force kernel: one GPU measured (round 5, k_nn_search_sorted: 35.9 ms),
-# 8 GPUs PREDICTED from the 125k-point shard's iteration time on one GPU (4.98 ms, profiles/r05w_baseline_configs.txt) + the
+# the headline workload (BASELINE config 4 at N = 8), brute-force kernel: one GPU measured (round 5, k_nn_search_sorted: 32.7 ms),
+# 8 GPUs PREDICTED from the 125k-point shard's iteration time on one GPU (4.53 ms, profiles/r05z_baseline_configs.txt) + the
 # exchange (derivation: docs/HISTORY.md 4.7)
-C4_PREDICTED_MS_PER_ITERATION = {1: 35.9, 8: 5.02}
+C4_PREDICTED_MS_PER_ITERATION = {1: 32.7, 8: 4.56}
 
 
 def c5_leg(args, n_gpus, in_process, world, rank, local_rank, devices, dev, backend):
@@ -528,6 +528,10 @@ def main():
     except Exception:
         brute_kind = 3.0
     try:
+        search_clock_mhz = eng.stat("search_clock_mhz")           # the shader clock during the last launch of the timed loop
+    except Exception:
+        search_clock_mhz = None
+    try:
         launch_ms = eng.search_ms()
     except Exception:
         launch_ms = np.zeros(0)
@@ -622,6 +626,19 @@ def main():
                     need_s = per_pair * pairs * ((1.0 - half_share) / (cm["tlaneops"] * 1e12) + half_share / (cm["tlaneops_min3"] * 1e12))
                     mix_frac[when] = need_s / (nn_ms * 1e-3)
             mix_frac = mix_frac or None
+        # ... and at the clock the chip held DURING the search (one workgroup's cycle counter against its constant-rate counter,
+        # OA_STAT_SEARCH_CLOCK_MHZ): issue rates scale with the clock, so the burns' cycles per instruction (mean of the two)
+        # price the executed instructions in cycles, against launch time x that clock
+        mix_at_kernel_clock = None
+        burns = [cm for cm in (ceil_before, ceil_after) if cm.get("tlaneops", 0) > 0 and cm.get("tlaneops_min3", 0) > 0 and cm.get("shader_clock_mhz", 0) > 0]
+        if half_share is not None and burns and search_clock_mhz and search_clock_mhz > 0:
+            lanes = 256.0 * 4.0 * 64.0                                       # lane-ops per wave-instruction x SIMDs
+            cpi_full = float(np.mean([cm["shader_clock_mhz"] * 1e6 * lanes / (cm["tlaneops"] * 1e12) for cm in burns]))
+            cpi_half = float(np.mean([cm["shader_clock_mhz"] * 1e6 * lanes / (cm["tlaneops_min3"] * 1e12) for cm in burns]))
+            need_cycles = per_pair * pairs / lanes * ((1.0 - half_share) * cpi_full + half_share * cpi_half)
+            mix_at_kernel_clock = {"shader_clock_mhz_during_search": search_clock_mhz,
+                                   "cycles_per_wave_instruction": {"v_add_f32": cpi_full, "v_min3_f32": cpi_half},
+                                   "frac": need_cycles / (nn_ms * 1e-3 * search_clock_mhz * 1e6)}
         out = {
             "metric": "ICP iterations/sec + ms/NN-search, 1M<->1M verts",
             "value": args.steps / elapsed,
@@ -669,6 +686,7 @@ def main():
                          # the executed instructions need at this box's rates / the time the launch took
                          "half_rate_instruction_share": half_share,
                          "frac_of_measured_mix_ceiling": mix_frac,
+                         "mix_ceiling_at_the_search_clock": mix_at_kernel_clock,
                          "formula": "frac = valu_instructions_per_pair x pairs_per_launch / avg_launch_ms / 78.6e12 lane-ops/s "
                                     "(256 CU x 4 SIMD x 32 lanes x 2.4 GHz); valu_instructions_per_pair = SQ_INSTS_VALU x 64 / "
                                     "pairs from the committed PMC pass (profiles/), avg_launch_ms = hipEvent pairs around "

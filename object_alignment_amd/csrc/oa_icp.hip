@@ -416,6 +416,8 @@ struct oa_ctx {
     double pivot[3] = { 0, 0, 0 };
     // launch geometry for k_nn_search
     int n_splits = 1, acc_blocks = 1;
+    int n_splits_seeded = 1;         // k_nn_search_sorted once the winner records hold seeds: more, shorter splits (plan_geometry)
+    bool win_seeds = false;          // an accumulation has written winner records since the last upload / oa_reset_seeds
     int tile_groups = oa::FTILE_GROUPS;   // LDS tile of k_nn_search_filtered: 256 groups, 64 for small targets
     int R_env = 0;                      // OA_NN_R override (0 = choose from the shard size)
     bool use_filter = true;
@@ -522,6 +524,18 @@ void plan_geometry(oa_ctx *c)
     const int forced = env_int("OA_NN_SPLITS", 0);
     if (forced > 0) splits = std::min(forced, tiles_total);
     c->n_splits = splits;                                          // the kernels cut the tiles into exactly this many ranges (split_range)
+    // k_nn_search_sorted with seeds: a workgroup's points reach levels 1-3 only in the split that holds their own slab, so short
+    // splits (>= 3 tiles each, up to 512 workgroups per CU in the grid) even the workgroups out and keep a split's few tiles in
+    // its XCD's L2: 1M <-> 1M 37.0 -> 34.5 ms, the 125k shard 5.14 -> 4.74 ms (tools/sweep_sorted_splits.py,
+    // profiles/r05y_sorted_splits.txt).  WITHOUT seeds every split has to find a best of its own first, and more splits cost
+    // (52 -> 80 ms at 136): the first search of a loop keeps the count above.
+    int seeded = std::min(tiles_total / 3, (c->n_cu * 512 + src_blocks - 1) / src_blocks);
+    if (seeded > 8) seeded = std::min(tiles_total, ((seeded + 7) / 8) * 8);
+    seeded = std::max(splits, seeded);
+    const int forced_seeded = env_int("OA_NN_SPLITS_SEEDED", 0);
+    if (forced > 0) seeded = splits;
+    if (forced_seeded > 0) seeded = std::min(forced_seeded, tiles_total);
+    c->n_splits_seeded = seeded;
     const int acc_cap = std::max(1, std::min(oa::ACC_MAX_BLOCKS, env_int("OA_ACC_BLOCKS", 512)));
     c->acc_blocks = std::max(1, std::min(acc_cap, (c->ns + oa::ACC_THREADS - 1) / oa::ACC_THREADS));
 }
@@ -827,7 +841,7 @@ int launch_nn_impl(oa_ctx *c, bool acc);
 int launch_nn(oa_ctx *c, bool acc = false)
 {
     const int rc = launch_nn_impl(c, acc);
-    if (rc == OA_OK) c->seeded = true;
+    if (rc == OA_OK) { c->seeded = true; if (acc && !c->surface) c->win_seeds = true; }
     return rc;
 }
 int launch_nn_impl(oa_ctx *c, bool acc)
@@ -911,10 +925,11 @@ int launch_nn_impl(oa_ctx *c, bool acc)
         const bool small = (c->tile_groups == 64);
 #define OA_NNS_ARGS c->d_state, c->d_src4, (const float4 *)c->d_tgs, (const float4 *)c->d_tfs, (const float4 *)c->d_tf3s, (const int4 *)c->d_tidx, \
                     (const float4 *)c->d_win, c->n_groups_pad, c->sax[0], c->sax[1], c->d_keys
+        const dim3 sgrid((unsigned)(c->win_seeds ? c->n_splits_seeded : c->n_splits), grid.y);   // (plan_geometry)
 #define OA_LAUNCH_S(RR)                                                                                              \
         do {                                                                                                         \
-            if (small) hipLaunchKernelGGL((oa::k_nn_search_sorted<RR, 64>), grid, block, 0, c->stream, OA_NNS_ARGS);  \
-            else hipLaunchKernelGGL((oa::k_nn_search_sorted<RR, oa::FTILE_GROUPS>), grid, block, 0, c->stream, OA_NNS_ARGS); \
+            if (small) hipLaunchKernelGGL((oa::k_nn_search_sorted<RR, 64>), sgrid, block, 0, c->stream, OA_NNS_ARGS);  \
+            else hipLaunchKernelGGL((oa::k_nn_search_sorted<RR, oa::FTILE_GROUPS>), sgrid, block, 0, c->stream, OA_NNS_ARGS); \
         } while (0)
         switch (c->R) {
         case 1: OA_LAUNCH_S(1); break;
@@ -954,6 +969,7 @@ int launch_nn_impl(oa_ctx *c, bool acc)
 
 int launch_accumulate(oa_ctx *c, bool emit, int *nn_idx, float *nn_d2)
 {
+    if (!c->surface) c->win_seeds = true;                          // (the winner records of this pass seed the next search)
     oa::PairOut po{};
     const oa::NormalTest nrm = normal_test(c);
     if (emit) {
@@ -2371,7 +2387,7 @@ int set_target_common(oa_ctx *c, const float *xyz, int64_t n, int on_device, boo
     c->filter_ok = false;
     c->nt = (int)n;
     c->n_groups_pad = 0;
-    c->seeded = false;
+    c->seeded = false; c->win_seeds = false;
     // {index, safe radius} per slot: only the vertex searches read it (8 bytes per source point)
     if (!vertex_index || !c->grid_safe) dev_free(c->d_wsafe);
     else if (c->d_prev && !c->d_wsafe) HIPCHK(dev_malloc(&c->d_wsafe, sizeof(uint2) * (size_t)c->ns_pad));
@@ -2927,7 +2943,7 @@ int source_reset(oa_ctx *c, long long count, long long begin, long long n_verts)
     HIPCHK(dev_malloc(&c->d_prev, sizeof(int) * (size_t)c->ns_pad));
     HIPCHK(dev_malloc(&c->d_win, sizeof(float4) * (size_t)c->ns_pad));
     if (c->grid_safe && !c->surface) HIPCHK(dev_malloc(&c->d_wsafe, sizeof(uint2) * (size_t)c->ns_pad));   // (a vertex target set later allocates it: set_target_common)
-    c->seeded = false;
+    c->seeded = false; c->win_seeds = false;
     HIPCHK(dev_malloc(&c->d_sel, sizeof(int) * (size_t)c->ns_pad));
     dev_free(c->d_todo_list); dev_free(c->d_todo_count); dev_free(c->d_ulist);
     HIPCHK(dev_malloc(&c->d_todo_list, sizeof(int) * (size_t)c->ns_pad));
@@ -3209,7 +3225,7 @@ OA_EXPORT int oa_reset_seeds(oa_ctx *c)
     if (!c) return fail(OA_E_BAD_ARG, "null context");
     if (!c->subs.empty()) { if (c->loop_active) multi_abort(c); c->loop_active = false; }
     OA_ROUTE_ALL(c, oa_reset_seeds(sub));
-    c->seeded = false;
+    c->seeded = false; c->win_seeds = false;
     c->loop_active = false;
     if (!c->d_prev) return OA_OK;
     int rc = use_device(c);
@@ -3274,6 +3290,12 @@ OA_EXPORT int oa_get_stat(oa_ctx *c, int what, double *value)
     if (what == OA_STAT_EXCHANGE_US) {                                  // the slowest device's mean wait for the world's sums (one GPU: 0)
         *value = c->last_exchange_us;
         for (oa_ctx *sub : c->subs) *value = std::max(*value, sub->last_exchange_us);
+        return OA_OK;
+    }
+    if (what == OA_STAT_SEARCH_CLOCK_MHZ) {                             // (the host mirror holds the device state of the last oa_run / oa_run_end)
+        const oa_ctx *s = c->subs.empty() ? c : c->subs[0];
+        const unsigned long long cyc = s->h_state.search_clk[0], ticks = s->h_state.search_clk[1];
+        *value = ticks > 0 ? (double)cyc / (double)ticks * s->wall_clock_khz * 1e-3 : 0.0;
         return OA_OK;
     }
     if (what == OA_STAT_RCCL_FALLBACKS) { *value = c->xch && !c->parent ? (double)c->xch->rccl_fallbacks : 0.0; return OA_OK; }

@@ -70,6 +70,9 @@ struct DevState {
     // kernel leave the end of the previous iteration in t_prev_end, k_pair_accumulate its own start in t_acc_start
     unsigned long long t_prev_end, t_acc_start;
     unsigned long long t_xchg_start;  // multi-GPU: when this device's sums of the iteration were ready for the exchange (StepRecord::exchange_ticks)
+    // shader cycles and constant-rate ticks one workgroup in the middle of the last k_nn_search_sorted launch lived for: the clock
+    // the chip held DURING the search (OA_STAT_SEARCH_CLOCK_MHZ; bench.py prices the measured issue rates at this clock)
+    unsigned long long search_clk[2];
     // Shards in the zone where the tree search wins while the pose still moves (stale seeds, long reach) and the grid
     // search once it has settled: both are enqueued every iteration and `tree_turn` says whose turn it is.  Set by the
     // host for the first search (no seeds: tree) and by the solve kernel afterwards, from the same quantity the grid
@@ -1173,7 +1176,10 @@ __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_sort
     static_assert(LOADS >= 1 && LOADS <= 3, "k_nn_search_sorted: 1 .. 3 float4 per thread and tile");
     __shared__ float4 tile[2][TILE_F4];
     __shared__ short ord[SORT_ORDER_MAX];
+    __shared__ unsigned long long clk0[2];
     const int tid = threadIdx.x;
+    const bool clk_wg = (blockIdx.x == 0 && blockIdx.y == gridDim.y / 2 && tid == 0);   // one workgroup dispatched mid-launch
+    if (clk_wg) { clk0[0] = (unsigned long long)__builtin_readcyclecounter(); clk0[1] = wall_clock64(); }
     const double qmax = st->qmax;
     const float cx = st->tc[0], cy = st->tc[1], cz = st->tc[2];
     const int base = blockIdx.y * (NN_THREADS * R);
@@ -1303,6 +1309,11 @@ __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_sort
 #undef OA_STG_ON
 #undef OA_TILE_AT
 
+    if (clk_wg) {
+        DevState *ws = const_cast<DevState *>(st);
+        ws->search_clk[0] = (unsigned long long)__builtin_readcyclecounter() - clk0[0];
+        ws->search_clk[1] = wall_clock64() - clk0[1];
+    }
     // a split reports when it has something to say (k_nn_search_filtered); the seed's owner: seed index mod splits
 #pragma unroll
     for (int r = 0; r < R; ++r) {

@@ -622,6 +622,8 @@ def test_bench_two_shards_reports_its_exchange(monkeypatch):
     assert 10.0 < c["after_timed_loop"]["tlaneops_min3"] < c["after_timed_loop"]["tlaneops"]     # the half-rate class, measured
     assert r["kernel"] == "k_nn_search_sorted" and 0.2 < r["half_rate_instruction_share"] < 0.5
     assert all(0.0 < v < 1.5 for v in r["frac_of_measured_mix_ceiling"].values()) and len(r["frac_of_measured_mix_ceiling"]) == 2
+    mk = r["mix_ceiling_at_the_search_clock"]                      # ... priced at the clock the chip held during the search itself
+    assert 800.0 < mk["shader_clock_mhz_during_search"] < 3000.0 and 0.0 < mk["frac"] < 1.5, mk
 
 
 # ---------------------------------------------------------------------------------------------------------------------
