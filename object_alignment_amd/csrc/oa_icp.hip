@@ -417,6 +417,7 @@ struct oa_ctx {
     // launch geometry for k_nn_search
     int n_splits = 1, acc_blocks = 1;
     int n_splits_seeded = 1;         // k_nn_search_sorted once the winner records hold seeds: more, shorter splits (plan_geometry)
+    bool nn_home_pass = true;        // the first search of a loop: k_nn_seed_sorted + a seeded launch (OA_NN_HOME_PASS=0: ONE unseeded launch)
     bool win_seeds = false;          // an accumulation has written winner records since the last upload / oa_reset_seeds
     int tile_groups = oa::FTILE_GROUPS;   // LDS tile of k_nn_search_filtered: 256 groups, 64 for small targets
     int R_env = 0;                      // OA_NN_R override (0 = choose from the shard size)
@@ -925,18 +926,35 @@ int launch_nn_impl(oa_ctx *c, bool acc)
         const bool small = (c->tile_groups == 64);
 #define OA_NNS_ARGS c->d_state, c->d_src4, (const float4 *)c->d_tgs, (const float4 *)c->d_tfs, (const float4 *)c->d_tf3s, (const int4 *)c->d_tidx, \
                     (const float4 *)c->d_win, c->n_groups_pad, c->sax[0], c->sax[1], c->d_keys
-        const dim3 sgrid((unsigned)(c->win_seeds ? c->n_splits_seeded : c->n_splits), grid.y);   // (plan_geometry)
+        // with seeds: one launch over n_splits_seeded splits.  Without (the first search of a loop): k_nn_seed_sorted -- every point
+        // against the tile that holds its own slab --, then the whole search seeded from what that left in keys (OA_NN_HOME_PASS=0:
+        // one unseeded launch over n_splits splits, as until r05z)
+        const bool two = !c->win_seeds && c->nn_home_pass && c->n_splits_seeded > 1;
+        dim3 sgrid((unsigned)((c->win_seeds || two) ? c->n_splits_seeded : c->n_splits), grid.y);
+        int pass = 0;
 #define OA_LAUNCH_S(RR)                                                                                              \
         do {                                                                                                         \
-            if (small) hipLaunchKernelGGL((oa::k_nn_search_sorted<RR, 64>), sgrid, block, 0, c->stream, OA_NNS_ARGS);  \
-            else hipLaunchKernelGGL((oa::k_nn_search_sorted<RR, oa::FTILE_GROUPS>), sgrid, block, 0, c->stream, OA_NNS_ARGS); \
+            if (small) hipLaunchKernelGGL((oa::k_nn_search_sorted<RR, 64>), sgrid, block, 0, c->stream, OA_NNS_ARGS, pass);  \
+            else hipLaunchKernelGGL((oa::k_nn_search_sorted<RR, oa::FTILE_GROUPS>), sgrid, block, 0, c->stream, OA_NNS_ARGS, pass); \
         } while (0)
-        switch (c->R) {
-        case 1: OA_LAUNCH_S(1); break;
-        case 2: OA_LAUNCH_S(2); break;
-        case 8: OA_LAUNCH_S(8); break;
-        default: OA_LAUNCH_S(4); break;
+#define OA_LAUNCH_S_R()                     \
+        switch (c->R) {                     \
+        case 1: OA_LAUNCH_S(1); break;      \
+        case 2: OA_LAUNCH_S(2); break;      \
+        case 8: OA_LAUNCH_S(8); break;      \
+        default: OA_LAUNCH_S(4); break;     \
         }
+        if (two) {
+            const dim3 sb((unsigned)((c->ns_pad + 255) / 256));
+            if (small) hipLaunchKernelGGL((oa::k_nn_seed_sorted<64>), sb, dim3(256), 0, c->stream, (const oa::DevState *)c->d_state, (const float4 *)c->d_src4, c->ns_pad,
+                                          (const float4 *)c->d_tgs, (const float4 *)c->d_tfs, (const int4 *)c->d_tidx, c->n_groups_pad, c->sax[0], c->d_keys);
+            else hipLaunchKernelGGL((oa::k_nn_seed_sorted<oa::FTILE_GROUPS>), sb, dim3(256), 0, c->stream, (const oa::DevState *)c->d_state, (const float4 *)c->d_src4, c->ns_pad,
+                                    (const float4 *)c->d_tgs, (const float4 *)c->d_tfs, (const int4 *)c->d_tidx, c->n_groups_pad, c->sax[0], c->d_keys);
+            HIPCHK(hipGetLastError());
+            pass = 2;
+        }
+        OA_LAUNCH_S_R();
+#undef OA_LAUNCH_S_R
 #undef OA_LAUNCH_S
 #undef OA_NNS_ARGS
     } else if (c->filter_ok && c->use_filter) {
@@ -1936,6 +1954,7 @@ OA_EXPORT int oa_create(oa_ctx **out, int device)
     c->turn_frac = env_double("OA_TURN_FRAC", 0.1);
     c->use_filter = env_int("OA_NN_FILTER", 1) != 0;
     c->nn_sort = env_int("OA_NN_SORT", 1) != 0;
+    c->nn_home_pass = env_int("OA_NN_HOME_PASS", 1) != 0;
     c->nn_mfma = env_int("OA_NN_MFMA", 0);
     c->mfma_wps = env_int("OA_MFMA_WPS", 4);
     c->grid_mode = env_int("OA_NN_GRID", -1);

@@ -1157,6 +1157,46 @@ __device__ __forceinline__ bool sorted_finish_group(const float4 AU, const float
     return improved;
 }
 
+// Seeds for the first search of a loop: every point against the ONE tile of the sorted images whose slab holds its own u (exact
+// metric, original indices, lowest index on ties) -> keys.  1024 pairs per point instead of N_t; what it leaves is a distance really
+// achieved (a valid starting best for k_nn_search_sorted pass 2), typically a few times the true nearest distance.
+template <int TG>
+__global__ __launch_bounds__(256) void k_nn_seed_sorted(const DevState *__restrict__ st, const float4 *__restrict__ src4, int ns_pad,
+                                                        const float4 *__restrict__ tgs, const float4 *__restrict__ tfs,
+                                                        const int4 *__restrict__ tidx, int n_groups_pad, int au,
+                                                        unsigned long long *__restrict__ keys)
+{
+    if (st->halt) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ns_pad) return;
+    const float4 p = src4[i];
+    float px, py, pz;
+    co_find(st, p.x, p.y, p.z, px, py, pz);
+    const float h[3] = { (float)((double)px - (double)st->tc[0]), (float)((double)py - (double)st->tc[1]), (float)((double)pz - (double)st->tc[2]) };
+    const float hu = au == 0 ? h[0] : (au == 1 ? h[1] : h[2]);
+    const int tiles = n_groups_pad / TG;
+    int a = 0, b = tiles;                                          // first tile that starts beyond hu
+    while (a < b) { const int mid = (a + b) >> 1; if (tfs[3ll * TG * mid].x <= hu) a = mid + 1; else b = mid; }
+    const long long g0 = (long long)(a > 0 ? a - 1 : 0) * TG;
+    float best = INFINITY;
+    uint32_t bi = IDX_NONE;
+    for (int g = 0; g < TG; ++g) {
+        const float4 *eg = tgs + 3ll * (g0 + g);
+        const float4 X = eg[0], Y = eg[1], Z = eg[2];
+        const int4 J = tidx[g0 + g];
+        const float e0 = d2_metric(px, py, pz, X.x, Y.x, Z.x), e1 = d2_metric(px, py, pz, X.y, Y.y, Z.y);
+        const float e2 = d2_metric(px, py, pz, X.z, Y.z, Z.z), e3 = d2_metric(px, py, pz, X.w, Y.w, Z.w);
+        if (e0 < best || (e0 == best && (uint32_t)J.x < bi)) { best = e0; bi = (uint32_t)J.x; }
+        if (e1 < best || (e1 == best && (uint32_t)J.y < bi)) { best = e1; bi = (uint32_t)J.y; }
+        if (e2 < best || (e2 == best && (uint32_t)J.z < bi)) { best = e2; bi = (uint32_t)J.z; }
+        if (e3 < best || (e3 == best && (uint32_t)J.w < bi)) { best = e3; bi = (uint32_t)J.w; }
+    }
+    if (best < INFINITY && bi != IDX_NONE) {                       // (pads: +inf coordinates, index -1 -- never a seed)
+        const unsigned long long key = ((unsigned long long)__float_as_uint(best) << 32) | bi;
+        if (key < keys[i]) keys[i] = key;                          // (keys: KEY_EMPTY, or what an earlier pass left)
+    }
+}
+
 constexpr int SORT_ORDER_MAX = 1024;      // tiles of one split whose middle-out order fits the LDS table (more: ascending)
 
 template <int R, int TG = FTILE_GROUPS>
@@ -1168,8 +1208,11 @@ __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_sort
                                                                  const int4 *__restrict__ tidx,
                                                                  const float4 *__restrict__ win,
                                                                  int n_groups_pad, int au, int av,
-                                                                 unsigned long long *__restrict__ keys)
+                                                                 unsigned long long *keys, int pass)
 {
+    // pass 0: seeds from the winner records of the last accumulation (none on the first search of a loop: every split then has to
+    // find a best of its own before it can skip anything).  pass 2: seeds from keys, where k_nn_seed_sorted has left every point's
+    // nearest vertex within its own slab -- a distance really achieved, usually a few times the true one: enough for level 0.
     if (st->halt) return;
     constexpr int TILE_F4 = TG * 3, LOADS = (TILE_F4 + NN_THREADS - 1) / NN_THREADS;   // TG = 256: 3 whole rounds; TG = 64: 192 of 256 threads
     constexpr bool WHOLE = TILE_F4 % NN_THREADS == 0;
@@ -1202,10 +1245,15 @@ __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_sort
         hd[r] = (au + av == 1) ? h2 : ((au + av == 2) ? h1 : h0);
         best[r] = INFINITY;
         bidx[r] = IDX_NONE;
-        const float4 sw = win ? win[i] : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+        const float4 sw = (win && pass == 0) ? win[i] : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
         if (__float_as_int(sw.w) >= 0) {
             const float d = d2_metric(px[r], py[r], pz[r], sw.x, sw.y, sw.z);
             if (d < INFINITY) { best[r] = d; bidx[r] = (uint32_t)__float_as_int(sw.w); }
+        }
+        if (pass == 2) {                                           // (a 64-bit load: whatever another split has merged by now is as good)
+            const unsigned long long k = __hip_atomic_load(keys + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float kd = __uint_as_float((uint32_t)(k >> 32));
+            if ((uint32_t)k != IDX_NONE && kd < INFINITY) { best[r] = kd; bidx[r] = (uint32_t)k; }
         }
         sorted_thresholds(best[r], hu[r], hv[r], hd[r], qmax, thr1[r], thr2[r]);
     }
@@ -1319,7 +1367,9 @@ __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_sort
     for (int r = 0; r < R; ++r) {
         const unsigned long long key = ((unsigned long long)__float_as_uint(best[r]) << 32) | bidx[r];
         unsigned long long *dst = keys + OA_SLOT(r);
-        if (gridDim.x == 1) *dst = key;
+        if (pass != 0) {                                           // merges into whatever keys holds: monotone
+            if (key < __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(dst, key);
+        } else if (gridDim.x == 1) *dst = key;
         else {
             // (the seed again, from the slot's record -- the same arithmetic as at the start -- instead of two registers per point
             //  held through the scan)

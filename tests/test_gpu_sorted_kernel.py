@@ -118,10 +118,13 @@ def test_sorted_kernel_answers_are_the_oracles(orc, case, sort, bigtile, monkeyp
     assert np.array_equal(idx2, r2) and np.array_equal(d22, rd22), (case, sort, "seeded")
 
 
+@pytest.mark.parametrize("home", ["1", "0"])
 @pytest.mark.parametrize("R,splits", [(1, 0), (2, 3), (8, 0), (4, 7), (4, 41)])
-def test_sorted_kernel_geometry_variants(orc, R, splits, monkeypatch):
-    """Points per thread and target splits (a seed's owner is seed index mod splits) -- same answers."""
+def test_sorted_kernel_geometry_variants(orc, R, splits, home, monkeypatch):
+    """Points per thread, target splits (a seed's owner is seed index mod splits) and the two forms of an unseeded search
+    (k_nn_seed_sorted + a launch seeded from keys; one unseeded launch) -- same answers."""
     from object_alignment_amd.engine import IcpEngine
+    monkeypatch.setenv("OA_NN_HOME_PASS", home)
     monkeypatch.setenv("OA_NN_R", str(R))
     if splits:
         monkeypatch.setenv("OA_NN_SPLITS", str(splits))
