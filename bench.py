@@ -257,10 +257,10 @@ def surface_leg(args, local_rank):
 # test, first 10 iterations; the 1-GPU figure is measured -- profiles/r03e_baseline_configs.txt --, the 8-GPU one predicted from
 # the per-shard search time + ~30 us of reduce / exchange / solve)
 C5_PREDICTED_MS_PER_ITERATION = {1: 2.06, 8: 0.35}
-# the headline workload (BASELINE config 4 at N = 8), brute-force kernel: one GPU measured (round 5, k_nn_search_sorted: 32.7 ms),
-# 8 GPUs PREDICTED from the 125k-point shard's iteration time on one GPU (4.53 ms, profiles/r05z_baseline_configs.txt) + the
+# the headline workload (BASELINE config 4 at N = 8), brute-force kernel: one GPU measured (round 5, k_nn_search_sorted: 31.1 ms),
+# 8 GPUs PREDICTED from the 125k-point shard's iteration time on one GPU (4.39 ms, profiles/r05z_baseline_configs.txt) + the
 # exchange (derivation: docs/HISTORY.md 4.7)
-C4_PREDICTED_MS_PER_ITERATION = {1: 32.7, 8: 4.56}
+C4_PREDICTED_MS_PER_ITERATION = {1: 31.1, 8: 4.42}
 
 
 def c5_leg(args, n_gpus, in_process, world, rank, local_rank, devices, dev, backend):

@@ -1157,6 +1157,47 @@ __device__ __forceinline__ bool sorted_finish_group(const float4 AU, const float
     return improved;
 }
 
+// Which of a wave's 64 R slots each lane takes as its point r, for k_nn_search_sorted: the slots in the order of their u (the
+// coordinate the target is sorted along) AT THE CURRENT POSE, so that point r of all lanes is the r-th slice of the wave's extent
+// in u -- a quarter (R = 4) of the slabs a plain run of 64 consecutive slots reaches into (level 1 runs per point r and wave).
+// One wave per 64 R slots; rank = number of slots with a smaller (key, position): a permutation whatever the values (NaN
+// included).  order[first + rank] = position of the slot within the wave's range.
+// (The same over a whole workgroup's 256 R slots -- sixteen thinner slices -- measured slower, 32.0 against 31.1 ms per iteration at
+// 1M <-> 1M: the lanes of a point r then spread over the workgroup's whole extent in the other two axes and levels 2 / 3 run for more
+// (wave, group) combinations.)
+template <int R>
+__global__ __launch_bounds__(64) void k_sorted_wave_order(const DevState *__restrict__ st, const float4 *__restrict__ src4, int au,
+                                                          unsigned short *__restrict__ order)
+{
+    constexpr int WAVES = 1;
+    constexpr int N = 64 * R * WAVES;
+    __shared__ uint32_t key[N];
+    const int t = threadIdx.x;
+    const long long first = (long long)blockIdx.x * N;
+    uint32_t mine[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const float4 p = src4[first + r * (64 * WAVES) + t];
+        float px, py, pz;
+        co_find(st, p.x, p.y, p.z, px, py, pz);
+        const float hu = au == 0 ? (float)((double)px - (double)st->tc[0]) : (au == 1 ? (float)((double)py - (double)st->tc[1]) : (float)((double)pz - (double)st->tc[2]));
+        const uint32_t b = __float_as_uint(hu);
+        mine[r] = (b & 0x80000000u) ? ~b : (b | 0x80000000u);     // unsigned order = float order (NaNs at the ends: still a total order)
+        key[r * (64 * WAVES) + t] = mine[r];
+    }
+    __syncthreads();
+    int rank[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) rank[r] = 0;
+    for (int j = 0; j < N; ++j) {
+        const uint32_t k = key[j];                                 // (broadcast read)
+#pragma unroll
+        for (int r = 0; r < R; ++r) rank[r] += (k < mine[r] || (k == mine[r] && j < r * (64 * WAVES) + t)) ? 1 : 0;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) order[first + rank[r]] = (unsigned short)(r * (64 * WAVES) + t);
+}
+
 // Seeds for the first search of a loop: every point against the ONE tile of the sorted images whose slab holds its own u (exact
 // metric, original indices, lowest index on ties) -> keys.  1024 pairs per point instead of N_t; what it leaves is a distance really
 // achieved (a valid starting best for k_nn_search_sorted pass 2), typically a few times the true nearest distance.
@@ -1208,7 +1249,8 @@ __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_sort
                                                                  const int4 *__restrict__ tidx,
                                                                  const float4 *__restrict__ win,
                                                                  int n_groups_pad, int au, int av,
-                                                                 unsigned long long *keys, int pass)
+                                                                 unsigned long long *keys, int pass,
+                                                                 const unsigned short *__restrict__ order)
 {
     // pass 0: seeds from the winner records of the last accumulation (none on the first search of a loop: every split then has to
     // find a best of its own before it can skip anything).  pass 2: seeds from keys, where k_nn_seed_sorted has left every point's
@@ -1228,8 +1270,10 @@ __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_sort
     const int base = blockIdx.y * (NN_THREADS * R);
     // a wave owns R x 64 CONSECUTIVE slots (neighbours in space: the smallest extent in u, the fewest slabs it must look into);
     // point r of a lane is slot base + slot_of(r)
-    const int wave_base = (tid >> 6) * (64 * R) + (tid & 63);
-#define OA_SLOT(r) (base + wave_base + (r) * 64)
+    // ... and WHICH of them is a lane's point r says k_sorted_wave_order: the wave's slots in the order of u, so that point r of all
+    // lanes is one slice of the wave's extent (order == nullptr: slot r * 64 + lane)
+    const int wave_first = base + (tid >> 6) * (64 * R);
+#define OA_SLOT(r) (wave_first + (order ? (int)order[wave_first + (r) * 64 + (tid & 63)] : (r) * 64 + (tid & 63)))
     float px[R], py[R], pz[R], hu[R], hv[R], hd[R], best[R], thr1[R], thr2[R];
     uint32_t bidx[R];
 #pragma unroll

@@ -191,3 +191,31 @@ def test_sorted_images_are_built_for_the_mode_that_uses_them(orc):
         idx, d2, _ = e.nn_search()
     r2, rd22 = orc.nn_brute(src, tgt[::-1].copy())
     assert np.array_equal(idx, r2) and np.array_equal(d2, rd22)
+
+
+@pytest.mark.parametrize("wave_order", ["1", "0"])
+def test_wave_order_changes_nothing_but_speed(orc, wave_order, monkeypatch):
+    """k_sorted_wave_order decides which slot a lane takes as its point r (the wave's slots in the order of u at the current
+    pose); every slot is still searched exactly once: same answers with it and without, for a rotated pose as well."""
+    from object_alignment_amd import synth
+    from object_alignment_amd.engine import IcpEngine
+    monkeypatch.setenv("OA_NN_WAVE_ORDER", wave_order)
+    monkeypatch.setenv("OA_NN_R", "4")
+    rng = np.random.default_rng(21)
+    tgt = rng.uniform(-1, 1, size=(70000, 3)).astype(np.float32)
+    src = (tgt[rng.permutation(70000)[:9000]] + rng.normal(0, 3e-3, size=(9000, 3))).astype(np.float32)
+    src[::97] = np.float32(np.nan)                       # (keys that do not order: still a permutation)
+    mxa = synth.rigid4(synth.rotation_from_rotvec([0.4, -0.9, 0.3]), [0.05, -0.02, 0.01])
+    eye = np.identity(4, dtype=np.float32)
+    with IcpEngine(0) as e:
+        e.set_search_mode("brute")
+        e.set_target(tgt)
+        e.set_source(src)
+        e.set_matrices(mxa, eye)
+        idx, d2, _ = e.nn_search()
+        e.make_pairs(1e30)
+        idx2, d22, _ = e.nn_search()
+    moved = np.array([orc.mat4_mul_vec3(mxa, p) for p in src], np.float32)
+    ridx, rd2 = orc.nn_brute(moved, tgt)
+    assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2, equal_nan=True)
+    assert np.array_equal(idx2, ridx) and np.array_equal(d22, rd2, equal_nan=True)
