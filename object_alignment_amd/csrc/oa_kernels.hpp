@@ -1238,7 +1238,10 @@ __global__ __launch_bounds__(256) void k_nn_seed_sorted(const DevState *__restri
     }
 }
 
-constexpr int SORT_ORDER_MAX = 1024;      // tiles of one split whose middle-out order fits the LDS table (more: ascending)
+constexpr int SORT_ORDER_MAX = 1024;
+#ifndef OA_SORTED_GW
+#define OA_SORTED_GW 64                   // groups of 4 sorted vertices per skip test of k_nn_search_sorted (a build-time knob for sweeps)
+#endif      // tiles of one split whose middle-out order fits the LDS table (more: ascending)
 
 template <int R, int TG = FTILE_GROUPS>
 __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_sorted(const DevState *__restrict__ st,
@@ -1354,27 +1357,41 @@ __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_sort
 #undef OA_STG_LOAD
         }
         const int gbase = g_begin + OA_TILE_AT(t) * TG;
-        // 16 targets x R points per skip test.  On gfx950 v_sub_f32 issues at full rate, v_min_f32, v_min3_f32 and v_cmp_*_f32 at
-        // half rate (tools/valu_rates.hip): the tree is all min3 (two comparisons per instruction), one compare per 16 targets.
-        constexpr int GW = 4;
+        // 4 GW = 256 vertices x R points per skip test.  On gfx950 v_sub_f32 issues at full rate, v_min_f32, v_min3_f32 and v_cmp_*_f32
+        // at half rate (tools/valu_rates.hip): the tree is all min3 (two comparisons per instruction), one compare per block.
+        // Which blocks go on to level 1 is decided by the slabs' u, not by the block size (256 sorted vertices of a million span
+        // 5e-4 of the axis, a point's reach 0.03), so larger blocks only save compares, branches and waits for the tile:
+        // 16 / 32 / 64 / 128 / 256 / 512 vertices 31.1 / 28.8 / 28.0 / 27.6 / 27.3 / 27.4 ms per iteration at 1M <-> 1M.
+        // The block is folded 16 vertices at a time, fully unrolled (the chain's value and the odd one out carried over; as a
+        // loop of four chunks per trip: 28.3 ms): 16 tile registers live.
+        constexpr int GW = OA_SORTED_GW < TG ? OA_SORTED_GW : TG;
+        static_assert(GW % 4 == 0 && TG % GW == 0, "k_nn_search_sorted: blocks of whole chunks of 16 vertices");
         for (int g = 0; g < TG; g += GW) {
-            float4 QU[GW];
+            float m[R], odd[R];
 #pragma unroll
-            for (int k = 0; k < GW; ++k) QU[k] = tile[cur][3 * (g + k)];
+            for (int c = 0; c < GW / 4; ++c) {
+                float4 QU[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) QU[k] = tile[cur][3 * (g + 4 * c + k)];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {                      // level 0: one subtract + half a min3 per pair, no branch inside
+                    float a[16];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        a[4 * k] = __builtin_fabsf(QU[k].x - hu[r]); a[4 * k + 1] = __builtin_fabsf(QU[k].y - hu[r]);
+                        a[4 * k + 2] = __builtin_fabsf(QU[k].z - hu[r]); a[4 * k + 3] = __builtin_fabsf(QU[k].w - hu[r]);
+                    }
+                    float v = c == 0 ? a[0] : __builtin_fminf(__builtin_fminf(m[r], odd[r]), a[0]);
+#pragma unroll
+                    for (int k = 1; k + 1 < 16; k += 2) v = __builtin_fminf(__builtin_fminf(v, a[k]), a[k + 1]);   // v_min3_f32
+                    m[r] = v;
+                    odd[r] = a[15];
+                }
+            }
             bool hit0 = false, hit[R];
 #pragma unroll
-            for (int r = 0; r < R; ++r) {                          // level 0: one subtract + half a min3 per pair, no branch inside
-                float a[4 * GW];
-#pragma unroll
-                for (int k = 0; k < GW; ++k) {
-                    a[4 * k] = __builtin_fabsf(QU[k].x - hu[r]); a[4 * k + 1] = __builtin_fabsf(QU[k].y - hu[r]);
-                    a[4 * k + 2] = __builtin_fabsf(QU[k].z - hu[r]); a[4 * k + 3] = __builtin_fabsf(QU[k].w - hu[r]);
-                }
-                float m = a[0];
-#pragma unroll
-                for (int k = 1; k + 1 < 4 * GW; k += 2) m = __builtin_fminf(__builtin_fminf(m, a[k]), a[k + 1]);   // v_min3_f32
-                m = __builtin_fminf(m, a[4 * GW - 1]);
-                hit[r] = !(m > thr1[r]);
+            for (int r = 0; r < R; ++r) {
+                hit[r] = !(__builtin_fminf(m[r], odd[r]) > thr1[r]);
                 hit0 |= hit[r];
             }
             if (!hit0) continue;
