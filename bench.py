@@ -58,13 +58,13 @@ HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F16_PEAK_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense f16 / bf16 MFMA (the experiment leg only)
 FLOP_PER_PAIR = 8                    # 3 sub, 3 mul, 2 add (difference-form squared distance), SURVEY.md 8d
 # hot loops, instructions per pair (the fallback when profiles/ holds no PMC pass for the kernel that ran):
-#   k_nn_search_sorted   (32 sub + 12 min + 8 min3 + 4 cmp) / 32 pairs = 1.75, + ~7 % of the blocks going on to level 1
+#   k_nn_search_sorted   (256 sub + 127 min3 + min + cmp) / 256 pairs = 1.5, + the blocks going on to level 1
 #   k_nn_search_filtered (64 fma + 16 min3 + 4 cmp) / 32 pairs
-VALU_PER_PAIR_ISA = {"k_nn_search_sorted": 1.95, "k_nn_search_filtered": 2.7}
+VALU_PER_PAIR_ISA = {"k_nn_search_sorted": 1.7, "k_nn_search_filtered": 2.7}
 # share of half-rate instructions (v_min_f32 / v_min3_f32 / v_cmp_*_f32, tools/valu_rates.hip) in the hot loop, from the ISA:
-#   k_nn_search_sorted   36 of 102 per 64 pairs (64 v_sub + v_mov | 28 v_min3 + 4 v_min + 4 v_cmp)
+#   k_nn_search_sorted   129 of 385 per point and block of 256 vertices (256 v_sub | 127 v_min3 + v_min + v_cmp)
 #   k_nn_search_filtered 20 of 84 per 32 pairs (64 v_fma | 16 v_min3 + 4 v_cmp)
-HALF_RATE_SHARE = {"k_nn_search_sorted": 36.0 / 102.0, "k_nn_search_filtered": 20.0 / 84.0}
+HALF_RATE_SHARE = {"k_nn_search_sorted": 129.0 / 385.0, "k_nn_search_filtered": 20.0 / 84.0}
 BRUTE_KERNELS = {3.0: "k_nn_search_sorted", 1.0: "k_nn_search_filtered", 2.0: "k_nn_search_mfma", 0.0: "k_nn_search"}
 KERNELS = {"brute": "k_nn_search_sorted", "grid": "k_nn_search_grid", "surface_grid": "k_tri_search_grid",
            "surface_tree": "k_bvh_search"}
@@ -257,10 +257,10 @@ def surface_leg(args, local_rank):
 # test, first 10 iterations; the 1-GPU figure is measured -- profiles/r03e_baseline_configs.txt --, the 8-GPU one predicted from
 # the per-shard search time + ~30 us of reduce / exchange / solve)
 C5_PREDICTED_MS_PER_ITERATION = {1: 2.06, 8: 0.35}
-# the headline workload (BASELINE config 4 at N = 8), brute-force kernel: one GPU measured (round 5, k_nn_search_sorted: 31.1 ms),
-# 8 GPUs PREDICTED from the 125k-point shard's iteration time on one GPU (4.39 ms, profiles/r05z_baseline_configs.txt) + the
+# the headline workload (BASELINE config 4 at N = 8), brute-force kernel: one GPU measured (round 5, k_nn_search_sorted: 27.4 ms),
+# 8 GPUs PREDICTED from the 125k-point shard's iteration time on one GPU (3.95 ms, profiles/r05z_baseline_configs.txt) + the
 # exchange (derivation: docs/HISTORY.md 4.7)
-C4_PREDICTED_MS_PER_ITERATION = {1: 31.1, 8: 4.42}
+C4_PREDICTED_MS_PER_ITERATION = {1: 27.4, 8: 3.98}
 
 
 def c5_leg(args, n_gpus, in_process, world, rank, local_rank, devices, dev, backend):
