@@ -249,7 +249,8 @@ int oa_nn_search(oa_ctx *ctx, int64_t *idx, float *d2, double *kernel_ms);
 
 /* ---- contract 2: affine_matrix_from_points(v0=A, v1=B, shear=False, scale, usesvd=True)
  *      (functions/general.py:105-217); alias calc_target_matrix in the Python host ------------ */
-/* A, B: 3 x K row-major doubles with leading dimension ld (host). */
+/* A, B: 3 x K row-major doubles with leading dimension ld (host).  with_scale: bit 0 = uniform scale (scale=True); bit 1 = the
+ * rotation through Horn's quaternion (usesvd=False, :191-206) instead of the SVD of the covariance (:179-190). */
 int oa_kabsch(oa_ctx *ctx, const double *A, const double *B, int64_t K, int64_t ld,
               int with_scale, double M[16]);
 /* The reference's full signature (functions/general.py:105): v0, v1 are ndims x K row-major doubles with leading

@@ -11,6 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liboa_icp.so")
+LIB_EXP_PATH = os.path.join(_HERE, "liboa_icp_exp.so")      # the same library + the experiments (csrc/oa_families.hpp: OA_EXPERIMENTS)
 
 OA_OK = 0
 OA_E_BAD_ARG = -1
@@ -59,14 +60,14 @@ class OaError(RuntimeError):
         self.msg = msg
 
 
-_lib = None
+_libs = {}
 
 
-def load():
-    """Load liboa_icp.so.  Raises (loudly) when the HIP extension has not been built."""
-    global _lib
-    if _lib is not None:
-        return _lib
+def load(experiments: bool = False):
+    """Load liboa_icp.so (experiments=True: liboa_icp_exp.so, the flavour the A/B tests use).  Raises (loudly) when the HIP
+    extension has not been built."""
+    if experiments in _libs:
+        return _libs[experiments]
     # One HIP runtime per process: PyTorch bundles its own libamdhip64.so.7.  If liboa_icp.so pulled in the
     # system copy first, torch would later fail with "No HIP GPUs are available"; importing torch first makes both
     # bind to the same runtime.  Without torch installed the system runtime is used.
@@ -76,7 +77,7 @@ def load():
         pass
     # Another BUILD of the same library (the sanitizer pass, A/B experiments) -- only when OA_ICP_LIB_DEBUG=1 says that the
     # override is meant, and never silently: an environment variable alone does not redirect what a production import loads.
-    path = LIB_PATH
+    path = LIB_EXP_PATH if experiments else LIB_PATH
     override = os.environ.get("OA_ICP_LIB")
     if override:
         if os.environ.get("OA_ICP_LIB_DEBUG") == "1":
@@ -131,13 +132,13 @@ def load():
     L.oa_iter_partial.argtypes = [vp, vp]
     L.oa_iter_finish.argtypes = [vp, vp]
     L.oa_run_end.argtypes = [vp, C.POINTER(Report)]
-    _lib = L
+    _libs[experiments] = L
     return L
 
 
-def check(rc):
+def check(rc, lib=None):
     if rc != OA_OK:
-        raise OaError(rc, load().oa_last_error().decode("utf-8", "replace"))
+        raise OaError(rc, (lib if lib is not None else load()).oa_last_error().decode("utf-8", "replace"))
     return rc
 
 

@@ -27,6 +27,7 @@ constexpr int AFF_TILE = 128;               // columns per LDS tile of k_affine_
 #if defined(__HIPCC__)
 
 // partials[block][0 .. 2n): sums of the block's columns of v0 (rows 0..n-1) and v1 (rows n..2n-1)
+#if !defined(OA_FAMILY_TU)      // plain kernels are compiled once, in the host translation unit (oa_icp.hip)
 __global__ __launch_bounds__(256) void k_affine_colsums(const double *__restrict__ v0, const double *__restrict__ v1, int n,
                                                         long long K, long long ld, double *__restrict__ partials)
 {
@@ -92,6 +93,7 @@ __global__ __launch_bounds__(256) void k_affine_gram(const double *__restrict__ 
     if (owner) partials[(long long)blockIdx.x * (AFF_M2 * AFF_M2) + t] = acc;
     else if (t < AFF_M2 * AFF_M2) partials[(long long)blockIdx.x * (AFF_M2 * AFF_M2) + t] = 0.0;
 }
+#endif  // !OA_FAMILY_TU
 
 // ---- small dense fp64 routines (one thread; sizes <= 16) ---------------------------------------------------------------
 // cyclic Jacobi on a symmetric m x m matrix: A -> diagonal (eigenvalues), V = eigenvectors in columns
@@ -298,6 +300,7 @@ __global__ void k_affine_solve(const double *__restrict__ colsums, const double 
 // ndims > 8: the same sums with one workgroup per row / per Gram entry (fixed order inside a workgroup: reproducible); the
 // layouts are those of the fixed-size kernels with D in place of AFF_MAXD.
 // colsums[r < n ? r : D + (r - n)] = sum over the columns of row r of [v0; v1]
+#if !defined(OA_FAMILY_TU)      // plain kernels are compiled once, in the host translation unit (oa_icp.hip)
 __global__ __launch_bounds__(256) void k_affine_rowsum_any(const double *__restrict__ v0, const double *__restrict__ v1, int n, int D,
                                                            long long K, long long ld, double *__restrict__ colsums)
 {
@@ -329,6 +332,7 @@ __global__ __launch_bounds__(256) void k_affine_gram_any(const double *__restric
     __syncthreads();
     if (threadIdx.x == 0) gram[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
 }
+#endif  // !OA_FAMILY_TU
 
 #endif  // __HIPCC__
 }  // namespace oa

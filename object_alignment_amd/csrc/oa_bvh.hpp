@@ -160,6 +160,7 @@ __global__ void k_bvh_leaf_boxes(const float4 *__restrict__ prims, int n_pad, in
 }
 
 // level l boxes from the 64 boxes below each; one wave per box, same launch shape
+#if !defined(OA_FAMILY_TU)      // plain kernels are compiled once, in the host translation unit (oa_icp.hip)
 __global__ void k_bvh_upper_boxes(const float4 *__restrict__ child, int n_child, int n_boxes, float4 *__restrict__ boxes)
 {
     const long long b = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -173,6 +174,7 @@ __global__ void k_bvh_upper_boxes(const float4 *__restrict__ child, int n_child,
     }
     bvh_wave_box_store(lo, hi, boxes, b);
 }
+#endif  // !OA_FAMILY_TU
 
 // ---- query ---------------------------------------------------------------------------------------------------------
 // lower bound of the squared distance from p to anything inside the box, as a float that never exceeds the real bound

@@ -106,6 +106,7 @@ __device__ __forceinline__ float grid_sqrt_up(float x)
 // cell_of: 2 ints per vertex -- its cell and its RANK among the cell's vertices (what the counting atomic returns): the
 // scatter then needs no second round of a million atomics on cursors (50 -> ~20 us of a 1M-vertex upload).  The rank is
 // the atomics' arrival order -- as arbitrary as the cursors' was; the order inside a cell is immaterial ((d2, index) min).
+#if !defined(OA_FAMILY_TU)      // plain kernels are compiled once, in the host translation unit (oa_icp.hip)
 __global__ void k_grid_count(const float *__restrict__ xyz, int nt, GridParams gp, int2 *__restrict__ cell_of,
                              int *__restrict__ counts)
 {
@@ -138,6 +139,7 @@ __global__ void k_grid_scatter(const float *__restrict__ xyz, int nt, const int2
     const int pos = cell_start[cr.x] + cr.y;
     sorted[pos] = make_float4(xyz[3ll * i], xyz[3ll * i + 1], xyz[3ll * i + 2], __int_as_float(i));
 }
+#endif  // !OA_FAMILY_TU
 
 // ---- the query's frame in the grid -----------------------------------------------------------------------------------
 // Located once per query in double (projection onto the grid's box, own cell, position inside that cell); everything
@@ -253,6 +255,7 @@ __device__ __forceinline__ float4 grid_ld_vertex(const float4 *__restrict__ base
 // from the radii when the winner changes); an entry whose index is not the seed's says nothing -- other kernels write
 // winner records and know nothing of this -- and is brought up to date by the search that finds it so.
 constexpr int SAFE_SCAN_MAX = 1024;
+#if !defined(OA_FAMILY_TU)      // plain kernels are compiled once, in the host translation unit (oa_icp.hip)
 __global__ void k_grid_safe_radius(const float4 *__restrict__ sorted, int nt, GridParams gp, const int *__restrict__ cell_start,
                                    float *__restrict__ safe_by_idx)
 {
@@ -292,6 +295,7 @@ __global__ void k_grid_safe_radius(const float4 *__restrict__ sorted, int nt, Gr
     }
     safe_by_idx[(uint32_t)__float_as_int(t.w)] = out;           // by ORIGINAL index: the searches look it up for a slot's winner
 }
+#endif  // !OA_FAMILY_TU
 
 __device__ __forceinline__ uint32_t grid_ld_safe(const float *__restrict__ base, int idx)
 {
@@ -738,6 +742,7 @@ __global__ __launch_bounds__(BT, OA_GRID_MIN_WAVES) void k_nn_search_grid(const 
 // non-zero entries of a[0 .. n): one count per WORKGROUP of a grid-stride launch, out[blockIdx.x] -- the host adds them up
 // (they go straight to mapped host memory, oa_icp.hip: result_buffer).  History: one atomic per wave -- 8000 of them on one
 // word for the 500k cells of a 1M-vertex target -- was 92 us of a 0.8 ms target upload; one per workgroup 8 us; none now.
+#if !defined(OA_FAMILY_TU)      // plain kernels are compiled once, in the host translation unit (oa_icp.hip)
 __global__ void k_count_nonzero(const int *__restrict__ a, int n, int *__restrict__ out)
 {
     __shared__ int part[16];
@@ -752,6 +757,7 @@ __global__ void k_count_nonzero(const int *__restrict__ a, int n, int *__restric
         out[blockIdx.x] = sum;
     }
 }
+#endif  // !OA_FAMILY_TU
 
 #endif  // __HIPCC__
 }  // namespace oa

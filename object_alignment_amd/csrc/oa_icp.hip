@@ -4,7 +4,6 @@
 // iterate loop and its split-phase form for one-process-per-GPU sharding.  No CPU fallback lives here: every
 // compute entry point needs a usable HIP device and fails loudly otherwise.
 #include <cstring>
-#include <rocprim/rocprim.hpp>
 #include <dlfcn.h>
 // librccl is loaded with dlopen on first use (liboa_icp.so has no link dependency on it); a ROCm install without the
 // RCCL development headers still builds this file from the handful of declarations the exchange needs
@@ -17,13 +16,7 @@ typedef enum { ncclFloat64 = 8, ncclDouble = 8 } ncclDataType_t;
 typedef enum { ncclSum = 0 } ncclRedOp_t;
 #endif
 
-#include "oa_kernels.hpp"
-#include "oa_grid.hpp"
-#include "oa_tri.hpp"
-#include "oa_tri_ring.hpp"
-#include "oa_bvh.hpp"
-#include "oa_affine.hpp"
-#include "oa_mfma.hpp"
+#include "oa_all.hpp"                // every kernel header + oa_families.hpp: the heavy templates are `extern` here, compiled in oa_fam_*.hip
 #include "oa_sort.hpp"
 #include "../../include/oa_icp.h"
 
@@ -348,9 +341,9 @@ struct oa_ctx {
     int n_cells = 0;
     int *d_cell_start = nullptr;
     float4 *d_sorted = nullptr;
-    int *d_todo_list = nullptr, *d_todo_count = nullptr;   // d_todo_count: {entries, most per wave} of the hand-over list; [2], [3]: the two counters of d_ulist (k_tri_accept)
-    int *d_ulist = nullptr;          // surface mode: the queries their seed and its neighbours did not settle (k_tri_accept -> k_tri_search_grid)
-    int u_slot = 0;                  // which of the two counters the next k_tri_accept launch fills (it zeroes the other one)
+    int *d_todo_list = nullptr, *d_todo_count = nullptr;   // d_todo_count: {entries, most per wave} of the hand-over list; from TODO_WORDS on: the two counter sets of d_ulist
+    int *d_ulist = nullptr;          // surface mode: the queries the front search (k_tri_settle) did not settle -> k_tri_search_grid (oa_tri.hpp: ulist_*)
+    int u_slot = 0;                  // which of the two counter sets the next front launch fills (it zeroes the other one)
     // surface mode (closest point on triangle, oa_tri.hpp)
     bool surface = false, tri_grid_ok = false;
     int n_tris = 0;
@@ -359,6 +352,15 @@ struct oa_ctx {
     int *d_tcell_start = nullptr;
     float4 *d_tcell_rec = nullptr;   // two float4 per cell-list entry: {disc centre, radius} {unit normal, triangle index}
     long long n_tri_entries = 0;     // entries of the triangle grid's cell lists
+    double tri_mean_diag = 0.0;      // mean bounding-box diagonal of the triangles (the cell sizes are multiples of it)
+    // the settled-pose search (oa_tri_fine.hpp): a sparse fine grid with inflated lists of whole triangles
+    int tri_fine = 0;                // OA_TRI_FINE (EXPERIMENT, off): 0 = never, 1 = built with the mesh when it has >= tri_fine_min_tris triangles, 2 = always
+    int tri_fine_min_tris = 200000;  // OA_TRI_FINE_MIN_TRIS (smaller meshes: short calls would pay ~80 us of build for a search they never reach)
+    bool tri_fine_ok = false;
+    oa::FineParams tfp;
+    uint4 *d_tfine_table = nullptr;
+    float4 *d_tfine_rec = nullptr;
+    long long n_fine_entries = 0;
     // seed + neighbours settle a query (oa_tri_ring.hpp): per triangle its neighbours' indices; the accept radius lives in d_tri9
     int *d_tri_ring = nullptr;
     bool tri_ring_ok = false;        // built for the current mesh
@@ -461,6 +463,7 @@ struct oa_ctx {
     std::vector<hipEvent_t> ev;
     int ev_used = 0;
     hipEvent_t ev_loop0 = nullptr, ev_loop1 = nullptr;
+    bool poll_mapped = false;           // the device can write h_poll (DevState::host_halt is set): else the kernels never report their progress there
     int32_t *h_poll = nullptr;          // pinned, device-mapped {halt, n, hand-over entries, most per wave, -, iteration whose exchange the stream has reached (k_reduce_partials), -, -}: the kernels mirror them here for the enqueuing host
     bool time_events = true;            // hipEvent pair around every search (brute force); else GPU-side stamps (see iter_fused)
     double wall_clock_khz = 100000.0;   // rate of wall_clock64()
@@ -481,6 +484,10 @@ struct oa_ctx {
 };
 
 namespace {
+
+// d_todo_count: TODO_WORDS ints for the tree's hand-over list, then two sets of the front search's list counters (ulist_*)
+constexpr int TODO_WORDS = 32, UCOUNT_WORDS = oa::ULIST_PARTS * oa::ULIST_STRIDE, TODO_COUNT_INTS = TODO_WORDS + 2 * UCOUNT_WORDS;
+inline int *ucount_set(const oa_ctx *c, int slot) { return c->d_todo_count + TODO_WORDS + slot * UCOUNT_WORDS; }
 
 int use_device(oa_ctx *c)
 {
@@ -648,26 +655,32 @@ inline bool bvh_whole(const oa_ctx *c, bool ok, int auto_max)
 }
 int build_grid(oa_ctx *c);
 int build_safe_radii(oa_ctx *c);
-// Stable sort of (30-bit Morton key, index) pairs on the context's stream, no wait: v_out = the sorted indices (v_in holds
-// 0, 1, 2, ... at every call site; k_out, the sorted keys, is written by rocprim only -- nobody reads it).  Between SORT_LSD_MIN
-// and SORT_LSD_MAX pairs the library's own three-pass LSD argsort (oa_sort.hpp; tools/sort_bench.hip has the crossovers),
-// outside rocprim's; both stable, hence the same permutation (OA_SORT_LSD=0: rocprim always, the A/B).
-int sort_pairs30(oa_ctx *c, const unsigned *k_in, unsigned *k_out, const int *v_in, int *v_out, size_t n)
+// Stable argsort of 30-bit Morton keys on the context's stream, no wait: v_out = the indices in the keys' stable ascending order
+// (v_in holds 0, 1, 2, ... at every call site and k_out, the sorted keys, is read by nobody: both stay in the signature for the
+// call sites' sake).  The library's own sorts (oa_sort.hpp): one workgroup up to SORT_SMALL_MAX keys, the three-pass LSD argsort
+// above that; rounds 4-5 still fell back on rocprim outside 65k .. 3M keys -- 628 of the library's 749 kernels were its
+// instantiations.
+int sort_order_bits(oa_ctx *c, const unsigned *keys, int *order, size_t n, int bits)
 {
-    static const long long lsd_min = env_int("OA_SORT_LSD", 1) ? (long long)env_int("OA_SORT_LSD_MIN", 65536) : -1;
-    static const long long lsd_max = (long long)env_int("OA_SORT_LSD_MAX", 3 << 20);
     DevTmp<char> tmp;
-    if (lsd_min >= 0 && (long long)n >= lsd_min && (long long)n <= lsd_max) {
-        HIPCHK(tmp.alloc(oa::sort_order_tmp_bytes(n)));
-        HIPCHK(oa::sort_order_lsd((void *)tmp.p, k_in, v_out, n, 30, c->stream));
-        return OA_OK;
-    }
-    size_t bytes = 0;
-    HIPCHK(rocprim::radix_sort_pairs(nullptr, bytes, k_in, k_out, v_in, v_out, n, 0, 30, c->stream));
-    HIPCHK(tmp.alloc(bytes));
-    HIPCHK(rocprim::radix_sort_pairs((void *)tmp.p, bytes, k_in, k_out, v_in, v_out, n, 0, 30, c->stream));
+    if (n > (size_t)oa::SORT_SMALL_MAX) HIPCHK(tmp.alloc(oa::sort_order_tmp_bytes(n)));
+    HIPCHK(oa::sort_order((void *)tmp.p, keys, order, n, bits, c->stream));
     return OA_OK;
 }
+int sort_pairs30(oa_ctx *c, const unsigned *k_in, unsigned *, const int *, int *v_out, size_t n)
+{
+    return sort_order_bits(c, k_in, v_out, n, 30);
+}
+// keys[0 .. n) (non-negative ints below 2^bits) -> sorted[] ascending and order[] = where each came from (stable)
+int sort_ints(oa_ctx *c, const int *keys, int *sorted, int *order, size_t n, int bits)
+{
+    int rc = sort_order_bits(c, (const unsigned *)keys, order, n, bits);
+    if (rc || n == 0) return rc;
+    hipLaunchKernelGGL(oa::k_gather_int, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, keys, (const int *)order, (int)n, sorted);
+    HIPCHK(hipGetLastError());
+    return OA_OK;
+}
+inline int bits_for(long long n_values) { int b = 1; while (b < 32 && (1ll << b) < n_values) ++b; return b; }
 constexpr long long SAFE_LAZY_ITERS = 8;   // OA_GRID_SAFE=1: loop iterations a target has to see before its safe radii are built
 // OA_GRID_SAFE=1: the radii are built once the target has seen SAFE_LAZY_ITERS iterations of a loop (counted once per iteration,
 // launch_search_accumulate).  The array is allocated with the grid; the build is ONE launch on the context's stream and no
@@ -682,6 +695,7 @@ int safe_radii_lazy(oa_ctx *c)
 int build_sorted_images(oa_ctx *c);
 int build_tri_grid(oa_ctx *c, const double *diag_sum_known = nullptr);
 int build_tri_ring(oa_ctx *c);
+int build_tri_fine(oa_ctx *c);
 // OA_TRI_RING=1: the neighbour lists are built once the mesh has served TRI_RING_LAZY_ITERS searches of a loop -- while the pose
 // still moves by a good part of a triangle no query is within its seed's accept radius, and a short early-exit call should not
 // pay for the build.  The buffer is allocated with the grid (never inside a loop: an allocation can wait for another stream,
@@ -812,6 +826,8 @@ SearchPlan search_plan(const oa_ctx *c)
         const bool dual = c->grid_mode == -1 && c->turns_on && c->ns <= tri_tree_early(c);
         // (with the neighbour lists: k_tri_accept + the search of what it leaves, which has no accumulating form)
         if (c->tri_ring_ok && c->tri_split && c->seeded) return PLAN_PLAIN;
+        // (the settled-pose search in front, oa_tri_fine.hpp: likewise k_tri_settle + the search of what it leaves)
+        if (c->tri_fine_ok && c->seeded && !dual && tri_grid_active(c)) return PLAN_PLAIN;
         return (tri_grid_active(c) && !dual && canon_blocks(c) > 0 && c->tri_acc) ? PLAN_GRID : PLAN_PLAIN;
     }
     if (bvh_whole(c, c->bvh_ok, vertex_tree_max(c))) return small ? PLAN_TREE : PLAN_PLAIN;
@@ -876,6 +892,7 @@ int launch_nn_impl(oa_ctx *c, bool acc)
             if (canon_threads(c) == 512) {
                 if (lanes == 4) hipLaunchKernelGGL((oa::k_nn_search_grid<4, true, 512>), ablocks, dim3(512), 0, c->stream, OA_GRID_ACC_ARGS, (unsigned long long *)nullptr, OA_GRID_SAFE_ARGS);
                 else if (lanes == 2) hipLaunchKernelGGL((oa::k_nn_search_grid<2, true, 512>), ablocks, dim3(512), 0, c->stream, OA_GRID_ACC_ARGS, (unsigned long long *)nullptr, OA_GRID_SAFE_ARGS);
+#if defined(OA_EXPERIMENTS)
                 else if (c->grid_stats) {                                // OA_GRID_STATS=1: instrumented launch, phase shares to stderr (synchronises)
                     DevTmp<unsigned long long> d_stats;
                     const size_t n_waves = (size_t)ablocks.x * 8;
@@ -896,6 +913,7 @@ int launch_nn_impl(oa_ctx *c, bool acc)
                             100.0 * h[oa::GRID_STAT_CYC_EPILOGUE] / ct, 100.0 * h[oa::GRID_STAT_CYC_EPI_PAIR] / ct, 100.0 * h[oa::GRID_STAT_CYC_EPI_REDUCE] / ct,
                             100.0 * h[oa::GRID_STAT_CYC_EPI_BARRIER] / ct);
                 }
+#endif
                 else hipLaunchKernelGGL((oa::k_nn_search_grid<1, true, 512>), ablocks, dim3(512), 0, c->stream, OA_GRID_ACC_ARGS, (unsigned long long *)nullptr, OA_GRID_SAFE_ARGS);
             } else {
                 if (lanes == 4) hipLaunchKernelGGL((oa::k_nn_search_grid<4, true, 256>), ablocks, dim3(256), 0, c->stream, OA_GRID_ACC_ARGS, (unsigned long long *)nullptr, OA_GRID_SAFE_ARGS);
@@ -915,16 +933,19 @@ int launch_nn_impl(oa_ctx *c, bool acc)
         return launch_bvh<false>(c, c->d_todo_list, c->d_todo_count);
     }
     if (c->ns_pad / (oa::NN_THREADS * c->R) > 65535)               // only the brute-force launch has this limit (grid.y)
-        return fail(OA_E_BAD_ARG, "shard of %d points exceeds the brute-force launch grid (use more shards or OA_NN_R=8)", c->ns);
+        return fail(OA_E_BAD_ARG, "shard of %d points exceeds the brute-force launch grid (use more shards)", c->ns);
 #define OA_NN_ARGS c->d_state, c->d_src4, c->d_tg, c->n_groups_pad, c->d_keys
 #define OA_NNF_ARGS c->d_state, c->d_src4, c->d_tg, c->d_tf, c->d_tf3, (const float4 *)c->d_win, c->n_groups_pad, c->d_keys
+#if defined(OA_EXPERIMENTS)
     if (c->filter_ok && c->use_filter && c->nn_mfma && c->d_tfm && c->R == 4 && c->tile_groups == oa::FTILE_GROUPS) {
 #define OA_MFMA_ARGS c->d_state, c->d_src4, c->d_tg, (const oa::half8 *)c->d_tfm, (const float4 *)c->d_win, c->n_groups_pad, c->mfma_sigma, c->d_keys
         if (c->mfma_wps == 2) hipLaunchKernelGGL(oa::k_nn_search_mfma<2>, grid, block, 0, c->stream, OA_MFMA_ARGS);
         else if (c->mfma_wps == 3) hipLaunchKernelGGL(oa::k_nn_search_mfma<3>, grid, block, 0, c->stream, OA_MFMA_ARGS);
         else hipLaunchKernelGGL(oa::k_nn_search_mfma<4>, grid, block, 0, c->stream, OA_MFMA_ARGS);
 #undef OA_MFMA_ARGS
-    } else if (c->filter_ok && c->use_filter && c->nn_sort && c->d_tfs) {
+    } else
+#endif
+    if (c->filter_ok && c->use_filter && c->nn_sort && c->d_tfs) {
         const bool small = (c->tile_groups == 64);
 #define OA_NNS_ARGS c->d_state, c->d_src4, (const float4 *)c->d_tgs, (const float4 *)c->d_tfs, (const float4 *)c->d_tf3s, (const int4 *)c->d_tidx, \
                     (const float4 *)c->d_win, c->n_groups_pad, c->sax[0], c->sax[1], c->d_keys
@@ -939,11 +960,16 @@ int launch_nn_impl(oa_ctx *c, bool acc)
             if (small) hipLaunchKernelGGL((oa::k_nn_search_sorted<RR, 64>), sgrid, block, 0, c->stream, OA_NNS_ARGS, pass, worder);  \
             else hipLaunchKernelGGL((oa::k_nn_search_sorted<RR, oa::FTILE_GROUPS>), sgrid, block, 0, c->stream, OA_NNS_ARGS, pass, worder); \
         } while (0)
+#if defined(OA_EXPERIMENTS)
+#define OA_LAUNCH_S_CASE8 case 8: OA_LAUNCH_S(8); break;
+#else
+#define OA_LAUNCH_S_CASE8
+#endif
 #define OA_LAUNCH_S_R()                     \
         switch (c->R) {                     \
         case 1: OA_LAUNCH_S(1); break;      \
         case 2: OA_LAUNCH_S(2); break;      \
-        case 8: OA_LAUNCH_S(8); break;      \
+        OA_LAUNCH_S_CASE8                   \
         default: OA_LAUNCH_S(4); break;     \
         }
         // the waves' slots in the order of u at this pose (k_sorted_wave_order: ~10 us in front of a 30 ms search)
@@ -969,9 +995,12 @@ int launch_nn_impl(oa_ctx *c, bool acc)
         }
         OA_LAUNCH_S_R();
 #undef OA_LAUNCH_S_R
+#undef OA_LAUNCH_S_CASE8
 #undef OA_LAUNCH_S
 #undef OA_NNS_ARGS
-    } else if (c->filter_ok && c->use_filter) {
+    }
+#if defined(OA_EXPERIMENTS)
+    else if (c->filter_ok && c->use_filter) {
         const bool small = (c->tile_groups == 64);
 #define OA_LAUNCH_F(RR)                                                                                              \
         do {                                                                                                         \
@@ -985,7 +1014,9 @@ int launch_nn_impl(oa_ctx *c, bool acc)
         default: OA_LAUNCH_F(4); break;
         }
 #undef OA_LAUNCH_F
-    } else {
+    }
+#endif
+    else {
         switch (c->R) {
         case 1: hipLaunchKernelGGL(oa::k_nn_search<1>, grid, block, 0, c->stream, OA_NN_ARGS); break;
         case 2: hipLaunchKernelGGL(oa::k_nn_search<2>, grid, block, 0, c->stream, OA_NN_ARGS); break;
@@ -1113,7 +1144,10 @@ void init_loop_state(oa_ctx *c, const oa_settings *st, int iters, bool cutoff = 
     s.cut_a = INFINITY; s.cut_b = 0.0;
     s.local_per_world = 0.0;
     s.host_halt = nullptr;
+    c->poll_mapped = false;
     s.t_prev_end = 0; s.t_acc_start = 0;
+    s.t_xchg_start = 0;                                             // (a stale stamp would leak into the first exchange_ticks of this loop)
+    s.search_clk[0] = 0; s.search_clk[1] = 0;                       // OA_STAT_SEARCH_CLOCK_MHZ: 0 unless THIS loop's search stamps it
     {   // first search of a loop: the tree (cold or stale seeds); a one-shot call on warm seeds: the grid
         const bool grid_up = c->surface ? c->tri_grid_ok : c->grid_ok;
         const oa::GridParams &g = c->surface ? c->tgp : c->gp;
@@ -1125,7 +1159,8 @@ void init_loop_state(oa_ctx *c, const oa_settings *st, int iters, bool cutoff = 
     }
     if (c->h_poll) {
         void *dp = nullptr;
-        if (hipHostGetDevicePointer(&dp, c->h_poll, 0) == hipSuccess) s.host_halt = (int32_t *)dp;
+        if (hipHostGetDevicePointer(&dp, c->h_poll, 0) == hipSuccess) { s.host_halt = (int32_t *)dp; c->poll_mapped = true; }
+        else (void)hipGetLastError();
     }
     if (cutoff && c->filter_ok && c->grid_mode != 0 && env_int("OA_NN_CUTOFF", 1)) {
         const double smin = min_singular_3x3(s.mx2) * (1.0 - 1e-9);
@@ -1180,7 +1215,7 @@ int begin_loop(oa_ctx *c, const oa_settings *st, int iters)
     init_loop_state(c, st, iters);
     *c->h_state_pin = c->h_state;                               // pinned staging copy (the stream is idle, see above)
     HIPCHK(hipMemcpyAsync(c->d_state, c->h_state_pin, sizeof(oa::DevState), hipMemcpyHostToDevice, c->stream));
-    if (c->d_todo_count) HIPCHK(hipMemsetAsync(c->d_todo_count, 0, 4 * sizeof(int), c->stream));   // kept at zero by k_solve_update ([2], [3]: by k_tri_accept)
+    if (c->d_todo_count) HIPCHK(hipMemsetAsync(c->d_todo_count, 0, TODO_COUNT_INTS * sizeof(int), c->stream));   // kept at zero by k_solve_update (the front search's counters: by its launches)
     c->u_slot = 0;
     if (!c->surface && (rc = safe_radii_lazy(c))) return rc;
     hipLaunchKernelGGL(oa::k_stamp_start, dim3(1), dim3(64), 0, c->stream, c->d_state);
@@ -1442,7 +1477,9 @@ int multi_wait(oa_ctx *p, bool abort_now = false, bool in_loop = true)
             all = false;
             const int at = c->h_poll ? ((volatile int32_t *)c->h_poll)[1] : 0;
             if (at != seen[i]) { seen[i] = at; moved = true; }
-            if (!c->h_poll || ((volatile int32_t *)c->h_poll)[5] > at) waiting = true;
+            // (a child whose progress words are not mapped can never show "in its exchange": it counts as waiting, so that a
+            //  hung collective is still aborted -- the clock then also runs through its searches, as before round 5)
+            if (!c->h_poll || !c->poll_mapped || ((volatile int32_t *)c->h_poll)[5] > at) waiting = true;
             if (!aborted && x->CommGetAsyncError && i < x->comms.size() && x->comms[i]) {
                 ncclResult_t ar = ncclSuccess;
                 if (x->CommGetAsyncError(x->comms[i], &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress) {
@@ -1961,6 +1998,8 @@ OA_EXPORT int oa_create(oa_ctx **out, int device)
     c->tri_ring = std::max(0, std::min(2, env_int("OA_TRI_RING", 0)));
     c->tri_ring_cap = env_double("OA_TRI_RING_CAP", 0.25);
     c->tri_split = env_int("OA_TRI_SPLIT", 1) != 0;
+    c->tri_fine = std::max(0, std::min(2, env_int("OA_TRI_FINE", 0)));   // EXPERIMENT (liboa_icp_exp.so), off: measured slower than the search it fronts, docs/HISTORY.md
+    c->tri_fine_min_tris = std::max(64, env_int("OA_TRI_FINE_MIN_TRIS", 200000));
     c->tri_split_lanes = env_int("OA_TRI_SPLIT_LANES", 1) != 0;
     c->tri_canon = env_int("OA_TRI_CANON", 1) != 0;
     c->list_blocks_per_cu = std::max(1, std::min(64, env_int("OA_LIST_BLOCKS_PER_CU", 16)));
@@ -1971,6 +2010,11 @@ OA_EXPORT int oa_create(oa_ctx **out, int device)
     c->nn_home_pass = env_int("OA_NN_HOME_PASS", 1) != 0;
     c->nn_wave_order = env_int("OA_NN_WAVE_ORDER", 1) != 0;
     c->nn_mfma = env_int("OA_NN_MFMA", 0);
+#if !defined(OA_EXPERIMENTS)
+    // the default library does not carry the experiments (oa_families.hpp): their knobs are inert here, liboa_icp_exp.so has them
+    c->nn_mfma = 0; c->tri_ring = 0; c->tri_fine = 0; c->nn_sort = true; c->grid_stats = false; c->tri_share = true;
+    if (c->R_env == 8) { c->R_env = 4; c->R = 4; }              // (8 points per thread: an OA_EXPERIMENTS instantiation)
+#endif
     c->mfma_wps = env_int("OA_MFMA_WPS", 4);
     c->grid_mode = env_int("OA_NN_GRID", -1);
     c->fused_acc = env_int("OA_FUSED_ACC", 1);
@@ -2121,7 +2165,7 @@ OA_EXPORT void oa_destroy(oa_ctx *c)
     OA_FREE(d_partials); OA_FREE(d_sums); OA_FREE(d_solve);
     OA_FREE(d_valid); OA_FREE(d_b); OA_FREE(d_dist); OA_FREE(d_counts); OA_FREE(d_offsets); OA_FREE(d_A); OA_FREE(d_B);
     OA_FREE(d_bvh_box); OA_FREE(d_bvh_prims); OA_FREE(d_tbvh_box); OA_FREE(d_tbvh_prims);
-    OA_FREE(d_tri9); OA_FREE(d_tcell_start); OA_FREE(d_tcell_rec); OA_FREE(d_tri_ring);
+    OA_FREE(d_tri9); OA_FREE(d_tcell_start); OA_FREE(d_tcell_rec); OA_FREE(d_tri_ring); OA_FREE(d_tfine_table); OA_FREE(d_tfine_rec);
     OA_FREE(d_sel); OA_FREE(d_src_n); OA_FREE(d_tgt_n); OA_FREE(d_src4o); OA_FREE(d_perm);
 #undef OA_FREE
     if (c->h_hist_map) (void)hipHostFree(c->h_hist_map);
@@ -2237,7 +2281,7 @@ int build_sorted_images(oa_ctx *c)
     return OA_OK;
 }
 
-int build_filter(oa_ctx *c)
+int build_filter(oa_ctx *c, bool vertex_target)
 {
     c->filter_ok = false;
     const int nb = 256;
@@ -2262,8 +2306,10 @@ int build_filter(oa_ctx *c)
     if (c->fax[0] > c->fax[1]) std::swap(c->fax[0], c->fax[1]);
     const int blocks = (c->n_groups_pad + 255) / 256;
     DevTmp<double> d_mx;
+#if defined(OA_EXPERIMENTS)        // the images in the caller's order are k_nn_search_filtered's (OA_NN_SORT=0); the launch below still finds qmax
     HIPCHK(dev_malloc(&c->d_tf, sizeof(float4) * 3 * (size_t)c->n_groups_pad));
     HIPCHK(dev_malloc(&c->d_tf3, sizeof(float4) * 2 * (size_t)c->n_groups_pad));
+#endif
     std::vector<double> mx((size_t)blocks);
     {
         // the workgroups' maxima straight into mapped host memory when they fit (result_buffer), else through a device buffer
@@ -2283,8 +2329,10 @@ int build_filter(oa_ctx *c)
     dev_free(c->d_tfs); dev_free(c->d_tf3s); dev_free(c->d_tgs); dev_free(c->d_tidx);
     // k_nn_search_sorted's images are built for the search mode that uses them: a target uploaded for the grid / tree searches
     // (OA_SEARCH_AUTO, the default) does not pay for them; oa_set_search_mode(OA_SEARCH_BRUTE) builds them when it finds none
-    if (c->grid_mode == 0) { const int rcs = build_sorted_images(c); if (rcs) return rcs; }
+    // (a mesh's surface searches never launch k_nn_search_sorted: no images, no sort -- ~36 B per vertex)
+    if (c->grid_mode == 0 && vertex_target) { const int rcs = build_sorted_images(c); if (rcs) return rcs; }
     dev_free(c->d_tfm);
+#if defined(OA_EXPERIMENTS)
     if (c->filter_ok && c->nn_mfma) {                            // experiment: the MFMA image (32 B per target)
         int e = 0;
         if (c->qmax > 0.0) { frexp(c->qmax, &e); }               // qmax = f 2^e, f in [0.5, 1)  ->  qmax 2^-e < 1
@@ -2295,6 +2343,7 @@ int build_filter(oa_ctx *c)
                            c->nt, n_targets_pad, c->tc[0], c->tc[1], c->tc[2], c->fax[0], c->fax[1], c->fax[2], c->mfma_sigma, c->d_tfm);
         HIPCHK(hipGetLastError());
     }
+#endif
     return OA_OK;
 }
 
@@ -2418,7 +2467,8 @@ int set_target_common(oa_ctx *c, const float *xyz, int64_t n, int on_device, boo
     dev_free(c->d_tgt_xyz); dev_free(c->d_tg); dev_free(c->d_tf); dev_free(c->d_tf3); dev_free(c->d_tfm);
     dev_free(c->d_tfs); dev_free(c->d_tf3s); dev_free(c->d_tgs); dev_free(c->d_tidx);
     dev_free(c->d_tri9); dev_free(c->d_tcell_start); dev_free(c->d_tcell_rec); dev_free(c->d_tri_ring);
-    c->tri_ring_ok = false;
+    dev_free(c->d_tfine_table); dev_free(c->d_tfine_rec);
+    c->tri_ring_ok = false; c->tri_fine_ok = false;
     dev_free(c->d_bvh_box); dev_free(c->d_bvh_prims); dev_free(c->d_tbvh_box); dev_free(c->d_tbvh_prims);
     c->surface = false; c->tri_grid_ok = false; c->n_tris = 0; c->bvh_ok = false; c->tbvh_ok = false;
     dev_free(c->d_tgt_n);
@@ -2455,7 +2505,7 @@ int set_target_common(oa_ctx *c, const float *xyz, int64_t n, int on_device, boo
     hipLaunchKernelGGL(oa::k_pack_target, dim3((c->n_groups_pad + 255) / 256), dim3(256), 0, c->stream, c->d_tgt_xyz,
                        c->nt, c->n_groups_pad, c->d_tg);
     HIPCHK(hipGetLastError());
-    int rcf = build_filter(c);                                      // (waits for the stream when it reads the bounding box: the copy above is done by then)
+    int rcf = build_filter(c, vertex_index);                                      // (waits for the stream when it reads the bounding box: the copy above is done by then)
     if (rcf) return rcf;
     if (vertex_index) {
         if ((rcf = build_grid(c))) return rcf;
@@ -2473,18 +2523,13 @@ OA_EXPORT int oa_set_target(oa_ctx *c, const float *xyz, int64_t n, int on_devic
 }
 
 namespace {
-struct IntToLL { __host__ __device__ long long operator()(int v) const { return (long long)v; } };
-
-// offsets[0..n] = exclusive prefix sums of counts[0..n-1] (offsets[n] = total); counts must hold n + 1 ints, the last 0.
+// offsets[0..n] = exclusive prefix sums of counts[0..n-1] (offsets[n] = total).
 // Enqueued, not waited for: `tmp` (the scan's temporary storage) belongs to the caller, who keeps it until the stream has
 // been synchronised (the wait in here was a 20-50 us hole in every grid build).
 int scan_counts(oa_ctx *c, const int *d_counts, int n, long long *d_off, DevTmp<char> &tmp)
 {
-    auto in = rocprim::make_transform_iterator(d_counts, IntToLL{});
-    size_t bytes = 0;
-    HIPCHK(rocprim::exclusive_scan(nullptr, bytes, in, d_off, 0ll, (size_t)n + 1, rocprim::plus<long long>(), c->stream));
-    HIPCHK(tmp.alloc(bytes));
-    HIPCHK(rocprim::exclusive_scan((void *)tmp.p, bytes, in, d_off, 0ll, (size_t)n + 1, rocprim::plus<long long>(), c->stream));
+    HIPCHK(tmp.alloc(oa::scan_tmp_bytes((size_t)n)));
+    HIPCHK(oa::scan_counts_ll((void *)tmp.p, d_counts, (size_t)n, d_off, c->stream));
     return OA_OK;
 }
 
@@ -2604,11 +2649,9 @@ int spatial_shard_members(oa_ctx *c, const float *d_xyz, long long n_verts, cons
     { const int rcs = sort_pairs30(c, k_in.p, k_out.p, v_in.p, order.p, (size_t)n); if (rcs) return rcs; }
     // this shard's range of the order, back in ascending selection position (= the caller's order inside the shard)
     HIPCHK(members.alloc((size_t)count));
-    size_t bytes2 = 0;
-    HIPCHK(rocprim::radix_sort_keys(nullptr, bytes2, order.p + begin, members.p, (size_t)count, 0, 32, c->stream));
-    DevTmp<char> tmp2;
-    HIPCHK(tmp2.alloc(bytes2));
-    HIPCHK(rocprim::radix_sort_keys((void *)tmp2.p, bytes2, order.p + begin, members.p, (size_t)count, 0, 32, c->stream));
+    DevTmp<int> ord2;
+    HIPCHK(ord2.alloc((size_t)count));
+    { const int rcs = sort_ints(c, order.p + begin, members.p, ord2.p, (size_t)count, bits_for(n_sel)); if (rcs) return rcs; }
     HIPCHK(hipStreamSynchronize(c->stream));                      // temporaries are released on return
     return OA_OK;
 }
@@ -2657,7 +2700,9 @@ int build_tri_grid(oa_ctx *c, const double *diag_sum_known)
 {
     c->tri_grid_ok = false;
     c->tri_ring_ok = false; c->tri_iters = 0;
+    c->tri_fine_ok = false;
     dev_free(c->d_tcell_start); dev_free(c->d_tcell_rec); dev_free(c->d_tri_ring);
+    dev_free(c->d_tfine_table); dev_free(c->d_tfine_rec);
     if (!c->filter_ok || c->grid_mode == 0 || c->n_tris < 64) return OA_OK;
     if ((long long)c->n_tris > (long long)oa::TRI_REC_INDEX_MASK) return OA_OK;     // (28-bit indices in the records: the tree takes such meshes)
     double diag_sum = 0.0;
@@ -2679,6 +2724,7 @@ int build_tri_grid(oa_ctx *c, const double *diag_sum_known)
         max_ext = std::max(max_ext, ext[a]);
         scale = std::max(scale, std::max(fabs(c->bb_lo[a]), fabs(c->bb_hi[a])));
     }
+    c->tri_mean_diag = diag_sum / (double)c->n_tris;
     double h = env_double("OA_TRI_CELL", 1.25) * diag_sum / (double)c->n_tris;  // mean triangle bbox diagonals per cell edge (1.5 until the scan
                                                                                  // became VALU-bound at the end of round 3: fewer records per cell now pay)
     if (!(h > 0.0) || !(h < INFINITY)) h = max_ext > 0.0 ? max_ext / 64.0 : 1.0;
@@ -2751,15 +2797,118 @@ int build_tri_grid(oa_ctx *c, const double *diag_sum_known)
                 entries, (double)entries / c->n_tris);
     if (c->tri_ring) {
         HIPCHK(dev_malloc(&c->d_tri_ring, sizeof(int) * (size_t)oa::TRI_RING_STRIDE * (size_t)c->n_tris));
-        if (c->tri_ring == 2) return build_tri_ring(c);
+        if (c->tri_ring == 2) { const int rcr = build_tri_ring(c); if (rcr) return rcr; }
+    }
+    if (c->tri_fine == 2 || (c->tri_fine == 1 && c->n_tris >= c->tri_fine_min_tris)) return build_tri_fine(c);
+    return OA_OK;
+}
+
+// The settled-pose structure (oa_tri_fine.hpp): sparse fine grid, inflated lists of whole triangles.  Built with the mesh (never
+// inside a loop: it allocates).  Gives up quietly -- the general search serves everything -- when the lists would explode
+// (triangles much larger than a cell after six coarsenings) or take more than OA_TRI_FINE_MAX_MB.
+int build_tri_fine(oa_ctx *c)
+{
+    c->tri_fine_ok = false;
+    dev_free(c->d_tfine_table); dev_free(c->d_tfine_rec);
+#if !defined(OA_EXPERIMENTS)
+    return OA_OK;                                                   // (OA_TRI_FINE is inert in the default library)
+#else
+    if (!c->tri_grid_ok || !c->tbvh_ok || !(c->tri_mean_diag > 0.0) || !(c->tri_mean_diag < INFINITY)) return OA_OK;
+    oa::FineParams fp{};
+    double h = env_double("OA_TRI_FINE_CELL", 0.5) * c->tri_mean_diag;
+    const double rho_frac = std::max(0.01, std::min(env_double("OA_TRI_FINE_RHO", 0.3), 4.0));
+    double ext[3], scale = 0.0, max_ext = 0.0;
+    for (int a = 0; a < 3; ++a) {
+        ext[a] = c->bb_hi[a] - c->bb_lo[a];
+        max_ext = std::max(max_ext, ext[a]);
+        scale = std::max(scale, std::max(fabs(c->bb_lo[a]), fabs(c->bb_hi[a])));
+    }
+    const unsigned long long max_entries = (unsigned long long)(std::max(16.0, env_double("OA_TRI_FINE_MAX_MB", 8192.0)) * 1048576.0 / 48.0);
+    constexpr size_t SLOT_WORDS = (size_t)oa::TOTAL_SLOTS * oa::TOTAL_STRIDE;
+    DevTmp<unsigned long long> d_total;
+    HIPCHK(d_total.alloc(SLOT_WORDS));
+    unsigned long long entries = 0;
+    bool sized = false;
+    for (int attempt = 0; attempt < 7 && !sized; ++attempt) {
+        fp.rho = rho_frac * h;
+        h = std::max(h, (max_ext + 2.0 * fp.rho * (1.0 + 1e-6)) / 1023.0);       // <= 1024 cells per axis: a cell id has 30 bits
+        fp.rho = rho_frac * h;
+        fp.rho_query = fp.rho * (1.0 - 1e-6);
+        fp.h = h; fp.inv_h = 1.0 / h;
+        for (int a = 0; a < 3; ++a) {
+            fp.lo[a] = c->bb_lo[a] - fp.rho * (1.0 + 1e-6) - 1e-300;
+            fp.hi[a] = c->bb_hi[a] + fp.rho * (1.0 + 1e-6) + 1e-300;
+            const long long n = (long long)floor((fp.hi[a] - fp.lo[a]) / h) + 1;
+            fp.n[a] = (int)std::max(1ll, std::min(n, 1024ll));
+        }
+        fp.scale = scale;
+        fp.slack = 1e-10 * scale + 1e-300;
+        HIPCHK(hipMemsetAsync(d_total, 0, sizeof(unsigned long long) * SLOT_WORDS, c->stream));
+        hipLaunchKernelGGL(oa::k_tfine_total, dim3((unsigned)((c->n_tris + 255) / 256)), dim3(256), 0, c->stream, (const float4 *)c->d_tri9, c->n_tris, fp, d_total.p);
+        HIPCHK(hipGetLastError());
+        unsigned long long slots[SLOT_WORDS];
+        { int rcr = read_small(c, slots, d_total, sizeof(slots)); if (rcr) return rcr; }
+        entries = 0;
+        for (int k = 0; k < oa::TOTAL_SLOTS; ++k) entries += slots[(size_t)k * oa::TOTAL_STRIDE];
+        if (entries == 0) return OA_OK;
+        if (entries > 40ull * (unsigned long long)c->n_tris + (1ull << 16) || entries > max_entries || entries >= (1ull << 31)) { h *= 1.5; continue; }
+        sized = true;
+    }
+    if (!sized) return OA_OK;
+    fp.cap = std::max(1, std::min(env_int("OA_TRI_FINE_CAP", 192), 1 << 20));
+    fp.gate = env_double("OA_TRI_FINE_GATE", 1e30) * fp.rho;
+    // the table: a power of two of slots, at most a third full for ordinary meshes (7-10 entries per occupied cell); a mesh whose
+    // cells hold one entry each overflows the probe limit instead -- then four times the slots, twice
+    unsigned long long want = std::max(1024ull, entries / 3ull);
+    for (int attempt = 0; attempt < 3; ++attempt, want *= 4ull) {
+        int log2 = 10;
+        while ((1ull << log2) < want && log2 < 30) ++log2;
+        const size_t n_slots = (size_t)1 << log2;
+        fp.slots_mask = (unsigned)(n_slots - 1);
+        fp.hash_shift = 32 - log2;
+        DevTmp<int> d_counts;                                        // [n_slots] counts, then the overflow flag
+        DevTmp<long long> d_off;
+        DevTmp<char> scan_tmp;
+        HIPCHK(dev_malloc(&c->d_tfine_table, sizeof(uint4) * n_slots));
+        HIPCHK(dev_malloc(&c->d_tfine_rec, sizeof(float4) * 3 * (size_t)entries));
+        HIPCHK(d_counts.alloc(n_slots + 2));
+        HIPCHK(d_off.alloc(n_slots + 1));
+        HIPCHK(hipMemsetAsync(c->d_tfine_table, 0xFF, sizeof(uint4) * n_slots, c->stream));
+        HIPCHK(hipMemsetAsync(d_counts, 0, sizeof(int) * (n_slots + 2), c->stream));
+        const dim3 tb((unsigned)((c->n_tris + 255) / 256));
+        hipLaunchKernelGGL(oa::k_tfine_count, tb, dim3(256), 0, c->stream, (const float4 *)c->d_tri9, c->n_tris, fp, c->d_tfine_table, d_counts.p, d_counts.p + n_slots + 1);
+        HIPCHK(hipGetLastError());
+        { int rcs = scan_counts(c, d_counts.p, (int)n_slots, d_off.p, scan_tmp); if (rcs) return rcs; }
+        hipLaunchKernelGGL(oa::k_tfine_fill, tb, dim3(256), 0, c->stream, (const float4 *)c->d_tri9, c->n_tris, fp, c->d_tfine_table, d_counts.p,
+                           (const long long *)d_off.p, c->d_tfine_rec);
+        hipLaunchKernelGGL(oa::k_tfine_finish, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, c->stream, c->d_tfine_table, (int)n_slots,
+                           (const long long *)d_off.p);
+        HIPCHK(hipGetLastError());
+        int overflow = 0;
+        { int rcr = read_small(c, &overflow, d_counts.p + n_slots + 1, sizeof(int)); if (rcr) return rcr; }   // (waits for the stream: the temporaries may go)
+        if (!overflow) {
+            c->tfp = fp;
+            c->n_fine_entries = (long long)entries;
+            c->tri_fine_ok = true;
+            if (c->debug)
+                fprintf(stderr, "[oa] tri fine grid: h=%g (%.2f mean diagonals) rho=%g cells=%dx%dx%d entries=%llu (%.2f per triangle, %.0f MB) table 2^%d slots\n",
+                        fp.h, fp.h / c->tri_mean_diag, fp.rho, fp.n[0], fp.n[1], fp.n[2], entries, (double)entries / c->n_tris, entries * 48.0 / 1048576.0, log2);
+            return OA_OK;
+        }
+        dev_free(c->d_tfine_table); dev_free(c->d_tfine_rec);
     }
     return OA_OK;
+#endif
 }
 
 // neighbour lists + accept radii (oa_tri_ring.hpp): one launch on the context's stream, no wait.  The accept radii are written
 // into d_tri9's spare lane, which k_pack_tris left at 0 = "never".
 int build_tri_ring(oa_ctx *c)
 {
+#if !defined(OA_EXPERIMENTS)
+    (void)c;
+    return OA_OK;                                                   // (OA_TRI_RING is inert in the default library)
+#else
     if (!c->tri_grid_ok || !c->d_tri_ring || c->tri_ring_ok) return OA_OK;
     const double cap = std::max(0.01, std::min(c->tri_ring_cap, 1.0)) * c->tgp.h;
     const dim3 blocks((unsigned)((c->n_tris + 255) / 256));
@@ -2783,6 +2932,7 @@ int build_tri_ring(oa_ctx *c)
     }
     c->tri_ring_ok = true;
     return OA_OK;
+#endif
 }
 
 int launch_tri_search(oa_ctx *c, bool acc)
@@ -2794,24 +2944,54 @@ int launch_tri_search(oa_ctx *c, bool acc)
                 (int)use_grid, (int)acc, c->ns, c->n_tris, (void *)c->d_state, (void *)c->d_src4, (void *)c->d_tri9, (void *)c->d_prev,
                 (void *)c->d_keys, (void *)c->d_todo_list, (void *)c->d_todo_count, (void *)c->d_tcell_start, (void *)c->d_tcell_rec);
     if (use_grid) {
-        if (!acc && !c->loop_active) { HIPCHK(hipMemsetAsync(c->d_todo_count, 0, 4 * sizeof(int), c->stream)); c->u_slot = 0; }
+        if (!acc && !c->loop_active) { HIPCHK(hipMemsetAsync(c->d_todo_count, 0, TODO_COUNT_INTS * sizeof(int), c->stream)); c->u_slot = 0; }
         if (c->loop_active) { const int rcr = tri_ring_lazy(c, true); if (rcr) return rcr; }
         const int *ring = c->tri_ring_ok ? c->d_tri_ring : nullptr;
         const bool dual = c->grid_mode == -1 && c->turns_on && c->ns <= tri_tree_early(c);
         // With the neighbour lists and seeds: k_tri_accept settles what seed + neighbours settle and lists the rest, the grid
         // search works through the list (oa_tri.hpp).  Not for the accumulating form (its rows go by workgroup), nor while tree
         // and grid take turns (DevState::tree_turn): those keep the test in the search's own prologue.
-        const bool split = ring && !acc && !dual && c->seeded && c->tri_split && c->d_ulist;
+        bool split = ring && !acc && !dual && c->seeded && c->tri_split && c->d_ulist;
         const int *qlist = nullptr, *qcount = nullptr;
-        if (split) {
+        int qcap = 0;
+        // The settled-pose search (oa_tri_fine.hpp) in front: one thread per query, its own cell's list of whole triangles; what it
+        // does not settle (reach beyond the lists' inflation, crowded cells, no seed) is the list the grid search works through
+#if defined(OA_EXPERIMENTS)
+        const bool fine = c->tri_fine_ok && !acc && !dual && c->seeded && c->d_ulist;
+        if (fine) {
+            const dim3 sblocks((unsigned)(((long long)c->ns * 4 + 255) / 256));     // four lanes per query
+            qcap = oa::ulist_cap((int)sblocks.x * 4, 16);           // 16 queries per wave
+#define OA_TSETTLE_ARGS (const oa::DevState *)c->d_state, (const float4 *)c->d_src4, c->ns, c->tfp, (const uint4 *)c->d_tfine_table, (const float4 *)c->d_tfine_rec, \
+                        (const float4 *)c->d_tri9, (const int *)c->d_prev, c->d_keys, c->d_ulist, qcap, ucount_set(c, c->u_slot), ucount_set(c, c->u_slot ^ 1)
+            if (c->grid_stats) {                                     // OA_GRID_STATS=1: instrumented launch, totals to stderr (synchronises)
+                DevTmp<unsigned long long> d_stats;
+                HIPCHK(d_stats.alloc(8));
+                HIPCHK(hipMemsetAsync(d_stats, 0, 8 * sizeof(unsigned long long), c->stream));
+                hipLaunchKernelGGL(oa::k_tri_settle<true>, sblocks, dim3(256), 0, c->stream, OA_TSETTLE_ARGS, d_stats.p);
+                HIPCHK(hipGetLastError());
+                unsigned long long h[8];
+                { int rcr = read_small(c, h, d_stats, sizeof(h)); if (rcr) return rcr; }
+                fprintf(stderr, "[oa] tri settle: %llu of %d queries settled (%.2f records each); the others: %llu no seed, %llu reach beyond rho, %llu outside the box, "
+                                "%llu cell not listed / over the cap\n", h[0], c->ns, (double)h[5] / (double)std::max(1ull, h[0]), h[1], h[2], h[3], h[4]);
+            } else
+            hipLaunchKernelGGL(oa::k_tri_settle<false>, sblocks, dim3(256), 0, c->stream, OA_TSETTLE_ARGS, (unsigned long long *)nullptr);
+#undef OA_TSETTLE_ARGS
+            HIPCHK(hipGetLastError());
+            qlist = c->d_ulist; qcount = ucount_set(c, c->u_slot);
+            c->u_slot ^= 1;
+            ring = nullptr;
+            split = true;
+        }
+        else if (split) {
             hipLaunchKernelGGL(oa::k_tri_accept, dim3((unsigned)((c->ns + 255) / 256)), dim3(256), 0, c->stream, (const oa::DevState *)c->d_state,
                                (const float4 *)c->d_src4, c->ns, (float)c->tgp.scale * 1.000001f, (const float4 *)c->d_tri9, (const int *)c->d_prev, ring,
-                               c->d_keys, c->d_ulist, c->d_todo_count + 2, c->u_slot);
+                               c->d_keys, c->d_ulist, (qcap = oa::ulist_cap((c->ns + 63) / 64, 64)), ucount_set(c, c->u_slot), ucount_set(c, c->u_slot ^ 1));
             HIPCHK(hipGetLastError());
-            qlist = c->d_ulist; qcount = c->d_todo_count + 2 + c->u_slot;
+            qlist = c->d_ulist; qcount = ucount_set(c, c->u_slot);
             c->u_slot ^= 1;
             ring = nullptr;                                          // (the list's queries failed that test already)
         }
+#endif
         if (dual) { int rcb = launch_bvh<true>(c, nullptr, nullptr, 1); if (rcb) return rcb; }    // runs when DevState::tree_turn
         const int turn = dual ? 0 : -1;
         const int lanes = tri_lanes_for(c);
@@ -2821,7 +3001,7 @@ int launch_tri_search(oa_ctx *c, bool acc)
             // the list's length decides the lanes per query, on the device (k_tri_search_grid: qmin / qmax): a 4-lane launch for
             // lists of up to `small` queries, and the shard's own geometry for longer ones
             const int small = std::min(c->ns, (c->n_tris >= 250000 ? 400 : 128) * c->n_cu);
-#define OA_TGRID_LIST_TAIL(lo, hi) (unsigned long long *)nullptr, oa::BvhParams{}, (const float4 *)nullptr, (const float4 *)nullptr, oa::NormalTest{}, (double *)nullptr, (const int *)nullptr, qlist, qcount, lo, hi
+#define OA_TGRID_LIST_TAIL(lo, hi) (unsigned long long *)nullptr, oa::BvhParams{}, (const float4 *)nullptr, (const float4 *)nullptr, oa::NormalTest{}, (double *)nullptr, (const int *)nullptr, qlist, qcount, lo, hi, qcap
             if (lanes != 4 && c->tri_split_lanes) {
                 hipLaunchKernelGGL(oa::k_tri_search_grid<4>, dim3((unsigned)(((long long)small * 4 + 255) / 256)), dim3(256), 0, c->stream, OA_TGRID_ARGS, OA_TGRID_LIST_TAIL(0, small));
                 if (lanes == 2) hipLaunchKernelGGL(oa::k_tri_search_grid<2>, gblocks, dim3(256), 0, c->stream, OA_TGRID_ARGS, OA_TGRID_LIST_TAIL(small, 0x7FFFFFFF));
@@ -2849,6 +3029,7 @@ int launch_tri_search(oa_ctx *c, bool acc)
 #define OA_TGRID_TAIL oa::BvhParams{}, (const float4 *)nullptr, (const float4 *)nullptr, oa::NormalTest{}, (double *)nullptr, ring, qlist, qcount
         if (lanes == 4) hipLaunchKernelGGL(oa::k_tri_search_grid<4>, gblocks, dim3(256), 0, c->stream, OA_TGRID_ARGS, (unsigned long long *)nullptr, OA_TGRID_TAIL);
         else if (lanes == 2) hipLaunchKernelGGL(oa::k_tri_search_grid<2>, gblocks, dim3(256), 0, c->stream, OA_TGRID_ARGS, (unsigned long long *)nullptr, OA_TGRID_TAIL);
+#if defined(OA_EXPERIMENTS)
         else if (c->grid_stats) {                                   // OA_GRID_STATS=1: instrumented launch, totals to stderr (synchronises)
             DevTmp<unsigned long long> d_stats;                     // one row of counters per wave (atomics on a dozen shared words slowed the launch 8x)
             const size_t n_waves = (size_t)gblocks.x * 4;
@@ -2878,6 +3059,7 @@ int launch_tri_search(oa_ctx *c, bool acc)
                     100.0 * (ct - h[oa::TRI_STAT_CYC_PROLOGUE] - h[oa::TRI_STAT_CYC_LIST] - h[oa::TRI_STAT_CYC_SCAN] - h[oa::TRI_STAT_CYC_FLUSH] - h[oa::TRI_STAT_CYC_BOOK]) / ct);
         }
         else if (!c->tri_share) hipLaunchKernelGGL((oa::k_tri_search_grid<1, false, false>), gblocks, dim3(256), 0, c->stream, OA_TGRID_ARGS, (unsigned long long *)nullptr, OA_TGRID_TAIL);
+#endif
         else hipLaunchKernelGGL(oa::k_tri_search_grid<1>, gblocks, dim3(256), 0, c->stream, OA_TGRID_ARGS, (unsigned long long *)nullptr, OA_TGRID_TAIL);
 #undef OA_TGRID_TAIL
 #undef OA_TGRID_ARGS
@@ -2988,9 +3170,9 @@ int source_reset(oa_ctx *c, long long count, long long begin, long long n_verts)
     HIPCHK(dev_malloc(&c->d_sel, sizeof(int) * (size_t)c->ns_pad));
     dev_free(c->d_todo_list); dev_free(c->d_todo_count); dev_free(c->d_ulist);
     HIPCHK(dev_malloc(&c->d_todo_list, sizeof(int) * (size_t)c->ns_pad));
-    HIPCHK(dev_malloc(&c->d_ulist, sizeof(int) * (size_t)c->ns_pad));
-    HIPCHK(dev_malloc(&c->d_todo_count, 4 * sizeof(int)));      // {entries of the hand-over list, most handed over by one wave, the two counters of d_ulist}
-    HIPCHK(hipMemsetAsync(c->d_todo_count, 0, 4 * sizeof(int), c->stream));
+    HIPCHK(dev_malloc(&c->d_ulist, sizeof(int) * ((size_t)c->ns_pad + 64 * (size_t)oa::ULIST_PARTS)));   // (ULIST_PARTS regions, each rounded up to whole waves)
+    HIPCHK(dev_malloc(&c->d_todo_count, TODO_COUNT_INTS * sizeof(int)));      // {entries of the hand-over list, most handed over by one wave, ...}, the two counter sets of d_ulist
+    HIPCHK(hipMemsetAsync(c->d_todo_count, 0, TODO_COUNT_INTS * sizeof(int), c->stream));
     c->u_slot = 0;
     // no seeds, empty keys, sel = 0, hand-over counters at zero: one launch
     hipLaunchKernelGGL(oa::k_init_slots, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, c->d_prev, c->d_win, c->d_wsafe, c->d_keys, c->d_sel,
@@ -3133,8 +3315,8 @@ int adopt_shard(oa_ctx *c, const oa_ctx *stage, const SelectionOrder &o, long lo
         return OA_OK;
     }
     const int n = (int)count;
-    DevTmp<int> pos, inv, slots;
-    HIPCHK(pos.alloc((size_t)n)); HIPCHK(inv.alloc((size_t)n)); HIPCHK(slots.alloc((size_t)n));
+    DevTmp<int> pos, inv;
+    HIPCHK(pos.alloc((size_t)n)); HIPCHK(inv.alloc((size_t)n));
     const bool local = stage->device == c->device;
 #define OA_RANGE_COPY(dst, src, bytes)                                                                                   \
     HIPCHK(local ? hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToDevice, c->stream)                             \
@@ -3147,13 +3329,8 @@ int adopt_shard(oa_ctx *c, const oa_ctx *stage, const SelectionOrder &o, long lo
     HIPCHK(dev_malloc(&c->d_members, sizeof(int) * (size_t)n));
     HIPCHK(dev_malloc(&c->d_perm, sizeof(int) * (size_t)n));
     HIPCHK(dev_malloc(&c->d_src4o, sizeof(float4) * (size_t)c->ns_pad));
-    hipLaunchKernelGGL(oa::k_iota, dim3((n + 255) / 256), dim3(256), 0, c->stream, slots.p, n);
-    HIPCHK(hipGetLastError());
-    size_t bytes = 0;
-    HIPCHK(rocprim::radix_sort_pairs(nullptr, bytes, pos.p, c->d_members, slots.p, inv.p, (size_t)n, 0, 32, c->stream));
-    DevTmp<char> tmp;
-    HIPCHK(tmp.alloc(bytes));
-    HIPCHK(rocprim::radix_sort_pairs((void *)tmp.p, bytes, pos.p, c->d_members, slots.p, inv.p, (size_t)n, 0, 32, c->stream));
+    // (inv = the shard's slots in ascending selection position: a stable argsort of pos; d_members = pos in that order)
+    { const int rcs = sort_ints(c, pos.p, c->d_members, inv.p, (size_t)n, 31); if (rcs) return rcs; }
     hipLaunchKernelGGL(oa::k_finish_shard, dim3((c->ns_pad + 255) / 256), dim3(256), 0, c->stream, (const int *)inv.p, n, c->ns_pad,
                        c->d_src4, c->d_sel, c->d_src4o, c->d_perm);
     HIPCHK(hipGetLastError());
@@ -3310,6 +3487,7 @@ OA_EXPORT int oa_get_stat(oa_ctx *c, int what, double *value)
             return OA_OK;
         }
         if (!c->surface || !c->tri_ring_ok || !c->d_tri_ring || !c->d_prev || !c->d_state || c->ns <= 0 || !c->seeded) return OA_OK;
+#if defined(OA_EXPERIMENTS)
         int rc = use_device(c);
         if (rc) return rc;
         DevTmp<unsigned long long> d_n;
@@ -3326,6 +3504,7 @@ OA_EXPORT int oa_get_stat(oa_ctx *c, int what, double *value)
             fprintf(stderr, "[oa] tri ring: %llu of %d queries settled by seed + neighbours; the others: %llu no seed, %llu seeds that never accept, %llu not certified, "
                             "distance + margins within 1x / 2x / 4x / 8x of the radius %llu / %llu / %llu / %llu, farther %llu\n",
                     n[0], c->ns, n[1], n[2], n[3], n[4], n[5], n[6], n[7], n[8]);
+#endif
         return OA_OK;
     }
     if (what == OA_STAT_EXCHANGE_US) {                                  // the slowest device's mean wait for the world's sums (one GPU: 0)
@@ -3364,8 +3543,12 @@ OA_EXPORT int oa_get_stat(oa_ctx *c, int what, double *value)
     case OA_STAT_N_TRIS: *value = (double)c->n_tris; return OA_OK;
     case OA_STAT_SURFACE: *value = c->surface ? 1.0 : 0.0; return OA_OK;
     case OA_STAT_BRUTE_KERNEL:
+#if defined(OA_EXPERIMENTS)
         *value = !(c->filter_ok && c->use_filter) ? 0.0
                  : ((c->nn_mfma && c->d_tfm && c->R == 4 && c->tile_groups == oa::FTILE_GROUPS) ? 2.0 : ((c->nn_sort && c->d_tfs) ? 3.0 : 1.0));
+#else
+        *value = (c->filter_ok && c->use_filter && c->nn_sort && c->d_tfs) ? 3.0 : 0.0;       // (launch_nn_impl: the sorted kernel, or the plain one)
+#endif
         return OA_OK;
     case OA_STAT_FAST_ITERATIONS: *value = (double)c->fast_iters; return OA_OK;
     case OA_STAT_HANDOVER_ENTRIES: *value = c->h_poll ? (double)c->h_poll[2] : 0.0; return OA_OK;
@@ -3413,13 +3596,13 @@ OA_EXPORT int oa_get_search_ms(oa_ctx *c, int32_t max_n, double *ms)
     return n;
 }
 
-// What the chip's vector ALUs issue RIGHT NOW: a burn of dependent-free v_fma_f32 chains on every SIMD for ~target_ms, timed
+// What the chip's vector ALUs issue RIGHT NOW: burns of dependent-free v_add_f32 / v_min3_f32 chains on every SIMD for ~target_ms, timed
 // with hipEvents and with the shader clock / the constant-rate clock read by the same wave at both ends.  bench.py runs it next to
 // the headline's timed loop: the brute-force search is bound by VALU issue, the clock under that load is 1.8-2.1 GHz rather
 // than the nominal 2.4 and moves from box to box -- with this figure beside it a 50 vs 58 ms launch explains itself.
 // out[0] = T lane-ops/s of v_add_f32 (two register sources: the issue rate -- 32 lanes per SIMD and clock), out[1] = shader clock
-// (MHz) during that burn, out[2] = duration of both burns (ms), out[3] = T lane-ops/s of v_fma_f32 with three register sources
-// (0.89 of the issue rate: operand reads)
+// (MHz) during that burn, out[2] = duration of both burns (ms), out[3] = T lane-ops/s of v_min3_f32 (the half-rate class the
+// search's minimum tree is made of: ~0.55 of out[0])
 OA_EXPORT int oa_measure_valu_ceiling(oa_ctx *c, double target_ms, double out[4])
 {
     if (!c || !out) return fail(OA_E_BAD_ARG, "oa_measure_valu_ceiling: null argument");

@@ -330,8 +330,47 @@ __host__ __device__ inline void rotation_from_covariance(const double H[9], doub
 }
 
 // Solve from the accumulated sums.  Returns false when K < 3 (the reference's ValueError).
+// Horn's closed form (functions/general.py:191-206, usesvd=False): the rotation is the unit quaternion that is the eigenvector of
+// the largest eigenvalue of the symmetric 4 x 4 matrix N built from the covariance (the reference hands N's lower triangle to
+// numpy.linalg.eigh); here a cyclic Jacobi diagonalisation in fp64.  H[3 i + j] = sum v1_i v0_j, as rotation_from_covariance takes it.
+__host__ __device__ inline void rotation_from_covariance_horn(const double H[9], double R[9])
+{
+    const double xx = H[0], yy = H[4], zz = H[8], xy = H[3], yz = H[7], zx = H[2], xz = H[6], yx = H[1], zy = H[5];
+    double N[4][4] = { { xx + yy + zz, yz - zy, zx - xz, xy - yx },
+                       { yz - zy, xx - yy - zz, xy + yx, zx + xz },
+                       { zx - xz, xy + yx, yy - xx - zz, yz + zy },
+                       { xy - yx, zx + xz, yz + zy, zz - xx - yy } };
+    double V[4][4] = { { 1, 0, 0, 0 }, { 0, 1, 0, 0 }, { 0, 0, 1, 0 }, { 0, 0, 0, 1 } };
+    for (int sweep = 0; sweep < 32; ++sweep) {
+        double off = 0.0, diag = 0.0;
+        for (int p = 0; p < 4; ++p) { diag += fabs(N[p][p]); for (int q = p + 1; q < 4; ++q) off += fabs(N[p][q]); }
+        if (!(off > 1e-300) || off <= 1e-18 * diag) break;
+        for (int p = 0; p < 3; ++p)
+            for (int q = p + 1; q < 4; ++q) {
+                if (N[p][q] == 0.0) continue;
+                const double theta = (N[q][q] - N[p][p]) / (2.0 * N[p][q]);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < 4; ++k) { const double a = N[k][p], b = N[k][q]; N[k][p] = c * a - sn * b; N[k][q] = sn * a + c * b; }
+                for (int k = 0; k < 4; ++k) { const double a = N[p][k], b = N[q][k]; N[p][k] = c * a - sn * b; N[q][k] = sn * a + c * b; }
+                for (int k = 0; k < 4; ++k) { const double a = V[k][p], b = V[k][q]; V[k][p] = c * a - sn * b; V[k][q] = sn * a + c * b; }
+            }
+    }
+    int m = 0;
+    for (int k = 1; k < 4; ++k) if (N[k][k] > N[m][m]) m = k;
+    double q[4] = { V[0][m], V[1][m], V[2][m], V[3][m] };
+    const double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+    if (!(n2 > 0.0)) { for (int k = 0; k < 9; ++k) R[k] = (k % 4 == 0) ? 1.0 : 0.0; return; }
+    const double f = sqrt(2.0 / n2);                                 // quaternion_matrix (:54-62): q *= sqrt(2 / n), then the outer products
+    for (int k = 0; k < 4; ++k) q[k] *= f;
+    const double w = q[0], x = q[1], y = q[2], z = q[3];
+    R[0] = 1.0 - y * y - z * z; R[1] = x * y - z * w;       R[2] = x * z + y * w;
+    R[3] = x * y + z * w;       R[4] = 1.0 - x * x - z * z; R[5] = y * z - x * w;
+    R[6] = x * z - y * w;       R[7] = y * z + x * w;       R[8] = 1.0 - x * x - y * y;
+}
+
 __host__ __device__ inline bool solve_from_sums(const double *s, const double pivot[3], bool with_scale, double M[16],
-                                                double *v_io = nullptr, bool v_valid = false)
+                                                double *v_io = nullptr, bool v_valid = false, bool horn = false)
 {
     const double K = s[S_K];
     if (!(K >= 3.0)) return false;
@@ -342,7 +381,8 @@ __host__ __device__ inline bool solve_from_sums(const double *s, const double pi
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) H[3 * i + j] = s[S_H + 3 * i + j] - K * cb[i] * ca[j];  // dot(v1c, v0c.T) (:181)
     double R[9];
-    rotation_from_covariance(H, R, v_io, v_valid);
+    if (horn) rotation_from_covariance_horn(H, R);                  // usesvd=False (:191-206)
+    else rotation_from_covariance(H, R, v_io, v_valid);
     double sc = 1.0;
     if (with_scale) {                                                                    // :208-212
         const double n0 = s[S_AA] - K * (ca[0] * ca[0] + ca[1] * ca[1] + ca[2] * ca[2]);
@@ -462,6 +502,7 @@ __device__ __forceinline__ void load_tri(const float4 *__restrict__ tri9, long l
 // packing kernels (one-time)
 // ------------------------------------------------------------------------------------------------
 // source: gather xyz[vlist[(begin + i) * stride]] -> float4; the tail up to ns_pad repeats the last point
+#if !defined(OA_FAMILY_TU)      // plain kernels are compiled once, in the host translation unit (oa_icp.hip)
 __global__ void k_pack_source(const float *__restrict__ xyz, const long long *__restrict__ vlist, long long stride,
                               long long begin, const int *__restrict__ members, int ns, int ns_pad,
                               float4 *__restrict__ src4, int *__restrict__ sel_vertex)
@@ -484,6 +525,7 @@ __global__ void k_gather_rows3(const float *__restrict__ rows, const int *__rest
     const long long v = sel[i];
     out[3ll * i] = rows[3 * v]; out[3ll * i + 1] = rows[3 * v + 1]; out[3ll * i + 2] = rows[3 * v + 2];
 }
+#endif  // !OA_FAMILY_TU
 
 // 30-bit Morton key of a source point inside the source bounding box (spatial sort of the source slots: lanes of a
 // wave then work on neighbouring points, which turns the grid search's scattered reads into mostly shared lines)
@@ -497,6 +539,7 @@ __device__ __forceinline__ unsigned spread10(unsigned v)
     return v;
 }
 
+#if !defined(OA_FAMILY_TU)      // plain kernels are compiled once, in the host translation unit (oa_icp.hip)
 __global__ void k_morton_keys(const float4 *__restrict__ src4, int ns, float lx, float ly, float lz, float sx, float sy,
                               float sz, unsigned *__restrict__ keys, int *__restrict__ slots)
 {
@@ -599,6 +642,7 @@ __global__ void k_decode_keys(unsigned long long *__restrict__ keys, int n, int 
     if (idx) idx[o] = (j == IDX_NONE) ? -1ll : (long long)j;
     if (d2) d2[o] = __uint_as_float((uint32_t)(key >> 32));
 }
+#endif  // !OA_FAMILY_TU
 
 // ------------------------------------------------------------------------------------------------
 // k_nn_search
@@ -777,6 +821,7 @@ __device__ __forceinline__ void filter_thresholds(float best, float hu, float hv
 // filter images of the target, per group of 4 vertices.  (u, v, d) = fax: the axis of smallest extent is dropped by
 // the first-level score.   tf2: [-2qu][-2qv][qu^2+qv^2]  (tiled through LDS)     tf3: [-2qd][|q|^2]  (rare path, global)
 // Padding can never pass: its W2 / W3 are 3e38.
+#if !defined(OA_FAMILY_TU)      // plain kernels are compiled once, in the host translation unit (oa_icp.hip)
 __global__ void k_pack_filter(const float *__restrict__ xyz, int nt, int n_groups_pad, float cx, float cy, float cz,
                               int au, int av, int ad, float4 *__restrict__ tf2, float4 *__restrict__ tf3,
                               double *__restrict__ block_max_q2)
@@ -803,11 +848,13 @@ __global__ void k_pack_filter(const float *__restrict__ xyz, int nt, int n_group
                 a[0][k] = 0.f; a[1][k] = 0.f; a[2][k] = 0.f; w2[k] = 3.0e38f; w3[k] = 3.0e38f;
             }
         }
-        tf2[3ll * g] = make_float4(a[0][0], a[0][1], a[0][2], a[0][3]);
-        tf2[3ll * g + 1] = make_float4(a[1][0], a[1][1], a[1][2], a[1][3]);
-        tf2[3ll * g + 2] = make_float4(w2[0], w2[1], w2[2], w2[3]);
-        tf3[2ll * g] = make_float4(a[2][0], a[2][1], a[2][2], a[2][3]);
-        tf3[2ll * g + 1] = make_float4(w3[0], w3[1], w3[2], w3[3]);
+        if (tf2) {                                                   // (nullptr: only the maximum is wanted -- the images are k_nn_search_filtered's, an OA_EXPERIMENTS kernel)
+            tf2[3ll * g] = make_float4(a[0][0], a[0][1], a[0][2], a[0][3]);
+            tf2[3ll * g + 1] = make_float4(a[1][0], a[1][1], a[1][2], a[1][3]);
+            tf2[3ll * g + 2] = make_float4(w2[0], w2[1], w2[2], w2[3]);
+            tf3[2ll * g] = make_float4(a[2][0], a[2][1], a[2][2], a[2][3]);
+            tf3[2ll * g + 1] = make_float4(w3[0], w3[1], w3[2], w3[3]);
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_down(mx, off, 64); mx = o > mx ? o : mx; }
@@ -854,6 +901,7 @@ __global__ void k_bbox_partial(const float *__restrict__ xyz, int nt, float *__r
         out[blockIdx.x * 6 + a] = v;
     }
 }
+#endif  // !OA_FAMILY_TU
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
@@ -1045,6 +1093,7 @@ __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_filt
 // (lowest index on ties, as everywhere).  A split owns a seed when seed index mod splits = split (no position lookup).
 // Tiles are visited middle-out from the slab nearest to the workgroup's first point: an unseeded search (the first iteration of a
 // loop) then finds a tight best at once instead of sweeping towards it; with seeds the order is immaterial.
+#if !defined(OA_FAMILY_TU)      // plain kernels are compiled once, in the host translation unit (oa_icp.hip)
 __global__ void k_sort_keys_axis(const float *__restrict__ xyz, int nt, int axis, double lo, double scale, unsigned *__restrict__ keys,
                                  int *__restrict__ ids)
 {
@@ -1099,6 +1148,7 @@ __global__ void k_pack_sorted(const float *__restrict__ xyz, int nt, int n_group
     tgs[3ll * g + 2] = make_float4(e[2][0], e[2][1], e[2][2], e[2][3]);
     tidx[g] = make_int4(id[0], id[1], id[2], id[3]);
 }
+#endif  // !OA_FAMILY_TU
 
 // thr1: the 1-D gap's threshold (header above); thr2: the 2-D score's (filter_thresholds).  The 3-D score's is derived from thr2
 // where it is needed.
@@ -1783,6 +1833,7 @@ __global__ __launch_bounds__(ACC_THREADS) void k_pair_accumulate(const DevState 
 // Launched with the workgroup size the accumulating grid search of this shard uses (256 or 512 threads, oa_icp.hip:
 // canon_threads): the same workgroups, hence the same rows.
 constexpr int CANON_THREADS = 512;
+#if !defined(OA_FAMILY_TU)      // plain kernels are compiled once, in the host translation unit (oa_icp.hip)
 __global__ __launch_bounds__(CANON_THREADS) void k_pair_accumulate_canon(const DevState *__restrict__ st, const float4 *__restrict__ src4,
                                                                int ns, int L, const float *__restrict__ tgt_xyz,
                                                                unsigned long long *__restrict__ keys, int *__restrict__ prev,
@@ -1841,6 +1892,7 @@ __global__ __launch_bounds__(CANON_THREADS) void k_pair_accumulate_canon(const D
     block_store_pair(valid, (double)p.x - pvx, (double)p.y - pvy, (double)p.z - pvz, (double)bx - pvx, (double)by - pvy,
                      (double)bz - pvz, dist - st->d_pivot, red, partials + (long long)blockIdx.x * NSUMS);
 }
+#endif  // !OA_FAMILY_TU
 
 // ---- fixed-order reduction of the rows of per-workgroup partials (bitwise reproducible, no float atomics) -------------
 // A row is NSUMS doubles = 12 x 16 bytes.  1024 threads = 85 slices of 12 threads: slice s adds rows s, s + 85, ... in
@@ -1916,6 +1968,7 @@ __device__ __forceinline__ int rows_of(const RowSel &sel, const DevState *st)
 
 // stamp: where the launch leaves wall_clock64() at its start (the end of the search + accumulate part of the iteration,
 // DevState::t_acc_start), or nullptr
+#if !defined(OA_FAMILY_TU)      // plain kernels are compiled once, in the host translation unit (oa_icp.hip)
 __global__ __launch_bounds__(RED_THREADS) void k_reduce_partials(const DevState *__restrict__ st, const double *__restrict__ partials,
                                                                  RowSel sel, double *__restrict__ sums_out,
                                                                  unsigned long long *__restrict__ stamp)
@@ -1962,10 +2015,11 @@ __global__ void k_solve_only(const double *__restrict__ sums, double pvx, double
     double s[NSUMS], M[16];
     for (int k = 0; k < NSUMS; ++k) s[k] = sums[k];
     const double pv[3] = { pvx, pvy, pvz };
-    const bool ok = solve_from_sums(s, pv, with_scale != 0, M);
+    const bool ok = solve_from_sums(s, pv, (with_scale & 1) != 0, M, nullptr, false, (with_scale & 2) != 0);   // bit 1: Horn's quaternion branch
     for (int k = 0; k < 16; ++k) out[k] = ok ? M[k] : 0.0;
     out[16] = ok ? 1.0 : 0.0;
 }
+#endif  // !OA_FAMILY_TU
 
 // ------------------------------------------------------------------------------------------------
 // k_solve_update : operators/icp_align.py:106-149 (solve_update_block: two waves)
@@ -2115,6 +2169,7 @@ __device__ __forceinline__ void solve_update_block(DevState *__restrict__ st, co
 }
 
 // loop start: the first search begins (about) now
+#if !defined(OA_FAMILY_TU)      // plain kernels are compiled once, in the host translation unit (oa_icp.hip)
 __global__ void k_stamp_start(DevState *__restrict__ st)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) st->t_prev_end = wall_clock64();
@@ -2146,6 +2201,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce_solve_update(DevState *_
     if (threadIdx.x < NSUMS && sums_out) sums_out[threadIdx.x] = sums[threadIdx.x];
     solve_update_block(st, &cs, sums, hist, todo_count);
 }
+#endif  // !OA_FAMILY_TU
 
 // ------------------------------------------------------------------------------------------------
 // multi-device exchange (oa_create_multi): the per-iteration all-gather of the OA_NSUMS partial sums through
@@ -2198,6 +2254,7 @@ __global__ __launch_bounds__(256) void k_valu_burn(float *__restrict__ sink, flo
     if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = c1 - c0; clk[1] = w1 - w0; }
 }
 
+#if !defined(OA_FAMILY_TU)      // plain kernels are compiled once, in the host translation unit (oa_icp.hip)
 __global__ void k_fault_stall(const int32_t *release, unsigned long long max_ticks)
 {
     if (threadIdx.x != 0) return;
@@ -2354,6 +2411,7 @@ __global__ __launch_bounds__(256) void k_scatter_pairs(const unsigned char *__re
     B[k] = (double)b[3ll * i]; B[cap + k] = (double)b[3ll * i + 1]; B[2 * cap + k] = (double)b[3ll * i + 2];
     if (pos) pos[k] = members ? members[i] : (int)(begin + i);
 }
+#endif  // !OA_FAMILY_TU
 
 #endif  // __HIPCC__
 

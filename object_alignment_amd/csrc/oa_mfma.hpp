@@ -50,6 +50,7 @@ __device__ __forceinline__ void split2_f16(double x, _Float16 &h, _Float16 &l)
 // MFMA image of the target: per tile of 32 targets 64 x half8 -- slot (plane k8, row i) at tile * 64 + k8 * 32 + i holds
 // U[8 k8 .. 8 k8 + 7] of target 32 tile + i, so lane l of a wave reads slot tile * 64 + l (one contiguous KiB per tile).
 // Padding targets get w = 60000 (never below any representable threshold).
+#if !defined(OA_FAMILY_TU) && defined(OA_EXPERIMENTS)      // experiment: only in liboa_icp_exp.so's host translation unit
 __global__ void k_pack_filter_mfma(const float *__restrict__ xyz, int nt, int n_targets_pad, float cx, float cy, float cz,
                                    int au, int av, int ad, double sigma, half8 *__restrict__ img)
 {
@@ -83,6 +84,7 @@ __global__ void k_pack_filter_mfma(const float *__restrict__ xyz, int nt, int n_
     img[(long long)tile * 64 + i] = lo;
     img[(long long)tile * 64 + 32 + i] = hi;
 }
+#endif  // !OA_FAMILY_TU
 
 // the column of one point: v0 = V[0..7], v1 = V[8..15]
 __device__ __forceinline__ void mfma_point_column(float hu, float hv, float hd, float best, double qmax, double sigma,

@@ -65,6 +65,7 @@ __device__ __forceinline__ int sort_block_scan(int v, int *wave_tot /* __shared_
     return v + before;
 }
 
+#if !defined(OA_FAMILY_TU)      // plain kernels are compiled once, in the host translation unit (oa_icp.hip)
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_scan(int *__restrict__ hist, int n_tiles, int *__restrict__ totals)
 {
     __shared__ int wave_tot[SORT_WAVES];
@@ -80,6 +81,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scan(int *__restrict__ hi
     }
     if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
+#endif  // !OA_FAMILY_TU
 
 // PACKED_IN: the items are {key, value} pairs (else keys, the value of item i is i); LAST: only the values go out (the
 // callers want the order, nobody reads the sorted keys), else {key, value} pairs -- ONE scattered store per item either way:
@@ -197,6 +199,137 @@ inline hipError_t sort_order_lsd(void *tmp, const uint32_t *keys, int *order, si
         else hipLaunchKernelGGL((k_sort_scatter<true, false>), grid, blk, 0, stream, src, dst, (int)n, shift, n_tiles, (const int *)hist, (const int *)totals);
         src = dst;
     }
+    return hipGetLastError();
+}
+#endif
+
+// ---- small inputs: the same stable order from ONE workgroup -----------------------------------------------------------------
+// Up to SORT_SMALL_MAX keys: a bitonic sort of (key << 32 | index) in LDS -- the composite keys are distinct, so their
+// ascending order IS the stable order of the keys.  One launch (~10 us) where the three-pass argsort above needs nine
+// (29-40 us whatever n: tools/sort_bench.hip) -- an alignment call on a 2562-vertex mesh sorts twice in ~0.4 ms.
+constexpr int SORT_SMALL_MAX = 8192, SORT_SMALL_THREADS = 1024;
+
+#if defined(__HIPCC__)
+#if !defined(OA_FAMILY_TU)
+__global__ __launch_bounds__(SORT_SMALL_THREADS) void k_sort_small(const uint32_t *__restrict__ keys, int n, int *__restrict__ order)
+{
+    __shared__ unsigned long long a[SORT_SMALL_MAX];
+    int P = 64;
+    while (P < n) P <<= 1;                                           // padded to a power of two with keys that sort last
+    for (int i = threadIdx.x; i < P; i += SORT_SMALL_THREADS)
+        a[i] = i < n ? (((unsigned long long)keys[i] << 32) | (unsigned)i) : ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < (P >> 1); t += SORT_SMALL_THREADS) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), x = i | j;      // the pair (i, i ^ j), i < x
+                const unsigned long long u = a[i], v = a[x];
+                const bool up = (i & k) == 0;
+                if ((u > v) == up) { a[i] = v; a[x] = u; }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < n; i += SORT_SMALL_THREADS) order[i] = (int)(uint32_t)a[i];
+}
+
+// out[j] = src[idx[j]]
+__global__ void k_gather_int(const int *__restrict__ src, const int *__restrict__ idx, int n, int *__restrict__ out)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) out[j] = src[idx[j]];
+}
+#endif  // !OA_FAMILY_TU
+
+// the stable ascending order of keys[0 .. n) on their low `bits` bits, whatever n: one workgroup for small inputs, the
+// three-launch passes above otherwise.  tmp: sort_order_tmp_bytes(n) bytes (unused by the small path).
+inline hipError_t sort_order(void *tmp, const uint32_t *keys, int *order, size_t n, int bits, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    if (n <= (size_t)SORT_SMALL_MAX) {
+        hipLaunchKernelGGL(k_sort_small, dim3(1), dim3(SORT_SMALL_THREADS), 0, stream, keys, (int)n, order);
+        return hipGetLastError();
+    }
+    return sort_order_lsd(tmp, keys, order, n, bits, stream);
+}
+#endif
+
+// ---- exclusive prefix sums of int counts into 64-bit offsets (the grids' cell starts) -------------------------------------------
+// offsets[0 .. n] for counts[0 .. n): three plain launches, no workgroup waits for another (as the sort's passes):
+//   k_scan_tile_sums   per tile of SCAN_TILE counts its sum
+//   k_scan_tile_bases  one workgroup: exclusive scan of the tile sums, in place
+//   k_scan_apply       per tile: its counts' exclusive scan + the tile's base; the last tile also writes offsets[n]
+constexpr int SCAN_THREADS = 256, SCAN_ITEMS = 8, SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
+inline size_t scan_tmp_bytes(size_t n) { return sizeof(long long) * ((n + SCAN_TILE - 1) / SCAN_TILE + 1); }
+
+#if defined(__HIPCC__)
+#if !defined(OA_FAMILY_TU)
+__device__ __forceinline__ long long scan_block_ll(long long v, long long *wave_tot, long long &total)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (int)(blockDim.x >> 6);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const long long t = __shfl_up(v, o, 64); if (lane >= o) v += t; }
+    if (lane == 63) wave_tot[w] = v;
+    __syncthreads();
+    long long before = 0;
+    total = 0;
+    for (int k = 0; k < nw; ++k) { const long long t = wave_tot[k]; if (k < w) before += t; total += t; }
+    __syncthreads();
+    return v + before;                                               // inclusive
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_tile_sums(const int *__restrict__ counts, long long n, long long *__restrict__ tile_sums)
+{
+    __shared__ long long wave_tot[SCAN_THREADS / 64];
+    const long long base = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
+    long long s = 0;
+#pragma unroll
+    for (int r = 0; r < SCAN_ITEMS; ++r) if (base + r < n) s += counts[base + r];
+    long long total;
+    (void)scan_block_ll(s, wave_tot, total);
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_tile_bases(long long *__restrict__ tile_sums, long long n_tiles)
+{
+    __shared__ long long wave_tot[16];
+    long long carry = 0;
+    for (long long base = 0; base < n_tiles; base += 1024) {
+        const long long i = base + threadIdx.x;
+        const long long v = i < n_tiles ? tile_sums[i] : 0;
+        long long total;
+        const long long incl = scan_block_ll(v, wave_tot, total);
+        if (i < n_tiles) tile_sums[i] = carry + incl - v;
+        carry += total;
+    }
+    if (threadIdx.x == 0) tile_sums[n_tiles] = carry;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const int *__restrict__ counts, long long n, const long long *__restrict__ tile_sums,
+                                                             long long *__restrict__ offsets)
+{
+    __shared__ long long wave_tot[SCAN_THREADS / 64];
+    const long long base = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
+    int v[SCAN_ITEMS];
+    long long s = 0;
+#pragma unroll
+    for (int r = 0; r < SCAN_ITEMS; ++r) { v[r] = base + r < n ? counts[base + r] : 0; s += v[r]; }
+    long long total;
+    long long run = scan_block_ll(s, wave_tot, total) - s + tile_sums[blockIdx.x];
+#pragma unroll
+    for (int r = 0; r < SCAN_ITEMS; ++r) { if (base + r < n) offsets[base + r] = run; run += v[r]; }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) offsets[n] = tile_sums[gridDim.x];
+}
+#endif  // !OA_FAMILY_TU
+
+// offsets[0 .. n] = exclusive prefix sums of counts[0 .. n) (offsets[n] = the total); tmp: scan_tmp_bytes(n) bytes, 8-byte aligned
+inline hipError_t scan_counts_ll(void *tmp, const int *counts, size_t n, long long *offsets, hipStream_t stream)
+{
+    long long *tile_sums = (long long *)tmp;
+    const long long n_tiles = (long long)((n + SCAN_TILE - 1) / SCAN_TILE);
+    if (n_tiles == 0) return hipMemsetAsync(offsets, 0, sizeof(long long), stream);
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3((unsigned)n_tiles), dim3(SCAN_THREADS), 0, stream, counts, (long long)n, tile_sums);
+    hipLaunchKernelGGL(k_scan_tile_bases, dim3(1), dim3(1024), 0, stream, tile_sums, n_tiles);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)n_tiles), dim3(SCAN_THREADS), 0, stream, counts, (long long)n, (const long long *)tile_sums, offsets);
     return hipGetLastError();
 }
 #endif

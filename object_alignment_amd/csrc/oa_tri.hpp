@@ -22,6 +22,7 @@ namespace oa {
 
 #if defined(__HIPCC__)
 
+#if !defined(OA_FAMILY_TU)      // plain kernels are compiled once, in the host translation unit (oa_icp.hip)
 __global__ void k_pack_tris(const float *__restrict__ xyz, int n_verts, const int *__restrict__ tris, int n_tris,
                             float4 *__restrict__ tri9, int *__restrict__ bad)
 {
@@ -37,6 +38,7 @@ __global__ void k_pack_tris(const float *__restrict__ xyz, int n_verts, const in
     tri9[3ll * t + 1] = make_float4(q[4], q[5], q[6], q[7]);
     tri9[3ll * t + 2] = make_float4(q[8], 0.f, 0.f, 0.f);
 }
+#endif  // !OA_FAMILY_TU
 
 // Totals of the mesh builds (sum of diagonals, number of cell-list entries) are accumulated in TOTAL_SLOTS words, 128 bytes
 // apart, workgroup b adding to slot b mod TOTAL_SLOTS; the host adds the slots.  One word for everybody serialises: 7646
@@ -44,6 +46,7 @@ __global__ void k_pack_tris(const float *__restrict__ xyz, int n_verts, const in
 constexpr int TOTAL_SLOTS = 64, TOTAL_STRIDE = 16;                  // (stride in 8-byte words)
 
 // sum of triangle bounding-box diagonals (for the cell size) -- double atomics are fine here (one-time, not a result)
+#if !defined(OA_FAMILY_TU)      // plain kernels are compiled once, in the host translation unit (oa_icp.hip)
 __global__ void k_tri_diag_sum(const float4 *__restrict__ tri9, int n_tris, double *__restrict__ out)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -71,6 +74,7 @@ __global__ void k_tri_diag_sum(const float4 *__restrict__ tri9, int n_tris, doub
         if (t > 0.0) atomicAdd(out + (size_t)(blockIdx.x % TOTAL_SLOTS) * TOTAL_STRIDE, t);
     }
 }
+#endif  // !OA_FAMILY_TU
 
 __device__ __forceinline__ void tri_cell_range(const float4 *__restrict__ tri9, int t, const GridParams &gp, int lo[3], int hi[3], bool &ok)
 {
@@ -558,6 +562,48 @@ __device__ __forceinline__ void tri_scan_shared(const float *p, const float4 *__
     n_seg = 0;
 }
 
+// ---- the list of what a front search leaves over (k_tri_settle; the experiment k_tri_accept) ------------------------------------
+// Appends are one atomic per wave -- and 15 000 wave atomics on ONE word serialise at ~12 ns each (the whole launch, 190 us,
+// when nothing settles).  So the list has ULIST_PARTS parts, each with its own counter (128 bytes apart) and its own region of
+// `ulist` (`cap` slots); wave w appends to part w mod ULIST_PARTS.  A consumer adds the counters up and finds item t's part by
+// their prefix sums (ulist_item).  counters[0] < 0 says "the list is everybody" (k_tri_settle's gate).
+constexpr int ULIST_PARTS = 64, ULIST_STRIDE = 32;                   // (stride in ints)
+__host__ __device__ inline int ulist_cap(int n_waves, int per_wave) { return (n_waves + ULIST_PARTS - 1) / ULIST_PARTS * per_wave; }
+
+// called by a whole wave: lanes with `pred` append `item`.  wave_id: the wave's number in the launch
+__device__ __forceinline__ void ulist_append(int *__restrict__ ulist, int *__restrict__ counters, int cap, int wave_id, bool pred, int item)
+{
+    const unsigned long long m = __ballot(pred);
+    if (!m) return;
+    const int lane = threadIdx.x & 63, part = wave_id % ULIST_PARTS;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&counters[part * ULIST_STRIDE], __popcll(m));
+    base = __shfl(base, 0, 64);
+    if (pred) ulist[(long long)part * cap + base + __popcll(m & ((1ull << lane) - 1ull))] = item;
+}
+
+// total length (negative: everybody)
+__device__ __forceinline__ int ulist_total(const int *__restrict__ counters)
+{
+    const int c0 = counters[0];
+    if (c0 < 0) return -1;
+    int t = c0;
+    for (int k = 1; k < ULIST_PARTS; ++k) t += counters[k * ULIST_STRIDE];
+    return t;
+}
+
+// item t of the list (0 <= t < ulist_total)
+__device__ __forceinline__ int ulist_item(const int *__restrict__ ulist, const int *__restrict__ counters, int cap, int t)
+{
+    int part = 0, before = 0, run = 0;
+    for (int k = 0; k < ULIST_PARTS; ++k) {                           // (uniform loads; the compares are the only per-lane work)
+        const int c = counters[k * ULIST_STRIDE];
+        if (t >= run) { part = k; before = run; }
+        run += c;
+    }
+    return ulist[(long long)part * cap + (t - before)];
+}
+
 // ---- seed + neighbours settle a query (round 5; the build and the proof: oa_tri_ring.hpp) -------------------------------------
 constexpr int TRI_RING_MAX = 15;          // neighbours listed per triangle: ring[16 t .. 16 t + 14], ring[16 t + 15] = how many
 constexpr int TRI_RING_STRIDE = 16;       // ints per triangle (one 64-byte line)
@@ -603,15 +649,17 @@ __device__ __forceinline__ bool tri_ring_accepts(float d2, float accept, float d
 // shared scan, the pool and its flushes cost a wave nearly the same whether 3 or 64 of its lanes still search (measured: with
 // 95 % of the queries settled in the search's own prologue a launch took what it took before) -- and its 40 KB of LDS per
 // workgroup cap the chip at four such waves per SIMD.  Here: no LDS, half the registers; the list packs the rest densely.
-// ucount[slot] counts this launch's list (the launch zeroes the OTHER slot for the next one: the host alternates).
+// The list: ulist_* above (this launch zeroes the NEXT launch's counters: the host alternates between two sets).
+#if !defined(OA_FAMILY_TU) && defined(OA_EXPERIMENTS)      // experiment: only in liboa_icp_exp.so's host translation unit
 __global__ __launch_bounds__(256) void k_tri_accept(const DevState *__restrict__ st, const float4 *__restrict__ src4, int ns, float scalef,
                                                     const float4 *__restrict__ tri9, const int *__restrict__ prev,
                                                     const int *__restrict__ ring, unsigned long long *__restrict__ keys,
-                                                    int *__restrict__ ulist, int *__restrict__ ucount, int slot)
+                                                    int *__restrict__ ulist, int ulist_cap_, int *__restrict__ counters, int *__restrict__ counters_next)
 {
     if (st->halt) return;
-    if (blockIdx.x == 0 && threadIdx.x == 0) ucount[slot ^ 1] = 0;
-    const int i = xcd_block_index() * (int)blockDim.x + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x < ULIST_PARTS) counters_next[threadIdx.x * ULIST_STRIDE] = 0;
+    const int vb = xcd_block_index();
+    const int i = vb * (int)blockDim.x + threadIdx.x;
     const bool alive = i < ns;
     bool accepted = false;
     float best = INFINITY;
@@ -663,15 +711,9 @@ __global__ __launch_bounds__(256) void k_tri_accept(const DevState *__restrict__
     }
     if (accepted) keys[i] = ((unsigned long long)__float_as_uint(best) << 32) | bidx;
     // the others, packed: one atomic per wave
-    const unsigned long long todo = __ballot(alive && !accepted);
-    if (todo) {
-        const int lane = threadIdx.x & 63;
-        int base = 0;
-        if (lane == 0) base = atomicAdd(&ucount[slot], __popcll(todo));
-        base = __shfl(base, 0, 64);
-        if (alive && !accepted) ulist[base + __popcll(todo & ((1ull << lane) - 1ull))] = i;
-    }
+    ulist_append(ulist, counters, ulist_cap_, vb * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6), alive && !accepted, i);
 }
+#endif  // !OA_FAMILY_TU
 
 // L = 1, 2 or 4 lanes per query, as in k_nn_search_grid: the rows of a ring are dealt out to the lanes, every lane runs
 // both phases on its rows with its own state, and the lanes merge (d2, index) after every batch of rows.
@@ -706,7 +748,7 @@ __global__ __launch_bounds__(256, OA_TRI_MIN_WAVES) void k_tri_search_grid(const
                                                          double *__restrict__ partials = nullptr,
                                                          const int *__restrict__ ring = nullptr,
                                                          const int *__restrict__ qlist = nullptr, const int *__restrict__ qcount = nullptr,
-                                                         int qmin = 0, int qmax = 0x7FFFFFFF)
+                                                         int qmin = 0, int qmax = 0x7FFFFFFF, int qcap = 0)
 {
     // rows per lane and batch: nine rows of a ring at a time (dealt out to the L lanes of the query).  The rows of the
     // first block of a search are whole ranges (one per row); interior rows of later rings contribute their two end
@@ -739,26 +781,28 @@ __global__ __launch_bounds__(256, OA_TRI_MIN_WAVES) void k_tri_search_grid(const
     int n_loop_trips = 0;
     if (STATS) cyc_t0 = cyc_mark = (long long)__builtin_readcyclecounter();
 #define OA_TRI_STAMP(acc) do { if (STATS) { const long long now_ = (long long)__builtin_readcyclecounter(); acc += now_ - cyc_mark; cyc_mark = now_; } } while (0)
-    // qlist (not with ACC): the queries are qlist[0 .. *qcount) -- what k_tri_accept left over --, in the dispatcher's own
+    // qlist (not with ACC): the queries are the list (ulist_*) a front search -- k_tri_settle -- left over, in the dispatcher's own
     // workgroup order (the list is short: an XCD's contiguous share of the launch would leave seven XCDs idle)
-    const bool listed = !ACC && qlist != nullptr;
-    const int vb = listed ? (int)blockIdx.x : xcd_block_index();          // one contiguous part of the queries per XCD
-    const int gt = vb * (int)blockDim.x + threadIdx.x;
-    int i = gt / L;
-    const int sub = gt % L;                                         // the L lanes of a query are neighbours in a wave
+    bool listed = !ACC && qlist != nullptr;
     if (listed) {
         // The list's length is only known on the device, and it decides how many lanes a query should get (a short list leaves
         // the chip's wave slots empty: then the rows of a ring are dealt out to 4 lanes): the host enqueues one launch per
         // regime and each runs only when the length is in ITS range (qmin, qmax] -- an empty launch costs a few microseconds.
-        ns = *qcount;
-        if (ns <= qmin || ns > qmax) return;
-        if ((vb * (int)blockDim.x) / L >= ns) return;               // (the whole workgroup: before any barrier)
+        // A NEGATIVE length says "everybody" (k_tri_settle's gate): the launch sized for the shard runs as if it had no list.
+        const int qn = ulist_total(qcount);
+        if (qn < 0) { if (qmax != 0x7FFFFFFF) return; listed = false; }
+        else { ns = qn; if (ns <= qmin || ns > qmax) return; }
     }
+    const int vb = listed ? (int)blockIdx.x : xcd_block_index();          // one contiguous part of the queries per XCD
+    const int gt = vb * (int)blockDim.x + threadIdx.x;
+    int i = gt / L;
+    const int sub = gt % L;                                         // the L lanes of a query are neighbours in a wave
+    if (listed && (vb * (int)blockDim.x) / L >= ns) return;         // (the whole workgroup: before any barrier)
     // Lanes past the last query stay: phase 2 deals pool entries to ALL 64 lanes of the wave (entry e to lane e mod 64),
     // so a lane that left would take its share of the entries with it.  They repeat the last query without any say.
     const bool alive = i < ns;
     if (!alive) i = ns - 1;
-    if (listed) i = qlist[i];                                       // from here on: the query's slot
+    if (listed) i = ulist_item(qlist, qcount, qcap, i);             // from here on: the query's slot
     const float4 p4 = src4[i];
     float pf[3];
     co_find(st, p4.x, p4.y, p4.z, pf[0], pf[1], pf[2]);          // co_find (general.py:287)
@@ -1071,6 +1115,7 @@ __global__ __launch_bounds__(256, OA_TRI_MIN_WAVES) void k_tri_search_grid(const
 }
 
 // brute force over all triangles for every source point (OA_SEARCH_BRUTE; the oracle's oo_nn_tri_brute on the device)
+#if !defined(OA_FAMILY_TU)      // plain kernels are compiled once, in the host translation unit (oa_icp.hip)
 __global__ __launch_bounds__(256) void k_tri_search_all(const DevState *__restrict__ st,
                                                         const float4 *__restrict__ src4, int ns,
                                                         const float4 *__restrict__ tri9, int n_tris,
@@ -1089,6 +1134,7 @@ __global__ __launch_bounds__(256) void k_tri_search_all(const DevState *__restri
         keys[i] = ((unsigned long long)__float_as_uint(best) << 32) | bidx;
     }
 }
+#endif  // !OA_FAMILY_TU
 
 #endif  // __HIPCC__
 }  // namespace oa

@@ -266,6 +266,7 @@ __global__ __launch_bounds__(256) void k_tri_ring_build(float4 *__restrict__ tri
 
 // diagnostic (oa_get_stat OA_STAT_TRI_RING_ACCEPTS): how many queries the neighbour lists would settle at the current pose with
 // the current seeds -- the test of k_tri_search_grid's prologue, nothing written but the count
+#if !defined(OA_FAMILY_TU) && defined(OA_EXPERIMENTS)      // experiment: only in liboa_icp_exp.so's host translation unit
 __global__ __launch_bounds__(256) void k_tri_ring_count(const DevState *__restrict__ st, const float4 *__restrict__ src4, int ns, double scale,
                                                         const float4 *__restrict__ tri9, const int *__restrict__ prev,
                                                         unsigned long long *__restrict__ out, unsigned long long *__restrict__ out_why)
@@ -303,6 +304,7 @@ __global__ __launch_bounds__(256) void k_tri_ring_count(const DevState *__restri
     // within 2^k of the radius (k = 0 .. 3: up to 1x / 2x / 4x / 8x), [8]: farther
     if (out_why && i < ns && !accepted) atomicAdd(out_why + why, 1ull);
 }
+#endif  // !OA_FAMILY_TU
 
 #endif  // __HIPCC__
 }  // namespace oa

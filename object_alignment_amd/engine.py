@@ -69,17 +69,19 @@ class IcpEngine:
     RCCL's all-reduce over xGMI when the devices are distinct and librccl loads, else the mailbox), "rccl" or
     "mailbox"."""
 
-    def __init__(self, device: int = 0, devices=None, exchange=None):
-        self._L = capi.load()
+    def __init__(self, device: int = 0, devices=None, exchange=None, experiments: bool = False):
+        # experiments: liboa_icp_exp.so -- the default library + the A/B predecessors and measured-but-not-kept variants
+        # (csrc/oa_families.hpp); the OA_NN_SORT / OA_NN_MFMA / OA_TRI_RING / OA_GRID_STATS / OA_TRI_SHARE knobs only act there
+        self._L = capi.load(experiments=experiments)
         h = C.c_void_p()
         devs = resolve_devices(devices)
         if devs is None:
-            capi.check(self._L.oa_create(C.byref(h), int(device)))
+            self._chk(self._L.oa_create(C.byref(h), int(device)))
             self.devices = [int(device)]
             self.multi = False
         else:
             arr = (C.c_int * len(devs))(*devs)
-            capi.check(self._L.oa_create_multi(C.byref(h), arr, len(devs)))
+            self._chk(self._L.oa_create_multi(C.byref(h), arr, len(devs)))
             self.devices = devs
             self.multi = True
         self._h = h
@@ -92,12 +94,15 @@ class IcpEngine:
         if exchange is not None:
             self.set_exchange(exchange)
 
+    def _chk(self, rc):
+        return capi.check(rc, self._L)
+
     def set_exchange(self, mode):
         """'auto', 'rccl' (ncclAllReduce over xGMI) or 'mailbox' (all-gather through peer-mapped device mailboxes --
         pinned host memory without peer access --, rank-ordered sum)."""
         code = ({"auto": capi.OA_EXCHANGE_AUTO, "mailbox": capi.OA_EXCHANGE_MAILBOX, "rccl": capi.OA_EXCHANGE_RCCL}[mode]
                 if isinstance(mode, str) else int(mode))
-        capi.check(self._L.oa_set_exchange(self._h, code))
+        self._chk(self._L.oa_set_exchange(self._h, code))
 
     # ---- lifetime
     def close(self):
@@ -121,19 +126,19 @@ class IcpEngine:
         """stream_handle: integer hipStream_t, e.g. torch.cuda.current_stream().cuda_stream (0 = the legacy
         default stream); None = the context's private stream."""
         h = C.c_void_p(-1) if stream_handle is None else C.c_void_p(int(stream_handle))
-        capi.check(self._L.oa_set_stream(self._h, h))
+        self._chk(self._L.oa_set_stream(self._h, h))
 
     def set_search_mode(self, mode):
         """'auto' (default), 'brute' (north-star LDS-tiled brute force), 'grid' (uniform-grid exact search, far
         queries finished by the tree) or 'bvh' (every query through the bounding-box tree).
         All modes return identical correspondences."""
         code = {"auto": -1, "brute": 0, "grid": 1, "bvh": 2}[mode] if isinstance(mode, str) else int(mode)
-        capi.check(self._L.oa_set_search_mode(self._h, code))
+        self._chk(self._L.oa_set_search_mode(self._h, code))
 
     # ---- uploads
     def set_target(self, xyz):
         p, on_dev, keep, n = _device_ptr(xyz)
-        capi.check(self._L.oa_set_target(self._h, p, n, on_dev))
+        self._chk(self._L.oa_set_target(self._h, p, n, on_dev))
         self.n_target = n
         self.target_owner = None
         del keep
@@ -143,7 +148,7 @@ class IcpEngine:
         tris: (n, 3) vertex indices (triangulate quads/ngons first)."""
         p, on_dev, keep, n = _device_ptr(xyz)
         t = np.ascontiguousarray(tris, dtype=np.int32).reshape(-1, 3)
-        capi.check(self._L.oa_set_target_mesh(self._h, p, n, on_dev, t.ctypes.data_as(C.POINTER(C.c_int32)), len(t)))
+        self._chk(self._L.oa_set_target_mesh(self._h, p, n, on_dev, t.ctypes.data_as(C.POINTER(C.c_int32)), len(t)))
         self.n_target = n
         self.target_owner = None
         del keep
@@ -155,7 +160,7 @@ class IcpEngine:
             vp, nv = capi.iptr(vl), len(vl)
         else:
             vl, vp, nv = None, None, 0
-        capi.check(self._L.oa_set_source(self._h, p, n, on_dev, vp, nv, int(stride), int(shard_index), int(shard_count)))
+        self._chk(self._L.oa_set_source(self._h, p, n, on_dev, vp, nv, int(stride), int(shard_index), int(shard_count)))
         self.n_selected = int(self._L.oa_num_selected(self._h))
         self.source_owner = None
         del keep, vl
@@ -164,20 +169,20 @@ class IcpEngine:
         """Extension (not in the reference): drop pairs whose world-space normals differ by more than max_angle_deg.
         Call after set_source / set_target*; src_normals=None switches the test off."""
         if src_normals is None:
-            capi.check(self._L.oa_set_normals(self._h, None, 0, None, 0, 0.0))
+            self._chk(self._L.oa_set_normals(self._h, None, 0, None, 0, 0.0))
             return
         sn = capi.as_f32(src_normals).reshape(-1, 3)
         tn = capi.as_f32(tgt_normals).reshape(-1, 3) if tgt_normals is not None else None
-        capi.check(self._L.oa_set_normals(self._h, capi.fptr(sn), len(sn), capi.fptr(tn) if tn is not None else None,
+        self._chk(self._L.oa_set_normals(self._h, capi.fptr(sn), len(sn), capi.fptr(tn) if tn is not None else None,
                                           len(tn) if tn is not None else 0, float(max_angle_deg)))
 
     def set_matrices(self, mx_align, mx_base):
         a, b = capi.as_f32(mx_align, (4, 4)), capi.as_f32(mx_base, (4, 4))
-        capi.check(self._L.oa_set_matrices(self._h, capi.fptr(a), capi.fptr(b)))
+        self._chk(self._L.oa_set_matrices(self._h, capi.fptr(a), capi.fptr(b)))
 
     def reset_seeds(self):
         """Forget the previous searches' answers (the next search starts cold; results are unaffected)."""
-        capi.check(self._L.oa_reset_seeds(self._h))
+        self._chk(self._L.oa_reset_seeds(self._h))
 
     STATS = {"grid_cells": 1, "tri_grid_cells": 2, "tri_grid_entries": 3, "n_tris": 4, "surface": 5, "cache_bytes": 6,
              "brute_kernel": 7, "exchange": 8, "rccl_ranks": 9, "enqueue_us": 10, "host_threads": 11,
@@ -195,7 +200,7 @@ class IcpEngine:
 
     def stat(self, name) -> float:
         v = C.c_double(0.0)
-        capi.check(self._L.oa_get_stat(self._h, self.STATS[name] if isinstance(name, str) else int(name), C.byref(v)))
+        self._chk(self._L.oa_get_stat(self._h, self.STATS[name] if isinstance(name, str) else int(name), C.byref(v)))
         return float(v.value)
 
     def search_ms(self, max_n=1 << 16) -> np.ndarray:
@@ -203,13 +208,13 @@ class IcpEngine:
         out = np.zeros(int(max_n), np.float64)
         n = self._L.oa_get_search_ms(self._h, int(max_n), capi.dptr(out))
         if n < 0:
-            capi.check(n)
+            self._chk(n)
         return out[:n].copy()
 
     def valu_ceiling(self, target_ms=5.0) -> dict:
         """What the vector ALUs issue right now (oa_measure_valu_ceiling): v_add_f32 (the issue rate) and v_min3_f32 (the half-rate class) on every SIMD."""
         out = np.zeros(4, np.float64)
-        capi.check(self._L.oa_measure_valu_ceiling(self._h, float(target_ms), capi.dptr(out)))
+        self._chk(self._L.oa_measure_valu_ceiling(self._h, float(target_ms), capi.dptr(out)))
         return {"tlaneops": float(out[0]), "shader_clock_mhz": float(out[1]), "ms": float(out[2]), "tlaneops_min3": float(out[3])}
 
     def enqueued_iterations(self):
@@ -219,12 +224,12 @@ class IcpEngine:
 
     def matrix_world(self) -> np.ndarray:
         out = np.empty((4, 4), np.float32)
-        capi.check(self._L.oa_get_matrix_world(self._h, capi.fptr(out)))
+        self._chk(self._L.oa_get_matrix_world(self._h, capi.fptr(out)))
         return out
 
     def pivot(self) -> np.ndarray:
         out = np.empty(3, np.float64)
-        capi.check(self._L.oa_get_pivot(self._h, capi.dptr(out)))
+        self._chk(self._L.oa_get_pivot(self._h, capi.dptr(out)))
         return out
 
     # ---- contract 1
@@ -234,7 +239,7 @@ class IcpEngine:
         B = np.zeros((3, cap), np.float64)
         K = C.c_int64(0)
         ds = np.zeros(2, np.float64)
-        capi.check(self._L.oa_make_pairs(self._h, float(thresh), int(bool(calc_stats)), capi.dptr(A), capi.dptr(B),
+        self._chk(self._L.oa_make_pairs(self._h, float(thresh), int(bool(calc_stats)), capi.dptr(A), capi.dptr(B),
                                          cap, C.byref(K), capi.dptr(ds)))
         k = int(K.value)
         d_stats = [float(ds[0]), float(ds[1])] if calc_stats else None
@@ -246,20 +251,22 @@ class IcpEngine:
         if want_output:
             idx = np.empty(max(1, self.n_selected), np.int64)
             d2 = np.empty(max(1, self.n_selected), np.float32)
-            capi.check(self._L.oa_nn_search(self._h, capi.iptr(idx), capi.fptr(d2), C.byref(ms)))
+            self._chk(self._L.oa_nn_search(self._h, capi.iptr(idx), capi.fptr(d2), C.byref(ms)))
             return idx[: self.n_selected], d2[: self.n_selected], float(ms.value)
-        capi.check(self._L.oa_nn_search(self._h, None, None, C.byref(ms)))
+        self._chk(self._L.oa_nn_search(self._h, None, None, C.byref(ms)))
         return None, None, float(ms.value)
 
     # ---- contract 2
-    def kabsch(self, A, B, scale=False) -> np.ndarray:
+    def kabsch(self, A, B, scale=False, horn=False) -> np.ndarray:
+        """horn: the rotation through Horn's quaternion (the reference's usesvd=False branch, functions/general.py:191-206)
+        instead of the SVD of the covariance -- the same optimum, another route to it."""
         A = np.ascontiguousarray(A, np.float64)
         B = np.ascontiguousarray(B, np.float64)
         M = np.empty((4, 4), np.float64)
-        rc = self._L.oa_kabsch(self._h, capi.dptr(A), capi.dptr(B), A.shape[1], A.shape[1], int(bool(scale)), capi.dptr(M))
+        rc = self._L.oa_kabsch(self._h, capi.dptr(A), capi.dptr(B), A.shape[1], A.shape[1], int(bool(scale)) | (2 if horn else 0), capi.dptr(M))
         if rc == capi.OA_E_TOO_FEW_PAIRS:
             raise ValueError(REF_VALUEERROR)
-        capi.check(rc)
+        self._chk(rc)
         return M
 
     def affine_from_points(self, v0, v1, shear=True, scale=True) -> np.ndarray:
@@ -272,7 +279,7 @@ class IcpEngine:
                                            capi.dptr(M))
         if rc == capi.OA_E_TOO_FEW_PAIRS:
             raise ValueError(REF_VALUEERROR)
-        capi.check(rc)
+        self._chk(rc)
         return M
 
     def kabsch_from_sums(self, sums, pivot=None, scale=False) -> np.ndarray:
@@ -283,7 +290,7 @@ class IcpEngine:
                                          int(bool(scale)), capi.dptr(M))
         if rc == capi.OA_E_TOO_FEW_PAIRS:
             raise ValueError(REF_VALUEERROR)
-        capi.check(rc)
+        self._chk(rc)
         return M
 
     # ---- the loop
@@ -323,7 +330,7 @@ class IcpEngine:
             except Exception:
                 err.partial = None
             raise err
-        capi.check(rc)
+        self._chk(rc)
         return self._result(rep)
 
     def iterate(self, thresh=0.5, target_d=0.01, use_target=True, with_scale=False):
@@ -334,27 +341,27 @@ class IcpEngine:
         rc = self._L.oa_iterate(self._h, C.byref(st), capi.dptr(M), capi.dptr(s))
         if rc == capi.OA_E_TOO_FEW_PAIRS:
             raise ValueError(REF_VALUEERROR)
-        capi.check(rc)
+        self._chk(rc)
         return M, dict(K=int(s[0]), mean_dist=s[1], std_dist=s[2], translation=s[3], rot_angle=s[4],
                        converged=bool(s[5]))
 
     # ---- split phase (one process per GPU)
     def run_begin(self, iters=50, thresh=0.5, target_d=0.01, use_target=True, with_scale=False, early_exit=True):
         st = self._settings(iters, thresh, target_d, use_target, with_scale, early_exit)
-        capi.check(self._L.oa_run_begin(self._h, C.byref(st)))
+        self._chk(self._L.oa_run_begin(self._h, C.byref(st)))
 
     def iter_partial(self, sums_device_ptr: int):
-        capi.check(self._L.oa_iter_partial(self._h, C.c_void_p(sums_device_ptr)))
+        self._chk(self._L.oa_iter_partial(self._h, C.c_void_p(sums_device_ptr)))
 
     def iter_finish(self, sums_device_ptr: int):
-        capi.check(self._L.oa_iter_finish(self._h, C.c_void_p(sums_device_ptr)))
+        self._chk(self._L.oa_iter_finish(self._h, C.c_void_p(sums_device_ptr)))
 
     def run_end(self) -> RunResult:
         rep = capi.Report()
         rc = self._L.oa_run_end(self._h, C.byref(rep))
         if rc == capi.OA_E_TOO_FEW_PAIRS:
             raise ValueError(REF_VALUEERROR)
-        capi.check(rc)
+        self._chk(rc)
         return self._result(rep)
 
 

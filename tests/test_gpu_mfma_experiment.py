@@ -22,7 +22,7 @@ def _cofind(orc, src, mxa, mxb):
 def _engine(monkeypatch, mfma):
     from object_alignment_amd.engine import IcpEngine
     monkeypatch.setenv("OA_NN_MFMA", "1" if mfma else "0")
-    e = IcpEngine(0)
+    e = IcpEngine(0, experiments=True)
     e.set_search_mode("brute")
     return e
 
@@ -131,7 +131,7 @@ def test_mfma_experiment_is_off_by_default(monkeypatch):
     from object_alignment_amd.engine import IcpEngine
     monkeypatch.delenv("OA_NN_MFMA", raising=False)
     rng = np.random.default_rng(1)
-    with IcpEngine(0) as e:
+    with IcpEngine(0, experiments=True) as e:
         e.set_search_mode("brute")
         e.set_target(rng.normal(size=(NT, 3)).astype(np.float32))
         e.set_source(rng.normal(size=(NS, 3)).astype(np.float32))

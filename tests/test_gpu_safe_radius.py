@@ -123,7 +123,7 @@ def test_safe_radius_is_taken_once_the_pose_settles(capfd, monkeypatch):
     for env in ("2", "1", "0"):
         monkeypatch.setenv("OA_GRID_SAFE", env)                 # 2: radii built with the grid (the default builds them after 8 loop iterations)
         capfd.readouterr()
-        with IcpEngine(0) as e:
+        with IcpEngine(0, experiments=True) as e:               # (the instrumented launch is an OA_EXPERIMENTS kernel)
             e.set_search_mode("grid")
             e.set_target(tgt)
             e.set_source(src, stride=1)

@@ -97,13 +97,14 @@ def test_sorted_kernel_answers_are_the_oracles(orc, case, sort, bigtile, monkeyp
     monkeypatch.setenv("OA_NN_BIGTILE", bigtile)         # 1: the 1024-vertex LDS tile of large targets, also for these small ones
     tgt, src = _case(case)
     eye = np.identity(4, dtype=np.float32)
-    with IcpEngine(0) as e:
+    exp = sort == "0"                                    # the predecessor lives in liboa_icp_exp.so; the sorted kernel is tested in the default library
+    with IcpEngine(0, experiments=exp) as e:
         e.set_search_mode("brute")
         e.set_target(tgt)
         e.set_source(src)
         e.set_matrices(eye, eye)
         idx, d2, _ = e.nn_search()
-        assert e.stat("brute_kernel") == (KERNEL_OF[sort] if len(tgt) >= 2 else 1.0)    # (one vertex: nothing to order)
+        assert e.stat("brute_kernel") == (KERNEL_OF[sort] if len(tgt) >= 2 else (1.0 if exp else 0.0))    # (one vertex: nothing to order)
         ridx, rd2 = orc.nn_brute(src, tgt)
         assert np.array_equal(idx, ridx), (case, sort)
         assert np.array_equal(d2, rd2), (case, sort)
@@ -132,7 +133,7 @@ def test_sorted_kernel_geometry_variants(orc, R, splits, home, monkeypatch):
     tgt = rng.normal(size=(70000, 3)).astype(np.float32)
     src = rng.normal(size=(4100, 3)).astype(np.float32)
     eye = np.identity(4, dtype=np.float32)
-    with IcpEngine(0) as e:
+    with IcpEngine(0, experiments=(R == 8)) as e:        # (8 points per thread is an OA_EXPERIMENTS instantiation)
         e.set_search_mode("brute")
         e.set_target(tgt)
         e.set_source(src)
@@ -154,7 +155,7 @@ def test_sorted_and_filtered_loops_agree_bitwise(monkeypatch):
     out = {}
     for sort in ("1", "0"):
         monkeypatch.setenv("OA_NN_SORT", sort)
-        with IcpEngine(0) as e:
+        with IcpEngine(0, experiments=(sort == "0")) as e:  # the sorted kernel of the default library against its predecessor in liboa_icp_exp.so
             e.set_search_mode("brute")
             e.set_target(tgt)
             e.set_source(src)
@@ -179,7 +180,7 @@ def test_sorted_images_are_built_for_the_mode_that_uses_them(orc):
         e.set_target(tgt)                            # AUTO
         e.set_source(src)
         e.set_matrices(eye, eye)
-        assert e.stat("brute_kernel") == 1.0         # no sorted images yet: brute force would be k_nn_search_filtered
+        assert e.stat("brute_kernel") == 0.0         # no sorted images yet: brute force would be the plain k_nn_search (liboa_icp_exp.so: k_nn_search_filtered)
         idx, d2, _ = e.nn_search()
         assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2)
         e.set_search_mode("brute")
@@ -219,3 +220,30 @@ def test_wave_order_changes_nothing_but_speed(orc, wave_order, monkeypatch):
     ridx, rd2 = orc.nn_brute(moved, tgt)
     assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2, equal_nan=True)
     assert np.array_equal(idx2, ridx) and np.array_equal(d22, rd2, equal_nan=True)
+
+
+def test_sorted_kernel_on_a_2M_vertex_target(orc):
+    """BASELINE config 5's target size through the sorted images (1954 LDS tiles, the seeded launch's short splits): an unseeded
+    and a seeded search of 6000 points against 2M surface vertices, indices and distances the oracle's brute force."""
+    from object_alignment_amd import synth
+    from object_alignment_amd.engine import IcpEngine
+    tgt = synth.bunny_surface(2_000_000, 0.0)
+    rng = np.random.default_rng(55)
+    src = (tgt[rng.permutation(len(tgt))[:6000]] + rng.normal(0, 2e-3, size=(6000, 3))).astype(np.float32)
+    eye = np.identity(4, dtype=np.float32)
+    m = synth.rigid4(synth.rotation_from_rotvec([0.004, -0.003, 0.002]), [0.003, -0.002, 0.001])
+    with IcpEngine(0) as e:
+        e.set_search_mode("brute")
+        e.set_target(tgt)
+        e.set_source(src)
+        e.set_matrices(eye, eye)
+        idx, d2, _ = e.nn_search()
+        assert e.stat("brute_kernel") == 3.0
+        e.make_pairs(1e30)                               # winner records = seeds
+        e.set_matrices(m, eye)
+        idx2, d22, _ = e.nn_search()
+    ridx, rd2 = orc.nn_brute(src, tgt)
+    assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2)
+    moved = np.array([orc.mat4_mul_vec3(m, p) for p in src], np.float32)
+    r2, rd22 = orc.nn_brute(moved, tgt)
+    assert np.array_equal(idx2, r2) and np.array_equal(d22, rd22)

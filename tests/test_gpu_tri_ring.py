@@ -83,7 +83,7 @@ def test_ring_settled_queries_are_bit_exact(orc, case, lanes, monkeypatch):
     rng = np.random.default_rng(11)
     eye = np.identity(4, dtype=np.float32)
     settled = []
-    with IcpEngine(0) as e:
+    with IcpEngine(0, experiments=True) as e:
         e.set_search_mode("grid")
         e.set_target_mesh(v, t)
         assert e.stat("tri_ring") == 1.0
@@ -117,7 +117,7 @@ def test_ring_loop_equals_loop_without(orc, surface_case, monkeypatch):
     got = {}
     for ring in ("0", "1", "2"):
         monkeypatch.setenv("OA_TRI_RING", ring)
-        with IcpEngine(0) as e:
+        with IcpEngine(0, experiments=True) as e:
             e.set_search_mode("grid")
             e.set_target_mesh(v, t)
             e.set_source(src)

@@ -28,7 +28,7 @@ combos = [("surface", "grid"), ("surface", "bvh"), ("vertex", "grid"), ("vertex"
 if os.environ.get("ONLY"):                               # e.g. ONLY=surface:grid
     combos = [tuple(os.environ["ONLY"].split(":"))]
 for mode, search in combos:
-    with IcpEngine(0) as e:
+    with IcpEngine(0, experiments=os.environ.get("EXP", "0") == "1") as e:   # EXP=1: liboa_icp_exp.so (OA_GRID_STATS, OA_TRI_RING ...)
         e.set_search_mode(search)
         t0 = time.perf_counter()
         if mode == "surface":
