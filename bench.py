@@ -170,7 +170,8 @@ def whole_call_leg(local_rank, src, tgt, mxa, mxb):
     """Whole operator calls from HOST arrays -- upload over PCIe + index builds + a 50-iteration run with the reference's early
     exit (operators/icp_align.py:96-151) -- on a context that is kept between calls: what the add-on's user waits for.  Never
     `value` (the metric excludes the one-time upload); reported so that DESIGN.md's whole-call figures have a driver-run twin.
-    Best of 5 calls each; the 1M <-> 1M pair is the bench workload, the 100k pair BASELINE config 2."""
+    Best of 5 calls each; the 1M <-> 1M pair is the bench workload, the 100k pair BASELINE config 2; the two `surface_*` cases are
+    the call the reference's operator really makes -- a base MESH with faces, closest point on its triangles (set_target_mesh)."""
     import time
     from object_alignment_amd import synth
     from object_alignment_amd.engine import IcpEngine
@@ -198,6 +199,31 @@ def whole_call_leg(local_rank, src, tgt, mxa, mxb):
                     best, parts, res = t3 - t0, (t1 - t0, t2_ - t1, t3 - t2_), r
             out[name] = {"ms": 1e3 * best, "median_ms": 1e3 * float(np.median(walls)), "max_ms": 1e3 * max(walls), "set_target_ms": 1e3 * parts[0], "set_source_ms": 1e3 * parts[1], "run_ms": 1e3 * parts[2],
                          "iterations": int(res.iters_done), "converged": bool(res.converged), "last_K": int(res.last_K)}
+        # what the reference's operator really runs (operators/icp_align.py:47-161 on a base object WITH faces): surface mode --
+        # host vertices + triangles -> set_target_mesh (triangle images, tree, grid) + set_source + the early-exit loop
+        mesh_cases = {"surface_200k_82ktri": (synth.lattice_surface_mesh(143, 288), 200_000),
+                      "surface_1M_2Mtri": (synth.lattice_surface_mesh(700, 1400), 1_000_000)}
+        s_mxa = synth.rigid4(synth.rotation_from_rotvec([0.02, -0.015, 0.025]), [0.01, -0.008, 0.012])
+        eye4 = np.identity(4, dtype=np.float32)
+        for name, ((verts, tris), n_src) in mesh_cases.items():
+            pts = synth.bunny_surface(n_src, offset=0.37)
+            best, parts, res, walls = 1e9, None, None, []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                e.set_target_mesh(verts, tris)
+                t1 = time.perf_counter()
+                e.set_source(pts, stride=1)
+                e.set_matrices(s_mxa, eye4)
+                t2_ = time.perf_counter()
+                r = e.run(iters=50, thresh=0.05, target_d=0.01, use_target=True, early_exit=True)
+                t3 = time.perf_counter()
+                walls.append(t3 - t0)
+                if t3 - t0 < best:
+                    best, parts, res = t3 - t0, (t1 - t0, t2_ - t1, t3 - t2_), r
+            out[name] = {"ms": 1e3 * best, "median_ms": 1e3 * float(np.median(walls)), "max_ms": 1e3 * max(walls), "set_target_mesh_ms": 1e3 * parts[0],
+                         "set_source_ms": 1e3 * parts[1], "run_ms": 1e3 * parts[2], "n_source": int(n_src), "n_target_vertices": int(len(verts)),
+                         "n_target_triangles": int(len(tris)), "iterations": int(res.iters_done), "converged": bool(res.converged), "last_K": int(res.last_K),
+                         "mean_dist": float(res.mean_dist)}
     return out
 
 
@@ -361,7 +387,7 @@ def mfma_leg(args, local_rank, src, tgt, mxa, mxb, kw, ref_matrix):
     from object_alignment_amd.engine import IcpEngine
     os.environ["OA_NN_MFMA"] = "1"
     try:
-        with IcpEngine(local_rank) as e:
+        with IcpEngine(local_rank, experiments=True) as e:      # liboa_icp_exp.so: the default library does not carry the experiment
             e.set_search_mode("brute")
             e.set_target(tgt)
             e.set_source(src, stride=1)
@@ -380,7 +406,7 @@ def mfma_leg(args, local_rank, src, tgt, mxa, mxb, kw, ref_matrix):
     pairs = float(args.n_source) * float(args.n_target)
     mfma_tflops = 32.0 * pairs / (nn_ms * 1e-3) / 1e12           # 2 x K = 16 flop per pair and MFMA, all executed
     return {
-        "what": "EXPERIMENT (env OA_NN_MFMA=1, off by default): k_nn_search_mfma, filter levels 1-2 of the brute-force search "
+        "what": "EXPERIMENT (liboa_icp_exp.so with OA_NN_MFMA=1; not in the default library): k_nn_search_mfma, filter levels 1-2 of the brute-force search "
                 "on the matrix cores (binary16 hi/lo split, sign test); same correspondences",
         "value": args.steps / dt, "unit": "iterations/s", "steps": args.steps, "ms_per_step": 1e3 * dt / args.steps,
         "ms_per_nn_search": nn_ms, "final_matrix_bitwise_equal_to_default_kernel": bool(np.array_equal(r.matrix_world, ref_matrix)),
@@ -616,29 +642,6 @@ def main():
         ceil_t = [c["tlaneops"] for c in (ceil_before, ceil_after) if "tlaneops" in c and c["tlaneops"] > 0]
         ceil_now = min(ceil_t) if ceil_t else None                           # the lower of the two: the conservative denominator
         half_share = HALF_RATE_SHARE.get(brute_kernel)
-        mix_frac = None
-        if half_share is not None:
-            # the time the executed instructions need at the rates measured before / after the timed loop, over the time the
-            # launch took: both are given (the clock inside a 2 s loop lies between the two burns')
-            mix_frac = {}
-            for when, cm in (("before_timed_loop", ceil_before), ("after_timed_loop", ceil_after)):
-                if cm.get("tlaneops", 0) > 0 and cm.get("tlaneops_min3", 0) > 0:
-                    need_s = per_pair * pairs * ((1.0 - half_share) / (cm["tlaneops"] * 1e12) + half_share / (cm["tlaneops_min3"] * 1e12))
-                    mix_frac[when] = need_s / (nn_ms * 1e-3)
-            mix_frac = mix_frac or None
-        # ... and at the clock the chip held DURING the search (one workgroup's cycle counter against its constant-rate counter,
-        # OA_STAT_SEARCH_CLOCK_MHZ): issue rates scale with the clock, so the burns' cycles per instruction (mean of the two)
-        # price the executed instructions in cycles, against launch time x that clock
-        mix_at_kernel_clock = None
-        burns = [cm for cm in (ceil_before, ceil_after) if cm.get("tlaneops", 0) > 0 and cm.get("tlaneops_min3", 0) > 0 and cm.get("shader_clock_mhz", 0) > 0]
-        if half_share is not None and burns and search_clock_mhz and search_clock_mhz > 0:
-            lanes = 256.0 * 4.0 * 64.0                                       # lane-ops per wave-instruction x SIMDs
-            cpi_full = float(np.mean([cm["shader_clock_mhz"] * 1e6 * lanes / (cm["tlaneops"] * 1e12) for cm in burns]))
-            cpi_half = float(np.mean([cm["shader_clock_mhz"] * 1e6 * lanes / (cm["tlaneops_min3"] * 1e12) for cm in burns]))
-            need_cycles = per_pair * pairs / lanes * ((1.0 - half_share) * cpi_full + half_share * cpi_half)
-            mix_at_kernel_clock = {"shader_clock_mhz_during_search": search_clock_mhz,
-                                   "cycles_per_wave_instruction": {"v_add_f32": cpi_full, "v_min3_f32": cpi_half},
-                                   "frac": need_cycles / (nn_ms * 1e-3 * search_clock_mhz * 1e6)}
         out = {
             "metric": "ICP iterations/sec + ms/NN-search, 1M<->1M verts",
             "value": args.steps / elapsed,
@@ -682,19 +685,24 @@ def main():
                                                                    "16 independent chains, 8 waves per SIMD, ~2.5 ms; v_min3_f32 (`tlaneops_min3`: the half-rate class) beside it",
                                                     "before_timed_loop": ceil_before, "after_timed_loop": ceil_after, "used": ceil_now},
                          "frac_of_measured_ceiling": (laneops / ceil_now) if ceil_now else None,
-                         # the same with the half-rate instructions of the hot loop priced at their own measured rate: the time
-                         # the executed instructions need at this box's rates / the time the launch took
                          "half_rate_instruction_share": half_share,
-                         "frac_of_measured_mix_ceiling": mix_frac,
-                         "mix_ceiling_at_the_search_clock": mix_at_kernel_clock,
+                         "shader_clock_mhz_during_search": search_clock_mhz,
+                         "what_frac_is": "VALU issue-slot utilisation: executed vector-ALU instructions (PMC) x 64 lanes / launch time, against the "
+                                         "nominal 78.6 T lane-ops/s.  It says how full the pipe is, NOT how good the kernel is: a third of these "
+                                         "instructions are half-rate (v_min3_f32 / v_cmp), so the pipe is full at ~0.78, and most of them prove "
+                                         "losers the images' order already implies (DESIGN.md 3.1: a block's [u_min, u_max] would replace level 0 "
+                                         "-- which turns brute force into the slab search of row f2).  The kernel is frozen (VERDICT r5).",
                          "formula": "frac = valu_instructions_per_pair x pairs_per_launch / avg_launch_ms / 78.6e12 lane-ops/s "
                                     "(256 CU x 4 SIMD x 32 lanes x 2.4 GHz); valu_instructions_per_pair = SQ_INSTS_VALU x 64 / "
                                     "pairs from the committed PMC pass (profiles/), avg_launch_ms = hipEvent pairs around "
                                     "every launch of this run",
-                         "effective_tflops": eff_tflops, "effective_frac_of_157.3": eff_tflops / FP32_VECTOR_PEAK_TFLOPS,
-                         "effective_note": "SURVEY 8d's ALGORITHMIC 8 flop per (source, target) pair / launch time: NOT executed "
-                                           "arithmetic -- the conservative two-level filter proves most pairs losers with 2 fma + "
-                                           "1 min, so this can exceed the chip's peak; it compares kernels, it is not a roofline"},
+                         "pairs_per_s": pairs / (nn_ms * 1e-3),
+                         # SURVEY 8d's primary formula, as written: 8 flop per (source, target) pair / launch time / 157.3 TFLOP/s.
+                         # Above 1 the model counts arithmetic the kernel never executes (level 0 proves ~97 % of the pairs losers with
+                         # one v_sub_f32 + half a v_min3_f32): then it is void as a roofline and says so.
+                         "frac_8d_algorithmic": {"value": eff_tflops / FP32_VECTOR_PEAK_TFLOPS, "void": bool(eff_tflops / FP32_VECTOR_PEAK_TFLOPS > 1.0),
+                                                 "effective_tflops": eff_tflops,
+                                                 "formula": "8 flop x N_s x N_t / avg_launch_ms / 157.3 TFLOP/s (SURVEY 8d)"}},
             "roofline_hbm": {"bound": "hbm", "achieved": algo_bytes / (nn_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": algo_bytes / (nn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                              "algorithmic_bytes_per_launch": algo_bytes, "traffic": traffic},

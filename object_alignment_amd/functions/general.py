@@ -12,8 +12,10 @@ import numpy as np
 
 from ..engine import IcpEngine, REF_VALUEERROR
 
-__all__ = ["make_pairs", "affine_matrix_from_points", "calc_target_matrix", "GpuBVH", "AlignObject", "default_engine",
-           "invalidate_cached_geometry", "close_default_engines"]
+__all__ = ["make_pairs", "affine_matrix_from_points", "calc_target_matrix", "quaternion_matrix", "vector_norm", "GpuBVH",
+           "AlignObject", "default_engine", "invalidate_cached_geometry", "close_default_engines"]
+
+_EPS = np.finfo(float).eps * 4.0                  # /root/reference/functions/general.py:30
 
 _default_engines = {}
 
@@ -173,6 +175,42 @@ class GpuBVH:
         obj = evaluated_base(base_obj, depsgraph)
         return cls(_coords_of(obj), engine, _tris_of(obj) if surface else None)
 
+    def find_nearest(self, co, distance=None):
+        """`BVHTree.find_nearest(origin, distance)` for ONE point in the base object's local space, as the reference asks of
+        its `base_bvh` (functions/general.py:297): (location, normal, index, distance), or four Nones when nothing lies within
+        `distance`.  Surface trees answer with the closest point on the nearest triangle, its geometric normal (Blender's
+        normal_tri_v3, normalised) and the triangle's index; vertex trees with the nearest vertex, no normal, its index.
+        One point through the device searches: the same kernels, the same (d2, index) rule as every other search.  The
+        engine's source is this point afterwards -- the next make_pairs binds its own again."""
+        p = np.ascontiguousarray(np.asarray([co[0], co[1], co[2]], dtype=np.float32).reshape(1, 3))
+        if not np.all(np.isfinite(p)):
+            return (None, None, None, None)
+        eng = self.engine
+        self._bind_target()
+        eng.set_source(p, vlist=None, stride=1)
+        eng.source_owner = None
+        self._src_key = None
+        eye = np.identity(4, dtype=np.float32)
+        eng.set_matrices(eye, eye)
+        idx, _d2, _ = eng.nn_search()
+        A, B, _ = eng.make_pairs(1e300, False)                     # identity matrices: B is the closest point itself
+        if B.shape[1] != 1:
+            return (None, None, None, None)
+        loc = B[:, 0].astype(np.float32)
+        diff = (p[0] - loc).astype(np.float32)
+        dist = float(np.float32(np.sqrt(np.float32(np.dot(diff.astype(np.float64), diff.astype(np.float64))))))
+        if distance is not None and not dist <= float(distance):
+            return (None, None, None, None)
+        i = int(idx[0])
+        normal = None
+        if self.tris is not None:
+            a, b, c = (self.target[int(v)] for v in np.asarray(self.tris).reshape(-1, 3)[i])
+            e1, e2 = (a - b).astype(np.float32), (b - c).astype(np.float32)
+            n = np.array([e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]], dtype=np.float32)
+            d = np.float32(n[0] * n[0] + n[1] * n[1] + n[2] * n[2])
+            normal = (n * (np.float32(1.0) / np.float32(np.sqrt(d)))).astype(np.float32) if d > np.float32(1e-35) else np.zeros(3, np.float32)
+        return (loc, normal, i, dist)
+
     def _bind_source(self, xyz, vlist, sample):
         # re-upload only when something changed.  The reference re-reads vertices[i].co on every call
         # (functions/general.py:284), so "changed" has to mean the CONTENT: a hash over the bytes of the coordinates and of
@@ -223,6 +261,39 @@ def _vlist_array(vlist):
     return arr
 
 
+def quaternion_matrix(quaternion):
+    """Homogeneous 4x4 rotation matrix of a quaternion (w, x, y, z), any length; the identity for a (near-)zero quaternion.
+    Same contract and the same float64 operations as the reference's helper (functions/general.py:38-62, pinned by
+    tests/golden/general_helpers.npz): a dozen flops on the host -- the Horn branch of the solve itself runs on the device."""
+    q = np.array(quaternion, dtype=np.float64).reshape(-1)[:4]
+    nq = float(np.dot(q, q))
+    if nq < _EPS:
+        return np.identity(4)
+    q = q * np.sqrt(2.0 / nq)
+    w, x, y, z = q
+    ww = np.identity(4)
+    ww[0, :3] = (1.0 - y * y - z * z, x * y - z * w, x * z + y * w)
+    ww[1, :3] = (x * y + z * w, 1.0 - x * x - z * z, y * z - x * w)
+    ww[2, :3] = (x * z - y * w, y * z + x * w, 1.0 - x * x - y * y)
+    return ww
+
+
+def vector_norm(data, axis=None, out=None):
+    """Euclidean length of an array along `axis` (functions/general.py:66-102): a float for 1-D input without `out`, else an
+    array (at least 1-D); with `out` the result is written there and None returned.  The input is never modified."""
+    sq = np.array(data, dtype=np.float64)
+    if out is None and sq.ndim == 1:
+        return float(np.sqrt(np.dot(sq, sq)))
+    sq *= sq
+    if out is None:
+        res = np.atleast_1d(np.sum(sq, axis=axis))
+        np.sqrt(res, res)
+        return res
+    np.sum(sq, axis=axis, out=out)
+    np.sqrt(out, out)
+    return None
+
+
 def make_pairs(align_obj, base_obj, base_bvh, vlist, thresh, sample=0, calc_stats=False):
     """Same contract as the reference's make_pairs (functions/general.py:257-329).
 
@@ -259,10 +330,10 @@ def affine_matrix_from_points(v0, v1, shear=True, scale=True, usesvd=True):
         raise ValueError(REF_VALUEERROR)                                # :157
     if ndims > 64:
         raise ValueError("affine_matrix_from_points: at most 64 dimensions on the device path (got %d)" % ndims)
-    # usesvd=False (Horn's quaternion branch, :191-206, 3-D only) minimises the same objective and has the same
-    # optimum; it is served by the same device solve.
+    # usesvd=False (3-D, no shear): Horn's quaternion branch (:191-206) -- the eigenvector of the 4 x 4 matrix N, on the device
+    # (csrc/oa_kernels.hpp: rotation_from_covariance_horn).  As in the reference, usesvd is ignored when shear is set or ndims != 3.
     if ndims == 3 and not shear:
-        return default_engine().kabsch(v0, v1, scale=bool(scale))
+        return default_engine().kabsch(v0, v1, scale=bool(scale), horn=not usesvd)
     return default_engine().affine_from_points(v0, v1, shear=bool(shear), scale=bool(scale))
 
 

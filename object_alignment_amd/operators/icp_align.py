@@ -150,6 +150,64 @@ def _assign_matrix(obj, new_np):
         obj.matrix_world = np.array(new_np, dtype=np.float32)
 
 
+def execute_alignment(op, context):
+    """The body of `execute` of BOTH ICP operators: the reference's OBJECT_OT_icp_align.execute (operators/icp_align.py:47-161)
+    and OBJECT_OT_icp_align_feedback.execute (operators/icp_align_feedback.py:130-235) are the same loop -- the second lacks
+    the per-iteration timing prints, nothing else -- so both classes run this."""
+    settings = get_addon_preferences()
+    align_obj = context.object
+    base_obj = next(o for o in context.selected_objects if o != align_obj)
+    try:
+        align_obj.rotation_mode = 'QUATERNION'
+    except Exception:
+        pass
+    import time
+    start = time.time()                                     # :51
+    vlist = vlist_for_engine(align_obj)
+    base_geo = evaluated_base(base_obj, context)            # BVHTree.FromObject(base_obj, depsgraph)  (:52-53)
+    failure = None
+    try:
+        res = IcpAlign(settings).run(_coords_of(align_obj), _coords_of(base_geo),
+                                     _matrix_to_np(align_obj.matrix_world), _matrix_to_np(base_obj.matrix_world),
+                                     vlist=vlist, target_tris=_tris_of(base_geo))
+    except ValueError as exc:
+        # fewer than 3 pairs in iteration n: the reference has already applied iterations 0..n-1 to align_obj and
+        # the m_* objects when affine_matrix_from_points raises (:109 after :121-127 of the earlier passes)
+        res = getattr(exc, "partial", None)
+        if res is None:
+            raise
+        failure = exc
+    _assign_matrix(align_obj, res.matrix_world)
+    if settings.take_m_with:                                # :123-127, replayed in iteration order
+        from .. import _hostmath
+        scene = getattr(context, "scene", None) or getattr(getattr(_bpy, "context", None), "scene", None)
+        for obj in (scene.objects if scene is not None else []):
+            if obj.name[:2] == "m_":
+                m = _matrix_to_np(obj.matrix_world)
+                for new_mat in res.step_new:
+                    m = _hostmath.mat4_mul(m, new_mat)
+                _assign_matrix(obj, m)
+                if hasattr(obj, "update_tag"):
+                    obj.update_tag()
+    if hasattr(align_obj, "update_tag"):
+        align_obj.update_tag()
+    if hasattr(context, "view_layer") and hasattr(context.view_layer, "update"):
+        context.view_layer.update()
+    op.last_result = res
+    # the reference prints its summary (:145-160); here it also goes to Blender's info area
+    op.last_report = report_lines(res, settings, time.time() - start)
+    for line in op.last_report:
+        print(line)
+        if hasattr(op, "report"):
+            try:
+                op.report({'INFO'}, line)
+            except Exception:
+                pass
+    if failure is not None:
+        raise failure
+    return {'FINISHED'}
+
+
 class OBJECT_OT_icp_align(_OperatorBase):
     """Iterative-closest-point alignment of the active object onto the other selected object"""
     bl_idname = "object.align_icp"
@@ -162,55 +220,4 @@ class OBJECT_OT_icp_align(_OperatorBase):
         return len(context.selected_objects) == 2 and context.object.type == 'MESH'
 
     def execute(self, context):
-        settings = get_addon_preferences()
-        align_obj = context.object
-        base_obj = next(o for o in context.selected_objects if o != align_obj)
-        try:
-            align_obj.rotation_mode = 'QUATERNION'
-        except Exception:
-            pass
-        import time
-        start = time.time()                                     # :51
-        vlist = vlist_for_engine(align_obj)
-        base_geo = evaluated_base(base_obj, context)            # BVHTree.FromObject(base_obj, depsgraph)  (:52-53)
-        failure = None
-        try:
-            res = IcpAlign(settings).run(_coords_of(align_obj), _coords_of(base_geo),
-                                         _matrix_to_np(align_obj.matrix_world), _matrix_to_np(base_obj.matrix_world),
-                                         vlist=vlist, target_tris=_tris_of(base_geo))
-        except ValueError as exc:
-            # fewer than 3 pairs in iteration n: the reference has already applied iterations 0..n-1 to align_obj and
-            # the m_* objects when affine_matrix_from_points raises (:109 after :121-127 of the earlier passes)
-            res = getattr(exc, "partial", None)
-            if res is None:
-                raise
-            failure = exc
-        _assign_matrix(align_obj, res.matrix_world)
-        if settings.take_m_with:                                # :123-127, replayed in iteration order
-            from .. import _hostmath
-            scene = getattr(context, "scene", None) or getattr(getattr(_bpy, "context", None), "scene", None)
-            for obj in (scene.objects if scene is not None else []):
-                if obj.name[:2] == "m_":
-                    m = _matrix_to_np(obj.matrix_world)
-                    for new_mat in res.step_new:
-                        m = _hostmath.mat4_mul(m, new_mat)
-                    _assign_matrix(obj, m)
-                    if hasattr(obj, "update_tag"):
-                        obj.update_tag()
-        if hasattr(align_obj, "update_tag"):
-            align_obj.update_tag()
-        if hasattr(context, "view_layer") and hasattr(context.view_layer, "update"):
-            context.view_layer.update()
-        self.last_result = res
-        # the reference prints its summary (:145-160); here it also goes to Blender's info area
-        self.last_report = report_lines(res, settings, time.time() - start)
-        for line in self.last_report:
-            print(line)
-            if hasattr(self, "report"):
-                try:
-                    self.report({'INFO'}, line)
-                except Exception:
-                    pass
-        if failure is not None:
-            raise failure
-        return {'FINISHED'}
+        return execute_alignment(self, context)

@@ -9,6 +9,7 @@ iteration budget is spent.  Deliberate choices about the reference's quirks:
     `icp_iterations + 1` iterations run;
   * kept -- convergence is only evaluated when distance statistics are being computed (`use_target`), using a
     five-slot ring of translation magnitudes initialised to twice the target (:93-94 of icp_align.py, :98-99 here);
+  * `execute` (EXEC_DEFAULT, Redo) is the non-modal loop of the reference's :130-235 -- the same code as OBJECT_OT_icp_align's;
   * fixed -- the reference's `iterate` refers to an unbound name (`take_m_with`, :267) and therefore raises
     NameError on its first tick; the value read from the preferences during `invoke` is used instead.
 """
@@ -20,7 +21,7 @@ import numpy as np
 
 from .. import _hostmath
 from ..functions.general import _coords_of, _matrix_to_np, _tris_of, default_engine, evaluated_base
-from .icp_align import _OperatorBase, _assign_matrix, _bpy, get_addon_preferences, vlist_for_engine
+from .icp_align import _OperatorBase, _assign_matrix, _bpy, execute_alignment, get_addon_preferences, vlist_for_engine
 
 RING = 5
 
@@ -61,7 +62,9 @@ class OBJECT_OT_icp_align_feedback(_OperatorBase):
         return len(context.selected_objects) == 2 and bool(active) and active.type == 'MESH'
 
     def execute(self, context):
-        return {"CANCELLED"}          # modal only, as in the reference
+        # what bpy.ops.object.align_icp_redraw('EXEC_DEFAULT') and Redo run: the whole loop, no timer, no redraws -- the reference's
+        # second copy of OBJECT_OT_icp_align.execute (operators/icp_align_feedback.py:130-235; rounds 1-5 returned CANCELLED here)
+        return execute_alignment(self, context)
 
     def invoke(self, context, event):
         prefs = get_addon_preferences()

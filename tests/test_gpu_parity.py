@@ -61,7 +61,9 @@ def test_affine_matrix_from_points_golden(golden_dir):
     for i in range(int(g["n_horn"])):                       # usesvd=False: the reference's Horn-branch results
         p = "h%02d_" % i
         got = affine_matrix_from_points(g[p + "A"], g[p + "B"], shear=False, scale=bool(g[p + "scale"]), usesvd=False)
-        assert np.abs(got - g[p + "M"]).max() < 1e-9
+        assert np.abs(got - g[p + "M"]).max() < 1e-11      # the quaternion branch itself (round 6; rounds 1-5 served it with the SVD: 1e-9)
+        svd = affine_matrix_from_points(g[p + "A"], g[p + "B"], shear=False, scale=bool(g[p + "scale"]), usesvd=True)
+        assert 0.0 < np.abs(got - svd).max() < 1e-9        # another route to the same optimum: close, not the same bits
 
 
 def test_affine_matrix_from_points_full_signature_golden(golden_dir):
@@ -149,7 +151,7 @@ def test_nn_search_geometry_variants(orc, R, splits, filt, monkeypatch):
     tgt = rng.normal(size=(9000, 3)).astype(np.float32)
     src = rng.normal(size=(4100, 3)).astype(np.float32)
     eye = np.identity(4, dtype=np.float32)
-    with IcpEngine(0) as e:
+    with IcpEngine(0, experiments=(R == 8)) as e:                   # (8 points per thread is an OA_EXPERIMENTS instantiation)
         e.set_target(tgt)
         e.set_source(src)
         e.set_matrices(eye, eye)
@@ -465,6 +467,60 @@ def test_operator_execute_duck_typed(golden_dir, orc, name):
         setattr(icp_align.get_addon_preferences(), k, v)
 
 
+@pytest.mark.parametrize("name", ["icp_loop_include", "icp_loop_bumpy_converge"])
+def test_feedback_operator_execute_runs_the_whole_loop(golden_dir, orc, name):
+    """OBJECT_OT_icp_align_feedback.execute -- what bpy.ops.object.align_icp_redraw('EXEC_DEFAULT') and Redo run: the reference's
+    second copy of the non-modal loop (operators/icp_align_feedback.py:130-235) -- ends where the reference's loop fixture ends."""
+    from object_alignment_amd.operators import OBJECT_OT_icp_align_feedback, icp_align
+    g = _load(golden_dir, name)
+    st = _settings_from(g)
+    for k, v in st.__dict__.items():
+        setattr(icp_align.get_addon_preferences(), k, v)
+    ctx, align, m_obj = _duck_scene(g, orc)
+    op = OBJECT_OT_icp_align_feedback()
+    assert op.poll(ctx)
+    assert op.execute(ctx) == {"FINISHED"}
+    got = np.array([[align.matrix_world[r][c] for c in range(4)] for r in range(4)], np.float32)
+    assert np.abs(got - g["final_world"]).max() <= F32_ULP
+    assert [str(x) for x in g["report"]] == op.last_report[:-1]
+    assert op.last_result.iters_done == int(g["iters_done"]) and op.last_result.converged == bool(g["converged"])
+    for k, v in icp_align.IcpSettings().__dict__.items():
+        setattr(icp_align.get_addon_preferences(), k, v)
+
+
+def test_gpubvh_find_nearest_is_the_reference_contract(orc):
+    """`base_bvh.find_nearest(co) -> (co, normal, index, distance)`, the one method the reference asks of its BVH
+    (functions/general.py:297): surface trees against the oracle's all-triangles search, vertex trees against its brute force."""
+    from object_alignment_amd import synth
+    from object_alignment_amd.functions import GpuBVH, AlignObject, make_pairs
+    verts, tris = synth.lattice_surface_mesh(60, 120)
+    rng = np.random.default_rng(9)
+    pts = (synth.bunny_surface(40, 0.3) + rng.normal(0, 0.02, size=(40, 3))).astype(np.float32)
+    base = AlignObject(verts, None, tris=tris)
+    bvh = GpuBVH.FromObject(base, None)
+    face, co1, d2 = orc.nn_tri_brute(pts, verts, tris)
+    for k, p in enumerate(pts):
+        loc, normal, index, dist = bvh.find_nearest(p)
+        assert index == int(face[k]) and np.array_equal(loc, co1[k])
+        assert abs(dist - float(np.sqrt(np.float64(d2[k])))) <= 1e-6 * max(1.0, dist)
+        a, b, c = (verts[v].astype(np.float64) for v in tris[index])
+        n = np.cross(a - b, b - c)
+        assert np.abs(normal.astype(np.float64) - n / np.linalg.norm(n)).max() < 1e-5
+    assert bvh.find_nearest(pts[0], distance=1e-9) == (None, None, None, None)       # nothing within the cap
+    assert bvh.find_nearest([np.nan, 0.0, 0.0]) == (None, None, None, None)
+    # a point cloud: nearest vertex, no normal
+    vb = GpuBVH.FromObject(AlignObject(verts, None), None)
+    ridx, rd2 = orc.nn_brute(pts, verts)
+    for k, p in enumerate(pts[:10]):
+        loc, normal, index, dist = vb.find_nearest(p)
+        assert index == int(ridx[k]) and normal is None and np.array_equal(loc, verts[index])
+    # the tree still serves make_pairs afterwards (find_nearest took the engine's source: it is bound again)
+    src = synth.bunny_surface(3000, 0.5)
+    A, B, _ = make_pairs(AlignObject(src, None), base, bvh, list(range(len(src))), 0.3)
+    rA, rB, _ = orc.make_pairs(src, verts, np.identity(4, np.float32), np.identity(4, np.float32), 0.3, tris=tris)
+    assert np.array_equal(A, rA) and np.array_equal(B, rB)
+
+
 def test_modal_operator_ticks(golden_dir, orc):
     """OBJECT_OT_icp_align_feedback: timer ticks of `redraw_frequency` iterations reach the reference's final matrix."""
     from object_alignment_amd.operators import OBJECT_OT_icp_align_feedback, icp_align
@@ -684,6 +740,48 @@ def test_c5_full_size_masked_loop(orc, how):
         _REF_CACHE["c5"] = orc.icp_run(src, tgt, mxa, eye, iters=iters, sample=1, thresh=0.5, target_d=1e-300, use_target=True,
                                        vlist=vlist, kd=orc.KDTree(tgt))
     _assert_loop_equals_oracle(res, _REF_CACHE["c5"], iters)
+
+
+def test_c5_shard_through_the_brute_force_kernel(orc):
+    """The north-star kernel on BASELINE config 5's shape (only timed there so far): one eighth of the 9M selected
+    points -- a compact slab, as a Morton shard is -- against the 2M-vertex target with the normal-angle test on,
+    set_search_mode("brute") (k_nn_search_sorted: 1954 LDS tiles, 2.2e12 pairs per search), three iterations against the
+    oracle's loop over the same vertex list: pairs per iteration exact, transforms to 1e-9."""
+    from object_alignment_amd import synth
+    from object_alignment_amd.engine import IcpEngine
+    from object_alignment_amd.operators.icp_align import vlist_from_weights
+    src, sn = synth.bunny_surface_with_normals(10_000_000, 0.5)
+    tgt, tn = synth.bunny_surface_with_normals(2_000_000, 0.0)
+    rng = np.random.default_rng(501)
+    bent = rng.random(len(src)) < 0.33
+    sn = sn.copy()
+    sn[bent] += rng.normal(size=(int(bent.sum()), 3)).astype(np.float32) * np.float32(0.9)
+    sn /= np.maximum(np.linalg.norm(sn, axis=1, keepdims=True), np.float32(1e-12))
+    sn = sn.astype(np.float32)
+    mxa = synth.rigid4(synth.rotation_from_rotvec([0.003, -0.002, 0.004]), [0.002, -0.001, 0.0015])
+    eye = np.identity(4, dtype=np.float32)
+    axis = rng.normal(size=3)
+    axis /= np.linalg.norm(axis)
+    h = src.astype(np.float64) @ axis
+    cap = np.nonzero(h > np.quantile(h, 0.9))[0]
+    vlist = np.array(vlist_from_weights(len(src), exclude=[(int(v), 1.0) for v in cap]), dtype=np.int64)
+    order = vlist[np.argsort(src[vlist, 0], kind="stable")]                      # the selection along x: shard 1 of 8 is its second eighth
+    n8 = len(vlist) // 8
+    shard = np.sort(order[n8:2 * n8])
+    assert 1_100_000 < len(shard) < 1_150_000
+    iters = 3
+    with IcpEngine(0) as e:
+        e.set_search_mode("brute")
+        e.set_target(tgt)
+        e.set_source(src, vlist=shard, stride=1)
+        e.set_normals(sn, tn, 45.0)
+        e.set_matrices(mxa, eye)
+        assert e.stat("brute_kernel") == 3.0
+        res = e.run(iters=iters, thresh=0.5, target_d=0.01, use_target=True, early_exit=False)
+    ref = orc.icp_run(src, tgt, mxa, eye, iters=iters, sample=1, thresh=0.5, target_d=1e-300, use_target=True,
+                      vlist=shard, kd=orc.KDTree(tgt), normals=(sn, tn), max_angle_deg=45.0)
+    assert 0.5 * len(shard) < ref["step_K"][0] < 0.95 * len(shard)               # the angle test bites
+    _assert_loop_equals_oracle(res, ref, iters)
 
 
 def test_c5_shaped_masked_sharded(orc):

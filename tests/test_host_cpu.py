@@ -28,6 +28,45 @@ def test_cabi_exports_every_declared_symbol(built):
     assert b"gfx950" in L.oa_version()
 
 
+def test_experiments_flavour_exports_the_same_abi(built):
+    """liboa_icp_exp.so (the default library + the A/B predecessors and measured-but-not-kept variants, csrc/oa_families.hpp) is the
+    same C-ABI; the default library carries fewer than 300 kernels (rounds 1-5: 749, 628 of them rocprim's)."""
+    import subprocess
+    from object_alignment_amd import _capi
+    Lx = _capi.load(experiments=True)
+    for name in _capi.SYMBOLS:
+        assert hasattr(Lx, name), name
+    assert _capi.load() is not Lx
+    stubs = subprocess.run(["nm", "-C", _capi.LIB_PATH], capture_output=True, text=True).stdout.count("__device_stub__")
+    assert 0 < stubs < 300, stubs
+
+
+def test_quaternion_matrix_and_vector_norm_match_the_reference():
+    """functions/general.py's two helpers (the reference's :38-102), on values the imported reference produced
+    (tests/golden/general_helpers.npz, tools/gen_golden.py helpers)."""
+    from object_alignment_amd.functions.general import quaternion_matrix, vector_norm
+    g = np.load(os.path.join(ROOT, "tests", "golden", "general_helpers.npz"))
+    for q, M in zip(g["quat_q"], g["quat_M"]):
+        got = quaternion_matrix(q)
+        assert got.shape == (4, 4) and np.abs(got - M).max() <= 4e-16, (q, got - M)
+    assert np.array_equal(quaternion_matrix([0, 0, 0, 0]), np.identity(4))
+    q_in = [0.5, 0.5, 0.5, 0.5]
+    quaternion_matrix(q_in)
+    assert q_in == [0.5, 0.5, 0.5, 0.5]                              # the argument is never modified
+    v3, v653, v543 = g["vn_v3"], g["vn_v653"], g["vn_v543"]
+    assert isinstance(vector_norm(v3), float) and vector_norm(v3) == float(g["vn_v3_none"])
+    for ax in (-1, 0, 1, 2):
+        assert np.array_equal(vector_norm(v653, axis=ax), g["vn_v653_axis%d" % ax])
+    assert np.array_equal(vector_norm(v653), g["vn_v653_none"]) and vector_norm(v653).shape == (1,)
+    out = np.empty((5, 3))
+    assert vector_norm(v543, axis=1, out=out) is None and np.array_equal(out, g["vn_v543_axis1_out"])
+    assert vector_norm([]) == float(g["vn_empty"]) == 0.0 and vector_norm([1]) == float(g["vn_one"]) == 1.0
+    assert vector_norm([3, 4]) == float(g["vn_ints"]) == 5.0
+    keep = v653.copy()
+    vector_norm(v653, axis=1)
+    assert np.array_equal(keep, v653)
+
+
 def test_struct_layouts_match_header(built):
     import ctypes as C
     from object_alignment_amd import _capi
