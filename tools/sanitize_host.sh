@@ -19,9 +19,13 @@ case "$KIND" in
 esac
 case "$1" in
 build)
+  # the HOST unit instrumented (all the host code lives there), linked with the kernel families' ordinary objects
+  # (build/obj/oa_fam_*.o: device code + launch stubs only; `python -c "import __graft_entry__ as g; g.build_hip()"` makes them)
+  FAMS=$(ls "$REPO"/build/obj/oa_fam_*.o | grep -v "oa_fam_exp")
   cd "$REPO/object_alignment_amd/csrc" && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -g -std=c++17 -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form \
-      -fno-slp-vectorize -fPIC -shared -fvisibility=hidden -pthread $FLAGS -fno-gpu-sanitize -shared-libsan \
-      -fno-omit-frame-pointer -o "$SAN/liboa_icp_$KIND.so" oa_icp.hip && ls -la "$SAN/liboa_icp_$KIND.so" ;;
+      -fno-slp-vectorize -fPIC -fvisibility=hidden -pthread $FLAGS -fno-gpu-sanitize -fno-omit-frame-pointer -c oa_icp.hip -o "$SAN/oa_icp_$KIND.o" && \
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fvisibility=hidden -pthread $FLAGS -fno-gpu-sanitize -shared-libsan \
+      -o "$SAN/liboa_icp_$KIND.so" "$SAN/oa_icp_$KIND.o" $FAMS && ls -la "$SAN/liboa_icp_$KIND.so" ;;
 driver)
   # the C driver (tools/san_driver.c) against the instrumented library: no Python in the process (TSan cannot be preloaded
   # into this image's python; it runs here)
