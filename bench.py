@@ -19,22 +19,22 @@ N > 1: BASELINE config "1M <-> 1M, source sharded across N GPUs with ... covaria
        rank holds one context and the 24 sums go through torch.distributed's all_reduce (backend "nccl" = RCCL).
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel of the headline, the brute-force search
-k_nn_search_sorted (OA_NN_SORT=0: its predecessor k_nn_search_filtered).  It is bound by fp32 vector-ALU issue (SURVEY.md
-8d / docs/HISTORY.md 4.1), so
+k_nn_search_sorted.  It is bound by fp32 vector-ALU issue (SURVEY.md 8d / DESIGN.md 3.1), so
 
     roofline.achieved = executed VALU lane-ops/s = (SQ_INSTS_VALU per launch x 64 lanes) / average launch time
     roofline.peak     = 78.6e12 lane-ops/s       = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
-    roofline.frac     = achieved / peak          (<= 1 by construction)
+    roofline.frac     = achieved / peak          (<= 1 by construction): VALU ISSUE-SLOT UTILISATION -- how full the pipe is,
+                                                  not how good the kernel is (`what_frac_is`)
 
 with the instruction count from the committed PMC pass (profiles/hbm_traffic.json, stamped with the kernel name and
 the commit it was collected at) and the launch time measured live with hipEvents on the kernel's stream.  The chip does
-not hold 2.4 GHz under this load (1.8-2.1 GHz, box to box), so the line also carries every launch's time (`launch_ms`:
-min / median / max), what v_add_f32 (full rate) and v_min3_f32 (half rate) issue on THIS box right before and right after
-the timed loop (`measured_issue_ceiling`, with the shader clock under that load), `frac_of_measured_ceiling` (instructions
-counted alike) and `frac_of_measured_mix_ceiling` (the hot loop's share of half-rate instructions priced at their own rate).  The
-SURVEY's algorithmic figure -- 8 flop per (source, target) pair -- is reported as `effective_tflops`: the kernel's
-conservative filter proves most pairs losers in ~2 instructions, so that figure can exceed what the chip executes and
-is NOT a roofline fraction.  `cpu_baseline` times the CPU oracle (KD-tree + Kabsch; OpenMP on all host cores) on a
+not hold 2.4 GHz under every load, so the line also carries every launch's time (`launch_ms`: min / median / max), what
+v_add_f32 (full rate) and v_min3_f32 (half rate) issue on THIS box right before and right after the timed loop
+(`measured_issue_ceiling`, with the shader clock under that load), `frac_of_measured_ceiling` (instructions counted alike),
+`shader_clock_mhz_during_search`, `pairs_per_s`, and SURVEY 8d's algorithmic formula as written -- 8 flop per (source, target)
+pair / time / 157.3 TFLOP/s -- as `frac_8d_algorithmic` {value, void}: the kernel's conservative filter proves most pairs losers
+in 1.5 instructions, so that model counts arithmetic nobody executes; above 1 it is flagged void and is NOT a roofline fraction.
+`cpu_baseline` times the CPU oracle (KD-tree + Kabsch; OpenMP on all host cores) on a
 bounded sample of the same workload, rank 0, N = 1 only.
 """
 from __future__ import annotations

@@ -2704,7 +2704,7 @@ int build_tri_grid(oa_ctx *c, const double *diag_sum_known)
     dev_free(c->d_tcell_start); dev_free(c->d_tcell_rec); dev_free(c->d_tri_ring);
     dev_free(c->d_tfine_table); dev_free(c->d_tfine_rec);
     if (!c->filter_ok || c->grid_mode == 0 || c->n_tris < 64) return OA_OK;
-    if ((long long)c->n_tris > (long long)oa::TRI_REC_INDEX_MASK) return OA_OK;     // (28-bit indices in the records: the tree takes such meshes)
+    if ((long long)c->n_tris > (long long)oa::TRI_REC_INDEX_MASK || (long long)c->n_tris > (long long)oa::TRI_POOL_MAX_TRIS) return OA_OK;     // (28-bit indices in the records, 26 in the pool entries: the tree takes such meshes)
     double diag_sum = 0.0;
     if (diag_sum_known) diag_sum = *diag_sum_known;
     else {

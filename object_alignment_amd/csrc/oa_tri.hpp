@@ -270,13 +270,16 @@ __device__ __forceinline__ void tri_state_refresh(TriSearchState &s, double delt
 // A wave therefore pays ceil(contenders of all its lanes / 64) closest-point evaluations instead of the maximum over
 // its lanes per flush (PMC before: 65-80 evaluation trips per wave in the first iterations of a run, for 10-12
 // evaluations per query).
-constexpr int TRI_POOL = 288;      // pool entries per wave; a flush is due above TRI_POOL - 128
+// A pool entry is 6 bytes since round 6: (triangle << 6) | owner lane in one word (so the grid search takes meshes of up to 2^26
+// triangles; larger ones go through the tree alone) and the bound's upper 16 bits -- rounded DOWN, so the re-test of phase 2 B is a
+// little more permissive, never wrong.  Rounds 2-5: 9 bytes (index, owner, bound) and 288 entries in the same LDS.
+constexpr int TRI_POOL = 432;      // pool entries per wave; a flush is due above TRI_POOL - 128
+constexpr uint32_t TRI_POOL_MAX_TRIS = 1u << 26;
 constexpr int TRI_SEGS = 10;       // cell-list ranges of one batch of rows (9 rows of the first block, or 5 rows x 2 end cells)
 
 struct TriPool {                   // this wave's part of the workgroup's LDS
-    int *tid;
-    unsigned char *own;
-    float *key;
+    unsigned *to;                  // (triangle << 6) | owner lane
+    unsigned short *key;           // upper half of the bound's bits (a non-negative float, rounded down)
     unsigned long long *slot;      // one per lane: (bits(d2) << 32) | triangle of what others evaluated for it
     unsigned long long *first;     // one per lane: (bits(bound) << 32) | pool entry of its most promising survivor (~0: none)
     float4 *q4;                    // one per lane: its query and its reach (TriSearchState::reach), for whoever tests records on its behalf
@@ -329,9 +332,8 @@ __device__ __forceinline__ void tri_candidate(float px, float py, float pz, cons
         if (surv) ++*surv;
         const int lane = threadIdx.x & 63;
         const int dst = pool.n + __popcll(m & ((1ull << lane) - 1ull));
-        pool.tid[dst] = (int)(__float_as_uint(rec1.w) & TRI_REC_INDEX_MASK);
-        pool.own[dst] = (unsigned char)owner;
-        pool.key[dst] = lb;
+        pool.to[dst] = ((__float_as_uint(rec1.w) & TRI_REC_INDEX_MASK) << 6) | (unsigned)owner;
+        pool.key[dst] = (unsigned short)(__float_as_uint(lb) >> 16);
         // the owner's most promising survivor: smallest bound (lb >= +0: its bits order like its value; a NaN bound -- never
         // from a binned triangle -- sorts last and is evaluated with the rest)
         atomicMin(&pool.first[owner], ((unsigned long long)__float_as_uint(lb) << 32) | (unsigned long long)(unsigned)dst);
@@ -367,7 +369,7 @@ __device__ __forceinline__ void tri_pool_flush(const float *p, const float4 *__r
     const unsigned long long fs = __hip_atomic_load(&pool.first[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     const int kslot = fs == ~0ull ? -1 : (int)(uint32_t)fs;
     if (kslot >= 0 && !(__uint_as_float((uint32_t)(fs >> 32)) > s.thr)) {
-        const uint32_t t = (uint32_t)pool.tid[kslot];
+        const uint32_t t = pool.to[kslot] >> 6;
         const float4 u = tri9[3ll * t], v = tri9[3ll * t + 1], w = tri9[3ll * t + 2];
         tri_consider(p, u, v, w, t, s, delta, cutf, ev);
     }
@@ -379,14 +381,16 @@ __device__ __forceinline__ void tri_pool_flush(const float *p, const float4 *__r
         bool c = false;
         int own = 0, t = 0;
         float key = 0.f;
-        if (e < pool.n) { own = pool.own[e]; t = pool.tid[e]; key = pool.key[e]; }
+        unsigned to = 0u;
+        unsigned short kb = 0;
+        if (e < pool.n) { to = pool.to[e]; kb = pool.key[e]; own = (int)(to & 63u); t = (int)(to >> 6); key = __uint_as_float((unsigned)kb << 16); }
         const float othr = __shfl(s.thr, own, 64);
         const int oks = __shfl(kslot, own, 64), obi = __shfl((int)s.bidx, own, 64);
         if (e < pool.n) c = e != oks && t != obi && !(key > othr);
         const unsigned long long m = __ballot(c);
         if (c) {                                                   // dst <= e, and this trip's reads are done: in place is safe
             const int dst = n2 + __popcll(m & ((1ull << lane) - 1ull));
-            pool.own[dst] = (unsigned char)own; pool.tid[dst] = t; pool.key[dst] = key;
+            pool.to[dst] = to; pool.key[dst] = kb;
         }
         n2 += __popcll(m);
     }
@@ -397,7 +401,7 @@ __device__ __forceinline__ void tri_pool_flush(const float *p, const float4 *__r
             const int e = base + lane;
             int own = 0;
             uint32_t t = 0;
-            if (e < n2) { own = pool.own[e]; t = (uint32_t)pool.tid[e]; }
+            if (e < n2) { const unsigned to = pool.to[e]; own = (int)(to & 63u); t = to >> 6; }
             const float q0 = __shfl(p[0], own, 64), q1 = __shfl(p[1], own, 64), q2 = __shfl(p[2], own, 64);
             if (e < n2) {
                 const float4 u = tri9[3ll * t], v = tri9[3ll * t + 1], w = tri9[3ll * t + 2];
@@ -547,7 +551,9 @@ __device__ __forceinline__ void tri_scan_shared(const float *p, const float4 *__
             const float4 oa4 = pool.q4[st.own[0]], ob4 = pool.q4[st.own[1]];
             tri_candidate(oa4.x, oa4.y, oa4.z, st.r0[0], st.r1[0], st.act[0], oa4.w, oa4.w * oa4.w, st.own[0], eps_plane, pool, surv);
             tri_candidate(ob4.x, ob4.y, ob4.z, st.r0[1], st.r1[1], st.act[1], ob4.w, ob4.w * ob4.w, st.own[1], eps_plane, pool, surv);
-            // (each test adds <= 64 entries; after a flush an owner's reach may be shorter than what later tests read: never longer)
+            // (each test adds <= 64 entries; after a flush an owner's reach may be shorter than what later tests read: never longer.
+            //  Flushing only when the two tests' survivors would not fit -- test, count, flush, enter -- was measured in round 6:
+            //  slower, 0.355 against 0.340 ms per search: the survivors' bounds and flags live across the flush.)
             if (pool.n > TRI_POOL - 128) tri_pool_flush(p, tri9, s, pool, delta, cutf, ev, trips);
         };
         Step A, B;
@@ -730,6 +736,9 @@ enum { TRI_STAT_QUERIES, TRI_STAT_ROWS, TRI_STAT_ENTRIES, TRI_STAT_SURVIVORS, TR
 // fp64 sums are taken in the epilogue: one row of `partials` per workgroup, the rows k_pair_accumulate_canon writes for the
 // same shard, bit for bit (the host switches between the two from one iteration to the next, oa_icp.hip: grid_fast_now).
 // prev[] gets the winner (the next search's seed); keys[] is not written: nothing reads it inside the loop.
+#ifndef OA_TRI_LIST_REPS
+#define OA_TRI_LIST_REPS 3
+#endif
 template <int L, bool STATS = false, bool SHARE = true, bool ACC = false>
 #ifndef OA_TRI_MIN_WAVES
 #define OA_TRI_MIN_WAVES 4
@@ -757,9 +766,8 @@ __global__ __launch_bounds__(256, OA_TRI_MIN_WAVES) void k_tri_search_grid(const
     static_assert(RPL <= TRI_SEGS && (L == 1 || 2 * RPL <= TRI_SEGS), "a batch of rows must fit the per-thread range list");
     if (st->halt) return;
     if (turn >= 0 && (st->tree_turn != 0) != (turn != 0)) return;  // not this kernel's turn (DevState::tree_turn)
-    __shared__ int pool_tid[4][TRI_POOL];
-    __shared__ unsigned char pool_own[4][TRI_POOL];
-    __shared__ float pool_key[4][TRI_POOL];
+    __shared__ unsigned pool_to[4][TRI_POOL];
+    __shared__ unsigned short pool_key[4][TRI_POOL];
     __shared__ unsigned long long pool_slot[256], pool_first[256];
     __shared__ __attribute__((aligned(16))) int seg_j[TRI_SEGS][256];
     __shared__ __attribute__((aligned(16))) unsigned short seg_n[TRI_SEGS][256];                 // (a range is never longer than the budget it was charged to: < 65536, build_tri_grid)
@@ -769,7 +777,7 @@ __global__ __launch_bounds__(256, OA_TRI_MIN_WAVES) void k_tri_search_grid(const
     TriPool pool;
     {
         const int wv = threadIdx.x >> 6;
-        pool.tid = pool_tid[wv]; pool.own = pool_own[wv]; pool.key = pool_key[wv]; pool.slot = pool_slot + 64 * wv;
+        pool.to = pool_to[wv]; pool.key = pool_key[wv]; pool.slot = pool_slot + 64 * wv;
         pool.first = pool_first + 64 * wv;
         pool.q4 = SHARE ? owner_q4 + 64 * wv : nullptr;
         pool.n = 0;
@@ -922,6 +930,10 @@ __global__ __launch_bounds__(256, OA_TRI_MIN_WAVES) void k_tri_search_grid(const
             const int side = 2 * r + 1, n_rows = side * side;
             const unsigned div_mul = 65536u / (unsigned)side + 1u;  // k / side == (k * div_mul) >> 16 for k < 256, side <= 15
             const int rpl = GR;
+            // Several batches of rows per trip while the range list has room (round 6): far from the surface most rows of a ring are
+            // empty, and a trip -- the wave's scan and flush -- per nine rows made a ring-3 query take six trips for a handful of ranges
+            // (L == 1 takes as many rows of a batch as fit the list; with several lanes per query a batch goes in whole or not at all)
+            for (int rep = 0; rep < OA_TRI_LIST_REPS && !ring_done && n_seg + (L == 1 ? 2 : 2 * RPL) <= TRI_SEGS && budget >= 0; ++rep) {
             // rows of the ring: cell ranges first (independent loads), then the candidates -- as in k_nn_search_grid;
             // per-row arithmetic in float on the query's frame (GridQuery)
             int ja[GR], jb[GR], jc[GR], jd[GR];
@@ -977,6 +989,7 @@ __global__ __launch_bounds__(256, OA_TRI_MIN_WAVES) void k_tri_search_grid(const
             }
             b0 += consumed * L;
             ring_done = b0 >= n_rows;
+            }
         }
         // over its budget: the tree takes the query anyway -- with the seed's bound, which the records scanned so far rarely
         // improve on -- so what this batch listed is not scanned (crowded cells: up to `budget` records per lane for nothing)
@@ -990,7 +1003,7 @@ __global__ __launch_bounds__(256, OA_TRI_MIN_WAVES) void k_tri_search_grid(const
         // phase 2 now if somebody needs its final word on this ring (or gives up), or the pool is filling up; otherwise the
         // survivors wait for the next batch's (every flush costs the wave at least one evaluation trip)
         OA_TRI_STAMP(cyc_scan);
-        if (__any(busy && (ring_done || budget < 0)) || pool.n > TRI_POOL / 4)
+        if (__any(busy && (ring_done || budget < 0)) || pool.n > TRI_POOL / 4)          // (64 ... 304 measured in round 6: no difference)
             tri_pool_flush(pf, tri9, S, pool, delta, cutf, STATS ? &n_evals : nullptr, STATS ? &n_trips : nullptr);
         OA_TRI_STAMP(cyc_flush);
         over = busy && budget < 0;

@@ -621,9 +621,13 @@ def test_bench_two_shards_reports_its_exchange(monkeypatch):
     assert 0.0 < r["frac_of_measured_ceiling"] < 1.2
     assert 10.0 < c["after_timed_loop"]["tlaneops_min3"] < c["after_timed_loop"]["tlaneops"]     # the half-rate class, measured
     assert r["kernel"] == "k_nn_search_sorted" and 0.2 < r["half_rate_instruction_share"] < 0.5
-    assert all(0.0 < v < 1.5 for v in r["frac_of_measured_mix_ceiling"].values()) and len(r["frac_of_measured_mix_ceiling"]) == 2
-    mk = r["mix_ceiling_at_the_search_clock"]                      # ... priced at the clock the chip held during the search itself
-    assert 800.0 < mk["shader_clock_mhz_during_search"] < 3000.0 and 0.0 < mk["frac"] < 1.5, mk
+    # round 6: the line says what frac is, gives the pairs per second and SURVEY 8d's formula with a flag when it is void; the two
+    # mix-ceiling fields of round 5 (a fraction of a ceiling that read above 1) are gone
+    assert "issue-slot utilisation" in r["what_frac_is"] and r["pairs_per_s"] > 1e11
+    a8 = r["frac_8d_algorithmic"]
+    assert a8["value"] > 0.0 and a8["void"] == (a8["value"] > 1.0) and a8["effective_tflops"] > 0.0
+    assert "frac_of_measured_mix_ceiling" not in r and "mix_ceiling_at_the_search_clock" not in r
+    assert 800.0 < r["shader_clock_mhz_during_search"] < 3000.0
 
 
 # ---------------------------------------------------------------------------------------------------------------------
