@@ -487,7 +487,7 @@ namespace {
 
 // d_todo_count: TODO_WORDS ints for the tree's hand-over list, then two sets of the front search's list counters (ulist_*)
 constexpr int TODO_WORDS = 32, UCOUNT_WORDS = oa::ULIST_PARTS * oa::ULIST_STRIDE, TODO_COUNT_INTS = TODO_WORDS + 2 * UCOUNT_WORDS;
-[[maybe_unused]] inline int *ucount_set(const oa_ctx *c, int slot) { return c->d_todo_count + TODO_WORDS + slot * UCOUNT_WORDS; }
+inline int *ucount_set(const oa_ctx *c, int slot) { return c->d_todo_count + TODO_WORDS + slot * UCOUNT_WORDS; }
 
 int use_device(oa_ctx *c)
 {
