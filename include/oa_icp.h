@@ -120,8 +120,10 @@ int         oa_num_devices(oa_ctx *ctx);
 int         oa_set_exchange(oa_ctx *ctx, int mode);
 void        oa_destroy(oa_ctx *ctx);
 /* Released device blocks are kept in a process-wide cache for the next upload of the same size (hipFree costs
- * ~135 us a call): at most 256 MiB (env OA_DEV_CACHE_MB; OA_DEV_CACHE=0 switches it off), and nothing at all once
- * the last context has been destroyed.  This gives the cached blocks back immediately. */
+ * ~135 us a call, hipMalloc of 100 MB more): at most 256 MiB or what the library has had allocated at once, whichever is
+ * larger (so that a re-upload of the same geometry allocates nothing; env OA_DEV_CACHE_MB sets a fixed cap instead,
+ * OA_DEV_CACHE=0 switches the cache off), and nothing at all once the last context has been destroyed.  This gives
+ * the cached blocks back immediately. */
 void        oa_release_cached_memory(void);
 const char *oa_last_error(void);
 const char *oa_version(void);

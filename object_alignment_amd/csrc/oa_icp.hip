@@ -79,8 +79,9 @@ int fail(int code, const char *fmt, ...)
 // this stack (it synchronises the device), and an upload frees and reallocates ~25 buffers of unchanged size -- more
 // than half of oa_set_target + oa_set_source at 1M points.  A released block is kept for the next request of the same
 // size; blocks that sit unused for CACHE_MAX_AGE releases, or push the cache past its cap, are really freed.
-// The library is a guest in somebody else's process (Blender): the cap is 256 MiB by default (OA_DEV_CACHE_MB raises
-// or lowers it, OA_DEV_CACHE=0 switches the cache off), and when the last context is destroyed everything is freed.
+// The library is a guest in somebody else's process (Blender): the cap is 256 MiB or the library's own peak of live bytes,
+// whichever is larger (OA_DEV_CACHE_MB sets a fixed cap, OA_DEV_CACHE=0 switches the cache off), and when the last context is
+// destroyed everything is freed.
 // Releases are STREAM ORDERED, not device-synchronising: a block goes back tagged with the stream of the context that
 // used it (tl_stream, set by use_device).  The next owner on the same stream needs no wait at all (stream order); an
 // owner on another stream first waits for the releasing stream (rare: two contexts trading blocks).  Only a real hipFree
@@ -100,7 +101,13 @@ struct DevCache {
     static constexpr unsigned long long CACHE_MAX_AGE = 512;
 
     const bool enabled = !(getenv("OA_DEV_CACHE") && atoi(getenv("OA_DEV_CACHE")) == 0);   // OA_DEV_CACHE=0: plain hipMalloc / hipFree
-    const size_t max_bytes = (size_t)((getenv("OA_DEV_CACHE_MB") && *getenv("OA_DEV_CACHE_MB")) ? std::max(0.0, atof(getenv("OA_DEV_CACHE_MB"))) : 256.0) << 20;
+    const bool cap_given = getenv("OA_DEV_CACHE_MB") && *getenv("OA_DEV_CACHE_MB");
+    const size_t max_bytes = (size_t)(cap_given ? std::max(0.0, atof(getenv("OA_DEV_CACHE_MB"))) : 256.0) << 20;
+    // The cap follows what the process has had allocated AT ONCE (round 6): a 1.96M-triangle mesh is ~0.5 GB of images, lists and
+    // trees, and with a fixed 256 MiB every re-upload of it really freed and really allocated most of that -- 2.9 of the 4.8 ms of
+    // oa_set_target_mesh.  Idle, the cache never holds more than the library already needed live; an explicit OA_DEV_CACHE_MB wins.
+    size_t live_bytes = 0, peak_live = 0;
+    size_t cap() const { return cap_given ? max_bytes : std::max(max_bytes, peak_live); }
 
     hipError_t alloc(void **out, size_t bytes)
     {
@@ -118,6 +125,7 @@ struct DevCache {
                     free_blocks[i] = free_blocks.back();
                     free_blocks.pop_back();
                     live[*out] = { bytes, dev };
+                    live_bytes += bytes; peak_live = std::max(peak_live, live_bytes);
                     lk.unlock();
                     // same stream: stream order is enough.  Another stream (or none known): whatever the releasing
                     // stream still has in flight must finish first
@@ -132,7 +140,7 @@ struct DevCache {
             trim(0, 0);
             e = hipMalloc(out, bytes);
         }
-        if (e == hipSuccess) { std::lock_guard<std::mutex> lk(mu); live[*out] = { bytes, dev }; }
+        if (e == hipSuccess) { std::lock_guard<std::mutex> lk(mu); live[*out] = { bytes, dev }; live_bytes += bytes; peak_live = std::max(peak_live, live_bytes); }
         return e;
     }
 
@@ -146,11 +154,12 @@ struct DevCache {
         if (it == live.end()) { (void)hipFree(p); return; }
         Block b{ p, it->second.first, it->second.second, ++clock, tl_stream, settled };
         live.erase(it);
-        if (b.bytes > max_bytes) { (void)hipFree(p); return; }     // would not fit under the cap anyway (hipFree synchronises)
+        live_bytes -= std::min(live_bytes, b.bytes);
+        if (b.bytes > cap()) { (void)hipFree(p); return; }         // would not fit under the cap anyway (hipFree synchronises)
         if (!settled && !tl_stream_known) { (void)hipDeviceSynchronize(); b.settled = true; }   // no stream to order against
         free_blocks.push_back(b);
         cached_bytes += b.bytes;
-        trim_locked(max_bytes, CACHE_MAX_AGE);
+        trim_locked(cap(), CACHE_MAX_AGE);
     }
 
     // a stream is about to be destroyed (its device has been synchronised): its blocks have nothing in flight any more
@@ -184,6 +193,7 @@ struct DevCache {
         if (--contexts > 0) return;
         contexts = 0;
         trim_locked(0, 0);                                         // last context gone: give everything back
+        peak_live = live_bytes;
     }
 };
 
@@ -487,7 +497,7 @@ namespace {
 
 // d_todo_count: TODO_WORDS ints for the tree's hand-over list, then two sets of the front search's list counters (ulist_*)
 constexpr int TODO_WORDS = 32, UCOUNT_WORDS = oa::ULIST_PARTS * oa::ULIST_STRIDE, TODO_COUNT_INTS = TODO_WORDS + 2 * UCOUNT_WORDS;
-inline int *ucount_set(const oa_ctx *c, int slot) { return c->d_todo_count + TODO_WORDS + slot * UCOUNT_WORDS; }
+[[maybe_unused]] inline int *ucount_set(const oa_ctx *c, int slot) { return c->d_todo_count + TODO_WORDS + slot * UCOUNT_WORDS; }
 
 int use_device(oa_ctx *c)
 {
