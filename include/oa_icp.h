@@ -234,6 +234,8 @@ int oa_reset_seeds(oa_ctx *ctx);
                                        * fallback, when OA_STAT_RCCL_RANKS is back to 0 */
 #define OA_STAT_SEARCH_CLOCK_MHZ   26   /* shader clock during the last loop's k_nn_search_sorted launch (cycle counter / constant-rate counter of one
                                        * workgroup dispatched mid-launch); 0 when that kernel did not run.  Multi-device context: its first device */
+#define OA_STAT_BRUTE_QUEUE_WGS     27   /* workgroups of the last k_nn_search_sorted launch that took their (split, block) items off the work
+                                       * queue (long launches: as many as the chip holds); 0 = one workgroup per item, in launch order */
 #define OA_STAT_ENQUEUED_CHILD  1000   /* + i: the same count for child i alone */
 int oa_get_stat(oa_ctx *ctx, int what, double *value);
 /* why the exchange is what it is (AUTO's reason for not taking RCCL, librccl's error, "RCCL was aborted: ..."), or "" */

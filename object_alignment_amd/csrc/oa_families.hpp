@@ -18,7 +18,7 @@
 #define OA_SIG_NN_FILTERED const DevState *, const float4 *, const float4 *, const float4 *, const float4 *, const float4 *, int, unsigned long long *
 #define OA_SIG_WAVE_ORDER const DevState *, const float4 *, int, unsigned short *
 #define OA_SIG_SEED_SORTED const DevState *, const float4 *, int, const float4 *, const float4 *, const int4 *, int, int, unsigned long long *
-#define OA_SIG_NN_SORTED const DevState *, const float4 *, const float4 *, const float4 *, const float4 *, const int4 *, const float4 *, int, int, int, unsigned long long *, int, const unsigned short *
+#define OA_SIG_NN_SORTED const DevState *, const float4 *, const float4 *, const float4 *, const float4 *, const int4 *, const float4 *, int, int, int, unsigned long long *, int, const unsigned short *, int, int, const int *, int *
 #define OA_SIG_NN_GRID const DevState *, const float4 *, int, GridParams, const int *, const float4 *, float4 *, unsigned long long *, int *, int *, int, BvhParams, const float4 *, const float4 *, NormalTest, double *, unsigned long long *, const float *, uint2 *
 #define OA_SIG_TRI_GRID const DevState *, const float4 *, int, GridParams, const int *, const float4 *, const float4 *, int *, unsigned long long *, int *, int *, int, unsigned long long *, BvhParams, const float4 *, const float4 *, NormalTest, double *, const int *, const int *, const int *, int, int, int
 #define OA_SIG_TRI_SETTLE const DevState *, const float4 *, int, FineParams, const uint4 *, const float4 *, const float4 *, const int *, unsigned long long *, int *, int, int *, int *, unsigned long long *

@@ -421,6 +421,10 @@ struct oa_ctx {
     float4 *d_src4o = nullptr;       // the same points in the caller's (vlist) order -- only oa_make_pairs needs it
     int *d_perm = nullptr;           // sorted slot -> caller-order slot (nullptr: not sorted)
     unsigned short *d_worder = nullptr;   // k_sorted_wave_order: per wave of k_nn_search_sorted, its slots in the order of u (OA_NN_WAVE_ORDER=0: off)
+    int *d_homes = nullptr, *d_qcnt = nullptr;   // k_nn_search_sorted's work queue (oa_kernels.hpp): per block of source points its own split; the queues' counters
+    int nn_persist = 4;              // OA_NN_PERSIST: workgroups per CU that work the queue off (0: one workgroup per item, in launch order -- as until round 6)
+    int nn_queue_min = -1;           // OA_NN_QUEUE_MIN_ITEMS: launches of at least this many items go through the queue (-1: four per workgroup)
+    int last_queue_wgs = 0;          // OA_STAT_BRUTE_QUEUE_WGS
     bool nn_wave_order = true;
     long long src_n_verts = 0;
     // normal-angle rejection (extension)
@@ -967,8 +971,8 @@ int launch_nn_impl(oa_ctx *c, bool acc)
         int pass = 0;
 #define OA_LAUNCH_S(RR)                                                                                              \
         do {                                                                                                         \
-            if (small) hipLaunchKernelGGL((oa::k_nn_search_sorted<RR, 64>), sgrid, block, 0, c->stream, OA_NNS_ARGS, pass, worder);  \
-            else hipLaunchKernelGGL((oa::k_nn_search_sorted<RR, oa::FTILE_GROUPS>), sgrid, block, 0, c->stream, OA_NNS_ARGS, pass, worder); \
+            if (small) hipLaunchKernelGGL((oa::k_nn_search_sorted<RR, 64>), sgrid, block, 0, c->stream, OA_NNS_ARGS, pass, worder, q_splits, q_blocks, homes, qcnt);  \
+            else hipLaunchKernelGGL((oa::k_nn_search_sorted<RR, oa::FTILE_GROUPS>), sgrid, block, 0, c->stream, OA_NNS_ARGS, pass, worder, q_splits, q_blocks, homes, qcnt); \
         } while (0)
 #if defined(OA_EXPERIMENTS)
 #define OA_LAUNCH_S_CASE8 case 8: OA_LAUNCH_S(8); break;
@@ -994,6 +998,22 @@ int launch_nn_impl(oa_ctx *c, bool acc)
             HIPCHK(hipGetLastError());
             worder = c->d_worder;
         }
+        // long launches go through the work queue (oa_kernels.hpp): as many workgroups as the chip holds, the long items first
+        const int q_splits = (int)sgrid.x, q_blocks = (int)sgrid.y;
+        const long long q_wgs = (long long)c->n_cu * std::min(c->nn_persist, c->R <= 4 ? 4 : 2);
+        const bool queued = q_wgs > 0 && q_splits > 1 && (long long)q_splits * q_blocks >= (c->nn_queue_min >= 0 ? (long long)c->nn_queue_min : 4 * q_wgs);
+        c->last_queue_wgs = queued ? (int)q_wgs : 0;
+        if (queued) {
+            if (!c->d_homes) HIPCHK(dev_malloc(&c->d_homes, sizeof(int) * (size_t)q_blocks));
+            if (!c->d_qcnt) HIPCHK(dev_malloc(&c->d_qcnt, sizeof(int) * (size_t)(oa::SORTED_QUEUES * oa::SORTED_QUEUE_STRIDE)));
+            hipLaunchKernelGGL(oa::k_sorted_block_homes, dim3((unsigned)((std::max(q_blocks, oa::SORTED_QUEUES) + 63) / 64)), dim3(64), 0, c->stream,
+                               (const oa::DevState *)c->d_state, (const float4 *)c->d_src4, q_blocks, oa::NN_THREADS * c->R, (const float4 *)c->d_tfs,
+                               c->n_groups_pad, c->tile_groups, c->sax[0], q_splits, c->d_homes, c->d_qcnt);
+            HIPCHK(hipGetLastError());
+            sgrid = dim3((unsigned)q_wgs);
+        }
+        const int *homes = queued ? c->d_homes : nullptr;
+        int *qcnt = queued ? c->d_qcnt : nullptr;
         if (two) {
             const dim3 sb((unsigned)((c->ns_pad + 255) / 256));
             if (small) hipLaunchKernelGGL((oa::k_nn_seed_sorted<64>), sb, dim3(256), 0, c->stream, (const oa::DevState *)c->d_state, (const float4 *)c->d_src4, c->ns_pad,
@@ -2019,6 +2039,8 @@ OA_EXPORT int oa_create(oa_ctx **out, int device)
     c->nn_sort = env_int("OA_NN_SORT", 1) != 0;
     c->nn_home_pass = env_int("OA_NN_HOME_PASS", 1) != 0;
     c->nn_wave_order = env_int("OA_NN_WAVE_ORDER", 1) != 0;
+    c->nn_persist = std::max(0, std::min(16, env_int("OA_NN_PERSIST", 4)));
+    c->nn_queue_min = env_int("OA_NN_QUEUE_MIN_ITEMS", -1);
     c->nn_mfma = env_int("OA_NN_MFMA", 0);
 #if !defined(OA_EXPERIMENTS)
     // the default library does not carry the experiments (oa_families.hpp): their knobs are inert here, liboa_icp_exp.so has them
@@ -2170,7 +2192,7 @@ OA_EXPORT void oa_destroy(oa_ctx *c)
     (void)hipDeviceSynchronize();
     tl_stream_known = false;                                        // the stream below is about to go away
 #define OA_FREE(x) dev_free(c->x, true)
-    OA_FREE(d_tgt_xyz); OA_FREE(d_tg); OA_FREE(d_tf); OA_FREE(d_tf3); OA_FREE(d_tfs); OA_FREE(d_tf3s); OA_FREE(d_tgs); OA_FREE(d_tidx); OA_FREE(d_tfm); OA_FREE(d_members); OA_FREE(d_pos); OA_FREE(d_prev); OA_FREE(d_win); OA_FREE(d_worder); OA_FREE(d_wsafe); OA_FREE(d_safe_by_idx); OA_FREE(d_cell_start);
+    OA_FREE(d_tgt_xyz); OA_FREE(d_tg); OA_FREE(d_tf); OA_FREE(d_tf3); OA_FREE(d_tfs); OA_FREE(d_tf3s); OA_FREE(d_tgs); OA_FREE(d_tidx); OA_FREE(d_tfm); OA_FREE(d_members); OA_FREE(d_pos); OA_FREE(d_prev); OA_FREE(d_win); OA_FREE(d_worder); OA_FREE(d_homes); OA_FREE(d_qcnt); OA_FREE(d_wsafe); OA_FREE(d_safe_by_idx); OA_FREE(d_cell_start);
     OA_FREE(d_sorted); OA_FREE(d_todo_list); OA_FREE(d_todo_count); OA_FREE(d_ulist); OA_FREE(d_src4); OA_FREE(d_keys); OA_FREE(d_state);
     OA_FREE(d_partials); OA_FREE(d_sums); OA_FREE(d_solve);
     OA_FREE(d_valid); OA_FREE(d_b); OA_FREE(d_dist); OA_FREE(d_counts); OA_FREE(d_offsets); OA_FREE(d_A); OA_FREE(d_B);
@@ -3173,7 +3195,7 @@ int source_reset(oa_ctx *c, long long count, long long begin, long long n_verts)
     HIPCHK(dev_malloc(&c->d_keys, sizeof(unsigned long long) * (size_t)c->ns_pad));
     HIPCHK(dev_malloc(&c->d_prev, sizeof(int) * (size_t)c->ns_pad));
     HIPCHK(dev_malloc(&c->d_win, sizeof(float4) * (size_t)c->ns_pad));
-    dev_free(c->d_worder);
+    dev_free(c->d_worder); dev_free(c->d_homes);
     if (c->nn_wave_order && c->grid_mode == 0) HIPCHK(dev_malloc(&c->d_worder, sizeof(unsigned short) * (size_t)c->ns_pad));   // (brute force only; never inside a loop)
     if (c->grid_safe && !c->surface) HIPCHK(dev_malloc(&c->d_wsafe, sizeof(uint2) * (size_t)c->ns_pad));   // (a vertex target set later allocates it: set_target_common)
     c->seeded = false; c->win_seeds = false;
@@ -3522,6 +3544,7 @@ OA_EXPORT int oa_get_stat(oa_ctx *c, int what, double *value)
         for (oa_ctx *sub : c->subs) *value = std::max(*value, sub->last_exchange_us);
         return OA_OK;
     }
+    if (what == OA_STAT_BRUTE_QUEUE_WGS) { *value = (double)(c->subs.empty() ? c : c->subs[0])->last_queue_wgs; return OA_OK; }
     if (what == OA_STAT_SEARCH_CLOCK_MHZ) {                             // (the host mirror holds the device state of the last oa_run / oa_run_end)
         const oa_ctx *s = c->subs.empty() ? c : c->subs[0];
         const unsigned long long cyc = s->h_state.search_clk[0], ticks = s->h_state.search_clk[1];

@@ -695,6 +695,13 @@ __device__ __forceinline__ void split_range(int n_groups_pad, int tile_groups, i
     g_end = (int)((long long)(blockIdx.x + 1) * tiles / gridDim.x) * tile_groups;
 }
 
+__device__ __forceinline__ void split_range_of(int split, int n_splits, int n_groups_pad, int tile_groups, int &g_begin, int &g_end)
+{
+    const long long tiles = n_groups_pad / tile_groups;
+    g_begin = (int)((long long)split * tiles / n_splits) * tile_groups;
+    g_end = (int)((long long)(split + 1) * tiles / n_splits) * tile_groups;
+}
+
 template <int R>
 __global__ __launch_bounds__(NN_THREADS) void k_nn_search(const DevState *__restrict__ st,
                                                           const float4 *__restrict__ src4,
@@ -1288,6 +1295,45 @@ __global__ __launch_bounds__(256) void k_nn_seed_sorted(const DevState *__restri
     }
 }
 
+// The work queue of k_nn_search_sorted (round 6).  One workgroup per (split, block of 1024 source points) in launch order left the chip
+// 14 % (125k-point shard) to 9 % (1M points) short of the sum of its workgroups' own times (per-workgroup stamps, profiles/r06h):
+// a workgroup whose points have their own slabs in its split runs levels 1-3 and lives 3.5x as long as one that only proves
+// everything away at level 0 (a third of all slot time is theirs); with the hardware handing workgroups to the XCDs in strict
+// rotation, slots stand empty behind a full XCD (6-8 % of them at any time), and the launch ends on a few long workgroups (the last
+// twentieth of its span runs a third full).  So: as many workgroups as the chip holds, each taking (split, block) items off a
+// queue until none is left -- block after block, a block's items in the order of the distance of the split from the block's own slab
+// (its long items first).  NOT the long items of all blocks first: a long item waits on memory, a short one saturates the vector
+// ALU, and a CU that holds both kinds does better than two CUs with one kind each (all long items first: 4.27 instead of 3.99 ms for
+// the 125k-point shard, short items 58 us beside long ones and 75 us among themselves).  Eight queues, one per residue of the split
+// index mod 8, and a workgroup serves the queue of its own XCD first (XCC_ID): a split's tiles stay in one L2, as they did when the
+// launch order itself was the mapping.  The answers cannot depend on who does what: keys[] is merged with atomicMin.
+// Measured (profiles/r06h): 1M <-> 1M 27.6 -> 26.6 ms per search, config 5's shard 58.7 -> 57.3, the 125k shard 3.98 -> 3.93.
+// k_sorted_block_homes: per block of NN_THREADS x R slots the split that holds the u of its first point at the current pose, and
+// the queues' counters back to zero (it runs in front of every queued launch).
+constexpr int SORTED_QUEUES = 8, SORTED_QUEUE_STRIDE = 16;       // (counters 64 bytes apart)
+#if !defined(OA_FAMILY_TU)      // plain kernels are compiled once, in the host translation unit (oa_icp.hip)
+__global__ void k_sorted_block_homes(const DevState *__restrict__ st, const float4 *__restrict__ src4, int n_blocks, int block_slots,
+                                     const float4 *__restrict__ tfs, int n_groups_pad, int tg, int au, int n_splits,
+                                     int *__restrict__ homes, int *__restrict__ qcnt)
+{
+    const int y = blockIdx.x * blockDim.x + threadIdx.x;
+    if (y < SORTED_QUEUES) qcnt[y * SORTED_QUEUE_STRIDE] = 0;
+    if (y >= n_blocks) return;
+    const float4 p = src4[(long long)y * block_slots];
+    float px, py, pz;
+    co_find(st, p.x, p.y, p.z, px, py, pz);
+    const float hu = au == 0 ? (float)((double)px - (double)st->tc[0]) : (au == 1 ? (float)((double)py - (double)st->tc[1]) : (float)((double)pz - (double)st->tc[2]));
+    const int tiles = n_groups_pad / tg;
+    int a = 0, b = tiles;                                          // first tile that starts beyond hu (NaN: tile 0 -- any home is a valid order)
+    while (a < b) { const int mid = (a + b) >> 1; if (tfs[3ll * tg * mid].x <= hu) a = mid + 1; else b = mid; }
+    const long long tile = a > 0 ? a - 1 : 0;
+    int sp = (int)(tile * n_splits / tiles);                       // the split whose range [s tiles / S, (s + 1) tiles / S) holds the tile
+    while (sp + 1 < n_splits && (long long)(sp + 1) * tiles / n_splits <= tile) ++sp;
+    while (sp > 0 && (long long)sp * tiles / n_splits > tile) --sp;
+    homes[y] = sp;
+}
+#endif  // !OA_FAMILY_TU
+
 constexpr int SORT_ORDER_MAX = 1024;
 #ifndef OA_SORTED_GW
 #define OA_SORTED_GW 64                   // groups of 4 sorted vertices per skip test of k_nn_search_sorted (a build-time knob for sweeps)
@@ -1303,7 +1349,8 @@ __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_sort
                                                                  const float4 *__restrict__ win,
                                                                  int n_groups_pad, int au, int av,
                                                                  unsigned long long *keys, int pass,
-                                                                 const unsigned short *__restrict__ order)
+                                                                 const unsigned short *__restrict__ order,
+                                                                 int n_splits, int n_blocks, const int *__restrict__ homes, int *qcnt)
 {
     // pass 0: seeds from the winner records of the last accumulation (none on the first search of a loop: every split then has to
     // find a best of its own before it can skip anything).  pass 2: seeds from keys, where k_nn_seed_sorted has left every point's
@@ -1315,12 +1362,51 @@ __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_sort
     __shared__ float4 tile[2][TILE_F4];
     __shared__ short ord[SORT_ORDER_MAX];
     __shared__ unsigned long long clk0[2];
-    const int tid = threadIdx.x;
-    const bool clk_wg = (blockIdx.x == 0 && blockIdx.y == gridDim.y / 2 && tid == 0);   // one workgroup dispatched mid-launch
+    __shared__ int s_item[3];                                       // the workgroup's item {split, block}; [2]: the queues found empty so far
+    const int tid0 = threadIdx.x;
+    // qcnt == nullptr: one workgroup per (split, block), taken from the launch grid (n_splits = gridDim.x, n_blocks = gridDim.y)
+    const bool queued = qcnt != nullptr;
+    if (queued && tid0 == 0) s_item[2] = 0;
+  for (;;) {
+    // (the thread's index anew for every item: what is derived from it is then computed where it is used, as in the one-item form,
+    //  instead of being hoisted out of this loop and held in registers -- or scratch -- through the scan)
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    int split = (int)blockIdx.x, yblk = (int)blockIdx.y;
+    if (queued) {
+        if (tid == 0) {
+            // SORTED_QUEUES queues when they divide the splits (else one): queue q holds the splits s = q + nq j; item p of a queue
+            // is block p / per_q at rank p mod per_q, rank k being the split k steps (0, +1, -1, +2, ...) from the block's own
+            const int nq = (n_splits % SORTED_QUEUES == 0) ? SORTED_QUEUES : 1, per_q = n_splits / nq;
+            const int q_len = per_q * n_blocks;
+            unsigned xcc = 0;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            int got = -1, got_y = 0;
+            unsigned q_dry = (unsigned)s_item[2];
+            for (int a = 0; a < nq && got < 0; ++a) {
+                const int q = (int)((xcc + (unsigned)a) & (unsigned)(nq - 1));
+                if (q_dry & (1u << q)) continue;
+                const int pos = atomicAdd(qcnt + q * SORTED_QUEUE_STRIDE, 1);
+                if (pos >= q_len) { q_dry |= 1u << q; continue; }
+                got_y = pos / per_q;
+                const int k = pos - got_y * per_q;
+                int j0 = (homes[got_y] - q + nq / 2) / nq;          // the queue's split nearest to the block's own
+                j0 = j0 < 0 ? 0 : (j0 >= per_q ? per_q - 1 : j0);
+                int j = (j0 + ((k & 1) ? (k + 1) / 2 : -(k / 2))) % per_q;
+                if (j < 0) j += per_q;
+                got = q + nq * j;
+            }
+            s_item[0] = got; s_item[1] = got_y; s_item[2] = (int)q_dry;
+        }
+        __syncthreads();
+        split = __builtin_amdgcn_readfirstlane(s_item[0]); yblk = __builtin_amdgcn_readfirstlane(s_item[1]);   // (scalar registers, as blockIdx was)
+        if (split < 0) break;                                       // (the whole workgroup: nothing left anywhere)
+    } else { n_splits = (int)gridDim.x; n_blocks = (int)gridDim.y; }
+    const bool clk_wg = (split == 0 && yblk == n_blocks / 2 && tid == 0);   // one workgroup's item from the middle of the launch
     if (clk_wg) { clk0[0] = (unsigned long long)__builtin_readcyclecounter(); clk0[1] = wall_clock64(); }
     const double qmax = st->qmax;
     const float cx = st->tc[0], cy = st->tc[1], cz = st->tc[2];
-    const int base = blockIdx.y * (NN_THREADS * R);
+    const int base = yblk * (NN_THREADS * R);
     // a wave owns R x 64 CONSECUTIVE slots (neighbours in space: the smallest extent in u, the fewest slabs it must look into);
     // point r of a lane is slot base + slot_of(r)
     // ... and WHICH of them is a lane's point r says k_sorted_wave_order: the wave's slots in the order of u, so that point r of all
@@ -1356,7 +1442,7 @@ __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_sort
     }
 
     int g_begin, g_end;
-    split_range(n_groups_pad, TG, g_begin, g_end);
+    split_range_of(split, n_splits, n_groups_pad, TG, g_begin, g_end);
     const int n_tiles = (g_end - g_begin) / TG;
     const float4 *tsrc = tfs + 3ll * g_begin;
 
@@ -1480,7 +1566,7 @@ __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_sort
         unsigned long long *dst = keys + OA_SLOT(r);
         if (pass != 0) {                                           // merges into whatever keys holds: monotone
             if (key < __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(dst, key);
-        } else if (gridDim.x == 1) *dst = key;
+        } else if (n_splits == 1) *dst = key;
         else {
             // (the seed again, from the slot's record -- the same arithmetic as at the start -- instead of two registers per point
             //  held through the scan)
@@ -1493,10 +1579,12 @@ __global__ __launch_bounds__(NN_THREADS, (R <= 4 ? 4 : 2)) void k_nn_search_sort
             }
             const bool seeded = seed_idx != IDX_NONE;
             const bool improved = bidx[r] != seed_idx || best[r] != seed_d;
-            const bool owner = seeded && (seed_idx % gridDim.x) == blockIdx.x;
+            const bool owner = seeded && (int)(seed_idx % (uint32_t)n_splits) == split;
             if (!seeded || improved || owner) atomicMin(dst, key);
         }
     }
+    if (!queued) break;
+  }
 }
 
 #undef OA_SLOT

@@ -188,7 +188,7 @@ class IcpEngine:
              "brute_kernel": 7, "exchange": 8, "rccl_ranks": 9, "enqueue_us": 10, "host_threads": 11,
              "fast_iterations": 12, "handover_entries": 13, "handover_wave_max": 14, "enqueued_min": 15, "enqueued_max": 16,
              "watchdog_aborts": 17, "nn_ms_min": 18, "nn_ms_max": 19, "safe_radii": 20,
-             "tri_ring": 21, "tri_ring_accepts": 22, "exchange_us": 23, "rccl_fallbacks": 24, "rccl_ranks_last": 25, "search_clock_mhz": 26}
+             "tri_ring": 21, "tri_ring_accepts": 22, "exchange_us": 23, "rccl_fallbacks": 24, "rccl_ranks_last": 25, "search_clock_mhz": 26, "brute_queue_wgs": 27}
     EXCHANGE_NAMES = {-1: None, 0: "mailbox (pinned host memory)", 1: "rccl", 2: "mailbox (peer-mapped device memory)"}
 
     def exchange_info(self):

@@ -222,6 +222,38 @@ def test_wave_order_changes_nothing_but_speed(orc, wave_order, monkeypatch):
     assert np.array_equal(idx2, ridx) and np.array_equal(d22, rd2, equal_nan=True)
 
 
+@pytest.mark.parametrize("persist,n_src", [("4", 9000), ("1", 9000), ("4", 300), ("0", 9000)])
+def test_work_queue_changes_nothing_but_speed(orc, persist, n_src, monkeypatch):
+    """k_nn_search_sorted's work queue (long launches: as many workgroups as the chip holds take (split, block) items off eight
+    queues, oa_kernels.hpp) forced onto a small launch -- every item is still searched exactly once: unseeded (home pass + pass 2)
+    and seeded answers are the oracle's, with 1024 / 256 workgroups (more than items, fewer than items), one block, and without."""
+    from object_alignment_amd import synth
+    from object_alignment_amd.engine import IcpEngine
+    monkeypatch.setenv("OA_NN_PERSIST", persist)
+    monkeypatch.setenv("OA_NN_QUEUE_MIN_ITEMS", "0")
+    monkeypatch.setenv("OA_NN_R", "4")
+    rng = np.random.default_rng(77)
+    tgt = rng.uniform(-1, 1, size=(140000, 3)).astype(np.float32)
+    src = (tgt[rng.permutation(len(tgt))[:n_src]] + rng.normal(0, 3e-3, size=(n_src, 3))).astype(np.float32)
+    src[::89] = np.float32(np.nan)
+    mxa = synth.rigid4(synth.rotation_from_rotvec([0.3, 0.7, -0.2]), [0.02, -0.03, 0.01])
+    eye = np.identity(4, dtype=np.float32)
+    with IcpEngine(0) as e:
+        e.set_search_mode("brute")
+        e.set_target(tgt)
+        e.set_source(src)
+        e.set_matrices(mxa, eye)
+        idx, d2, _ = e.nn_search()
+        queued_first = e.stat("brute_queue_wgs")
+        e.make_pairs(1e30)                               # winner records = seeds
+        idx2, d22, _ = e.nn_search()
+        assert (e.stat("brute_queue_wgs") > 0) == (persist != "0") and (queued_first > 0) == (persist != "0")
+    moved = np.array([orc.mat4_mul_vec3(mxa, p) for p in src], np.float32)
+    ridx, rd2 = orc.nn_brute(moved, tgt)
+    assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2, equal_nan=True)
+    assert np.array_equal(idx2, ridx) and np.array_equal(d22, rd2, equal_nan=True)
+
+
 def test_sorted_kernel_on_a_2M_vertex_target(orc):
     """BASELINE config 5's target size through the sorted images (1954 LDS tiles, the seeded launch's short splits): an unseeded
     and a seeded search of 6000 points against 2M surface vertices, indices and distances the oracle's brute force."""
