@@ -283,10 +283,10 @@ def surface_leg(args, local_rank):
 # test, first 10 iterations; the 1-GPU figure is measured -- profiles/r03e_baseline_configs.txt --, the 8-GPU one predicted from
 # the per-shard search time + ~30 us of reduce / exchange / solve)
 C5_PREDICTED_MS_PER_ITERATION = {1: 2.06, 8: 0.35}
-# the headline workload (BASELINE config 4 at N = 8), brute-force kernel: one GPU measured (round 5, k_nn_search_sorted: 27.4 ms),
-# 8 GPUs PREDICTED from the 125k-point shard's iteration time on one GPU (3.95 ms, profiles/r05z_baseline_configs.txt) + the
+# the headline workload (BASELINE config 4 at N = 8), brute-force kernel: one GPU measured (round 6, k_nn_search_sorted through its work queue: 26.4 ms),
+# 8 GPUs PREDICTED from the 125k-point shard's search time on one GPU (3.93 ms, profiles/r06z_baseline_configs.txt) + the
 # exchange (derivation: docs/HISTORY.md 4.7)
-C4_PREDICTED_MS_PER_ITERATION = {1: 27.4, 8: 3.98}
+C4_PREDICTED_MS_PER_ITERATION = {1: 26.4, 8: 3.96}
 
 
 def c5_leg(args, n_gpus, in_process, world, rank, local_rank, devices, dev, backend):
@@ -689,9 +689,12 @@ def main():
                          "shader_clock_mhz_during_search": search_clock_mhz,
                          "what_frac_is": "VALU issue-slot utilisation: executed vector-ALU instructions (PMC) x 64 lanes / launch time, against the "
                                          "nominal 78.6 T lane-ops/s.  It says how full the pipe is, NOT how good the kernel is: a third of these "
-                                         "instructions are half-rate (v_min3_f32 / v_cmp), so the pipe is full at ~0.78, and most of them prove "
-                                         "losers the images' order already implies (DESIGN.md 3.1: a block's [u_min, u_max] would replace level 0 "
-                                         "-- which turns brute force into the slab search of row f2).  The kernel is frozen (VERDICT r5).",
+                                         "instructions are of the half-rate class (v_min3_f32 / v_cmp: at 4 cycles each the pipe would be full at "
+                                         "0.75-0.78 -- round 5's reading of 0.79; since the work queue of round 6 the launch reaches 0.82-0.83, so "
+                                         "that class costs less in this mix than a burn of it measures and round 5's 'full pipe' had idle in it), "
+                                         "and most of them prove losers the images' order already implies (DESIGN.md 3.1: a block's [u_min, u_max] "
+                                         "would replace level 0 -- which turns brute force into the slab search of row f2).  The loop is frozen "
+                                         "(VERDICT r5); round 6 changed who runs which piece of it (DESIGN.md 3.1, the work queue).",
                          "formula": "frac = valu_instructions_per_pair x pairs_per_launch / avg_launch_ms / 78.6e12 lane-ops/s "
                                     "(256 CU x 4 SIMD x 32 lanes x 2.4 GHz); valu_instructions_per_pair = SQ_INSTS_VALU x 64 / "
                                     "pairs from the committed PMC pass (profiles/), avg_launch_ms = hipEvent pairs around "

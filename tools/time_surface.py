@@ -37,8 +37,9 @@ for mode, search in combos:
             e.set_target(tgt)
         e.set_source(src, stride=1)
         up = time.perf_counter() - t0
-        for it in (5, 30):
+        for it in [int(a) for a in os.environ.get("ITERS", "5,30").split(",")]:     # ITERS=1,3: other loop lengths from the same cold start
             e.set_matrices(mxa, mxb)
+            if os.environ.get("WG_LOG_DIR"): os.environ["OA_WG_LOG"] = os.path.join(os.environ["WG_LOG_DIR"], "it%d.bin" % it)   # (instrumented builds only)
             t0 = time.perf_counter()
             r = e.run(iters=it, thresh=0.05, early_exit=False)
             wall = time.perf_counter() - t0
