@@ -639,8 +639,17 @@ def main():
         else:
             par = ("one process per GPU: source sharded x%d, target replicated, all-reduce of 24 f64 per iteration (%s)"
                    % (world, exchange))
+        # the burn's issue rate PER CLOCK (it runs at whatever clock the box holds for 5 ms: 2090-2420 MHz seen), priced at the clock one
+        # workgroup of the search stamped DURING the search -- the lower of the two burns at their own clocks when that stamp is missing.
+        # (Round 6: the lower burn alone read 0.99-1.005 of itself once the work queue had taken the idle out of the launch: a burn at
+        #  2087 MHz is no ceiling for a search at 2350.)
         ceil_t = [c["tlaneops"] for c in (ceil_before, ceil_after) if "tlaneops" in c and c["tlaneops"] > 0]
-        ceil_now = min(ceil_t) if ceil_t else None                           # the lower of the two: the conservative denominator
+        per_clock = [c["tlaneops"] * 1e6 / c["shader_clock_mhz"] for c in (ceil_before, ceil_after)
+                     if c.get("tlaneops", 0) > 0 and c.get("shader_clock_mhz", 0) > 0]                 # lane-ops per shader cycle, whole chip
+        if per_clock and search_clock_mhz:
+            ceil_now = max(per_clock) * search_clock_mhz * 1e-6
+        else:
+            ceil_now = min(ceil_t) if ceil_t else None
         half_share = HALF_RATE_SHARE.get(brute_kernel)
         out = {
             "metric": "ICP iterations/sec + ms/NN-search, 1M<->1M verts",
@@ -683,7 +692,10 @@ def main():
                          "frac_of_nominal": laneops / VALU_PEAK_TLANEOPS,
                          "measured_issue_ceiling": {"unit": "Tlane-op/s", "instruction": "v_add_f32 (two register sources: one wave-instruction per SIMD every two cycles = 32 lanes per clock), "
                                                                    "16 independent chains, 8 waves per SIMD, ~2.5 ms; v_min3_f32 (`tlaneops_min3`: the half-rate class) beside it",
-                                                    "before_timed_loop": ceil_before, "after_timed_loop": ceil_after, "used": ceil_now},
+                                                    "before_timed_loop": ceil_before, "after_timed_loop": ceil_after, "used": ceil_now,
+                                                    "used_is": "the higher of the two burns' lane-ops per shader cycle x shader_clock_mhz_during_search "
+                                                               "(nominal: 32768 lane-ops per cycle); without that clock: the lower burn as measured",
+                                                    "lane_ops_per_cycle": (max(per_clock) if per_clock else None)},
                          "frac_of_measured_ceiling": (laneops / ceil_now) if ceil_now else None,
                          "half_rate_instruction_share": half_share,
                          "shader_clock_mhz_during_search": search_clock_mhz,
