@@ -59,7 +59,9 @@
 // ---- closest point on triangles: oa_fam_tri.hip ---------------------------------------------------------------------
 #define OA_FAMILY_TRI(X)                                                                                                \
     OA_K(X, k_tri_search_grid, OA_SIG_TRI_GRID, 1) OA_K(X, k_tri_search_grid, OA_SIG_TRI_GRID, 2)                       \
-    OA_K(X, k_tri_search_grid, OA_SIG_TRI_GRID, 4)
+    OA_K(X, k_tri_search_grid, OA_SIG_TRI_GRID, 4)                                                                      \
+    OA_K(X, k_tri_search_grid, OA_SIG_TRI_GRID, 1, false, true, false, 64) OA_K(X, k_tri_search_grid, OA_SIG_TRI_GRID, 2, false, true, false, 64) \
+    OA_K(X, k_tri_search_grid, OA_SIG_TRI_GRID, 4, false, true, false, 64)
 #define OA_FAMILY_TRI_ACC(X)                                                                                            \
     OA_K(X, k_tri_search_grid, OA_SIG_TRI_GRID, 1, false, true, true) OA_K(X, k_tri_search_grid, OA_SIG_TRI_GRID, 2, false, true, true) \
     OA_K(X, k_tri_search_grid, OA_SIG_TRI_GRID, 4, false, true, true)

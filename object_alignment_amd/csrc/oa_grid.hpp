@@ -37,6 +37,8 @@ struct GridParams {
     float  eps_plane;        // triangle grid: how far a triangle's corners may lie from the plane of its record (oa_tri.hpp)
     int    drop_over;        // triangle grid: a query whose listed cells exceed its budget scans none of them (OA_TRI_DROP_OVER)
     double moving_h;         // the pose "still moves" (budget_moving applies) while last step's translation + rotation x size exceeds this
+    double xcd_moving_h;     // triangle grid: ... while last step's motion exceeds THIS (a multiple of moving_h: far queries, whose cost follows the region)
+    int    xcd_chunk;        // triangle grid: while the pose still moves an XCD's share of a launch is every eighth chunk of this many x 256 queries (0: always one contiguous eighth; oa_kernels.hpp: xcd_block_index_chunked)
 };
 
 // host: fill the float fields from h / slack

@@ -376,6 +376,7 @@ struct oa_ctx {
     bool tri_ring_ok = false;        // built for the current mesh
     int tri_ring = 0;                // OA_TRI_RING (EXPERIMENT, off: exact, measured, not faster -- docs/HISTORY.md 4.5): 0 = never; 1 = built once a mesh has seen TRI_RING_LAZY_ITERS searches of a loop; 2 = built with the grid
     double tri_ring_cap = 0.25;      // OA_TRI_RING_CAP: clearances are looked for up to this fraction of a cell edge
+    bool tri_wave_wgs = true;        // OA_TRI_WAVE_WGS=0 (A/B): the plain surface search in workgroups of 256 queries also for long launches, as until round 6
     bool tri_split_lanes = true;     // OA_TRI_SPLIT_LANES=0 (A/B): the list is always searched with the shard's own lanes per query
     bool tri_split = true;           // OA_TRI_SPLIT=0 (A/B): the seed + neighbours test stays in the grid search's prologue (no k_tri_accept launch)
     long long tri_iters = 0;         // loop searches enqueued since the mesh was set
@@ -2028,6 +2029,7 @@ OA_EXPORT int oa_create(oa_ctx **out, int device)
     c->tri_ring = std::max(0, std::min(2, env_int("OA_TRI_RING", 0)));
     c->tri_ring_cap = env_double("OA_TRI_RING_CAP", 0.25);
     c->tri_split = env_int("OA_TRI_SPLIT", 1) != 0;
+    c->tri_wave_wgs = env_int("OA_TRI_WAVE_WGS", 1) != 0;
     c->tri_fine = std::max(0, std::min(2, env_int("OA_TRI_FINE", 0)));   // EXPERIMENT (liboa_icp_exp.so), off: measured slower than the search it fronts, docs/HISTORY.md
     c->tri_fine_min_tris = std::max(64, env_int("OA_TRI_FINE_MIN_TRIS", 200000));
     c->tri_split_lanes = env_int("OA_TRI_SPLIT_LANES", 1) != 0;
@@ -2788,6 +2790,8 @@ int build_tri_grid(oa_ctx *c, const double *diag_sum_known)
         gp.eps_plane = (float)(8.0 * 5.9604644775390625e-08 * scale + 1e-37);
         gp.drop_over = env_int("OA_TRI_DROP_OVER", 1);
         gp.moving_h = env_double("OA_TRI_MOVING_FRAC", 0.25) * gp.h;
+        gp.xcd_chunk = std::max(0, std::min(4096, env_int("OA_TRI_XCD_CHUNK", 8)));
+        gp.xcd_moving_h = env_double("OA_TRI_XCD_MOVING_FRAC", 0.5) * gp.h;
         n_cells = (int)total;
         // (the entry total behind the counts, 8-byte aligned: one memset for both)
         const size_t total_at = ((size_t)n_cells + 2) & ~(size_t)1;
@@ -3059,7 +3063,16 @@ int launch_tri_search(oa_ctx *c, bool acc)
             return OA_OK;
         }
 #define OA_TGRID_TAIL oa::BvhParams{}, (const float4 *)nullptr, (const float4 *)nullptr, oa::NormalTest{}, (double *)nullptr, ring, qlist, qcount
-        if (lanes == 4) hipLaunchKernelGGL(oa::k_tri_search_grid<4>, gblocks, dim3(256), 0, c->stream, OA_TGRID_ARGS, (unsigned long long *)nullptr, OA_TGRID_TAIL);
+        // long plain searches: one wave per workgroup (k_tri_search_grid, BT = 64): a slot is free again when ITS wave is through
+        const long long wblocks = ((long long)c->ns * lanes + 63) / 64;
+        const bool wave_wgs = c->tri_wave_wgs && !qlist && !c->grid_stats && c->tri_share && wblocks >= (long long)c->n_cu * 32;
+        if (wave_wgs) {
+            const dim3 wb((unsigned)wblocks);
+            if (lanes == 4) hipLaunchKernelGGL((oa::k_tri_search_grid<4, false, true, false, 64>), wb, dim3(64), 0, c->stream, OA_TGRID_ARGS, (unsigned long long *)nullptr, OA_TGRID_TAIL);
+            else if (lanes == 2) hipLaunchKernelGGL((oa::k_tri_search_grid<2, false, true, false, 64>), wb, dim3(64), 0, c->stream, OA_TGRID_ARGS, (unsigned long long *)nullptr, OA_TGRID_TAIL);
+            else hipLaunchKernelGGL((oa::k_tri_search_grid<1, false, true, false, 64>), wb, dim3(64), 0, c->stream, OA_TGRID_ARGS, (unsigned long long *)nullptr, OA_TGRID_TAIL);
+        }
+        else if (lanes == 4) hipLaunchKernelGGL(oa::k_tri_search_grid<4>, gblocks, dim3(256), 0, c->stream, OA_TGRID_ARGS, (unsigned long long *)nullptr, OA_TGRID_TAIL);
         else if (lanes == 2) hipLaunchKernelGGL(oa::k_tri_search_grid<2>, gblocks, dim3(256), 0, c->stream, OA_TGRID_ARGS, (unsigned long long *)nullptr, OA_TGRID_TAIL);
 #if defined(OA_EXPERIMENTS)
         else if (c->grid_stats) {                                   // OA_GRID_STATS=1: instrumented launch, totals to stderr (synchronises)

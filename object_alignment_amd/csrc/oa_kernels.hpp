@@ -681,6 +681,33 @@ __device__ __forceinline__ int xcd_block_index()
     return x * q + (x < r ? x : r) + (b >> 3);
 }
 
+// The same in chunks (round 6, k_tri_search_grid while the pose still moves): an XCD's share of the launch is every eighth CHUNK of
+// `chunk` consecutive workgroups instead of one contiguous eighth of them all.  The queries are in Morton order, their cost follows
+// the geometry, and a contiguous eighth is one region of the object: on the first search of a cold start XCD 0's share took 825 us
+// of slot time where the mean was 642, and the launch ended with it (1004 us; per-workgroup stamps, profiles/r06i) -- seven XCDs
+// idle for a third of the launch.  Chunks hand every XCD the same mix of regions; once the pose has settled the contiguous share
+// is the faster one again (neighbours read the same cell lists and triangles: 0.341 against 0.355 ms per search), so the search
+// picks by the test its candidate budget already makes.  The last, partial round of chunks goes by the plain order.
+__device__ __forceinline__ int xcd_block_index_chunked(int chunk)
+{
+    const int nb = (int)gridDim.x, b = (int)blockIdx.x;
+    if (nb < 1024) return b;
+    const int round = 8 * chunk, full = nb / round * round;         // workgroups in whole rounds of 8 chunks
+    if (b >= full) return b;
+    const int x = b & 7, k = b >> 3;                                // XCD, and this workgroup's number on it
+    return (k / chunk) * round + x * chunk + k % chunk;
+}
+
+// "The pose still moves": first search of a loop, or last iteration's translation + rotation x object size above `threshold`
+// (local units) -- the test behind the grid searches' budget_moving
+__device__ __forceinline__ bool pose_moving(const DevState *__restrict__ st, double scale, double threshold)
+{
+    if (st->n == 0) return true;
+    if (!st->use_target) return false;
+    const int last = (st->n + 4) % 5;
+    return (st->ring_t[last] + st->ring_r[last] * scale) * st->local_per_world > threshold;
+}
+
 // Target split of workgroup blockIdx.x: tiles [x T / n, (x + 1) T / n) of the T tiles (of `tile_groups` groups each), n =
 // gridDim.x.  Split sizes differ by at most one tile, every split is non-empty (n <= T), and n stays what the host chose -- a
 // multiple of 8 above 8, so that the dispatcher's round-robin (workgroup b on XCD b % 8) pins every split to ONE XCD, whose

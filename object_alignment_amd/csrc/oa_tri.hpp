@@ -447,9 +447,10 @@ __device__ __forceinline__ float4 tri_ld_rec(const float4 *__restrict__ base, in
 
 // every lane walks ITS ranges, four records per trip; the wave leaves when every lane is through: a wave pays
 // max-over-lanes(records) trips (round 2 / 3; kept for A/B: OA_TRI_SHARE=0)
+template <int BT>
 __device__ __forceinline__ void tri_scan_segments(const float *p, const float4 *__restrict__ cell_rec,
                                                   const float4 *__restrict__ tri9, TriSearchState &s, float eps_plane,
-                                                  const int (*seg_j)[256], const unsigned short (*seg_n)[256], int &n_seg, TriPool &pool,
+                                                  const int (*seg_j)[BT], const unsigned short (*seg_n)[BT], int &n_seg, TriPool &pool,
                                                   double delta, float cutf, int *surv = nullptr, int *ev = nullptr, int *trips = nullptr)
 {
     const int lane = threadIdx.x & 63;
@@ -497,9 +498,10 @@ __device__ __forceinline__ void tri_scan_segments(const float *p, const float4 *
 // many cannot change it.  The threshold of the plane / disc bound is reach^2 here (>= TriSearchState::thr: reach >= r (1 + 3e-6),
 // thr = r^2 (1 + 3e-6)(1 + 1.1e-6) -- a hair looser, one multiplication instead of a second cross-lane value); an owner's reach
 // only changes in a flush, which the whole wave takes together and which republishes it.
+template <int BT>
 __device__ __forceinline__ void tri_scan_shared(const float *p, const float4 *__restrict__ cell_rec,
                                                 const float4 *__restrict__ tri9, TriSearchState &s, float eps_plane,
-                                                const int (*seg_j)[256], const unsigned short (*seg_n)[256], int &n_seg, unsigned *tab,
+                                                const int (*seg_j)[BT], const unsigned short (*seg_n)[BT], int &n_seg, unsigned *tab,
                                                 TriPool &pool, double delta, float cutf, int *surv = nullptr, int *ev = nullptr,
                                                 int *trips = nullptr)
 {
@@ -739,11 +741,11 @@ enum { TRI_STAT_QUERIES, TRI_STAT_ROWS, TRI_STAT_ENTRIES, TRI_STAT_SURVIVORS, TR
 #ifndef OA_TRI_LIST_REPS
 #define OA_TRI_LIST_REPS 3
 #endif
-template <int L, bool STATS = false, bool SHARE = true, bool ACC = false>
+template <int L, bool STATS = false, bool SHARE = true, bool ACC = false, int BT = 256>
 #ifndef OA_TRI_MIN_WAVES
 #define OA_TRI_MIN_WAVES 4
 #endif
-__global__ __launch_bounds__(256, OA_TRI_MIN_WAVES) void k_tri_search_grid(const DevState *__restrict__ st,
+__global__ __launch_bounds__(BT, OA_TRI_MIN_WAVES) void k_tri_search_grid(const DevState *__restrict__ st,
                                                          const float4 *__restrict__ src4, int ns, GridParams gp,
                                                          const int *__restrict__ cell_start,
                                                          const float4 *__restrict__ cell_rec,
@@ -766,13 +768,16 @@ __global__ __launch_bounds__(256, OA_TRI_MIN_WAVES) void k_tri_search_grid(const
     static_assert(RPL <= TRI_SEGS && (L == 1 || 2 * RPL <= TRI_SEGS), "a batch of rows must fit the per-thread range list");
     if (st->halt) return;
     if (turn >= 0 && (st->tree_turn != 0) != (turn != 0)) return;  // not this kernel's turn (DevState::tree_turn)
-    __shared__ unsigned pool_to[4][TRI_POOL];
-    __shared__ unsigned short pool_key[4][TRI_POOL];
-    __shared__ unsigned long long pool_slot[256], pool_first[256];
-    __shared__ __attribute__((aligned(16))) int seg_j[TRI_SEGS][256];
-    __shared__ __attribute__((aligned(16))) unsigned short seg_n[TRI_SEGS][256];                 // (a range is never longer than the budget it was charged to: < 65536, build_tri_grid)
-    __shared__ unsigned chunk_tab[SHARE ? 4 : 1][SHARE ? 64 * TRI_SHARE_Q : 1];
-    __shared__ float4 owner_q4[SHARE ? 256 : 1];
+    // BT = 64 (round 6, the plain searches of long loops): ONE wave per workgroup.  The waves of this search share nothing, but a
+    // workgroup's slot is only free again when its slowest wave is through.
+    static_assert(BT == 256 || (BT == 64 && !ACC), "the accumulating search's rows of partials are workgroups of 256 queries");
+    __shared__ unsigned pool_to[BT / 64][TRI_POOL];
+    __shared__ unsigned short pool_key[BT / 64][TRI_POOL];
+    __shared__ unsigned long long pool_slot[BT], pool_first[BT];
+    __shared__ __attribute__((aligned(16))) int seg_j[TRI_SEGS][BT];
+    __shared__ __attribute__((aligned(16))) unsigned short seg_n[TRI_SEGS][BT];                 // (a range is never longer than the budget it was charged to: < 65536, build_tri_grid)
+    __shared__ unsigned chunk_tab[SHARE ? BT / 64 : 1][SHARE ? 64 * TRI_SHARE_Q : 1];
+    __shared__ float4 owner_q4[SHARE ? BT : 1];
     int n_seg = 0;
     TriPool pool;
     {
@@ -801,7 +806,9 @@ __global__ __launch_bounds__(256, OA_TRI_MIN_WAVES) void k_tri_search_grid(const
         if (qn < 0) { if (qmax != 0x7FFFFFFF) return; listed = false; }
         else { ns = qn; if (ns <= qmin || ns > qmax) return; }
     }
-    const int vb = listed ? (int)blockIdx.x : xcd_block_index();          // one contiguous part of the queries per XCD
+    // one contiguous part of the queries per XCD -- in chunks while the pose still moves (xcd_block_index_chunked)
+    const bool moving = pose_moving(st, gp.scale, gp.moving_h);
+    const int vb = listed ? (int)blockIdx.x : ((gp.xcd_chunk > 0 && pose_moving(st, gp.scale, gp.xcd_moving_h)) ? xcd_block_index_chunked(gp.xcd_chunk * (256 / BT)) : xcd_block_index());
     const int gt = vb * (int)blockDim.x + threadIdx.x;
     int i = gt / L;
     const int sub = gt % L;                                         // the L lanes of a query are neighbours in a wave
@@ -884,9 +891,7 @@ __global__ __launch_bounds__(256, OA_TRI_MIN_WAVES) void k_tri_search_grid(const
     int budget = gp.budget;
     int budget_extra = 0;                                            // what the larger budget added (wave-uniform)
     {
-        const int last = (st->n + 4) % 5;
-        const double moved = st->use_target && st->n > 0 ? (st->ring_t[last] + st->ring_r[last] * gp.scale) * st->local_per_world : 0.0;
-        if (st->n == 0 || moved > gp.moving_h) budget = gp.budget_moving;
+        if (moving) budget = gp.budget_moving;
         if (L > 1) budget = budget / L + 8;
         budget_extra = budget - (L > 1 ? gp.budget / L + 8 : gp.budget);
     }
@@ -1087,7 +1092,7 @@ __global__ __launch_bounds__(256, OA_TRI_MIN_WAVES) void k_tri_search_grid(const
             if ((threadIdx.x & 63) == 0) atomicAdd(todo_count, __popcll(todo));
             // this wave's columns of the range lists are free now: per level 256 B of bounds (seg_j), the mask and the node (seg_n)
             const int lane = threadIdx.x & 63, col0 = threadIdx.x & ~63;
-            const BvhLds lds{ (float *)&seg_j[0][col0], 256, (unsigned long long *)&seg_n[0][col0], 64, (int *)((char *)&seg_n[0][col0] + 8), 128 };
+            const BvhLds lds{ (float *)&seg_j[0][col0], BT, (unsigned long long *)&seg_n[0][col0], BT / 4, (int *)((char *)&seg_n[0][col0] + 8), BT / 2 };
             while (todo) {
                 const int l = __ffsll((long long)todo) - 1;
                 todo &= todo - 1ull;
