@@ -1433,6 +1433,34 @@ def test_surface_full_size_property(orc):
 
 
 @pytest.mark.gpu
+def test_surface_launch_shapes_change_nothing_but_speed(monkeypatch):
+    """Round 6's launch shapes of the plain surface search -- one wave per workgroup for long launches (OA_TRI_WAVE_WGS), an XCD's
+    share in chunks while the pose is far off and contiguous once it has settled (OA_TRI_XCD_CHUNK) -- against workgroups of 256
+    queries on contiguous shares throughout: twelve iterations from a cold start at the bench's surface_path sizes pass through
+    both regimes; every iteration's statistics, the final matrix and a one-shot search's answers are the same bits."""
+    from object_alignment_amd import synth
+    from object_alignment_amd.engine import IcpEngine
+    verts, tris = synth.lattice_surface_mesh(700, 1400)
+    src = synth.bunny_surface(1_000_000, offset=0.37)
+    mxa = synth.rigid4(synth.rotation_from_rotvec([0.02, -0.015, 0.025]), [0.01, -0.008, 0.012])
+    eye = np.identity(4, dtype=np.float32)
+    got = []
+    for wave_wgs, chunk in (("0", "0"), ("1", "8"), ("1", "0")):
+        monkeypatch.setenv("OA_TRI_WAVE_WGS", wave_wgs)
+        monkeypatch.setenv("OA_TRI_XCD_CHUNK", chunk)
+        with IcpEngine(0) as e:
+            e.set_target_mesh(verts, tris)
+            e.set_source(src)
+            e.set_matrices(mxa, eye)
+            idx, d2, _ = e.nn_search()
+            r = e.run(iters=12, thresh=0.05, early_exit=False)
+            got.append((idx, d2, np.array(e.matrix_world()), r.last_K, r.mean_dist))
+    for other in got[1:]:
+        assert np.array_equal(got[0][0], other[0]) and np.array_equal(got[0][1], other[1])
+        assert np.array_equal(got[0][2], other[2]) and got[0][3] == other[3] and got[0][4] == other[4]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["auto", "grid"])
 def test_step_mode_equals_fused_loop_surface_and_shards(mode):
     """oa_iterate (one iteration per call, the modal operator's step) and oa_run (the whole loop enqueued ahead, with
